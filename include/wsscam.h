@@ -1,0 +1,196 @@
+/*
+ * wsscam.h -- C ABI of libwsscam, the MI355X (gfx950) implementation of the
+ * CAM pseudo-label hot path of lyndonchan/wsss-analysis.
+ *
+ * The reference has no FFI for this path: it is Python calling torch / Keras /
+ * cv2 / pydensecrf.  Each entry point below names the reference code it
+ * replaces (file:line under the reference tree).  The Python shim in
+ * wsss-analysis_amd/wsscam binds exactly these symbols with ctypes and keeps
+ * the reference's Python signatures and on-disk formats on top of them.
+ *
+ * Conventions
+ *   - every function returns 0 (WSC_OK) or a negative wsc_status; nothing
+ *     throws, nothing calls exit().  wsc_last_error() returns a thread-local
+ *     message for the last failing call on this thread.
+ *   - all data pointers named *_dev are DEVICE pointers (hipMalloc'ed memory,
+ *     e.g. torch.Tensor.data_ptr() or wsc_malloc); pointers named *_host are
+ *     host pointers.  The caller owns every buffer it passes in; the library
+ *     owns only what a wsc_*_create returned.
+ *   - a wsc_ctx is bound to one device and one HIP stream.  All work of a ctx
+ *     is enqueued on that stream and is asynchronous unless stated; wsc_sync
+ *     waits for it.  Distinct ctxs may be used from distinct threads.
+ *   - there is no CPU fallback: if no gfx950 device is present
+ *     wsc_ctx_create fails with WSC_ERR_NO_DEVICE.
+ */
+#ifndef WSSCAM_H
+#define WSSCAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSC_VERSION 100 /* 0.1.0 */
+
+typedef enum wsc_status {
+    WSC_OK = 0,
+    WSC_ERR_INVALID = -1,     /* bad argument (shape, null pointer, enum) */
+    WSC_ERR_NO_DEVICE = -2,   /* no HIP device / wrong architecture */
+    WSC_ERR_HIP = -3,         /* a HIP runtime call failed */
+    WSC_ERR_MISSING_KEY = -4, /* state-dict key missing (strict load) */
+    WSC_ERR_SHAPE = -5,       /* state-dict tensor has the wrong shape */
+    WSC_ERR_NOMEM = -6,
+    WSC_ERR_KEY_RANGE = -7,   /* CRF lattice coordinate outside packed-key range */
+    WSC_ERR_CAPACITY = -8     /* CRF hash table / vertex capacity exceeded */
+} wsc_status;
+
+/* architectures: 03b_irn/net/{resnet50_cam,vgg16_cam,m7_cam}.py */
+typedef enum wsc_arch {
+    WSC_ARCH_RESNET50_CAM = 0, /* net/resnet50.py:57-108 + resnet50_cam.py:12-20,55-70 */
+    WSC_ARCH_VGG16_CAM = 1,    /* net/vgg16.py:44 + common_cnn.py:128-141 + vgg16_cam.py:24-60 */
+    WSC_ARCH_M7_CAM = 2        /* net/m7.py:41 + m7_cam.py:22-57 */
+} wsc_arch;
+
+/* arithmetic of the conv stack */
+typedef enum wsc_precision {
+    WSC_PREC_BF16 = 0,  /* bf16 operands, fp32 MFMA accumulation, bf16 activations in HBM */
+    WSC_PREC_BF16X3 = 1 /* split-bf16 (hi+lo) operands, 3 MFMA products: fp32-class accuracy */
+} wsc_precision;
+
+typedef struct wsc_ctx wsc_ctx; /* device + stream + workspace arena */
+typedef struct wsc_net wsc_net; /* immutable packed weights of one CNN */
+typedef struct wsc_crf wsc_crf; /* lattices (Gaussian + bilateral) of a batch of images */
+
+/* A named host tensor of a torch state_dict (float32, C-contiguous). */
+typedef struct wsc_tensor_desc {
+    const char *name;  /* e.g. "resnet50.layer1.0.conv1.weight" */
+    const float *data; /* host pointer */
+    int32_t ndim;
+    int64_t shape[4];
+} wsc_tensor_desc;
+
+/* ---- library / context ------------------------------------------------ */
+
+int wsc_version(void);
+const char *wsc_last_error(void);
+
+/* device: HIP device ordinal.  stream: a hipStream_t to enqueue on (e.g.
+ * torch.cuda.current_stream().cuda_stream), or NULL to let the ctx create and
+ * own a stream.  Replaces `model.cuda()` / `cuda.device(process_id)`
+ * (03b_irn/step/make_cam.py:31-33). */
+int wsc_ctx_create(int device, void *stream, wsc_ctx **out);
+void wsc_ctx_destroy(wsc_ctx *ctx);
+int wsc_sync(wsc_ctx *ctx);
+/* name of the device's gcnArchName ("gfx950...") and CU count */
+int wsc_device_info(wsc_ctx *ctx, char *arch_name, size_t arch_name_len, int *num_cus);
+
+/* device memory helpers so a host without torch can drive the library
+ * (replace tensor.cuda() / .cpu(): make_cam.py:48,81-82) */
+int wsc_malloc(wsc_ctx *ctx, size_t bytes, void **dptr_out);
+int wsc_free(wsc_ctx *ctx, void *dptr);
+int wsc_memcpy_h2d(wsc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes); /* async on ctx stream */
+int wsc_memcpy_d2h(wsc_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* synchronises */
+int wsc_memset(wsc_ctx *ctx, void *dst_dev, int value, size_t bytes);
+
+/* timing on the ctx stream with HIP events (bench.py's roofline leg):
+ * wsc_timer_begin/_end bracket a region; _end synchronises and returns ms. */
+int wsc_timer_begin(wsc_ctx *ctx);
+int wsc_timer_end(wsc_ctx *ctx, float *ms_out);
+
+/* ---- CNN + CAM head --------------------------------------------------- */
+
+/* Build a network from a state_dict.  Replaces model construction +
+ * load_state_dict(strict=True) + .eval() + .cuda()
+ * (03b_irn/step/make_cam.py:96-100, 33).  Inference BatchNorm
+ * (net/resnet50.py:11-14, eps from "<bn>.eps" if given else 1e-5) is folded
+ * into per-channel scale/shift applied in the conv epilogue.
+ * Missing keys -> WSC_ERR_MISSING_KEY, wrong shapes -> WSC_ERR_SHAPE. */
+int wsc_net_create(wsc_ctx *ctx, int arch, const wsc_tensor_desc *weights, int n_weights,
+                   int num_classes, int precision, wsc_net **out);
+void wsc_net_destroy(wsc_net *net);
+/* spatial size of the CAM for an S x S input (21 for resnet50 @321, 40 vgg16 @321, 56 m7 @224) */
+int wsc_net_cam_size(const wsc_net *net, int S, int *h_out);
+/* channels of the last conv feature map (2048 / 1024 / 256) */
+int wsc_net_feat_channels(const wsc_net *net, int *f_out);
+
+/* CAM.forward for a batch of B images (resnet50_cam.py:55-70, vgg16_cam.py:24-50):
+ *   x_dev   float32 [B][2][3][S][S]  -- per image: original and h-flipped sample,
+ *           exactly the "img" tensor of VOC12ClassificationDatasetMSF
+ *           (voc12/dataloader.py:240)
+ *   cam_dev float32 [B][C][h][w]     -- relu(conv1x1(feat)) of sample 0 plus the
+ *           w-flipped map of sample 1
+ *   score_dev float32 [B][C] or NULL -- sigmoid(Linear(GAP(feat of sample 0)))
+ *           (vgg16_cam.py:34-36); NULL for resnet50 which has no classifier branch
+ * Asynchronous on the ctx stream. */
+int wsc_net_forward_cam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int S,
+                        float *cam_dev, float *score_dev);
+
+/* Last-conv feature map for Grad-CAM style heads (02_cues/utilities.py:129-132,
+ * K.function([input],[conv_output])): feat_dev float32 [N][h][w][F] (NHWC as Keras). */
+int wsc_net_forward_features(wsc_ctx *ctx, const wsc_net *net, const float *x_dev /*[N][3][S][S]*/,
+                             int N, int S, float *feat_dev);
+
+/* One nn.Conv2d (+ per-channel scale/shift, residual add, ReLU) through the production
+ * implicit-GEMM kernel with NCHW float32 tensors on the device -- the unit the per-layer
+ * numerics tests drive (conv shape classes of SURVEY.md section 8 a4/a6).  w_host is OIHW.
+ * Cin must be <= 4 (stem-style, small-Cin path) or a multiple of 64; Cout a multiple of 8. */
+int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int W, const float *w_host,
+                    int Cout, int kh, int kw, int stride, int pad, const float *scale_host,
+                    const float *shift_host, const float *residual_dev, int relu, int precision,
+                    float *y_dev);
+
+/* ---- CAM tail ---------------------------------------------------------- */
+
+/* make_cam._work tail for a batch (03b_irn/step/make_cam.py:41-42,62-76 with
+ * misc.imutils.get_strided_size / get_strided_up_size):
+ * for image b with original size (H0,W0)=size_hw[b], valid classes
+ * keys[key_off[b] .. key_off[b+1]) :
+ *   strided  = bilinear(cam[b], ((H0-1)/4+1, (W0-1)/4+1), align_corners=False)[keys]
+ *   high_res = bilinear(cam[b], (((H0-1)/16+1)*16, ...))[keys][:, :H0, :W0]
+ *   each channel divided by (its spatial max + 1e-5)
+ * Outputs are packed back to back: image b's strided block starts at float
+ * offset strided_off[b] (K_b*h4*w4 floats), high_res at highres_off[b]
+ * (K_b*H0*W0 floats); the caller computes the offsets (prefix sums).
+ * All descriptor arrays are HOST pointers (copied by the call). */
+int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w,
+                        const int32_t *size_hw_host /*[B][2]*/, const int32_t *keys_host,
+                        const int32_t *key_off_host /*[B+1]*/, const int64_t *strided_off_host /*[B]*/,
+                        const int64_t *highres_off_host /*[B]*/, float *strided_dev, float *highres_dev);
+
+/* F.interpolate(mode='bilinear', align_corners=False) on float32 [C][h][w] -> [C][H][W]
+ * (make_cam.py:64-69; also resize_stack 02_cues/utilities.py:20-40 up to the
+ * cv2/torch border convention). */
+int wsc_bilinear_resize(wsc_ctx *ctx, const float *src_dev, int C, int h, int w, float *dst_dev, int H,
+                        int W);
+
+/* ---- dense CRF (pydensecrf replacement) -------------------------------- */
+
+/* DenseCRF2D(W,H,M) + addPairwiseGaussian(sxy=g_sxy) + addPairwiseBilateral(
+ * sxy=bi_sxy, srgb=bi_srgb, rgbim) for a batch of B images of one size
+ * (03c_hsn/utilities.py:427-440; misc.imutils.crf_inference_label call sites
+ * 03b_irn/step/cam_to_ir_label.py:35-67): builds both permutohedral lattices
+ * and the symmetric normalisation vectors, which depend on the image only and
+ * are reused by every mean-field iteration.
+ *   rgb_dev uint8 [B][H][W][3] (HWC, as np.uint8(images[i])). */
+int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, float g_sxy,
+                   float bi_sxy, float bi_srgb, wsc_crf **out);
+void wsc_crf_destroy(wsc_crf *crf);
+/* number of occupied lattice vertices per image: v_gauss/v_bilat int32[B] host arrays (may be NULL) */
+int wsc_crf_lattice_sizes(wsc_ctx *ctx, const wsc_crf *crf, int32_t *v_gauss_host,
+                          int32_t *v_bilat_host);
+
+/* d.setUnaryEnergy(U); Q = d.inference(n_iters) with Potts compatibilities
+ * g_compat / bi_compat (03c_hsn/utilities.py:431-442):
+ *   unary_dev float32 [B][M][H*W]  (= -log p, as unary_from_softmax returns it)
+ *   q_dev     float32 [B][M][H*W]  or NULL   (np.array(Q))
+ *   argmax_dev int32  [B][H*W]     or NULL   (np.argmax(Q, axis=0))
+ * M <= 32. */
+int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M, float g_compat,
+                      float bi_compat, int n_iters, float *q_dev, int32_t *argmax_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSSCAM_H */

@@ -1,0 +1,159 @@
+// api.hip -- context, error plumbing, memory helpers and timers of the C ABI (include/wsscam.h).
+#include "common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+static thread_local char g_err[1024] = "";
+
+void wsc_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int wsc_ctx_workspace(wsc_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->ws_bytes) {
+        // everything already enqueued may still read the old arena
+        WSC_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->ws) WSC_HIP(hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+        const size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&ctx->ws, want);
+        if (e != hipSuccess) {
+            wsc_set_error("workspace hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+            return WSC_ERR_NOMEM;
+        }
+        ctx->ws_bytes = want;
+    }
+    *out = ctx->ws;
+    return WSC_OK;
+}
+
+extern "C" {
+
+int wsc_version(void) { return WSC_VERSION; }
+const char *wsc_last_error(void) { return g_err; }
+
+int wsc_ctx_create(int device, void *stream, wsc_ctx **out) {
+    WSC_CHECK(out != nullptr, WSC_ERR_INVALID, "wsc_ctx_create: out is null");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        wsc_set_error("no HIP device available (%s); libwsscam has no CPU fallback",
+                      e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return WSC_ERR_NO_DEVICE;
+    }
+    WSC_CHECK(device >= 0 && device < count, WSC_ERR_INVALID, "device %d out of range [0,%d)", device, count);
+    WSC_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    WSC_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        wsc_set_error("device %d is %s; libwsscam is built for gfx950 only", device, prop.gcnArchName);
+        return WSC_ERR_NO_DEVICE;
+    }
+    wsc_ctx *ctx = new wsc_ctx();
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    ctx->arch = prop.gcnArchName;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->own_stream = false;
+    } else {
+        WSC_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    WSC_HIP(hipEventCreate(&ctx->ev0));
+    WSC_HIP(hipEventCreate(&ctx->ev1));
+    *out = ctx;
+    return WSC_OK;
+}
+
+void wsc_ctx_destroy(wsc_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int wsc_sync(wsc_ctx *ctx) {
+    WSC_CHECK(ctx, WSC_ERR_INVALID, "wsc_sync: null ctx");
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    return WSC_OK;
+}
+
+int wsc_device_info(wsc_ctx *ctx, char *arch_name, size_t arch_name_len, int *num_cus) {
+    WSC_CHECK(ctx, WSC_ERR_INVALID, "wsc_device_info: null ctx");
+    if (arch_name && arch_name_len > 0) {
+        strncpy(arch_name, ctx->arch.c_str(), arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    if (num_cus) *num_cus = ctx->num_cus;
+    return WSC_OK;
+}
+
+int wsc_malloc(wsc_ctx *ctx, size_t bytes, void **dptr_out) {
+    WSC_CHECK(ctx && dptr_out, WSC_ERR_INVALID, "wsc_malloc: null argument");
+    WSC_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr_out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        wsc_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return WSC_ERR_NOMEM;
+    }
+    return WSC_OK;
+}
+
+int wsc_free(wsc_ctx *ctx, void *dptr) {
+    WSC_CHECK(ctx, WSC_ERR_INVALID, "wsc_free: null ctx");
+    if (!dptr) return WSC_OK;
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    WSC_HIP(hipFree(dptr));
+    return WSC_OK;
+}
+
+int wsc_memcpy_h2d(wsc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    WSC_CHECK(ctx && (bytes == 0 || (dst_dev && src_host)), WSC_ERR_INVALID, "wsc_memcpy_h2d: null argument");
+    if (bytes == 0) return WSC_OK;
+    WSC_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // pageable source: the runtime has staged it when the call returns
+    return WSC_OK;
+}
+
+int wsc_memcpy_d2h(wsc_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    WSC_CHECK(ctx && (bytes == 0 || (dst_host && src_dev)), WSC_ERR_INVALID, "wsc_memcpy_d2h: null argument");
+    if (bytes == 0) return WSC_OK;
+    WSC_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    return WSC_OK;
+}
+
+int wsc_memset(wsc_ctx *ctx, void *dst_dev, int value, size_t bytes) {
+    WSC_CHECK(ctx && (bytes == 0 || dst_dev), WSC_ERR_INVALID, "wsc_memset: null argument");
+    if (bytes == 0) return WSC_OK;
+    WSC_HIP(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    return WSC_OK;
+}
+
+int wsc_timer_begin(wsc_ctx *ctx) {
+    WSC_CHECK(ctx, WSC_ERR_INVALID, "wsc_timer_begin: null ctx");
+    WSC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return WSC_OK;
+}
+
+int wsc_timer_end(wsc_ctx *ctx, float *ms_out) {
+    WSC_CHECK(ctx && ms_out, WSC_ERR_INVALID, "wsc_timer_end: null argument");
+    WSC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    WSC_HIP(hipEventSynchronize(ctx->ev1));
+    WSC_HIP(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+    return WSC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,191 @@
+// cam_tail.hip -- the tail of make_cam._work for a batch of images
+// (03b_irn/step/make_cam.py:41-42, 62-76):
+//   strided_cam = F.interpolate(cam, strided_size, 'bilinear', align_corners=False)[valid_cat]
+//   highres_cam = F.interpolate(cam, strided_up_size, ...)[valid_cat][:, :H0, :W0]
+//   x /= F.adaptive_max_pool2d(x, (1,1)) + 1e-5      (per channel)
+// HBM-bound on the output write (K*(h4*w4 + H0*W0)*4 bytes per image); the 21x21 source
+// map of a job lives in LDS.  Two launches: (1) per-channel spatial max of the upsampled
+// maps, (2) recompute + divide + one coalesced write.  Nothing but the final result is
+// ever written to HBM.
+//
+// Bilinear arithmetic follows torch's CPU kernel for align_corners=False:
+//   scale = in/out (fp32); src = scale*(dst+0.5)-0.5, clamped at 0; i0=(int)src;
+//   i1 = i0 + (i0 < in-1); l1 = src - i0; l0 = 1 - l1;
+//   out = lh0*(lw0*a + lw1*b) + lh1*(lw0*c + lw1*d)
+#include "common.h"
+
+namespace {
+
+struct TailJob {
+    long long cam_off;     // float offset of cam[b][key] (h*w floats)
+    long long strided_off; // float offset of this channel's strided output
+    long long highres_off; // float offset of this channel's high_res output
+    int H0, W0, h4, w4, Hu, Wu;
+};
+
+constexpr int PIX_PER_BLOCK = 4096;
+
+__device__ __forceinline__ void src_index(int dst, float scale, int in, int &i0, int &i1, float &l0, float &l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+    l0 = 1.f - l1;
+}
+
+__device__ __forceinline__ float bilerp(const float *src, int w, int y0, int y1, float ly0, float ly1, int x0, int x1,
+                                        float lx0, float lx1) {
+    const float top = lx0 * src[y0 * w + x0] + lx1 * src[y0 * w + x1];
+    const float bot = lx0 * src[y1 * w + x0] + lx1 * src[y1 * w + x1];
+    return ly0 * top + ly1 * bot;
+}
+
+// WRITE = false: atomicMax the per-job maxima; WRITE = true: write v / (max + 1e-5).
+template <bool WRITE>
+__global__ __launch_bounds__(256) void cam_tail_kernel(const float *__restrict__ cam, const TailJob *__restrict__ jobs,
+                                                       int h, int w, unsigned int *__restrict__ mx,
+                                                       float *__restrict__ strided, float *__restrict__ highres) {
+    extern __shared__ float src[]; // h*w
+    const TailJob job = jobs[blockIdx.y];
+    const int n_hi = job.H0 * job.W0;
+    const int n_st = job.h4 * job.w4;
+    const int start = blockIdx.x * PIX_PER_BLOCK;
+    if (start >= n_hi + n_st) return;
+    for (int i = threadIdx.x; i < h * w; i += blockDim.x) src[i] = cam[job.cam_off + i];
+    __syncthreads();
+
+    const float sh_hi = (float)h / (float)job.Hu, sw_hi = (float)w / (float)job.Wu;
+    const float sh_st = (float)h / (float)job.h4, sw_st = (float)w / (float)job.w4;
+    float d_hi = 1.f, d_st = 1.f;
+    if (WRITE) {
+        d_hi = __uint_as_float(mx[2 * blockIdx.y]) + 1e-5f;
+        d_st = __uint_as_float(mx[2 * blockIdx.y + 1]) + 1e-5f;
+    }
+    float m_hi = 0.f, m_st = 0.f;
+    const int end = min(start + PIX_PER_BLOCK, n_hi + n_st);
+    for (int i = start + threadIdx.x; i < end; i += blockDim.x) {
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        if (i < n_hi) {
+            const int yy = i / job.W0, xx = i - yy * job.W0;
+            src_index(yy, sh_hi, h, y0, y1, ly0, ly1);
+            src_index(xx, sw_hi, w, x0, x1, lx0, lx1);
+            const float v = bilerp(src, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1);
+            if (WRITE) highres[job.highres_off + i] = v / d_hi;
+            else m_hi = fmaxf(m_hi, v);
+        } else {
+            const int k = i - n_hi;
+            const int yy = k / job.w4, xx = k - yy * job.w4;
+            src_index(yy, sh_st, h, y0, y1, ly0, ly1);
+            src_index(xx, sw_st, w, x0, x1, lx0, lx1);
+            const float v = bilerp(src, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1);
+            if (WRITE) strided[job.strided_off + k] = v / d_st;
+            else m_st = fmaxf(m_st, v);
+        }
+    }
+    if (!WRITE) {
+        // CAM values are >= 0 (ReLU + ReLU), so the uint order of the bits is the float order
+        for (int o = 32; o > 0; o >>= 1) {
+            m_hi = fmaxf(m_hi, __shfl_down(m_hi, o, 64));
+            m_st = fmaxf(m_st, __shfl_down(m_st, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (m_hi > 0.f) atomicMax(&mx[2 * blockIdx.y], __float_as_uint(m_hi));
+            if (m_st > 0.f) atomicMax(&mx[2 * blockIdx.y + 1], __float_as_uint(m_st));
+        }
+    }
+}
+
+// plain F.interpolate(bilinear, align_corners=False): [C][h][w] -> [C][H][W]
+__global__ void bilinear_kernel(const float *__restrict__ src, int C, int h, int w, float *__restrict__ dst, int H,
+                                int W) {
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const long long total = (long long)C * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        const long long r = i / W;
+        const int yy = (int)(r % H);
+        const int c = (int)(r / H);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index(yy, sh, h, y0, y1, ly0, ly1);
+        src_index(xx, sw, w, x0, x1, lx0, lx1);
+        dst[i] = bilerp(src + (long long)c * h * w, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w,
+                        const int32_t *size_hw_host, const int32_t *keys_host, const int32_t *key_off_host,
+                        const int64_t *strided_off_host, const int64_t *highres_off_host, float *strided_dev,
+                        float *highres_dev) {
+    WSC_CHECK(ctx && cam_dev && size_hw_host && key_off_host && strided_off_host && highres_off_host,
+              WSC_ERR_INVALID, "wsc_cam_postprocess: null argument");
+    WSC_CHECK(B > 0 && C > 0 && h > 0 && w > 0, WSC_ERR_INVALID, "wsc_cam_postprocess: bad shape");
+    WSC_CHECK((size_t)h * w * sizeof(float) <= 64 * 1024, WSC_ERR_INVALID, "CAM %dx%d too large for the LDS tile", h, w);
+    WSC_HIP(hipSetDevice(ctx->device));
+    std::vector<TailJob> jobs;
+    int max_pix = 0;
+    for (int b = 0; b < B; ++b) {
+        const int H0 = size_hw_host[2 * b], W0 = size_hw_host[2 * b + 1];
+        WSC_CHECK(H0 > 0 && W0 > 0, WSC_ERR_INVALID, "image %d has size %dx%d", b, H0, W0);
+        // misc.imutils.get_strided_size(size, 4) / get_strided_up_size(size, 16)
+        const int h4 = (H0 - 1) / 4 + 1, w4 = (W0 - 1) / 4 + 1;
+        const int Hu = ((H0 - 1) / 16 + 1) * 16, Wu = ((W0 - 1) / 16 + 1) * 16;
+        const int K = key_off_host[b + 1] - key_off_host[b];
+        WSC_CHECK(K >= 0, WSC_ERR_INVALID, "key_off must be non-decreasing");
+        WSC_CHECK((long long)H0 * W0 + (long long)h4 * w4 < (1ll << 31), WSC_ERR_INVALID, "image %d too large", b);
+        for (int j = 0; j < K; ++j) {
+            const int key = keys_host[key_off_host[b] + j];
+            WSC_CHECK(key >= 0 && key < C, WSC_ERR_INVALID, "image %d: class key %d outside [0,%d)", b, key, C);
+            TailJob t;
+            t.cam_off = ((long long)b * C + key) * h * w;
+            t.strided_off = strided_off_host[b] + (long long)j * h4 * w4;
+            t.highres_off = highres_off_host[b] + (long long)j * H0 * W0;
+            t.H0 = H0; t.W0 = W0; t.h4 = h4; t.w4 = w4; t.Hu = Hu; t.Wu = Wu;
+            jobs.push_back(t);
+            max_pix = std::max(max_pix, H0 * W0 + h4 * w4);
+        }
+    }
+    if (jobs.empty()) return WSC_OK;
+    WSC_CHECK(strided_dev && highres_dev, WSC_ERR_INVALID, "wsc_cam_postprocess: null output");
+    WSC_CHECK(jobs.size() <= 65535, WSC_ERR_INVALID, "too many (image, class) jobs in one call: %zu", jobs.size());
+    // descriptor + maxima live in a small per-call device allocation released on the stream
+    const size_t jb = jobs.size() * sizeof(TailJob), mb = jobs.size() * 2 * sizeof(unsigned int);
+    char *d = nullptr;
+    WSC_HIP(hipMallocAsync((void **)&d, jb + mb, ctx->stream));
+    WSC_HIP(hipMemcpyAsync(d, jobs.data(), jb, hipMemcpyHostToDevice, ctx->stream));
+    WSC_HIP(hipMemsetAsync(d + jb, 0, mb, ctx->stream));
+    // jobs is pageable host memory: make sure the copy has consumed it before it goes away
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    const dim3 grid((max_pix + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, (unsigned)jobs.size());
+    const size_t lds = (size_t)h * w * sizeof(float);
+    hipLaunchKernelGGL(cam_tail_kernel<false>, grid, dim3(256), lds, ctx->stream, cam_dev, (const TailJob *)d, h, w,
+                       (unsigned int *)(d + jb), strided_dev, highres_dev);
+    hipLaunchKernelGGL(cam_tail_kernel<true>, grid, dim3(256), lds, ctx->stream, cam_dev, (const TailJob *)d, h, w,
+                       (unsigned int *)(d + jb), strided_dev, highres_dev);
+    WSC_HIP(hipGetLastError());
+    WSC_HIP(hipFreeAsync(d, ctx->stream));
+    return WSC_OK;
+}
+
+int wsc_bilinear_resize(wsc_ctx *ctx, const float *src_dev, int C, int h, int w, float *dst_dev, int H, int W) {
+    WSC_CHECK(ctx && src_dev && dst_dev, WSC_ERR_INVALID, "wsc_bilinear_resize: null argument");
+    WSC_CHECK(C > 0 && h > 0 && w > 0 && H > 0 && W > 0, WSC_ERR_INVALID, "wsc_bilinear_resize: bad shape");
+    WSC_HIP(hipSetDevice(ctx->device));
+    const long long total = (long long)C * H * W;
+    long long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, src_dev, C, h, w, dst_dev, H, W);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,102 @@
+// common.h -- shared declarations of libwsscam (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/wsscam.h"
+
+typedef uint16_t bf16_t; // raw bfloat16 bits
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// ---- bf16 helpers (host + device), round-to-nearest-even --------------------
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    uint32_t u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40); // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(bf16_t h) {
+    union { float f; uint32_t u; } v;
+    v.u = ((uint32_t)h) << 16;
+    return v.f;
+}
+
+// ---- error plumbing -----------------------------------------------------------
+void wsc_set_error(const char *fmt, ...);
+#define WSC_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            wsc_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,                   \
+                          hipGetErrorString(_e));                                              \
+            return WSC_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+#define WSC_CHECK(cond, code, ...)                                                             \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            wsc_set_error(__VA_ARGS__);                                                        \
+            return (code);                                                                     \
+        }                                                                                      \
+    } while (0)
+#define WSC_TRY(expr)                                                                          \
+    do {                                                                                       \
+        int _s = (expr);                                                                       \
+        if (_s != WSC_OK) return _s;                                                           \
+    } while (0)
+
+// ---- context --------------------------------------------------------------------
+struct wsc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 0;
+    std::string arch;
+    // grow-only workspace arena (activations, CRF scratch); never freed before destroy
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    // small pinned staging buffer for descriptor uploads
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+int wsc_ctx_workspace(wsc_ctx *ctx, size_t bytes, void **out);
+
+// ---- conv (implicit GEMM) -----------------------------------------------------------
+// One conv layer as the kernel sees it.  Activations are NHWC bf16; in split
+// precision every activation has a second ("lo") plane.
+struct ConvLaunch {
+    const bf16_t *x, *x_lo;     // input  [N][H][W][Cin]   (Cin = 4 in small-Cin mode)
+    const bf16_t *w;            // packed [CoutPad][Kw] bf16, K order (kh, kw, cin); split: [hi K | lo K]
+    const float *s1, *b1;       // y = acc*s1 + b1 (folded BN, or conv bias with s1 = 1)
+    const float *s2, *b2;       // optional post-ReLU affine (VGG's conv->ReLU->BN order), or null
+    const bf16_t *res, *res_lo; // optional residual [M][Cout]
+    bf16_t *y, *y_lo;           // output [M][Cout] bf16 (may be null when y_f32 is set)
+    float *y_f32;               // optional fp32 output [M][Cout]
+    int N, H, W, Cin, Ho, Wo, Cout, CoutPad;
+    int kh, kw, stride, pad;
+    int relu;
+    int small_cin; // 0: generic (Cin % 64 == 0); else log2(slots per kernel row): 2 = 7x7 stem, 1 = 3x3 Cin<=4
+    int split;     // 1: bf16x3
+};
+int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p);
+
+// ---- misc kernels ---------------------------------------------------------------------
+int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo);
+int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, int C, int k,
+                   int stride, int pad, int Ho, int Wo, bf16_t *y, bf16_t *y_lo);
+// cam[b][c][y][x] = relu(head[2b][y][x][c]) + relu(head[2b+1][y][w-1-x][c])   (head fp32 NHWC, stride Cs)
+int launch_flip_add(wsc_ctx *ctx, const float *head, int B, int h, int w, int C, int Cs, float *cam);
+// score[b][c] = sigmoid(sum_f mean_hw(feat[2b])[f] * Wc[c][f] + bias[c])
+int launch_gap_linear_sigmoid(wsc_ctx *ctx, const bf16_t *feat, const bf16_t *feat_lo, int B, int hw, int F,
+                              const float *Wc, const float *bias, int C, float *score);
+int launch_bf16_to_f32(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, size_t n, float *y);
+int launch_nchw_to_nhwc(wsc_ctx *ctx, const float *x, int N, int C, int HW, bf16_t *y, bf16_t *y_lo);
+int launch_nhwc_to_nchw(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int C, int HW, float *y);

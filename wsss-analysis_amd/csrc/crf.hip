@@ -1,0 +1,967 @@
+// crf.hip -- dense-CRF mean-field inference on permutohedral lattices (pydensecrf replacement).
+//
+// Reference call sites: 03c_hsn/utilities.py:427-444 (dcrf_process), the
+// misc.imutils.crf_inference_label calls of 03b_irn/step/cam_to_ir_label.py:35-67 and
+// lib.crf.crf_inference of 03a_sec-dsrg (SEC.py:275, DSRG.py:328, model.py:689-693).
+// Algorithm: Kraehenbuehl & Koltun's DenseCRF with Adams/Baek/Davis permutohedral
+// filtering, NORMALIZE_SYMMETRIC kernels, Potts compatibility (see oracle/densecrf_ref.c
+// for the CPU restatement this file is checked against).
+//
+// Data layout in HBM (whole batch of B images of H x W, N = H*W pixels each):
+//   lattice vertex rows of ALL images share one index space: row 0 is a permanent zero row
+//   (a missing blur neighbour points at it), image 0's vertices follow in first-touch
+//   raster order (the CPU reference's insertion order), then image 1's, ...
+//   offset[e], bary[e]   e = (b*N + n)*(d+1) + r : row id / barycentric weight of the r-th
+//                        enclosing simplex vertex of pixel n
+//   csr_start[row], csr_pix[], csr_w[] : per row, the pixels splatting into it (gather form
+//                        of the splat: no float atomics in the iteration loop)
+//   nbr[j][row] = (n1, n2) : blur neighbours along axis j
+//   norm[b*N+n]          : 1/sqrt(Lattice(1)+1e-20)
+//   val[row][M]          : lattice values, class-minor (M contiguous floats per row)
+//   Q[pixel][M], U[pixel][M] : pixel-major, class-minor
+// Every iteration kernel is a flat, fully coalesced pass over these arrays; all are
+// HBM-bound (SURVEY.md section 8d gives the algorithmic byte count).
+//
+// This file is compiled with -ffp-contract=off: the simplex search compares rounded
+// float expressions and must not be re-associated into FMAs, or pixels near a cell
+// boundary land in a different (equally valid) simplex than the CPU reference picks.
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+constexpr unsigned long long EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+
+struct LatticeDev {
+    int d = 0;
+    int rows = 0;               // total rows incl. the zero row (Vtot + 1)
+    int32_t *offset = nullptr;  // [B*N*(d+1)]
+    float *bary = nullptr;      // [B*N*(d+1)]
+    float *norm = nullptr;      // [B*N]
+    int32_t *csr_start = nullptr; // [rows + 1]
+    int32_t *csr_pix = nullptr;   // [B*N*(d+1)]  global pixel index
+    float *csr_w = nullptr;       // [B*N*(d+1)]
+    int2 *nbr = nullptr;          // [(d+1)][rows]
+    float alpha = 0.f;
+    std::vector<int32_t> v_per_image;
+};
+
+} // namespace
+
+struct wsc_crf {
+    wsc_ctx *ctx = nullptr;
+    int B = 0, H = 0, W = 0, N = 0;
+    LatticeDev lat[2]; // 0: Gaussian (d=2), 1: bilateral (d=5)
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
+// Pack the d hashed lattice coordinates into 64 bits.  d=2: 32 bits each; d=5: 12 bits each.
+template <int D>
+__device__ __forceinline__ bool pack_key(const int *key, unsigned long long &out) {
+    if (D == 2) {
+        out = ((unsigned long long)(unsigned)(key[0] + 0x40000000) << 32) | (unsigned)(key[1] + 0x40000000);
+        return true;
+    }
+    unsigned long long k = 0;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const int v = key[i] + 2048;
+        ok = ok && v >= 0 && v < 4096;
+        k = (k << 12) | (unsigned long long)(v & 4095);
+    }
+    out = k;
+    return ok;
+}
+template <int D>
+__device__ __forceinline__ void unpack_key(unsigned long long k, int *key) {
+    if (D == 2) {
+        key[0] = (int)(unsigned)(k >> 32) - 0x40000000;
+        key[1] = (int)(unsigned)(k & 0xffffffffu) - 0x40000000;
+        return;
+    }
+#pragma unroll
+    for (int i = D - 1; i >= 0; --i) {
+        key[i] = (int)(k & 4095) - 2048;
+        k >>= 12;
+    }
+}
+
+__device__ __forceinline__ int hash_insert(unsigned long long *table, unsigned mask, unsigned long long key) {
+    unsigned slot = (unsigned)mix64(key) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&table[slot], EMPTY_KEY, key);
+        if (prev == EMPTY_KEY || prev == key) return (int)slot;
+        slot = (slot + 1) & mask;
+    }
+}
+__device__ __forceinline__ int hash_lookup(const unsigned long long *table, unsigned mask, unsigned long long key) {
+    unsigned slot = (unsigned)mix64(key) & mask;
+    for (;;) {
+        const unsigned long long cur = table[slot];
+        if (cur == key) return (int)slot;
+        if (cur == EMPTY_KEY) return -1;
+        slot = (slot + 1) & mask;
+    }
+}
+
+struct EmbedArgs {
+    const uint8_t *rgb; // [B][N][3]
+    int B, H, W, N;
+    float inv_sxy_den, inv_srgb_den; // sxy, srgb (divisors, applied with '/')
+    float scale[5];
+    unsigned long long *table; // [B][cap]
+    unsigned cap_mask;
+    long long cap;
+    int32_t *eslot;  // [B*N*(d+1)] table slot of each entry
+    float *bary;     // [B*N*(d+1)]
+    int32_t *first;  // [B*cap] smallest entry index touching the slot
+    int *err;        // key range error flag
+};
+
+// Step 1 of the lattice build: elevate every pixel's feature vector, find its simplex and
+// barycentric weights (exactly as Permutohedral::init does), insert the d+1 vertex keys
+// into the image's hash table.
+template <int D>
+__global__ __launch_bounds__(256) void lattice_embed_kernel(EmbedArgs a) {
+    const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x; // global pixel
+    if (gp >= (long long)a.B * a.N) return;
+    const int b = (int)(gp / a.N);
+    const int n = (int)(gp - (long long)b * a.N);
+    const int y = n / a.W, x = n - y * a.W;
+
+    float f[D];
+    f[0] = (float)x / a.inv_sxy_den;
+    f[1] = (float)y / a.inv_sxy_den;
+    if (D == 5) {
+        const uint8_t *px = a.rgb + gp * 3;
+        f[2] = (float)(int)px[0] / a.inv_srgb_den;
+        f[3] = (float)(int)px[1] / a.inv_srgb_den;
+        f[4] = (float)(int)px[2] / a.inv_srgb_den;
+    }
+    float elevated[D + 1], rem0[D + 1];
+    int rank[D + 1];
+    float sm = 0.f;
+#pragma unroll
+    for (int j = D; j > 0; --j) {
+        const float cf = f[j - 1] * a.scale[j - 1];
+        elevated[j] = sm - (float)j * cf;
+        sm += cf;
+    }
+    elevated[0] = sm;
+
+    const float down_factor = 1.0f / (float)(D + 1);
+    const float up_factor = (float)(D + 1);
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i <= D; ++i) {
+        const float v = down_factor * elevated[i];
+        const float up = ceilf(v) * up_factor;
+        const float down = floorf(v) * up_factor;
+        int rd2;
+        if (up - elevated[i] < elevated[i] - down) rd2 = (int)(short)up;
+        else rd2 = (int)(short)down;
+        rem0[i] = (float)rd2;
+        sum = (int)((float)sum + (float)rd2 * down_factor); // int += float, truncating
+    }
+#pragma unroll
+    for (int i = 0; i <= D; ++i) rank[i] = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const float di = elevated[i] - rem0[i];
+#pragma unroll
+        for (int j = i + 1; j <= D; ++j) {
+            if (di < elevated[j] - rem0[j]) rank[i]++;
+            else rank[j]++;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i <= D; ++i) {
+        rank[i] += sum;
+        if (rank[i] < 0) {
+            rank[i] += D + 1;
+            rem0[i] += (float)(D + 1);
+        } else if (rank[i] > D) {
+            rank[i] -= D + 1;
+            rem0[i] -= (float)(D + 1);
+        }
+    }
+    float bary[D + 2];
+#pragma unroll
+    for (int i = 0; i <= D + 1; ++i) bary[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i <= D; ++i) {
+        const float v = (elevated[i] - rem0[i]) * down_factor;
+        // bary[D - rank[i]] += v; bary[D - rank[i] + 1] -= v;   (static indexing via selects)
+#pragma unroll
+        for (int s = 0; s <= D + 1; ++s) {
+            if (s == D - rank[i]) bary[s] += v;
+            if (s == D - rank[i] + 1) bary[s] -= v;
+        }
+    }
+    bary[0] = (float)((double)bary[0] + (1.0 + (double)bary[D + 1]));
+
+    unsigned long long *table = a.table + (long long)b * a.cap;
+    int32_t *first = a.first + (long long)b * a.cap;
+    const long long e0 = gp * (D + 1);
+#pragma unroll
+    for (int r = 0; r <= D; ++r) {
+        int key[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            // canonical[r][rank[i]] = rank[i] <= D - r ? r : r - (D+1)
+            const int can = rank[i] <= D - r ? r : r - (D + 1);
+            key[i] = (int)(short)(rem0[i] + (float)can);
+        }
+        unsigned long long pk;
+        if (!pack_key<D>(key, pk)) *a.err = 1;
+        const int slot = hash_insert(table, a.cap_mask, pk);
+        a.eslot[e0 + r] = slot;
+        a.bary[e0 + r] = bary[r];
+        atomicMin(&first[slot], n * (D + 1) + r);
+    }
+}
+
+// flag[e] = 1 if entry e is the first (raster order) toucher of its vertex
+__global__ void flag_first_kernel(const int32_t *__restrict__ eslot, const int32_t *__restrict__ first, long long cap,
+                                  int N, int dp1, long long total, unsigned *__restrict__ flag) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long per_img = (long long)N * dp1;
+        const int b = (int)(e / per_img);
+        const int local = (int)(e - b * per_img);
+        flag[e] = first[(long long)b * cap + eslot[e]] == local ? 1u : 0u;
+    }
+}
+
+// ---- flat exclusive scan (3 kernels), unsigned 32-bit -------------------------------
+constexpr int SCAN_CHUNK = 4096; // elements per block (256 threads x 16)
+
+__device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigned *lds, unsigned &total) {
+    // inclusive wave scan
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds[wv] = x;
+    __syncthreads();
+    unsigned base = 0;
+    for (int i = 0; i < wv; ++i) base += lds[i];
+    total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const unsigned *__restrict__ in, long long n,
+                                                          unsigned *__restrict__ sums) {
+    __shared__ unsigned lds[4];
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
+    unsigned s = 0;
+    for (int i = 0; i < 16; ++i) {
+        const long long idx = base + i * 256 + threadIdx.x;
+        if (idx < n) s += in[idx];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+// single block: exclusive scan of sums[0..m) in place; writes the grand total to sums[m]
+__global__ __launch_bounds__(256) void scan_sums_kernel(unsigned *__restrict__ sums, int m) {
+    __shared__ unsigned lds[4];
+    unsigned carry = 0;
+    for (int base = 0; base < m; base += 256) {
+        const int idx = base + threadIdx.x;
+        const unsigned v = idx < m ? sums[idx] : 0u;
+        unsigned total;
+        const unsigned ex = block_exclusive_scan_256(v, lds, total);
+        if (idx < m) sums[idx] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) sums[m] = carry;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const unsigned *__restrict__ in, long long n,
+                                                         const unsigned *__restrict__ sums, unsigned *__restrict__ out) {
+    __shared__ unsigned lds[4];
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
+    unsigned carry = sums[blockIdx.x];
+    // thread t owns 16 consecutive elements [t*16, t*16+16)
+    unsigned v[16];
+    unsigned s = 0;
+    const long long t0 = base + (long long)threadIdx.x * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        v[i] = (t0 + i < n) ? in[t0 + i] : 0u;
+        s += v[i];
+    }
+    unsigned total;
+    unsigned ex = carry + block_exclusive_scan_256(s, lds, total);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (t0 + i < n) out[t0 + i] = ex;
+        ex += v[i];
+    }
+}
+
+int exclusive_scan(wsc_ctx *ctx, const unsigned *in, long long n, unsigned *out, unsigned *sums /* nblk+1 */) {
+    const int nblk = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk), dim3(256), 0, ctx->stream, in, n, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, ctx->stream, sums, nblk);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(256), 0, ctx->stream, in, n, sums, out);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+// first-toucher entries publish the row id of their slot and the slot's key
+__global__ void assign_ids_kernel(const int32_t *__restrict__ eslot, const unsigned *__restrict__ flag,
+                                  const unsigned *__restrict__ prefix, const unsigned long long *__restrict__ table,
+                                  long long cap, int N, int dp1, long long total, int32_t *__restrict__ slot2row,
+                                  unsigned long long *__restrict__ rowkey, int32_t *__restrict__ rowimg) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        if (!flag[e]) continue;
+        const int b = (int)(e / ((long long)N * dp1));
+        const long long s = (long long)b * cap + eslot[e];
+        const int row = 1 + (int)prefix[e];
+        slot2row[s] = row;
+        rowkey[row] = table[s];
+        rowimg[row] = b;
+    }
+}
+
+// offset[e] = row of entry e; count entries per row
+__global__ void remap_count_kernel(const int32_t *__restrict__ eslot, const int32_t *__restrict__ slot2row,
+                                   long long cap, int N, int dp1, long long total, int32_t *__restrict__ offset,
+                                   unsigned *__restrict__ count) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(e / ((long long)N * dp1));
+        const int row = slot2row[(long long)b * cap + eslot[e]];
+        offset[e] = row;
+        atomicAdd(&count[row], 1u);
+    }
+}
+
+__global__ void csr_fill_kernel(const int32_t *__restrict__ offset, const float *__restrict__ bary, int dp1,
+                                long long total, const unsigned *__restrict__ start, unsigned *__restrict__ cursor,
+                                int32_t *__restrict__ csr_pix, float *__restrict__ csr_w) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int row = offset[e];
+        const unsigned pos = start[row] + atomicAdd(&cursor[row], 1u);
+        csr_pix[pos] = (int32_t)(e / dp1);
+        csr_w[pos] = bary[e];
+    }
+}
+
+// Within a row, order the gathered pixels ascending (the CPU reference's splat order): the
+// atomic cursor of csr_fill_kernel fills a row in arbitrary order, and a fixed order makes
+// the fp32 sums of the iteration loop bit-reproducible from run to run.
+// Short rows: one thread each, insertion sort.  Long rows are queued for the block sort.
+constexpr int SORT_SHORT = 32;
+constexpr int SORT_LDS_MAX = 8192; // rows longer than this keep their fill order
+
+__global__ void csr_sort_short_kernel(const unsigned *__restrict__ start, int rows, int32_t *__restrict__ csr_pix,
+                                      float *__restrict__ csr_w, unsigned *__restrict__ n_long,
+                                      int32_t *__restrict__ long_rows) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+        const unsigned s = start[row], e = start[row + 1];
+        const int len = (int)(e - s);
+        if (len > SORT_SHORT) {
+            if (len <= SORT_LDS_MAX) long_rows[atomicAdd(n_long, 1u)] = row;
+            continue;
+        }
+        int32_t *p = csr_pix + s;
+        float *w = csr_w + s;
+        for (int i = 1; i < len; ++i) {
+            const int32_t kp = p[i];
+            const float kw = w[i];
+            int j = i - 1;
+            while (j >= 0 && p[j] > kp) {
+                p[j + 1] = p[j];
+                w[j + 1] = w[j];
+                --j;
+            }
+            p[j + 1] = kp;
+            w[j + 1] = kw;
+        }
+    }
+}
+
+// one block per queued long row: bitonic sort of (pixel, weight) pairs in LDS
+__global__ __launch_bounds__(256) void csr_sort_long_kernel(const unsigned *__restrict__ start,
+                                                            const unsigned *__restrict__ n_long,
+                                                            const int32_t *__restrict__ long_rows,
+                                                            int32_t *__restrict__ csr_pix, float *__restrict__ csr_w) {
+    extern __shared__ __attribute__((aligned(16))) char sort_lds[];
+    int32_t *kp = reinterpret_cast<int32_t *>(sort_lds);
+    float *kw = reinterpret_cast<float *>(sort_lds + SORT_LDS_MAX * sizeof(int32_t));
+    const unsigned nl = *n_long;
+    for (unsigned li = blockIdx.x; li < nl; li += gridDim.x) {
+        const int row = long_rows[li];
+        const unsigned s = start[row];
+        const int len = (int)(start[row + 1] - s);
+        int n2 = 64;
+        while (n2 < len) n2 <<= 1;
+        for (int i = threadIdx.x; i < n2; i += 256) {
+            kp[i] = i < len ? csr_pix[s + i] : 0x7fffffff;
+            kw[i] = i < len ? csr_w[s + i] : 0.f;
+        }
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < n2; i += 256) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const bool up = (i & k) == 0;
+                        const int32_t a = kp[i], b = kp[ixj];
+                        if ((a > b) == up) {
+                            kp[i] = b; kp[ixj] = a;
+                            const float t = kw[i]; kw[i] = kw[ixj]; kw[ixj] = t;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = threadIdx.x; i < len; i += 256) {
+            csr_pix[s + i] = kp[i];
+            csr_w[s + i] = kw[i];
+        }
+        __syncthreads();
+    }
+}
+
+// blur neighbours of every row along every axis (Permutohedral::init, second half)
+template <int D>
+__global__ void neighbors_kernel(const unsigned long long *__restrict__ rowkey, const int32_t *__restrict__ rowimg,
+                                 const unsigned long long *__restrict__ table, const int32_t *__restrict__ slot2row,
+                                 long long cap, unsigned cap_mask, int rows, int2 *__restrict__ nbr) {
+    const long long total = (long long)rows * (D + 1);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i / rows);
+        const int row = (int)(i - (long long)j * rows);
+        if (row == 0) {
+            nbr[i] = make_int2(0, 0);
+            continue;
+        }
+        int key[D], k1[D], k2[D];
+        unpack_key<D>(rowkey[row], key);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            k1[k] = key[k] - 1;
+            k2[k] = key[k] + 1;
+        }
+        if (j < D) {
+            // static indexing
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (k == j) {
+                    k1[k] = key[k] + D;
+                    k2[k] = key[k] - D;
+                }
+        }
+        const int b = rowimg[row];
+        const unsigned long long *tb = table + (long long)b * cap;
+        const int32_t *s2r = slot2row + (long long)b * cap;
+        unsigned long long p1, p2;
+        int r1 = 0, r2 = 0;
+        if (pack_key<D>(k1, p1)) {
+            const int s = hash_lookup(tb, cap_mask, p1);
+            if (s >= 0) r1 = s2r[s];
+        }
+        if (pack_key<D>(k2, p2)) {
+            const int s = hash_lookup(tb, cap_mask, p2);
+            if (s >= 0) r2 = s2r[s];
+        }
+        nbr[i] = make_int2(r1, r2);
+    }
+}
+
+// ---- iteration kernels ------------------------------------------------------------------
+
+// Splat in gather form: val[row][m] = sum over the row's pixels of w * (norm[p] * Q[p][m]).
+// MP lanes cooperate on one row (lane m < M active); the pixel list is read once per group.
+// NORM_IN = false: splat of the all-ones vector (M = 1) for the normalisation pass.
+template <int MP, bool ONES>
+__global__ __launch_bounds__(256) void splat_kernel(const unsigned *__restrict__ start,
+                                                    const int32_t *__restrict__ csr_pix,
+                                                    const float *__restrict__ csr_w, const float *__restrict__ norm,
+                                                    const float *__restrict__ q, int M, int rows,
+                                                    float *__restrict__ val) {
+    constexpr int GPB = 256 / MP; // groups per block
+    const int m = threadIdx.x % MP;
+    const int g = threadIdx.x / MP;
+    for (long long row = (long long)blockIdx.x * GPB + g; row < rows; row += (long long)gridDim.x * GPB) {
+        if (row == 0) {
+            if (m < M) val[m] = 0.f;
+            continue;
+        }
+        const unsigned s = start[row], e = start[row + 1];
+        float acc = 0.f;
+        if (m < M) {
+            for (unsigned i = s; i < e; ++i) {
+                const int p = csr_pix[i];
+                const float w = csr_w[i];
+                const float in = ONES ? 1.f : q[(long long)p * M + m] * norm[p];
+                acc += w * in;
+            }
+            val[row * M + m] = acc;
+        }
+    }
+}
+
+// One blur pass along one lattice axis: out[row][m] = in[row][m] + 0.5*(in[n1][m] + in[n2][m]).
+// Flat over rows*M elements: perfectly coalesced reads of `in` and writes of `out`; the two
+// neighbour rows are gathered as M-float runs.
+__global__ __launch_bounds__(256) void blur_kernel(const float *__restrict__ in, const int2 *__restrict__ nbr, int M,
+                                                   long long total, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / M);
+        const int m = (int)(i - (long long)row * M);
+        if (row == 0) {
+            out[i] = 0.f;
+            continue;
+        }
+        const int2 nb = nbr[row];
+        out[i] = in[i] + 0.5f * (in[(long long)nb.x * M + m] + in[(long long)nb.y * M + m]);
+    }
+}
+
+// Slice of the ones-filter and norm = 1/sqrt(x + 1e-20)   (DenseKernel::initLattice)
+__global__ void slice_norm_kernel(const int32_t *__restrict__ offset, const float *__restrict__ bary, int dp1,
+                                  float alpha, const float *__restrict__ val, long long npix,
+                                  float *__restrict__ norm) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int r = 0; r < dp1; ++r) acc += bary[p * dp1 + r] * val[offset[p * dp1 + r]] * alpha;
+        norm[p] = (float)(1.0 / sqrt((double)acc + 1e-20));
+    }
+}
+
+struct UpdateArgs {
+    const int32_t *off_g, *off_b;
+    const float *bary_g, *bary_b;
+    const float *norm_g, *norm_b;
+    const float *val_g, *val_b;
+    const float *u; // [pixel][M]
+    float *q;       // [pixel][M]
+    float alpha_g, alpha_b, compat_g, compat_b;
+    int M;
+    long long npix;
+};
+
+// Slice both lattices, add the unary, softmax over classes (DenseCRF::inference loop body):
+//   E = -U - (-wG * normG * sliceG) - (-wB * normB * sliceB);  Q = expAndNormalize(E)
+// MP lanes per pixel; reductions by xor-shuffles inside the group.
+template <int MP>
+__global__ __launch_bounds__(256) void slice_update_kernel(UpdateArgs a) {
+    constexpr int GPB = 256 / MP;
+    const int m = threadIdx.x % MP;
+    const int g = threadIdx.x / MP;
+    const bool act = m < a.M;
+    for (long long p = (long long)blockIdx.x * GPB + g; p < a.npix; p += (long long)gridDim.x * GPB) {
+        float sg = 0.f, sb = 0.f;
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                sg += a.bary_g[p * 3 + r] * a.val_g[(long long)a.off_g[p * 3 + r] * a.M + m] * a.alpha_g;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                sb += a.bary_b[p * 6 + r] * a.val_b[(long long)a.off_b[p * 6 + r] * a.M + m] * a.alpha_b;
+        }
+        float e = -3.0e38f;
+        if (act) {
+            e = -a.u[p * a.M + m];
+            e -= -a.compat_g * (sg * a.norm_g[p]);
+            e -= -a.compat_b * (sb * a.norm_b[p]);
+        }
+        float mx = e;
+#pragma unroll
+        for (int o = MP / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float ex = act ? expf(e - mx) : 0.f;
+        float sum = ex;
+#pragma unroll
+        for (int o = MP / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (act) a.q[p * a.M + m] = ex / sum;
+    }
+}
+
+constexpr int TP = 128; // pixels per block of the layout-changing kernels
+
+// unary [B][M][N] (class-major) -> U [pixel][M] and Q = softmax(-U); TP pixels per block.
+__global__ __launch_bounds__(TP) void init_q_kernel(const float *__restrict__ unary, int M, int N,
+                                                     float *__restrict__ u, float *__restrict__ q) {
+    extern __shared__ float tile[]; // [M][TP+1] twice
+    float *tu = tile, *tq = tile + (size_t)M * (TP + 1);
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * TP;
+    const int np = min(TP, N - n0);
+    const float *src = unary + (long long)b * M * N;
+    for (int m = 0; m < M; ++m)
+        if ((int)threadIdx.x < np) tu[m * (TP + 1) + threadIdx.x] = src[(long long)m * N + n0 + threadIdx.x];
+    __syncthreads();
+    if ((int)threadIdx.x < np) {
+        float mx = -3.0e38f;
+        for (int m = 0; m < M; ++m) mx = fmaxf(mx, -tu[m * (TP + 1) + threadIdx.x]);
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const float e = expf(-tu[m * (TP + 1) + threadIdx.x] - mx);
+            tq[m * (TP + 1) + threadIdx.x] = e;
+            s += e;
+        }
+        for (int m = 0; m < M; ++m) tq[m * (TP + 1) + threadIdx.x] = tq[m * (TP + 1) + threadIdx.x] / s;
+    }
+    __syncthreads();
+    const long long obase = ((long long)b * N + n0) * M;
+    for (int i = threadIdx.x; i < np * M; i += TP) {
+        const int n = i / M, m = i - n * M;
+        u[obase + i] = tu[m * (TP + 1) + n];
+        q[obase + i] = tq[m * (TP + 1) + n];
+    }
+}
+
+// Q [pixel][M] -> q_out [B][M][N] and/or argmax [B][N]
+__global__ __launch_bounds__(TP) void finish_kernel(const float *__restrict__ q, int M, int N,
+                                                    float *__restrict__ q_out, int32_t *__restrict__ argmax) {
+    extern __shared__ float tile[]; // [M][TP+1]
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * TP;
+    const int np = min(TP, N - n0);
+    const long long ibase = ((long long)b * N + n0) * M;
+    for (int i = threadIdx.x; i < np * M; i += TP) {
+        const int n = i / M, m = i - n * M;
+        tile[m * (TP + 1) + n] = q[ibase + i];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < np) {
+        if (q_out)
+            for (int m = 0; m < M; ++m)
+                q_out[((long long)b * M + m) * N + n0 + threadIdx.x] = tile[m * (TP + 1) + threadIdx.x];
+        if (argmax) {
+            int best = 0;
+            float bv = tile[threadIdx.x];
+            for (int m = 1; m < M; ++m) {
+                const float v = tile[m * (TP + 1) + threadIdx.x];
+                if (v > bv) {
+                    bv = v;
+                    best = m;
+                }
+            }
+            argmax[(long long)b * N + n0 + threadIdx.x] = best;
+        }
+    }
+}
+
+__global__ void fill_u32_kernel(unsigned *p, unsigned v, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+__global__ void fill_u64_kernel(unsigned long long *p, unsigned long long v, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+inline int grid1d(long long total, int per_block = 256, int cap = 256 * 32) {
+    long long g = (total + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int crf_alloc(wsc_crf *crf, size_t bytes, void **out) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        wsc_set_error("CRF hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return WSC_ERR_NOMEM;
+    }
+    crf->allocs.push_back(p);
+    *out = p;
+    return WSC_OK;
+}
+
+struct TempBuf { // build-time scratch released at the end of wsc_crf_create
+    std::vector<void *> ptrs;
+    int alloc(size_t bytes, void **out) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) {
+            wsc_set_error("CRF scratch hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return WSC_ERR_NOMEM;
+        }
+        ptrs.push_back(p);
+        *out = p;
+        return WSC_OK;
+    }
+    ~TempBuf() {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+};
+
+template <int MP>
+void launch_splat(wsc_ctx *ctx, const LatticeDev &L, const float *q, int M, float *val, bool ones) {
+    const int gpb = 256 / MP;
+    const int grid = grid1d(L.rows, gpb, 256 * 64);
+    if (ones)
+        hipLaunchKernelGGL((splat_kernel<MP, true>), dim3(grid), dim3(256), 0, ctx->stream,
+                           (const unsigned *)L.csr_start, L.csr_pix, L.csr_w, L.norm, q, M, L.rows, val);
+    else
+        hipLaunchKernelGGL((splat_kernel<MP, false>), dim3(grid), dim3(256), 0, ctx->stream,
+                           (const unsigned *)L.csr_start, L.csr_pix, L.csr_w, L.norm, q, M, L.rows, val);
+}
+
+void splat_dispatch(wsc_ctx *ctx, const LatticeDev &L, const float *q, int M, float *val, bool ones) {
+    if (M <= 1) launch_splat<1>(ctx, L, q, M, val, ones);
+    else if (M <= 2) launch_splat<2>(ctx, L, q, M, val, ones);
+    else if (M <= 4) launch_splat<4>(ctx, L, q, M, val, ones);
+    else if (M <= 8) launch_splat<8>(ctx, L, q, M, val, ones);
+    else if (M <= 16) launch_splat<16>(ctx, L, q, M, val, ones);
+    else launch_splat<32>(ctx, L, q, M, val, ones);
+}
+
+// d+1 blur passes, ping-pong between a and b; returns the buffer holding the result
+float *blur_all(wsc_ctx *ctx, const LatticeDev &L, int M, float *a, float *b) {
+    const long long total = (long long)L.rows * M;
+    for (int j = 0; j <= L.d; ++j) {
+        hipLaunchKernelGGL(blur_kernel, dim3(grid1d(total, 256, 256 * 64)), dim3(256), 0, ctx->stream, a,
+                           L.nbr + (long long)j * L.rows, M, total, b);
+        float *t = a; a = b; b = t;
+    }
+    return a;
+}
+
+template <int D>
+int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy, float srgb) {
+    wsc_ctx *ctx = crf->ctx;
+    const int B = crf->B, N = crf->N, dp1 = D + 1;
+    const long long npix = (long long)B * N;
+    const long long total = npix * dp1;
+    WSC_CHECK(total < (1ll << 31), WSC_ERR_CAPACITY, "CRF batch too large: %lld lattice entries", total);
+    L.d = D;
+    L.alpha = 1.0f / (1.0f + powf(2.0f, -(float)D));
+    long long cap = 1;
+    while (cap < 2ll * N * dp1) cap <<= 1;
+    WSC_CHECK(B * cap < (1ll << 31), WSC_ERR_CAPACITY, "CRF batch too large for the hash tables");
+
+    TempBuf tmp;
+    unsigned long long *table;
+    int32_t *first, *eslot, *slot2row, *rowimg;
+    unsigned *flag, *prefix, *sums, *count, *cursor;
+    unsigned long long *rowkey;
+    int *err;
+    WSC_TRY(tmp.alloc(sizeof(unsigned long long) * B * cap, (void **)&table));
+    WSC_TRY(tmp.alloc(sizeof(int32_t) * B * cap, (void **)&first));
+    WSC_TRY(tmp.alloc(sizeof(int32_t) * B * cap, (void **)&slot2row));
+    WSC_TRY(tmp.alloc(sizeof(int32_t) * total, (void **)&eslot));
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * total, (void **)&flag));
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * (total + 1), (void **)&prefix));
+    const int nblk = (int)((total + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * (nblk + 2), (void **)&sums));
+    WSC_TRY(tmp.alloc(sizeof(int), (void **)&err));
+    WSC_TRY(crf_alloc(crf, sizeof(int32_t) * total, (void **)&L.offset));
+    WSC_TRY(crf_alloc(crf, sizeof(float) * total, (void **)&L.bary));
+    WSC_TRY(crf_alloc(crf, sizeof(float) * npix, (void **)&L.norm));
+    WSC_TRY(crf_alloc(crf, sizeof(int32_t) * total, (void **)&L.csr_pix));
+    WSC_TRY(crf_alloc(crf, sizeof(float) * total, (void **)&L.csr_w));
+
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(grid1d(B * cap)), dim3(256), 0, ctx->stream, table, EMPTY_KEY,
+                       (long long)B * cap);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(grid1d(B * cap)), dim3(256), 0, ctx->stream, (unsigned *)first,
+                       0x7fffffffu, (long long)B * cap);
+    WSC_HIP(hipMemsetAsync(err, 0, sizeof(int), ctx->stream));
+
+    EmbedArgs ea;
+    ea.rgb = rgb_dev; ea.B = B; ea.H = crf->H; ea.W = crf->W; ea.N = N;
+    ea.inv_sxy_den = sxy; ea.inv_srgb_den = srgb;
+    {   // Permutohedral::init: scale_factor[i] = 1/sqrt((i+2)(i+1)) * sqrt(2/3)*(d+1)
+        const float inv_std_dev = (float)(std::sqrt(2.0 / 3.0) * (D + 1));
+        for (int i = 0; i < 5; ++i)
+            ea.scale[i] = i < D ? (float)(1.0 / std::sqrt((double)((i + 2) * (i + 1))) * inv_std_dev) : 0.f;
+    }
+    ea.table = table; ea.cap_mask = (unsigned)(cap - 1); ea.cap = cap;
+    ea.eslot = eslot; ea.bary = L.bary; ea.first = first; ea.err = err;
+    hipLaunchKernelGGL(lattice_embed_kernel<D>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ea);
+    hipLaunchKernelGGL(flag_first_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, first, cap, N, dp1,
+                       total, flag);
+    WSC_TRY(exclusive_scan(ctx, flag, total, prefix, sums));
+    // vertex counts: grand total and per-image boundaries
+    int herr = 0;
+    unsigned vtot = 0;
+    WSC_HIP(hipMemcpyAsync(&vtot, sums + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    WSC_HIP(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned> bound(B, 0);
+    for (int b = 1; b < B; ++b)
+        WSC_HIP(hipMemcpyAsync(&bound[b], prefix + (long long)b * N * dp1, sizeof(unsigned), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    WSC_CHECK(herr == 0, WSC_ERR_KEY_RANGE,
+              "CRF lattice coordinate outside the packed-key range (sxy=%g srgb=%g too small for this image size)",
+              (double)sxy, (double)srgb);
+    L.rows = (int)vtot + 1;
+    L.v_per_image.resize(B);
+    for (int b = 0; b < B; ++b) L.v_per_image[b] = (int)((b + 1 < B ? bound[b + 1] : vtot) - bound[b]);
+
+    WSC_TRY(tmp.alloc(sizeof(unsigned long long) * L.rows, (void **)&rowkey));
+    WSC_TRY(tmp.alloc(sizeof(int32_t) * L.rows, (void **)&rowimg));
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&count));
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&cursor));
+    WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (L.rows + 2), (void **)&L.csr_start));
+    WSC_TRY(crf_alloc(crf, sizeof(int2) * (size_t)dp1 * L.rows, (void **)&L.nbr));
+    WSC_HIP(hipMemsetAsync(count, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
+    WSC_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
+
+    hipLaunchKernelGGL(assign_ids_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, flag, prefix, table,
+                       cap, N, dp1, total, slot2row, rowkey, rowimg);
+    hipLaunchKernelGGL(remap_count_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, slot2row, cap, N,
+                       dp1, total, L.offset, count);
+    {
+        unsigned *sums2;
+        const int nb2 = (L.rows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        WSC_TRY(tmp.alloc(sizeof(unsigned) * (nb2 + 2), (void **)&sums2));
+        WSC_TRY(exclusive_scan(ctx, count, L.rows + 1, (unsigned *)L.csr_start, sums2));
+    }
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1, total,
+                       (const unsigned *)L.csr_start, cursor, L.csr_pix, L.csr_w);
+    {
+        unsigned *n_long;
+        int32_t *long_rows;
+        WSC_TRY(tmp.alloc(sizeof(unsigned), (void **)&n_long));
+        WSC_TRY(tmp.alloc(sizeof(int32_t) * L.rows, (void **)&long_rows));
+        WSC_HIP(hipMemsetAsync(n_long, 0, sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(csr_sort_short_kernel, dim3(grid1d(L.rows, 64)), dim3(64), 0, ctx->stream,
+                           (const unsigned *)L.csr_start, L.rows, L.csr_pix, L.csr_w, n_long, long_rows);
+        hipLaunchKernelGGL(csr_sort_long_kernel, dim3(2048), dim3(256), SORT_LDS_MAX * 8, ctx->stream,
+                           (const unsigned *)L.csr_start, (const unsigned *)n_long, (const int32_t *)long_rows,
+                           L.csr_pix, L.csr_w);
+    }
+    hipLaunchKernelGGL(neighbors_kernel<D>, dim3(grid1d((long long)L.rows * dp1)), dim3(256), 0, ctx->stream, rowkey,
+                       rowimg, table, slot2row, cap, (unsigned)(cap - 1), L.rows, L.nbr);
+    WSC_HIP(hipGetLastError());
+
+    // norm = 1/sqrt(Lattice(1) + 1e-20)
+    float *va, *vb;
+    WSC_TRY(tmp.alloc(sizeof(float) * L.rows, (void **)&va));
+    WSC_TRY(tmp.alloc(sizeof(float) * L.rows, (void **)&vb));
+    splat_dispatch(ctx, L, nullptr, 1, va, true);
+    float *res = blur_all(ctx, L, 1, va, vb);
+    hipLaunchKernelGGL(slice_norm_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1,
+                       L.alpha, res, npix, L.norm);
+    WSC_HIP(hipGetLastError());
+    WSC_HIP(hipStreamSynchronize(ctx->stream)); // scratch is freed by ~TempBuf
+    return WSC_OK;
+}
+
+template <int MP>
+void launch_update(wsc_ctx *ctx, const UpdateArgs &a) {
+    const int gpb = 256 / MP;
+    hipLaunchKernelGGL(slice_update_kernel<MP>, dim3(grid1d(a.npix, gpb, 256 * 64)), dim3(256), 0, ctx->stream, a);
+}
+
+} // namespace
+
+extern "C" {
+
+int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, float g_sxy, float bi_sxy,
+                   float bi_srgb, wsc_crf **out) {
+    WSC_CHECK(ctx && rgb_dev && out, WSC_ERR_INVALID, "wsc_crf_create: null argument");
+    WSC_CHECK(B > 0 && H > 0 && W > 0, WSC_ERR_INVALID, "wsc_crf_create: B=%d H=%d W=%d", B, H, W);
+    WSC_CHECK(g_sxy > 0.f && bi_sxy > 0.f && bi_srgb > 0.f, WSC_ERR_INVALID,
+              "wsc_crf_create: kernel widths must be positive");
+    WSC_HIP(hipSetDevice(ctx->device));
+    wsc_crf *crf = new wsc_crf();
+    crf->ctx = ctx; crf->B = B; crf->H = H; crf->W = W; crf->N = H * W;
+    int st = build_lattice<2>(crf, crf->lat[0], rgb_dev, g_sxy, 1.f);
+    if (st == WSC_OK) st = build_lattice<5>(crf, crf->lat[1], rgb_dev, bi_sxy, bi_srgb);
+    if (st != WSC_OK) {
+        wsc_crf_destroy(crf);
+        return st;
+    }
+    *out = crf;
+    return WSC_OK;
+}
+
+void wsc_crf_destroy(wsc_crf *crf) {
+    if (!crf) return;
+    (void)hipStreamSynchronize(crf->ctx->stream);
+    for (void *p : crf->allocs) (void)hipFree(p);
+    delete crf;
+}
+
+int wsc_crf_lattice_sizes(wsc_ctx *ctx, const wsc_crf *crf, int32_t *v_gauss_host, int32_t *v_bilat_host) {
+    WSC_CHECK(ctx && crf, WSC_ERR_INVALID, "wsc_crf_lattice_sizes: null argument");
+    for (int b = 0; b < crf->B; ++b) {
+        if (v_gauss_host) v_gauss_host[b] = crf->lat[0].v_per_image[b];
+        if (v_bilat_host) v_bilat_host[b] = crf->lat[1].v_per_image[b];
+    }
+    return WSC_OK;
+}
+
+int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M, float g_compat, float bi_compat,
+                      int n_iters, float *q_dev, int32_t *argmax_dev) {
+    WSC_CHECK(ctx && crf && unary_dev, WSC_ERR_INVALID, "wsc_crf_inference: null argument");
+    WSC_CHECK(M >= 1 && M <= 32, WSC_ERR_INVALID, "wsc_crf_inference: M=%d outside [1,32]", M);
+    WSC_CHECK(n_iters >= 0, WSC_ERR_INVALID, "wsc_crf_inference: n_iters=%d", n_iters);
+    WSC_HIP(hipSetDevice(ctx->device));
+    const int B = crf->B, N = crf->N;
+    const long long npix = (long long)B * N;
+    const LatticeDev &G = crf->lat[0], &Bl = crf->lat[1];
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t qb = al(sizeof(float) * npix * M);
+    const size_t vg = al(sizeof(float) * (size_t)G.rows * M), vb = al(sizeof(float) * (size_t)Bl.rows * M);
+    void *ws;
+    WSC_TRY(wsc_ctx_workspace(ctx, 2 * qb + 2 * vg + 2 * vb, &ws));
+    char *p = (char *)ws;
+    float *u = (float *)p; p += qb;
+    float *q = (float *)p; p += qb;
+    float *vg0 = (float *)p; p += vg;
+    float *vg1 = (float *)p; p += vg;
+    float *vb0 = (float *)p; p += vb;
+    float *vb1 = (float *)p; p += vb;
+
+    const dim3 tgrid((N + TP - 1) / TP, B);
+    hipLaunchKernelGGL(init_q_kernel, tgrid, dim3(TP), 2 * (size_t)M * (TP + 1) * sizeof(float), ctx->stream,
+                       unary_dev, M, N, u, q);
+    for (int it = 0; it < n_iters; ++it) {
+        splat_dispatch(ctx, G, q, M, vg0, false);
+        float *rg = blur_all(ctx, G, M, vg0, vg1);
+        splat_dispatch(ctx, Bl, q, M, vb0, false);
+        float *rb = blur_all(ctx, Bl, M, vb0, vb1);
+        UpdateArgs a;
+        a.off_g = G.offset; a.off_b = Bl.offset; a.bary_g = G.bary; a.bary_b = Bl.bary;
+        a.norm_g = G.norm; a.norm_b = Bl.norm; a.val_g = rg; a.val_b = rb;
+        a.u = u; a.q = q;
+        a.alpha_g = G.alpha; a.alpha_b = Bl.alpha; a.compat_g = g_compat; a.compat_b = bi_compat;
+        a.M = M; a.npix = npix;
+        if (M <= 1) launch_update<1>(ctx, a);
+        else if (M <= 2) launch_update<2>(ctx, a);
+        else if (M <= 4) launch_update<4>(ctx, a);
+        else if (M <= 8) launch_update<8>(ctx, a);
+        else if (M <= 16) launch_update<16>(ctx, a);
+        else launch_update<32>(ctx, a);
+    }
+    if (q_dev || argmax_dev)
+        hipLaunchKernelGGL(finish_kernel, tgrid, dim3(TP), (size_t)M * (TP + 1) * sizeof(float), ctx->stream, q, M, N,
+                           q_dev, argmax_dev);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,243 @@
+// misc_kernels.hip -- the small HBM-bound kernels around the conv stack.
+#include "common.h"
+
+namespace {
+
+// float32 NCHW [N][3][H][W] -> bf16 NHWC4 [N][H][W][4] (4th channel zero), optional lo plane.
+// Replaces img.cuda() + the layout torch/cuDNN picks internally (make_cam.py:48).
+__global__ void nchw_to_nhwc4_kernel(const float *__restrict__ x, int N, int HW, bf16_t *__restrict__ y,
+                                     bf16_t *__restrict__ y_lo) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / HW;
+        const int p = (int)(i - n * HW);
+        const float *s = x + n * 3 * HW + p;
+        const float c0 = s[0], c1 = s[HW], c2 = s[2 * HW];
+        const bf16_t h0 = f32_to_bf16(c0), h1 = f32_to_bf16(c1), h2 = f32_to_bf16(c2);
+        reinterpret_cast<uint2 *>(y)[i] = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2);
+        if (y_lo != nullptr) {
+            const bf16_t l0 = f32_to_bf16(c0 - bf16_to_f32(h0)), l1 = f32_to_bf16(c1 - bf16_to_f32(h1)),
+                         l2 = f32_to_bf16(c2 - bf16_to_f32(h2));
+            reinterpret_cast<uint2 *>(y_lo)[i] = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2);
+        }
+    }
+}
+
+// nn.MaxPool2d(k, stride, pad) on NHWC bf16, 8 channels per thread.
+// resnet50.py:64 (3x3 s2 p1), common_cnn.py:131-132 (2x2 s2).
+__global__ void maxpool_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ x_lo, int N, int H,
+                               int W, int C, int k, int stride, int pad, int Ho, int Wo,
+                               bf16_t *__restrict__ y, bf16_t *__restrict__ y_lo) {
+    const int C8 = C >> 3;
+    const long long total = (long long)N * Ho * Wo * C8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        long long pix = i / C8;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        float best[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best[j] = -3.0e38f;
+        for (int dy = 0; dy < k; ++dy) {
+            const int hi = ho * stride - pad + dy;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int wi = wo * stride - pad + dx;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const long long o = (((long long)n * H + hi) * W + wi) * C + c8 * 8;
+                const uint4 v = *reinterpret_cast<const uint4 *>(x + o);
+                const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[2 * j] = bf16_to_f32((bf16_t)(vw[j] & 0xffffu));
+                    f[2 * j + 1] = bf16_to_f32((bf16_t)(vw[j] >> 16));
+                }
+                if (x_lo != nullptr) {
+                    const uint4 l = *reinterpret_cast<const uint4 *>(x_lo + o);
+                    const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f[2 * j] += bf16_to_f32((bf16_t)(lw[j] & 0xffffu));
+                        f[2 * j + 1] += bf16_to_f32((bf16_t)(lw[j] >> 16));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], f[j]);
+            }
+        }
+        uint32_t hw[4], lw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16_t h0 = f32_to_bf16(best[2 * j]), h1 = f32_to_bf16(best[2 * j + 1]);
+            hw[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            const bf16_t l0 = f32_to_bf16(best[2 * j] - bf16_to_f32(h0));
+            const bf16_t l1 = f32_to_bf16(best[2 * j + 1] - bf16_to_f32(h1));
+            lw[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        }
+        const long long oo = (((long long)n * Ho + ho) * Wo + wo) * C + c8 * 8;
+        *reinterpret_cast<uint4 *>(y + oo) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        if (y_lo != nullptr) *reinterpret_cast<uint4 *>(y_lo + oo) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+}
+
+// x = relu(head); cam = x[0] + x[1].flip(-1)   (resnet50_cam.py:66-68, vgg16_cam.py:49-50)
+// head: fp32 [2B][h][w][Cs] (NHWC, first C channels valid) -> cam fp32 [B][C][h][w]
+__global__ void flip_add_kernel(const float *__restrict__ head, int B, int h, int w, int C, int Cs,
+                                float *__restrict__ cam) {
+    const long long total = (long long)B * C * h * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % w);
+        long long r = i / w;
+        const int yy = (int)(r % h);
+        r /= h;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const float a = head[(((long long)(2 * b) * h + yy) * w + xx) * Cs + c];
+        const float f = head[(((long long)(2 * b + 1) * h + yy) * w + (w - 1 - xx)) * Cs + c];
+        cam[i] = fmaxf(a, 0.f) + fmaxf(f, 0.f);
+    }
+}
+
+// Classifier branch of vgg16_cam.py:34-36 on sample 0 of each image:
+// score[b][c] = sigmoid(bias[c] + sum_f Wc[c][f] * mean_hw feat[2b][.][f])
+// one block per image; feat NHWC bf16 (+ lo plane).  hw < 0 selects the global max of m7
+// (m7_cam.py:32-35: MaxPool 2x2 then AdaptiveMaxPool2d((1,1))).
+__global__ void gap_linear_sigmoid_kernel(const bf16_t *__restrict__ feat, const bf16_t *__restrict__ feat_lo,
+                                          int hw, int F, const float *__restrict__ Wc,
+                                          const float *__restrict__ bias, int C, float *__restrict__ score) {
+    extern __shared__ float gap[]; // F floats
+    const int b = blockIdx.x;
+    const long long img = (long long)(2 * b) * (hw < 0 ? -hw : hw) * F;
+    const bf16_t *f0 = feat + img;
+    const bf16_t *l0 = feat_lo ? feat_lo + img : nullptr;
+    const bool use_max = hw < 0; // m7: AdaptiveMaxPool2d((1,1)) instead of the average
+    const int npix = use_max ? -hw : hw;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        float s = use_max ? -3.0e38f : 0.f;
+        for (int p = 0; p < npix; ++p) {
+            float v = bf16_to_f32(f0[(long long)p * F + f]);
+            if (l0) v += bf16_to_f32(l0[(long long)p * F + f]);
+            s = use_max ? fmaxf(s, v) : s + v;
+        }
+        gap[f] = use_max ? s : s / (float)npix;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int c = wv; c < C; c += nw) {
+        float s = 0.f;
+        for (int f = lane; f < F; f += 64) s += gap[f] * Wc[(long long)c * F + f];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) score[(long long)b * C + c] = 1.f / (1.f + expf(-(s + (bias ? bias[c] : 0.f))));
+    }
+}
+
+__global__ void bf16_to_f32_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ x_lo, size_t n,
+                                   float *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = bf16_to_f32(x[i]);
+        if (x_lo) v += bf16_to_f32(x_lo[i]);
+        y[i] = v;
+    }
+}
+
+// generic layout changes for the single-layer entry point (wsc_conv2d_nchw)
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, int N, int C, int HW, bf16_t *__restrict__ y,
+                                    bf16_t *__restrict__ y_lo) {
+    const long long total = (long long)N * C * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long r = i / C;
+        const int p = (int)(r % HW);
+        const long long n = r / HW;
+        const float v = x[(n * C + c) * HW + p];
+        const bf16_t h = f32_to_bf16(v);
+        y[i] = h;
+        if (y_lo) y_lo[i] = f32_to_bf16(v - bf16_to_f32(h));
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ x_lo, int N, int C,
+                                    int HW, float *__restrict__ y) {
+    const long long total = (long long)N * C * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const long long r = i / HW;
+        const int c = (int)(r % C);
+        const long long n = r / C;
+        const long long src = (n * HW + p) * C + c;
+        float v = bf16_to_f32(x[src]);
+        if (x_lo) v += bf16_to_f32(x_lo[src]);
+        y[i] = v;
+    }
+}
+
+inline int grid_for(long long total, int block = 256, int cap = 256 * 16) {
+    long long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+} // namespace
+
+int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo) {
+    const long long total = (long long)N * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, N, H * W, y,
+                       y_lo);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, int C, int k,
+                   int stride, int pad, int Ho, int Wo, bf16_t *y, bf16_t *y_lo) {
+    WSC_CHECK(C % 8 == 0, WSC_ERR_INVALID, "maxpool: C=%d not a multiple of 8", C);
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, x_lo, N, H, W, C, k,
+                       stride, pad, Ho, Wo, y, y_lo);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+int launch_flip_add(wsc_ctx *ctx, const float *head, int B, int h, int w, int C, int Cs, float *cam) {
+    const long long total = (long long)B * C * h * w;
+    hipLaunchKernelGGL(flip_add_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, head, B, h, w, C, Cs,
+                       cam);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+int launch_gap_linear_sigmoid(wsc_ctx *ctx, const bf16_t *feat, const bf16_t *feat_lo, int B, int hw, int F,
+                              const float *Wc, const float *bias, int C, float *score) {
+    hipLaunchKernelGGL(gap_linear_sigmoid_kernel, dim3(B), dim3(256), F * sizeof(float), ctx->stream, feat,
+                       feat_lo, hw, F, Wc, bias, C, score);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+int launch_bf16_to_f32(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, size_t n, float *y) {
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for((long long)n)), dim3(256), 0, ctx->stream, x, x_lo, n,
+                       y);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+int launch_nchw_to_nhwc(wsc_ctx *ctx, const float *x, int N, int C, int HW, bf16_t *y, bf16_t *y_lo) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)N * C * HW)), dim3(256), 0, ctx->stream, x, N, C,
+                       HW, y, y_lo);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+int launch_nhwc_to_nchw(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int C, int HW, float *y) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)N * C * HW)), dim3(256), 0, ctx->stream, x, x_lo,
+                       N, C, HW, y);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}

@@ -1,0 +1,601 @@
+// net.hip -- host side of the CAM networks: state_dict -> packed device weights, and the
+// per-batch launch sequence.
+//
+// Reference being replaced:
+//   resnet50_cam : 03b_irn/net/resnet50.py:17-108 assembled by resnet50_cam.py:12-20 with
+//                  strides=(2,2,2,1); CAM.forward resnet50_cam.py:55-70
+//   vgg16_cam    : net/vgg16.py:44 cfg + common_cnn.py:128-141 make_layers
+//                  (conv(bias) -> ReLU -> BatchNorm(eps=1e-3)); vgg16_cam.py:24-50
+//   m7_cam       : net/m7.py:41 cfg; m7_cam.py:22-47 (Grad-CAM weights as the 1x1 head)
+//   construction/load: 03b_irn/step/make_cam.py:96-100
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+
+namespace {
+
+struct HostTensor {
+    const float *data;
+    int ndim;
+    int64_t shape[4];
+    int64_t numel() const {
+        int64_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= shape[i];
+        return n;
+    }
+};
+typedef std::unordered_map<std::string, HostTensor> Dict;
+
+struct ConvW {
+    bf16_t *w = nullptr;
+    float *s1 = nullptr, *b1 = nullptr, *s2 = nullptr, *b2 = nullptr;
+    int Cin = 0, Cout = 0, CoutPad = 0, kh = 1, kw = 1, stride = 1, pad = 0, relu = 0, small_cin = 0;
+};
+
+enum OpType { OP_CONV = 0, OP_POOL = 1 };
+struct Op {
+    int type;
+    int conv;         // index into convs (OP_CONV)
+    int in, out, res; // activation buffer ids; res = -1 if none; in = -1 means the NHWC4 input
+    int pk, ps, pp;   // pool kernel / stride / pad
+};
+
+} // namespace
+
+struct wsc_net {
+    wsc_ctx *ctx = nullptr;
+    int arch = 0, C = 0, split = 0, F = 0;
+    std::vector<ConvW> convs;
+    std::vector<Op> ops;
+    int final_buf = 0;
+    ConvW head;
+    float *cls_w = nullptr, *cls_b = nullptr; // classifier branch (vgg16 / m7), fp32 [Ccls][F]
+    int Ccls = 0;
+    int cls_max = 0; // 1: global max pooling (m7), 0: global average (vgg16)
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+int upload(wsc_net *net, const void *host, size_t bytes, void **out) {
+    void *d = nullptr;
+    WSC_HIP(hipMalloc(&d, bytes));
+    net->allocs.push_back(d);
+    WSC_HIP(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+    *out = d;
+    return WSC_OK;
+}
+
+int get(const Dict &d, const std::string &k, int ndim, const HostTensor **out) {
+    auto it = d.find(k);
+    WSC_CHECK(it != d.end(), WSC_ERR_MISSING_KEY, "state_dict: missing key '%s'", k.c_str());
+    WSC_CHECK(it->second.ndim == ndim, WSC_ERR_SHAPE, "state_dict: '%s' has ndim %d, expected %d", k.c_str(),
+              it->second.ndim, ndim);
+    WSC_CHECK(it->second.data != nullptr, WSC_ERR_INVALID, "state_dict: '%s' has a null data pointer", k.c_str());
+    *out = &it->second;
+    return WSC_OK;
+}
+bool has(const Dict &d, const std::string &k) { return d.find(k) != d.end(); }
+
+// Fold inference batch-norm y = (x - mean) / sqrt(var + eps) * gamma + beta into scale/shift.
+int fold_bn(const Dict &d, const std::string &bn, int C, double eps_default, std::vector<float> &s,
+            std::vector<float> &b) {
+    const HostTensor *g, *be, *mu, *var;
+    WSC_TRY(get(d, bn + ".weight", 1, &g));
+    WSC_TRY(get(d, bn + ".bias", 1, &be));
+    WSC_TRY(get(d, bn + ".running_mean", 1, &mu));
+    WSC_TRY(get(d, bn + ".running_var", 1, &var));
+    WSC_CHECK(g->shape[0] == C && be->shape[0] == C && mu->shape[0] == C && var->shape[0] == C, WSC_ERR_SHAPE,
+              "state_dict: batch-norm '%s' is not %d channels", bn.c_str(), C);
+    double eps = eps_default;
+    auto it = d.find(bn + ".eps");
+    if (it != d.end() && it->second.data) eps = it->second.data[0];
+    s.resize(C);
+    b.resize(C);
+    for (int c = 0; c < C; ++c) {
+        const double sc = (double)g->data[c] / std::sqrt((double)var->data[c] + eps);
+        s[c] = (float)sc;
+        b[c] = (float)((double)be->data[c] - (double)mu->data[c] * sc);
+    }
+    return WSC_OK;
+}
+
+// Pack OIHW fp32 weights to [CoutPad][Kw] bf16 in the kernel's K order.
+int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, int small_cin,
+              const std::vector<float> &s1, const std::vector<float> &b1, const std::vector<float> *s2,
+              const std::vector<float> *b2, ConvW *out) {
+    const int Cout = (int)w->shape[0], Cin = (int)w->shape[1], kh = (int)w->shape[2], kw = (int)w->shape[3];
+    ConvW c;
+    c.Cout = Cout;
+    c.CoutPad = Cout <= 64 ? 64 : ((Cout + 127) / 128) * 128;
+    c.kh = kh; c.kw = kw; c.stride = stride; c.pad = pad; c.relu = relu; c.small_cin = small_cin;
+    int Kbase;
+    if (small_cin == 0) {
+        WSC_CHECK(Cin % 64 == 0, WSC_ERR_SHAPE, "conv with Cin=%d is not supported (need a multiple of 64)", Cin);
+        c.Cin = Cin;
+        Kbase = kh * kw * Cin;
+    } else {
+        WSC_CHECK(Cin <= 4, WSC_ERR_SHAPE, "small-Cin conv needs Cin <= 4, got %d", Cin);
+        WSC_CHECK(kw <= (2 << small_cin), WSC_ERR_SHAPE, "small-Cin conv: kw=%d too wide", kw);
+        c.Cin = 4;
+        Kbase = (((kh << small_cin) + 7) / 8) * 64;
+    }
+    const int planes = net->split ? 2 : 1;
+    const int Kw = Kbase * planes;
+    std::vector<bf16_t> wp((size_t)c.CoutPad * Kw, 0);
+    for (int co = 0; co < Cout; ++co) {
+        bf16_t *row = wp.data() + (size_t)co * Kw;
+        auto put = [&](int k, float v) {
+            const bf16_t h = f32_to_bf16(v);
+            row[k] = h;
+            if (net->split) row[Kbase + k] = f32_to_bf16(v - bf16_to_f32(h));
+        };
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int r = 0; r < kh; ++r)
+                for (int s = 0; s < kw; ++s) {
+                    const float v = w->data[(((size_t)co * Cin + ci) * kh + r) * kw + s];
+                    if (small_cin == 0) {
+                        put((r * kw + s) * Cin + ci, v);
+                    } else {
+                        // kernel row r owns 2^small_cin slots of 8 = (2 pixels x 4 channels)
+                        put((r << small_cin) * 8 + s * 4 + ci, v);
+                    }
+                }
+    }
+    WSC_TRY(upload(net, wp.data(), wp.size() * sizeof(bf16_t), (void **)&c.w));
+    auto up_vec = [&](const std::vector<float> &v, float **dst) -> int {
+        std::vector<float> p(c.CoutPad, 0.f);
+        for (int i = 0; i < Cout; ++i) p[i] = v[i];
+        return upload(net, p.data(), p.size() * sizeof(float), (void **)dst);
+    };
+    WSC_TRY(up_vec(s1, &c.s1));
+    WSC_TRY(up_vec(b1, &c.b1));
+    if (s2) {
+        WSC_TRY(up_vec(*s2, &c.s2));
+        WSC_TRY(up_vec(*b2, &c.b2));
+    }
+    *out = c;
+    return WSC_OK;
+}
+
+int add_conv_op(wsc_net *net, const ConvW &c, int in, int out, int res) {
+    net->convs.push_back(c);
+    Op op;
+    op.type = OP_CONV; op.conv = (int)net->convs.size() - 1; op.in = in; op.out = out; op.res = res;
+    op.pk = op.ps = op.pp = 0;
+    net->ops.push_back(op);
+    return WSC_OK;
+}
+void add_pool_op(wsc_net *net, int k, int s, int p, int in, int out) {
+    Op op;
+    op.type = OP_POOL; op.conv = -1; op.in = in; op.out = out; op.res = -1; op.pk = k; op.ps = s; op.pp = p;
+    net->ops.push_back(op);
+}
+
+// ResNet conv (bias-free) + FixedBatchNorm.
+int resnet_conv(wsc_net *net, const Dict &d, const std::string &conv, const std::string &bn, int stride, int pad,
+                int relu, int small_cin, int in, int out, int res) {
+    const HostTensor *w;
+    WSC_TRY(get(d, conv + ".weight", 4, &w));
+    std::vector<float> s, b;
+    WSC_TRY(fold_bn(d, bn, (int)w->shape[0], 1e-5, s, b));
+    ConvW c;
+    WSC_TRY(make_conv(net, w, stride, pad, relu, small_cin, s, b, nullptr, nullptr, &c));
+    return add_conv_op(net, c, in, out, res);
+}
+
+int build_resnet50(wsc_net *net, const Dict &d) {
+    // stem: conv1 7x7 s2 p3 + bn1 + relu, maxpool 3x3 s2 p1          (resnet50.py:62-64, 96-99)
+    WSC_TRY(resnet_conv(net, d, "resnet50.conv1", "resnet50.bn1", 2, 3, 1, /*small_cin*/ 2, -1, 0, -1));
+    add_pool_op(net, 3, 2, 1, 0, 1);
+    int cur = 1;
+    const int planes[4] = {64, 128, 256, 512};
+    const int blocks[4] = {3, 4, 6, 3};
+    const int strides[4] = {1, 2, 2, 1}; // resnet50_cam.py:15 strides=(2,2,2,1): [0] is the stem
+    for (int L = 0; L < 4; ++L) {
+        (void)planes;
+        for (int bi = 0; bi < blocks[L]; ++bi) {
+            const std::string pre = "resnet50.layer" + std::to_string(L + 1) + "." + std::to_string(bi);
+            const int s = bi == 0 ? strides[L] : 1;
+            int f[3], nf = 0;
+            for (int i = 0; i < 4 && nf < 3; ++i)
+                if (i != cur) f[nf++] = i;
+            // Bottleneck.forward, resnet50.py:34-54; the stride sits on conv2 (resnet50.py:24)
+            WSC_TRY(resnet_conv(net, d, pre + ".conv1", pre + ".bn1", 1, 0, 1, 0, cur, f[0], -1));
+            WSC_TRY(resnet_conv(net, d, pre + ".conv2", pre + ".bn2", s, 1, 1, 0, f[0], f[1], -1));
+            int res = cur;
+            if (has(d, pre + ".downsample.0.weight")) {
+                WSC_TRY(resnet_conv(net, d, pre + ".downsample.0", pre + ".downsample.1", s, 0, 0, 0, cur, f[2], -1));
+                res = f[2];
+            }
+            WSC_TRY(resnet_conv(net, d, pre + ".conv3", pre + ".bn3", 1, 0, 1, 0, f[1], f[0], res));
+            cur = f[0];
+        }
+    }
+    net->final_buf = cur;
+    // CAM head: F.conv2d(x, classifier.weight), resnet50_cam.py:65 (ReLU + flip-add are a separate kernel)
+    const HostTensor *cw;
+    WSC_TRY(get(d, "classifier.weight", 4, &cw));
+    WSC_CHECK(cw->shape[0] == net->C && cw->shape[2] == 1 && cw->shape[3] == 1, WSC_ERR_SHAPE,
+              "classifier.weight must be [%d][F][1][1]", net->C);
+    net->F = (int)cw->shape[1];
+    std::vector<float> one(net->C, 1.f), zero(net->C, 0.f);
+    WSC_TRY(make_conv(net, cw, 1, 0, 0, 0, one, zero, nullptr, nullptr, &net->head));
+    return WSC_OK;
+}
+
+// VGG-style stacks of common_cnn.make_layers: cfg entries >0 = conv out channels, -1 = 'M', -2 = 'D'.
+int build_plain_stack(wsc_net *net, const Dict &d, const std::string &root,
+                      const std::vector<std::pair<std::string, std::vector<int>>> &cfg, int *cur_io,
+                      int *feat_channels) {
+    int cur = *cur_io;
+    int in_ch = 3;
+    bool first = true;
+    for (const auto &layer : cfg) {
+        int idx = 0;
+        for (int v : layer.second) {
+            if (v == -1) { // nn.MaxPool2d(2, 2), common_cnn.py:131-132
+                const int out = (cur + 1) & 1;
+                add_pool_op(net, 2, 2, 0, cur, out);
+                cur = out;
+                idx += 1;
+            } else if (v == -2) { // nn.Dropout: identity in eval()
+                idx += 1;
+            } else {
+                const std::string key = root + "." + layer.first + "." + std::to_string(idx);
+                const HostTensor *w, *bias;
+                WSC_TRY(get(d, key + ".weight", 4, &w));
+                WSC_TRY(get(d, key + ".bias", 1, &bias));
+                WSC_CHECK(w->shape[0] == v && w->shape[1] == in_ch && w->shape[2] == 3 && w->shape[3] == 3,
+                          WSC_ERR_SHAPE, "'%s.weight' must be [%d][%d][3][3]", key.c_str(), v, in_ch);
+                std::vector<float> one(v, 1.f), bb(bias->data, bias->data + v);
+                const std::string bn = root + "." + layer.first + "." + std::to_string(idx + 2);
+                ConvW c;
+                if (has(d, bn + ".running_mean")) { // conv -> ReLU -> BatchNorm(eps=1e-3): common_cnn.py:138
+                    std::vector<float> s2, b2;
+                    WSC_TRY(fold_bn(d, bn, v, 1e-3, s2, b2));
+                    WSC_TRY(make_conv(net, w, 1, 1, 1, first ? 1 : 0, one, bb, &s2, &b2, &c));
+                    idx += 3;
+                } else {
+                    WSC_TRY(make_conv(net, w, 1, 1, 1, first ? 1 : 0, one, bb, nullptr, nullptr, &c));
+                    idx += 2;
+                }
+                const int in = first ? -1 : cur;
+                const int out = first ? 0 : ((cur + 1) & 1);
+                WSC_TRY(add_conv_op(net, c, in, out, -1));
+                cur = out;
+                in_ch = v;
+                first = false;
+            }
+        }
+    }
+    *cur_io = cur;
+    *feat_channels = in_ch;
+    return WSC_OK;
+}
+
+int build_vgg16(wsc_net *net, const Dict &d) {
+    const std::vector<std::pair<std::string, std::vector<int>>> cfg = {
+        {"layer1", {64, 64, -1}},
+        {"layer2", {128, 128, -1}},
+        {"layer3", {256, 256, 256, -1}},
+        {"layer4", {512, 512, 512, 512, 512, 512}},
+        {"layer5", {1024, -2, 1024, -2}}}; // vgg16.py:44
+    int cur = 0;
+    WSC_TRY(build_plain_stack(net, d, "vgg16", cfg, &cur, &net->F));
+    net->final_buf = cur;
+    const HostTensor *lw;
+    WSC_TRY(get(d, "vgg16.classifier.0.weight", 2, &lw));
+    WSC_CHECK(lw->shape[0] >= net->C && lw->shape[1] == net->F, WSC_ERR_SHAPE,
+              "vgg16.classifier.0.weight must be [>=%d][%d]", net->C, net->F);
+    // CAM head = the Linear weight as a 1x1 kernel: vgg16_cam.py:48
+    HostTensor hw = *lw;
+    hw.ndim = 4; hw.shape[0] = net->C; hw.shape[2] = 1; hw.shape[3] = 1;
+    std::vector<float> one(net->C, 1.f), zero(net->C, 0.f);
+    WSC_TRY(make_conv(net, &hw, 1, 0, 0, 0, one, zero, nullptr, nullptr, &net->head));
+    net->Ccls = net->C;
+    net->cls_max = 0;
+    WSC_TRY(upload(net, lw->data, (size_t)net->C * net->F * sizeof(float), (void **)&net->cls_w));
+    if (has(d, "vgg16.classifier.0.bias")) {
+        const HostTensor *lb;
+        WSC_TRY(get(d, "vgg16.classifier.0.bias", 1, &lb));
+        WSC_TRY(upload(net, lb->data, (size_t)net->C * sizeof(float), (void **)&net->cls_b));
+    }
+    return WSC_OK;
+}
+
+int build_m7(wsc_net *net, const Dict &d) {
+    const std::vector<std::pair<std::string, std::vector<int>>> cfg = {
+        {"layer1", {64, 64, -1}}, {"layer2", {128, 128, -1}}, {"layer3_p1", {256, 256, 256}}}; // m7.py:41
+    int cur = 0;
+    WSC_TRY(build_plain_stack(net, d, "m7", cfg, &cur, &net->F));
+    net->final_buf = cur;
+    // Grad-CAM weights (F x C) transposed as the 1x1 head: m7_cam.py:45-46
+    const HostTensor *gw;
+    WSC_TRY(get(d, "gradcam_weights", 2, &gw));
+    WSC_CHECK(gw->shape[0] == net->F && gw->shape[1] == net->C, WSC_ERR_SHAPE, "gradcam_weights must be [%d][%d]",
+              net->F, net->C);
+    std::vector<float> wt((size_t)net->C * net->F);
+    for (int f = 0; f < net->F; ++f)
+        for (int c = 0; c < net->C; ++c) wt[(size_t)c * net->F + f] = gw->data[(size_t)f * net->C + c];
+    HostTensor hw;
+    hw.data = wt.data(); hw.ndim = 4; hw.shape[0] = net->C; hw.shape[1] = net->F; hw.shape[2] = 1; hw.shape[3] = 1;
+    std::vector<float> one(net->C, 1.f), zero(net->C, 0.f);
+    WSC_TRY(make_conv(net, &hw, 1, 0, 0, 0, one, zero, nullptr, nullptr, &net->head));
+    // classifier branch: layer3_p2 (MaxPool 2x2 + Dropout) -> AdaptiveMaxPool2d(1) -> Linear + Sigmoid
+    // (m7_cam.py:32-35).  max over 2x2-pooled map == global max when h, w are even.
+    const HostTensor *lw;
+    WSC_TRY(get(d, "m7.classifier.0.weight", 2, &lw));
+    WSC_CHECK(lw->shape[0] >= net->C && lw->shape[1] == net->F, WSC_ERR_SHAPE,
+              "m7.classifier.0.weight must be [>=%d][%d]", net->C, net->F);
+    net->Ccls = net->C;
+    net->cls_max = 1;
+    WSC_TRY(upload(net, lw->data, (size_t)net->C * net->F * sizeof(float), (void **)&net->cls_w));
+    if (has(d, "m7.classifier.0.bias")) {
+        const HostTensor *lb;
+        WSC_TRY(get(d, "m7.classifier.0.bias", 1, &lb));
+        WSC_TRY(upload(net, lb->data, (size_t)net->C * sizeof(float), (void **)&net->cls_b));
+    }
+    return WSC_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Plan {
+    std::vector<int> H, W, C; // per op output dims
+    size_t max_act = 0;       // elements
+    int hf = 0, wf = 0;       // final feature map size
+};
+
+int plan_dims(const wsc_net *net, int N, int S, Plan *pl) {
+    int bh[4] = {0, 0, 0, 0}, bw[4] = {0, 0, 0, 0}, bc[4] = {0, 0, 0, 0};
+    pl->max_act = 0;
+    for (const Op &op : net->ops) {
+        int H = op.in < 0 ? S : bh[op.in], W = op.in < 0 ? S : bw[op.in], C = op.in < 0 ? 4 : bc[op.in];
+        int Ho, Wo, Co;
+        if (op.type == OP_CONV) {
+            const ConvW &c = net->convs[op.conv];
+            Ho = (H + 2 * c.pad - c.kh) / c.stride + 1;
+            Wo = (W + 2 * c.pad - c.kw) / c.stride + 1;
+            Co = c.Cout;
+            WSC_CHECK(C == c.Cin, WSC_ERR_INVALID, "internal: channel mismatch %d vs %d", C, c.Cin);
+        } else {
+            Ho = (H + 2 * op.pp - op.pk) / op.ps + 1;
+            Wo = (W + 2 * op.pp - op.pk) / op.ps + 1;
+            Co = C;
+        }
+        WSC_CHECK(Ho > 0 && Wo > 0, WSC_ERR_INVALID, "input size %d too small for this network", S);
+        bh[op.out] = Ho; bw[op.out] = Wo; bc[op.out] = Co;
+        pl->H.push_back(Ho); pl->W.push_back(Wo); pl->C.push_back(Co);
+        const size_t e = (size_t)N * Ho * Wo * Co;
+        if (e > pl->max_act) pl->max_act = e;
+    }
+    pl->hf = bh[net->final_buf];
+    pl->wf = bw[net->final_buf];
+    return WSC_OK;
+}
+
+// Runs the conv stack on N samples; returns pointers to the final feature map planes.
+int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, int S, size_t extra_bytes,
+                 const bf16_t **feat, const bf16_t **feat_lo, int *hf, int *wf, void **extra) {
+    Plan pl;
+    WSC_TRY(plan_dims(net, N, S, &pl));
+    const int planes = net->split ? 2 : 1;
+    const size_t in_bytes = align_up((size_t)N * S * S * 4 * sizeof(bf16_t), 256);
+    const size_t act_bytes = align_up(pl.max_act * sizeof(bf16_t), 256);
+    const size_t total = in_bytes * planes + act_bytes * 4 * planes + align_up(extra_bytes, 256);
+    void *ws;
+    WSC_TRY(wsc_ctx_workspace(ctx, total, &ws));
+    char *p = (char *)ws;
+    bf16_t *xin = (bf16_t *)p; p += in_bytes;
+    bf16_t *xin_lo = nullptr;
+    if (net->split) { xin_lo = (bf16_t *)p; p += in_bytes; }
+    bf16_t *buf[4], *buf_lo[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i) {
+        buf[i] = (bf16_t *)p; p += act_bytes;
+        if (net->split) { buf_lo[i] = (bf16_t *)p; p += act_bytes; }
+    }
+    *extra = (void *)p;
+
+    WSC_TRY(launch_nchw_to_nhwc4(ctx, x_dev, N, S, S, xin, xin_lo));
+    int bh[4] = {0, 0, 0, 0}, bw[4] = {0, 0, 0, 0}, bc[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < net->ops.size(); ++i) {
+        const Op &op = net->ops[i];
+        const int H = op.in < 0 ? S : bh[op.in], W = op.in < 0 ? S : bw[op.in], C = op.in < 0 ? 4 : bc[op.in];
+        const bf16_t *src = op.in < 0 ? xin : buf[op.in];
+        const bf16_t *src_lo = op.in < 0 ? xin_lo : buf_lo[op.in];
+        if (op.type == OP_CONV) {
+            const ConvW &c = net->convs[op.conv];
+            ConvLaunch L;
+            memset(&L, 0, sizeof(L));
+            L.x = src; L.x_lo = src_lo; L.w = c.w;
+            L.s1 = c.s1; L.b1 = c.b1; L.s2 = c.s2; L.b2 = c.b2;
+            L.res = op.res >= 0 ? buf[op.res] : nullptr;
+            L.res_lo = op.res >= 0 ? buf_lo[op.res] : nullptr;
+            L.y = buf[op.out]; L.y_lo = buf_lo[op.out]; L.y_f32 = nullptr;
+            L.N = N; L.H = H; L.W = W; L.Cin = c.Cin; L.Ho = pl.H[i]; L.Wo = pl.W[i];
+            L.Cout = c.Cout; L.CoutPad = c.CoutPad;
+            L.kh = c.kh; L.kw = c.kw; L.stride = c.stride; L.pad = c.pad; L.relu = c.relu;
+            L.small_cin = c.small_cin; L.split = net->split;
+            WSC_TRY(conv_igemm_launch(ctx, L));
+        } else {
+            WSC_TRY(launch_maxpool(ctx, src, src_lo, N, H, W, C, op.pk, op.ps, op.pp, pl.H[i], pl.W[i], buf[op.out],
+                                   buf_lo[op.out]));
+        }
+        bh[op.out] = pl.H[i]; bw[op.out] = pl.W[i]; bc[op.out] = pl.C[i];
+    }
+    *feat = buf[net->final_buf];
+    *feat_lo = buf_lo[net->final_buf];
+    *hf = pl.hf;
+    *wf = pl.wf;
+    return WSC_OK;
+}
+
+} // namespace
+
+// GAP / global-max + Linear + Sigmoid, defined in misc_kernels.hip (avg) -- the max flavour
+// is selected by a negative hw.
+extern "C" {
+
+int wsc_net_create(wsc_ctx *ctx, int arch, const wsc_tensor_desc *weights, int n_weights, int num_classes,
+                   int precision, wsc_net **out) {
+    WSC_CHECK(ctx && weights && out && n_weights > 0, WSC_ERR_INVALID, "wsc_net_create: null argument");
+    WSC_CHECK(num_classes > 0 && num_classes <= 64, WSC_ERR_INVALID, "num_classes=%d outside [1,64]", num_classes);
+    WSC_CHECK(precision == WSC_PREC_BF16 || precision == WSC_PREC_BF16X3, WSC_ERR_INVALID, "unknown precision %d",
+              precision);
+    WSC_HIP(hipSetDevice(ctx->device));
+    Dict d;
+    for (int i = 0; i < n_weights; ++i) {
+        WSC_CHECK(weights[i].name != nullptr, WSC_ERR_INVALID, "weights[%d].name is null", i);
+        WSC_CHECK(weights[i].ndim >= 0 && weights[i].ndim <= 4, WSC_ERR_SHAPE, "'%s': ndim %d unsupported",
+                  weights[i].name, weights[i].ndim);
+        HostTensor t;
+        t.data = weights[i].data;
+        t.ndim = weights[i].ndim;
+        for (int k = 0; k < 4; ++k) t.shape[k] = k < t.ndim ? weights[i].shape[k] : 1;
+        if (t.ndim == 0) { t.ndim = 1; t.shape[0] = 1; }
+        d[weights[i].name] = t;
+    }
+    wsc_net *net = new wsc_net();
+    net->ctx = ctx;
+    net->arch = arch;
+    net->C = num_classes;
+    net->split = precision == WSC_PREC_BF16X3 ? 1 : 0;
+    int st;
+    switch (arch) {
+    case WSC_ARCH_RESNET50_CAM: st = build_resnet50(net, d); break;
+    case WSC_ARCH_VGG16_CAM: st = build_vgg16(net, d); break;
+    case WSC_ARCH_M7_CAM: st = build_m7(net, d); break;
+    default:
+        wsc_set_error("unknown arch %d", arch);
+        st = WSC_ERR_INVALID;
+    }
+    if (st != WSC_OK) {
+        wsc_net_destroy(net);
+        return st;
+    }
+    *out = net;
+    return WSC_OK;
+}
+
+void wsc_net_destroy(wsc_net *net) {
+    if (!net) return;
+    for (void *p : net->allocs) (void)hipFree(p);
+    delete net;
+}
+
+int wsc_net_cam_size(const wsc_net *net, int S, int *h_out) {
+    WSC_CHECK(net && h_out, WSC_ERR_INVALID, "wsc_net_cam_size: null argument");
+    Plan pl;
+    WSC_TRY(plan_dims(net, 1, S, &pl));
+    *h_out = pl.hf;
+    return WSC_OK;
+}
+
+int wsc_net_feat_channels(const wsc_net *net, int *f_out) {
+    WSC_CHECK(net && f_out, WSC_ERR_INVALID, "wsc_net_feat_channels: null argument");
+    *f_out = net->F;
+    return WSC_OK;
+}
+
+int wsc_net_forward_cam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int S, float *cam_dev,
+                        float *score_dev) {
+    WSC_CHECK(ctx && net && x_dev && cam_dev, WSC_ERR_INVALID, "wsc_net_forward_cam: null argument");
+    WSC_CHECK(B > 0 && S > 0, WSC_ERR_INVALID, "wsc_net_forward_cam: B=%d S=%d", B, S);
+    WSC_CHECK(score_dev == nullptr || net->cls_w != nullptr, WSC_ERR_INVALID,
+              "this architecture has no classifier branch (score_dev must be NULL)");
+    WSC_HIP(hipSetDevice(ctx->device));
+    const int N = 2 * B;
+    Plan pl;
+    WSC_TRY(plan_dims(net, N, S, &pl));
+    const size_t head_bytes = (size_t)N * pl.hf * pl.wf * net->C * sizeof(float);
+    const bf16_t *feat, *feat_lo;
+    int hf, wf;
+    void *extra;
+    WSC_TRY(run_backbone(ctx, net, x_dev, N, S, head_bytes, &feat, &feat_lo, &hf, &wf, &extra));
+    float *head_out = (float *)extra;
+    ConvLaunch L;
+    memset(&L, 0, sizeof(L));
+    const ConvW &c = net->head;
+    L.x = feat; L.x_lo = feat_lo; L.w = c.w; L.s1 = c.s1; L.b1 = c.b1;
+    L.y_f32 = head_out;
+    L.N = N; L.H = hf; L.W = wf; L.Cin = c.Cin; L.Ho = hf; L.Wo = wf; L.Cout = c.Cout; L.CoutPad = c.CoutPad;
+    L.kh = 1; L.kw = 1; L.stride = 1; L.pad = 0; L.relu = 0; L.small_cin = 0; L.split = net->split;
+    WSC_TRY(conv_igemm_launch(ctx, L));
+    WSC_TRY(launch_flip_add(ctx, head_out, B, hf, wf, net->C, net->C, cam_dev));
+    if (score_dev != nullptr)
+        WSC_TRY(launch_gap_linear_sigmoid(ctx, feat, feat_lo, B, net->cls_max ? -(hf * wf) : hf * wf, net->F,
+                                          net->cls_w, net->cls_b, net->Ccls, score_dev));
+    return WSC_OK;
+}
+
+int wsc_net_forward_features(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, int S, float *feat_dev) {
+    WSC_CHECK(ctx && net && x_dev && feat_dev, WSC_ERR_INVALID, "wsc_net_forward_features: null argument");
+    WSC_CHECK(N > 0 && S > 0, WSC_ERR_INVALID, "wsc_net_forward_features: N=%d S=%d", N, S);
+    WSC_HIP(hipSetDevice(ctx->device));
+    const bf16_t *feat, *feat_lo;
+    int hf, wf;
+    void *extra;
+    WSC_TRY(run_backbone(ctx, net, x_dev, N, S, 0, &feat, &feat_lo, &hf, &wf, &extra));
+    return launch_bf16_to_f32(ctx, feat, feat_lo, (size_t)N * hf * wf * net->F, feat_dev);
+}
+
+// One convolution layer through the production kernel, NCHW fp32 in / out (layout changes and
+// weight packing included): y = [relu]( conv(x, w) * scale + shift [+ residual] ).
+int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int W, const float *w_host, int Cout,
+                    int kh, int kw, int stride, int pad, const float *scale_host, const float *shift_host,
+                    const float *residual_dev, int relu, int precision, float *y_dev) {
+    WSC_CHECK(ctx && x_dev && w_host && y_dev, WSC_ERR_INVALID, "wsc_conv2d_nchw: null argument");
+    WSC_CHECK(Cout % 8 == 0, WSC_ERR_INVALID, "wsc_conv2d_nchw: Cout=%d must be a multiple of 8", Cout);
+    WSC_HIP(hipSetDevice(ctx->device));
+    wsc_net tmp;
+    tmp.ctx = ctx;
+    tmp.split = precision == WSC_PREC_BF16X3 ? 1 : 0;
+    HostTensor wt;
+    wt.data = w_host; wt.ndim = 4; wt.shape[0] = Cout; wt.shape[1] = Cin; wt.shape[2] = kh; wt.shape[3] = kw;
+    std::vector<float> s1(Cout, 1.f), b1(Cout, 0.f);
+    if (scale_host) s1.assign(scale_host, scale_host + Cout);
+    if (shift_host) b1.assign(shift_host, shift_host + Cout);
+    int small = 0;
+    if (Cin <= 4) small = kw <= 4 ? 1 : 2;
+    ConvW c;
+    int st = make_conv(&tmp, &wt, stride, pad, relu, small, s1, b1, nullptr, nullptr, &c);
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *p : tmp.allocs) (void)hipFree(p);
+    };
+    if (st != WSC_OK) { cleanup(); return st; }
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    const int planes = tmp.split ? 2 : 1;
+    const size_t in_e = (size_t)N * H * W * c.Cin, out_e = (size_t)N * Ho * Wo * Cout;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    void *ws;
+    st = wsc_ctx_workspace(ctx, planes * (al(in_e * 2) + 2 * al(out_e * 2)), &ws);
+    if (st != WSC_OK) { cleanup(); return st; }
+    char *p = (char *)ws;
+    bf16_t *xi = (bf16_t *)p; p += al(in_e * 2);
+    bf16_t *xi_lo = nullptr; if (tmp.split) { xi_lo = (bf16_t *)p; p += al(in_e * 2); }
+    bf16_t *yo = (bf16_t *)p; p += al(out_e * 2);
+    bf16_t *yo_lo = nullptr; if (tmp.split) { yo_lo = (bf16_t *)p; p += al(out_e * 2); }
+    bf16_t *ri = nullptr, *ri_lo = nullptr;
+    if (residual_dev) { ri = (bf16_t *)p; p += al(out_e * 2); if (tmp.split) { ri_lo = (bf16_t *)p; p += al(out_e * 2); } }
+    if (small) st = launch_nchw_to_nhwc4(ctx, x_dev, N, H, W, xi, xi_lo);
+    else st = launch_nchw_to_nhwc(ctx, x_dev, N, Cin, H * W, xi, xi_lo);
+    if (st == WSC_OK && residual_dev) st = launch_nchw_to_nhwc(ctx, residual_dev, N, Cout, Ho * Wo, ri, ri_lo);
+    if (st == WSC_OK) {
+        ConvLaunch L;
+        memset(&L, 0, sizeof(L));
+        L.x = xi; L.x_lo = xi_lo; L.w = c.w; L.s1 = c.s1; L.b1 = c.b1; L.res = ri; L.res_lo = ri_lo;
+        L.y = yo; L.y_lo = yo_lo;
+        L.N = N; L.H = H; L.W = W; L.Cin = c.Cin; L.Ho = Ho; L.Wo = Wo; L.Cout = Cout; L.CoutPad = c.CoutPad;
+        L.kh = kh; L.kw = kw; L.stride = stride; L.pad = pad; L.relu = relu; L.small_cin = small; L.split = tmp.split;
+        st = conv_igemm_launch(ctx, L);
+    }
+    if (st == WSC_OK) st = launch_nhwc_to_nchw(ctx, yo, yo_lo, N, Cout, Ho * Wo, y_dev);
+    cleanup();
+    return st;
+}
+
+} // extern "C"

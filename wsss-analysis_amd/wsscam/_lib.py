@@ -1,0 +1,373 @@
+"""ctypes binding of libwsscam.so (the C ABI of include/wsscam.h).
+
+The product path has no CPU fallback: if the shared library is missing, or no gfx950
+device is present, the calls fail loudly (WscError).
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwsscam.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "wsscam.h"))
+
+WSC_OK = 0
+WSC_ERR_INVALID = -1
+WSC_ERR_NO_DEVICE = -2
+WSC_ERR_HIP = -3
+WSC_ERR_MISSING_KEY = -4
+WSC_ERR_SHAPE = -5
+WSC_ERR_NOMEM = -6
+WSC_ERR_KEY_RANGE = -7
+WSC_ERR_CAPACITY = -8
+
+ARCH_RESNET50_CAM = 0
+ARCH_VGG16_CAM = 1
+ARCH_M7_CAM = 2
+
+PREC_BF16 = 0
+PREC_BF16X3 = 1
+
+
+class WscError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("libwsscam error %d: %s" % (status, message))
+        self.status = status
+
+
+class TensorDesc(ctypes.Structure):
+    _fields_ = [
+        ("name", ctypes.c_char_p),
+        ("data", ctypes.POINTER(ctypes.c_float)),
+        ("ndim", ctypes.c_int32),
+        ("shape", ctypes.c_int64 * 4),
+    ]
+
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/wsscam.h declares
+_SIGNATURES = {
+    "wsc_version": (_i, []),
+    "wsc_last_error": (ctypes.c_char_p, []),
+    "wsc_ctx_create": (_i, [_i, _vp, ctypes.POINTER(_vp)]),
+    "wsc_ctx_destroy": (None, [_vp]),
+    "wsc_sync": (_i, [_vp]),
+    "wsc_device_info": (_i, [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(_i)]),
+    "wsc_malloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "wsc_free": (_i, [_vp, _vp]),
+    "wsc_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "wsc_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "wsc_memset": (_i, [_vp, _vp, _i, _sz]),
+    "wsc_timer_begin": (_i, [_vp]),
+    "wsc_timer_end": (_i, [_vp, ctypes.POINTER(_f)]),
+    "wsc_net_create": (_i, [_vp, _i, ctypes.POINTER(TensorDesc), _i, _i, _i, ctypes.POINTER(_vp)]),
+    "wsc_net_destroy": (None, [_vp]),
+    "wsc_net_cam_size": (_i, [_vp, _i, ctypes.POINTER(_i)]),
+    "wsc_net_feat_channels": (_i, [_vp, ctypes.POINTER(_i)]),
+    "wsc_net_forward_cam": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "wsc_net_forward_features": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "wsc_conv2d_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "wsc_cam_postprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
+    "wsc_crf_create": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _f, ctypes.POINTER(_vp)]),
+    "wsc_crf_destroy": (None, [_vp]),
+    "wsc_crf_lattice_sizes": (_i, [_vp, _vp, _vp, _vp]),
+    "wsc_crf_inference": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
+}
+
+
+def header_symbols():
+    """Function names declared in include/wsscam.h."""
+    with open(HEADER_PATH) as fh:
+        text = fh.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wsc_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load libwsscam.so (no GPU needed for loading; compute calls need one)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WscError(WSC_ERR_NO_DEVICE,
+                       "libwsscam.so not built at %s -- run `python __graft_entry__.py` (there is no "
+                       "CPU fallback for the product path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check_exports():
+    """Every symbol the header declares must be exported and bound."""
+    lib = load()
+    declared = header_symbols()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    unbound = [s for s in declared if s not in _SIGNATURES]
+    if missing or unbound:
+        raise WscError(WSC_ERR_INVALID, "missing exports %s / unbound %s" % (missing, unbound))
+    return declared
+
+
+def check(status):
+    if status != WSC_OK:
+        raise WscError(status, load().wsc_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(x):
+    """Device pointer of a DeviceBuffer / torch tensor / int, or host pointer of a numpy array."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):  # torch tensor
+        return x.data_ptr()
+    raise TypeError("cannot take a pointer of %r" % type(x))
+
+
+class Context:
+    """wsc_ctx: one device + one stream (make_cam.py:31-33 `cuda.device(process_id)`)."""
+
+    def __init__(self, device=0, stream=None):
+        lib = load()
+        h = _vp()
+        check(lib.wsc_ctx_create(int(device), stream, ctypes.byref(h)))
+        self.h = h
+        self.device = device
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.wsc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self._lib.wsc_sync(self.h))
+
+    def device_info(self):
+        buf = ctypes.create_string_buffer(128)
+        n = _i()
+        check(self._lib.wsc_device_info(self.h, buf, 128, ctypes.byref(n)))
+        return buf.value.decode(), n.value
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, int(nbytes))
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = DeviceBuffer(self, arr.nbytes)
+        check(self._lib.wsc_memcpy_h2d(self.h, buf.ptr, arr.ctypes.data, arr.nbytes))
+        self.sync()  # arr may be a temporary
+        return buf
+
+    def to_host(self, buf, shape, dtype, offset_bytes=0):
+        out = np.empty(shape, dtype=dtype)
+        check(self._lib.wsc_memcpy_d2h(self.h, out.ctypes.data, _ptr(buf) + offset_bytes, out.nbytes))
+        return out
+
+    def timer_begin(self):
+        check(self._lib.wsc_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = _f()
+        check(self._lib.wsc_timer_end(self.h, ctypes.byref(ms)))
+        return ms.value
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes owned through wsc_malloc / wsc_free."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = nbytes
+        p = _vp()
+        check(ctx._lib.wsc_malloc(ctx.h, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if getattr(self, "ptr", None) and self.ctx.h:
+            self.ctx._lib.wsc_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def make_tensor_descs(state_dict):
+    """dict name -> numpy float32 array  ->  (ctypes array of TensorDesc, keep-alive list)."""
+    keep = []
+    items = []
+    for name, arr in state_dict.items():
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32))
+        if a.ndim > 4:
+            continue
+        keep.append(a)
+        d = TensorDesc()
+        d.name = name.encode()
+        d.data = a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        d.ndim = a.ndim
+        for k in range(4):
+            d.shape[k] = a.shape[k] if k < a.ndim else 1
+        items.append(d)
+    arr_t = TensorDesc * len(items)
+    return arr_t(*items), keep
+
+
+class Net:
+    """wsc_net: packed weights of one CAM network."""
+
+    def __init__(self, ctx, arch, state_dict, num_classes, precision=PREC_BF16):
+        self.ctx = ctx
+        self.arch = arch
+        self.num_classes = num_classes
+        self.precision = precision
+        descs, keep = make_tensor_descs(state_dict)
+        h = _vp()
+        check(ctx._lib.wsc_net_create(ctx.h, arch, descs, len(descs), num_classes, precision, ctypes.byref(h)))
+        del keep
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.sync()
+            self.ctx._lib.wsc_net_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def cam_size(self, S):
+        n = _i()
+        check(self.ctx._lib.wsc_net_cam_size(self.h, S, ctypes.byref(n)))
+        return n.value
+
+    def feat_channels(self):
+        n = _i()
+        check(self.ctx._lib.wsc_net_feat_channels(self.h, ctypes.byref(n)))
+        return n.value
+
+    def forward_cam(self, x_dev, B, S, cam_dev, score_dev=None):
+        check(self.ctx._lib.wsc_net_forward_cam(self.ctx.h, self.h, _ptr(x_dev), B, S, _ptr(cam_dev),
+                                                _ptr(score_dev)))
+
+    def forward_features(self, x_dev, N, S, feat_dev):
+        check(self.ctx._lib.wsc_net_forward_features(self.ctx.h, self.h, _ptr(x_dev), N, S, _ptr(feat_dev)))
+
+
+def cam_postprocess(ctx, cam_dev, B, C, h, w, sizes, keys_per_image, strided_dev=None, highres_dev=None):
+    """Batched make_cam tail.  sizes: [(H0, W0)], keys_per_image: list of int sequences.
+
+    Returns (strided_dev, highres_dev, strided_off, highres_off, shapes) where shapes[b] =
+    (K, h4, w4, H0, W0); buffers are allocated when not given.
+    """
+    size_hw = np.asarray(sizes, dtype=np.int32).reshape(B, 2)
+    key_off = np.zeros(B + 1, dtype=np.int32)
+    for b in range(B):
+        key_off[b + 1] = key_off[b] + len(keys_per_image[b])
+    keys = np.zeros(max(int(key_off[-1]), 1), dtype=np.int32)
+    for b in range(B):
+        keys[key_off[b]:key_off[b + 1]] = np.asarray(keys_per_image[b], dtype=np.int32)
+    s_off = np.zeros(B, dtype=np.int64)
+    h_off = np.zeros(B, dtype=np.int64)
+    shapes = []
+    s_tot = 0
+    h_tot = 0
+    for b in range(B):
+        H0, W0 = int(size_hw[b, 0]), int(size_hw[b, 1])
+        h4, w4 = (H0 - 1) // 4 + 1, (W0 - 1) // 4 + 1
+        K = int(key_off[b + 1] - key_off[b])
+        s_off[b] = s_tot
+        h_off[b] = h_tot
+        s_tot += K * h4 * w4
+        h_tot += K * H0 * W0
+        shapes.append((K, h4, w4, H0, W0))
+    if strided_dev is None:
+        strided_dev = ctx.alloc(max(s_tot, 1) * 4)
+    if highres_dev is None:
+        highres_dev = ctx.alloc(max(h_tot, 1) * 4)
+    check(ctx._lib.wsc_cam_postprocess(ctx.h, _ptr(cam_dev), B, C, h, w, size_hw.ctypes.data, keys.ctypes.data,
+                                       key_off.ctypes.data, s_off.ctypes.data, h_off.ctypes.data,
+                                       _ptr(strided_dev), _ptr(highres_dev)))
+    return strided_dev, highres_dev, s_off, h_off, shapes
+
+
+def conv2d_nchw(ctx, x_dev, N, Cin, H, W, w, stride, pad, scale=None, shift=None, residual_dev=None, relu=False,
+                precision=PREC_BF16, y_dev=None):
+    """One conv layer through the production kernel (test/diagnostic entry)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    Cout, _, kh, kw = w.shape
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if y_dev is None:
+        y_dev = ctx.alloc(N * Cout * Ho * Wo * 4)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
+    check(ctx._lib.wsc_conv2d_nchw(ctx.h, _ptr(x_dev), N, Cin, H, W, w.ctypes.data, Cout, kh, kw, stride, pad,
+                                   None if sc is None else sc.ctypes.data, None if sh is None else sh.ctypes.data,
+                                   _ptr(residual_dev), int(relu), precision, _ptr(y_dev)))
+    return y_dev, (N, Cout, Ho, Wo)
+
+
+def bilinear_resize(ctx, src_dev, C, h, w, dst_dev, H, W):
+    check(ctx._lib.wsc_bilinear_resize(ctx.h, _ptr(src_dev), C, h, w, _ptr(dst_dev), H, W))
+
+
+class Crf:
+    """wsc_crf: lattices of a batch of images (DenseCRF2D + addPairwise*)."""
+
+    def __init__(self, ctx, rgb_dev, B, H, W, g_sxy, bi_sxy, bi_srgb):
+        self.ctx = ctx
+        self.B, self.H, self.W = B, H, W
+        h = _vp()
+        check(ctx._lib.wsc_crf_create(ctx.h, _ptr(rgb_dev), B, H, W, float(g_sxy), float(bi_sxy), float(bi_srgb),
+                                      ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx._lib.wsc_crf_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def lattice_sizes(self):
+        vg = np.zeros(self.B, dtype=np.int32)
+        vb = np.zeros(self.B, dtype=np.int32)
+        check(self.ctx._lib.wsc_crf_lattice_sizes(self.ctx.h, self.h, vg.ctypes.data, vb.ctypes.data))
+        return vg, vb
+
+    def inference(self, unary_dev, M, g_compat, bi_compat, n_iters, q_dev=None, argmax_dev=None):
+        check(self.ctx._lib.wsc_crf_inference(self.ctx.h, self.h, _ptr(unary_dev), M, float(g_compat),
+                                              float(bi_compat), int(n_iters), _ptr(q_dev), _ptr(argmax_dev)))

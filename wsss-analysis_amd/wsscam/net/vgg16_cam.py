@@ -1,0 +1,59 @@
+"""Modified-VGG16 CAM network -- mirror of 03b_irn/net/vgg16_cam.py (CAM.forward :24-60) on
+net/vgg16.py:44 + common_cnn.make_layers :128-141.  Weights: a torch-style state_dict with keys
+`vgg16.layer<L>.<idx>.{weight,bias,...}`, `vgg16.classifier.0.{weight,bias}` and `thresholds`
+(what common_cnn._load_pretrained leaves in the module after transplanting the Keras .h5/.mat,
+common_cnn.py:25-82)."""
+import numpy as np
+
+from .. import _lib
+from .common import DeviceCAMBase
+
+ADP_INDS_X17 = [2, 3, 4, 6, 7, 8, 9, 12, 13, 14, 16, 17, 18, 21, 22, 23, 25, 26, 28, 29, 30, 32, 33, 35, 37, 38, 40,
+                45, 48, 49, 50]  # common_cam.py:26-29
+
+
+class CAM(DeviceCAMBase):
+    arch = _lib.ARCH_VGG16_CAM
+    root = "vgg16"
+
+    def __init__(self, model_dir=None, dataset="voc12", tag="", num_classes=20, use_cls=None, precision=None):
+        super().__init__(num_classes, precision)
+        self.model_dir = model_dir
+        self.dataset = dataset
+        self.tag = tag
+        self.use_cls = use_cls
+        self.thresholds = 0.5 * np.ones(num_classes, dtype=np.float32)  # common_cnn.py:22
+
+    def load_state_dict(self, state_dict, strict=True):
+        super().load_state_dict(state_dict, strict)
+        if "thresholds" in self._sd:
+            self.thresholds = np.asarray(self._sd.pop("thresholds"), dtype=np.float32)
+        return self
+
+    def predict_labels(self, score):
+        """vgg16_cam.py:37-45: score >= thresholds; if nothing passes on non-ADP data force argmax."""
+        y = score >= self.thresholds[:len(score)]
+        if self.dataset not in ("adp_morph", "adp_func") and y.sum() == 0:
+            y[np.argmax(score)] = True
+        if "X1.7" in self.tag:
+            y = y[ADP_INDS_X17]
+        return y
+
+    def forward(self, x, x_orig=None):
+        """-> (cam (C,h,w), y bool (C,)).  The ADP background/other-channel synthesis of
+        common_cam.py:31-92 (x_orig branch) is not part of this round."""
+        if self.dataset in ("adp_morph", "adp_func"):
+            raise NotImplementedError("ADP CAM modifications (common_cam.py:31-92) are not implemented yet")
+        is_torch = hasattr(x, "detach")
+        xn = x.detach().cpu().numpy() if is_torch else np.asarray(x)
+        cam, score = self.forward_batch(xn[None], want_score=True)
+        cam, y = cam[0], self.predict_labels(score[0])
+        if "X1.7" in self.tag:
+            cam = cam[ADP_INDS_X17]
+        if is_torch:
+            import torch
+
+            return torch.from_numpy(cam), torch.from_numpy(y)
+        return cam, y
+
+    __call__ = forward

@@ -1,0 +1,140 @@
+"""make_cam step -- drop-in for 03b_irn/step/make_cam.py (run :95-124, _work :25-93).
+
+Same `run(args)` contract: builds the CAM network named by args.cam_network, loads weights,
+builds the MSF dataset, splits it round-robin over the GPUs and writes one
+`<cam_out_dir>/<name>.npy` per image holding the pickled dict
+{"keys": int64[K], "cam": float32[K,h4,w4], "high_res": float32[K,H0,W0]}
+(`high_res` omitted for deepglobe, three empty arrays when no class is valid) that
+eval_cam.py:48-58, cam_to_ir_label.py:27-33 and make_sem_seg_labels.py:61-66 consume.
+
+What changes is underneath: instead of one image (2 samples) per launch, each process batches
+`args.cam_batch_images` images (default 32 = 64 samples) through libwsscam -- conv stack, CAM head
++ flip-add, both bilinear resizes and the per-class max-normalisation all on the device -- and
+only the final maps cross PCIe.  One process per GPU, disjoint shards, no collective
+(make_cam.py:120-122).
+"""
+import importlib
+import os
+
+import numpy as np
+
+from .. import _lib
+from ..misc import torchutils
+
+
+def _valid_cat(args, pack, score, model):
+    """make_cam.py:49-54: GT image-level labels on 'train' splits, predicted labels otherwise."""
+    if "train" in args.split:
+        label = np.asarray(pack["label"])
+    else:
+        if score is None:
+            raise ValueError("split %r needs predicted labels but %s has no classifier branch"
+                             % (args.split, type(model).__name__))
+        label = model.predict_labels(score)
+        if getattr(args, "use_cls", None) is not None:
+            label = label[args.use_cls]
+    return np.nonzero(np.asarray(label))[0].astype(np.int64)
+
+
+def _save(args, name, keys, strided, highres):
+    path = os.path.join(args.cam_out_dir, name + ".npy")
+    if len(keys) == 0:  # make_cam.py:86-88
+        np.save(path, {"keys": np.empty(0), "cam": np.empty(0), "high_res": np.empty(0)})
+    elif args.dataset in ("deepglobe", "deepglobe_balanced"):  # make_cam.py:83-85
+        np.save(path, {"keys": keys, "cam": strided})
+    else:  # make_cam.py:80-82
+        np.save(path, {"keys": keys, "cam": strided, "high_res": highres})
+
+
+def process_batch(model, packs, args, save=True):
+    """One device batch: list of dataset items -> list of result dicts (and .npy files)."""
+    ctx = model.ctx
+    B = len(packs)
+    x = np.stack([np.asarray(p["img"], dtype=np.float32) for p in packs])  # (B,2,3,S,S)
+    S = x.shape[-1]
+    C = model.num_classes
+    h = model.cam_size(S)
+    has_cls = model.arch != _lib.ARCH_RESNET50_CAM
+    x_dev = ctx.to_device(x)
+    cam_dev = ctx.alloc(B * C * h * h * 4)
+    score_dev = ctx.alloc(B * C * 4) if has_cls else None
+    model.forward_batch_device(x_dev, B, S, cam_dev, score_dev)
+    score = ctx.to_host(score_dev, (B, C), np.float32) if has_cls else None
+    keys = [_valid_cat(args, p, None if score is None else score[b], model) for b, p in enumerate(packs)]
+    sizes = [tuple(int(v) for v in p["size"]) for p in packs]
+    s_dev, h_dev, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, B, C, h, h, sizes, keys)
+    s_tot = sum(k * a * b for (k, a, b, _, _) in shapes)
+    h_tot = sum(k * a * b for (k, _, _, a, b) in shapes)
+    strided = ctx.to_host(s_dev, (max(s_tot, 1),), np.float32)
+    highres = ctx.to_host(h_dev, (max(h_tot, 1),), np.float32)
+    out = []
+    for b, p in enumerate(packs):
+        K, h4, w4, H0, W0 = shapes[b]
+        sc = strided[s_off[b]:s_off[b] + K * h4 * w4].reshape(K, h4, w4).copy()
+        hc = highres[h_off[b]:h_off[b] + K * H0 * W0].reshape(K, H0, W0).copy()
+        if save:
+            _save(args, p["name"], keys[b], sc, hc)
+        out.append({"keys": keys[b], "cam": sc, "high_res": hc})
+    return out
+
+
+def _work(process_id, model, dataset, args):
+    """Per-GPU worker (make_cam.py:25-93): shard `process_id` of the dataset on device `process_id`."""
+    databin = dataset[process_id]
+    model.cuda(process_id)
+    bs = int(getattr(args, "cam_batch_images", 32))
+    n = len(databin)
+    for i0 in range(0, n, bs):
+        packs = [databin[i] for i in range(i0, min(i0 + bs, n))]
+        # images in one batch must share the network input size (outsize is fixed per run)
+        process_batch(model, packs, args, save=True)
+    model.ctx.sync()
+
+
+def _device_count():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+def build_dataset(args):
+    if getattr(args, "dataset_obj", None) is not None:
+        return args.dataset_obj
+    if args.dataset == "voc12":
+        from ..voc12 import dataloader
+
+        return dataloader.VOC12ClassificationDatasetMSF(args.val_list, norm_mode=args.norm_mode,
+                                                        outsize=args.outsize, dev_root=args.dev_root,
+                                                        scales=args.cam_scales)
+    raise KeyError("Dataset %s not yet implemented" % args.dataset)
+
+
+def run(args):
+    """03b_irn/step/make_cam.py:95-124."""
+    mod = args.cam_network
+    if not mod.startswith("wsscam."):
+        mod = "wsscam." + mod  # the reference passes 'net.resnet50_cam'
+    model = getattr(importlib.import_module(mod), "CAM")(args.model_dir, args.dataset, args.tag,
+                                                         args.num_classes, args.use_cls)
+    if getattr(args, "state_dict", None) is not None:
+        model.load_state_dict(args.state_dict, strict=True)
+    else:
+        import torch
+
+        model.load_state_dict(torch.load(args.cam_weights_name + ".pth", map_location="cpu"), strict=True)
+    model.eval()
+
+    n_gpus = int(getattr(args, "n_gpus", 0)) or _device_count()
+    if n_gpus < 1:
+        raise _lib.WscError(_lib.WSC_ERR_NO_DEVICE, "make_cam needs at least one gfx950 device")
+    os.makedirs(args.cam_out_dir, exist_ok=True)
+    dataset = torchutils.split_dataset(build_dataset(args), n_gpus)
+
+    if n_gpus == 1:
+        _work(0, model, dataset, args)
+    else:
+        # one OS process per GPU, as multiprocessing.spawn(_work, nprocs=n_gpus) does (make_cam.py:122);
+        # each child creates its own HIP context after the fork-less spawn
+        import torch.multiprocessing as mp
+
+        mp.spawn(_work, nprocs=n_gpus, args=(model, dataset, args), join=True)

@@ -1,0 +1,104 @@
+"""VOC12 MSF classification dataset -- input contract of make_cam
+(03b_irn/voc12/dataloader.py: load_img_name_list :60-66, TorchvisionResize :68-78,
+TorchvisionNormalize :80-106, VOC12ClassificationDatasetMSF :210-246).
+
+Items are dicts {"name", "img": float32 (2,3,S,S) [orig, h-flip], "size": (H0,W0), "label"}.
+JPEG decode uses PIL (imageio/cv2 are not in this image).  The float64 bilinear resize follows
+cv2.resize's INTER_LINEAR half-pixel convention; cv2 itself is absent offline so bit parity of
+this host-side resize is unpinned -- it is I/O, outside the device hot path."""
+import os
+
+import numpy as np
+
+IMG_FOLDER_NAME = "JPEGImages"
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def decode_int_filename(int_filename):
+    s = str(int(int_filename))
+    return s[:4] + "_" + s[4:]
+
+
+def load_img_name_list(dataset_path):
+    names = [l.strip() for l in open(dataset_path) if l.strip()]
+    return np.array([np.int32(int(n.split("_")[0]) * 1e6 + int(n.split("_")[1])) for n in names])
+
+
+def get_img_path(img_name, voc12_root):
+    if not isinstance(img_name, str):
+        img_name = decode_int_filename(img_name)
+    return os.path.join(voc12_root, IMG_FOLDER_NAME, img_name + ".jpg")
+
+
+def resize_bilinear_f64(img, out_hw):
+    H, W = img.shape[:2]
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    im = np.asarray(img, dtype=np.float64)
+    if (H, W) == (oh, ow):
+        return im
+    ys = np.clip((np.arange(oh) + 0.5) * H / oh - 0.5, 0, H - 1)
+    xs = np.clip((np.arange(ow) + 0.5) * W / ow - 0.5, 0, W - 1)
+    y0 = np.floor(ys).astype(int)
+    x0 = np.floor(xs).astype(int)
+    y1 = np.minimum(y0 + 1, H - 1)
+    x1 = np.minimum(x0 + 1, W - 1)
+    wy = (ys - y0)[:, None, None]
+    wx = (xs - x0)[None, :, None]
+    top = im[y0][:, x0] * (1 - wx) + im[y0][:, x1] * wx
+    bot = im[y1][:, x0] * (1 - wx) + im[y1][:, x1] * wx
+    return top * (1 - wy) + bot * wy
+
+
+class TorchvisionNormalize:
+    def __init__(self, norm_mode="int"):
+        self.norm_mode = norm_mode
+        if norm_mode == "int":
+            self.mean, self.std = (104.0, 117.0, 123.0), (255.0, 255.0, 255.0)
+        elif norm_mode == "float":
+            self.mean, self.std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+        elif norm_mode is not None:
+            raise ValueError("norm_mode value is not 'int' or 'float'")
+
+    def __call__(self, img):
+        proc = np.empty(img.shape, np.float32)
+        img = np.float32(img)
+        for c in range(3):
+            if self.norm_mode == "int":
+                proc[..., c] = (img[..., c] - self.mean[c]) / self.std[c]
+            elif self.norm_mode == "float":
+                proc[..., c] = (img[..., c] / 255.0 - self.mean[c]) / self.std[c]
+            else:
+                return img
+        return proc
+
+
+def msf_pack(img_u8, outsize, norm):
+    x = norm(resize_bilinear_f64(img_u8, outsize) if outsize is not None else np.asarray(img_u8, np.float64))
+    x = np.transpose(x, (2, 0, 1))
+    return np.stack([x, np.flip(x, -1)], axis=0).astype(np.float32)
+
+
+class VOC12ClassificationDatasetMSF:
+    def __init__(self, img_name_list_path, dev_root, norm_mode="float", outsize=None, scales=(1.0,),
+                 cls_labels_path=None):
+        assert norm_mode in ["float", "int"]
+        assert outsize in [(321, 321), (224, 224), None]
+        assert tuple(scales) == (1.0,), "multi-scale inference (pil_rescale) is not implemented"
+        self.img_name_list = load_img_name_list(img_name_list_path)
+        self.dev_root = dev_root
+        self.outsize = outsize
+        self.norm = TorchvisionNormalize(norm_mode)
+        cls_labels_path = cls_labels_path or os.path.join(_HERE, "cls_labels.npy")
+        cls = np.load(cls_labels_path, allow_pickle=True).item()
+        self.label_list = np.array([cls[n] for n in self.img_name_list])
+
+    def __len__(self):
+        return len(self.img_name_list)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+
+        name_str = decode_int_filename(self.img_name_list[idx])
+        img = np.asarray(Image.open(get_img_path(name_str, self.dev_root)).convert("RGB"))
+        return {"name": name_str, "img": msf_pack(img, self.outsize, self.norm), "size": (img.shape[0], img.shape[1]),
+                "label": self.label_list[idx]}
