@@ -1,0 +1,311 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of CAM + dense-CRF pseudo-label generation (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of 32 synthetic VOC-like images resident
+in HBM (BASELINE config 2/3: ResNet50 CAM + dense-CRF, 321x321, batch 32 images = 64 samples):
+
+  wsc_net_forward_cam      ResNet50 (strides 2,2,2,1) on orig+flip, 1x1 CAM head, ReLU, flip-add
+  wsc_cam_postprocess      make_cam tail for the image's GT classes at its native size
+                           (strided /4 map + high-res map, per-class max-normalised)
+  wsc_cam_postprocess      all 20 class maps at 321x321 (the CRF's probability stack)
+  wsc_unary_from_maps      [bg=0.15 | maps] -> -log(clip(p)) unaries, M = 21
+  wsc_crf_create           Gaussian + bilateral permutohedral lattices of the 32 images
+  wsc_crf_inference        10 mean-field iterations -> arg-max label map
+
+N > 1: one process per GPU (torch.distributed.run), every rank owns its own batch (the dataset is
+image-sharded, images[g::G]); no data-path collective, only the timing barrier.  scaling = weak.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "wsss-analysis_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GFLOP_PER_IMAGE = 54.923  # ResNet50-CAM, 2 samples of 321x321 incl. head
+S = 321
+NUM_CLASSES = 20
+CRF_CFG = (1.5, 3.0, 40.0, 13.0, 10.0, 10)  # 03c_hsn/demo.py:157-165 VOC-VGG16 / DeepGlobe
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0}
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="images per step per GPU")
+    ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "bf16x3"])
+    ap.add_argument("--workload", default="cam_crf", choices=["cam_crf", "cam"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def crf_bytes_per_image(N, M, T, vg, vb):
+    """algorithmic HBM bytes of the mean-field loop for one image."""
+    per_it = N * M * 4  # read U
+    for d, V in ((2, vg), (5, vb)):
+        per_it += N * M * 4            # read Q (splat)
+        per_it += N * (d + 1) * 8      # splat idx + weight
+        per_it += 2 * (d + 1) * V * M * 4  # blur read + write
+        per_it += N * (d + 1) * 8      # slice idx + weight
+        per_it += N * M * 4            # write message
+    per_it += N * M * 4                # write Q
+    return T * per_it
+
+
+class Workload:
+    def __init__(self, device, batch, precision, workload, seed):
+        import numpy as np
+
+        from oracle import cnn_ref  # synthetic-input generator only (no compute of the product path)
+        from wsscam import _lib
+
+        self.np, self._lib = np, _lib
+        self.B, self.workload = batch, workload
+        self.ctx = _lib.Context(device)
+        prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3}[precision]
+        sd = {k: v.numpy() for k, v in cnn_ref.make_resnet50_cam_state_dict(NUM_CLASSES, seed=0).items()}
+        self.net = _lib.Net(self.ctx, _lib.ARCH_RESNET50_CAM, sd, NUM_CLASSES, prec)
+        self.h = self.net.cam_size(S)
+        rng = np.random.default_rng(20121 + seed)
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "resnet50_cam.npz"))
+        labels = gold["trainaug_labels"]
+        xs, rgbs, self.sizes, self.keys = [], [], [], []
+        for i in range(batch):
+            H0, W0 = cnn_ref.VOC_SIZES[(i + seed) % len(cnn_ref.VOC_SIZES)]
+            img = cnn_ref.synth_image(rng, H0, W0)
+            r = cnn_ref.resize_bilinear_f64(img, (S, S))
+            x = np.transpose(cnn_ref.normalize_int(r), (2, 0, 1))
+            xs.append(np.stack([x, np.flip(x, -1)], 0))
+            rgbs.append(np.clip(np.rint(r), 0, 255).astype(np.uint8))
+            self.sizes.append((H0, W0))
+            self.keys.append(np.nonzero(labels[(i + seed * batch) % len(labels)])[0].astype(np.int32))
+        self.x_host = np.ascontiguousarray(np.stack(xs), dtype=np.float32)
+        self.rgb_host = np.ascontiguousarray(np.stack(rgbs))
+        ctx = self.ctx
+        self.x_dev = ctx.to_device(self.x_host)
+        self.rgb_dev = ctx.to_device(self.rgb_host)
+        self.cam_dev = ctx.alloc(batch * NUM_CLASSES * self.h * self.h * 4)
+        # native-size make_cam outputs
+        s_tot = sum(len(k) * ((H - 1) // 4 + 1) * ((W - 1) // 4 + 1) for k, (H, W) in zip(self.keys, self.sizes))
+        h_tot = sum(len(k) * H * W for k, (H, W) in zip(self.keys, self.sizes))
+        self.strided_dev = ctx.alloc(max(s_tot, 1) * 4)
+        self.highres_dev = ctx.alloc(max(h_tot, 1) * 4)
+        # CRF stack
+        N = S * S
+        self.all_keys = [np.arange(NUM_CLASSES, dtype=np.int32)] * batch
+        self.maps_dev = ctx.alloc(batch * NUM_CLASSES * N * 4)
+        self.maps_s_dev = ctx.alloc(batch * NUM_CLASSES * ((S - 1) // 4 + 1) ** 2 * 4)
+        self.unary_dev = ctx.alloc(batch * (NUM_CLASSES + 1) * N * 4)
+        self.label_dev = ctx.alloc(batch * N * 4)
+        self.vg = self.vb = None
+
+    # -- pieces ------------------------------------------------------------------------------
+    def run_cnn(self):
+        self.net.forward_cam(self.x_dev, self.B, S, self.cam_dev, None)
+
+    def run_tail(self):
+        self._lib.cam_postprocess(self.ctx, self.cam_dev, self.B, NUM_CLASSES, self.h, self.h, self.sizes, self.keys,
+                                  self.strided_dev, self.highres_dev)
+
+    def run_unary(self):
+        self._lib.cam_postprocess(self.ctx, self.cam_dev, self.B, NUM_CLASSES, self.h, self.h, [(S, S)] * self.B,
+                                  self.all_keys, self.maps_s_dev, self.maps_dev)
+        self._lib.unary_from_maps(self.ctx, self.maps_dev, self.B, NUM_CLASSES, S * S, 0.15, self.unary_dev)
+
+    def crf_create(self):
+        return self._lib.Crf(self.ctx, self.rgb_dev, self.B, S, S, CRF_CFG[0], CRF_CFG[2], CRF_CFG[3])
+
+    def crf_infer(self, crf):
+        crf.inference(self.unary_dev, NUM_CLASSES + 1, CRF_CFG[1], CRF_CFG[4], CRF_CFG[5], None, self.label_dev)
+
+    def step(self):
+        self.run_cnn()
+        self.run_tail()
+        if self.workload == "cam_crf":
+            self.run_unary()
+            crf = self.crf_create()
+            if self.vg is None:
+                self.vg, self.vb = crf.lattice_sizes()
+            self.crf_infer(crf)
+            self.ctx.sync()
+            crf.close()
+
+    def timed(self, fn, reps):
+        """Average device time of fn() over reps, HIP events on the ctx stream."""
+        self.ctx.sync()
+        self.ctx.timer_begin()
+        for _ in range(reps):
+            fn()
+        return self.ctx.timer_end() / reps
+
+
+def cpu_baseline(wl, budget_s):
+    """Oracle on the host cores: torch-CPU fp32 restatement of make_cam._work (batch = 1 image, as the
+    reference runs it) + the single-threaded C dense-CRF restatement (pydensecrf is single-threaded).
+    kind = "port": the reference itself cannot travel to the GPU box."""
+    import numpy as np
+    import torch
+
+    from oracle import cnn_ref
+    from tests import helpers
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = cnn_ref.make_resnet50_cam_state_dict(NUM_CLASSES, seed=0)
+    n_cam, t_cam = 0, 0.0
+    cams = []
+    t_budget = budget_s * 0.5
+    while n_cam < wl.B and (n_cam < 2 or t_cam < t_budget):
+        x = torch.from_numpy(wl.x_host[n_cam])
+        lab = torch.zeros(NUM_CLASSES)
+        lab[torch.from_numpy(wl.keys[n_cam].astype(np.int64))] = 1
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            cam = cnn_ref.resnet50_cam_forward(x, sd)
+            valid = torch.nonzero(lab)[:, 0]
+            cnn_ref.make_cam_tail(cam, wl.sizes[n_cam], valid)
+        t_cam += time.perf_counter() - t0
+        cams.append(cam)
+        n_cam += 1
+    n_crf, t_crf = 0, 0.0
+    if wl.workload == "cam_crf":
+        while n_crf < n_cam and (n_crf < 1 or t_crf < budget_s * 0.5):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                _, hi = cnn_ref.make_cam_tail(cams[n_crf], (S, S), torch.arange(NUM_CLASSES))
+            v = np.concatenate([np.full((1, S * S), 0.15, np.float32), hi.numpy().reshape(NUM_CLASSES, -1)], 0)
+            p = v / v.sum(0, keepdims=True)
+            U = -np.log(np.clip(p, 1e-5, 1.0)).astype(np.float32)
+            helpers.crf_oracle(wl.rgb_host[n_crf], U, CRF_CFG)
+            t_crf += time.perf_counter() - t0
+            n_crf += 1
+    per_img = t_cam / n_cam + (t_crf / n_crf if n_crf else 0.0)
+    return {"value": round(1.0 / per_img, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d images torch-CPU fp32 ResNet50-CAM+tail (%.2f s/img, %d threads) + %d images C dense-CRF "
+                      "M=21 T=10 (%.2f s/img, 1 thread)" % (n_cam, t_cam / n_cam, cores, n_crf,
+                                                            t_crf / n_crf if n_crf else 0.0)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # not launched through torch.distributed.run: start it as a child (nothing touched the GPU yet)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = Workload(local_rank, args.batch, args.precision, args.workload, seed=rank)
+
+    def barrier():
+        wl.ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    wl.ctx.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    # ---- per-stage device times (HIP events on the ctx stream), same resident inputs -------------
+    reps = 5
+    t_cnn = wl.timed(wl.run_cnn, reps)
+    t_tail = wl.timed(wl.run_tail, reps)
+    stages = {"cnn_ms": round(t_cnn, 4), "tail_ms": round(t_tail, 4)}
+    roof_mfma = {"bound": "mfma", "achieved": round(GFLOP_PER_IMAGE * wl.B / t_cnn, 2),
+                 "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s", "traffic": None,
+                 "kernel": "conv_igemm_kernel (whole conv stack, %d launches)" % 55}
+    roof_mfma["frac"] = round(roof_mfma["achieved"] / roof_mfma["peak"], 4)
+    roofline = roof_mfma
+    if args.workload == "cam_crf":
+        t_un = wl.timed(wl.run_unary, reps)
+        t0c = time.perf_counter()
+        crf = wl.crf_create()
+        wl.ctx.sync()
+        t_create = (time.perf_counter() - t0c) * 1e3
+        t_inf = wl.timed(lambda: wl.crf_infer(crf), 3)
+        crf.close()
+        vg, vb = float(wl.vg.mean()), float(wl.vb.mean())
+        by = crf_bytes_per_image(S * S, NUM_CLASSES + 1, CRF_CFG[5], vg, vb)
+        stages.update({"unary_ms": round(t_un, 4), "crf_create_ms": round(t_create, 4), "crf_infer_ms": round(t_inf, 4),
+                       "lattice_vertices_gauss": round(vg, 1), "lattice_vertices_bilat": round(vb, 1)})
+        roof_hbm = {"bound": "hbm", "achieved": round(by * wl.B / (t_inf * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "traffic": None,
+                    "kernel": "CRF mean-field loop (splat/blur/slice, %d iterations)" % CRF_CFG[5]}
+        roof_hbm["frac"] = round(roof_hbm["achieved"] / roof_hbm["peak"], 4)
+        if t_inf > t_cnn:
+            roofline = roof_hbm
+            stages["roofline_mfma"] = roof_mfma
+        else:
+            stages["roofline_hbm"] = roof_hbm
+
+    if rank == 0:
+        images = args.batch * args.steps * world
+        out = {
+            "metric": "images/sec CAM+CRF pseudo-labels, VOC2012 321x321",
+            "value": round(images / elapsed, 3),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": "ResNet50 CAM + dense-CRF (M=21, 10 mean-field iters), 321x321, batch %d "
+                                   "images (=%d samples) per GPU, image-sharded" % (args.batch, 2 * args.batch)
+                       if args.workload == "cam_crf" else
+                       "ResNet50 CAM (make_cam), 321x321, batch %d images per GPU" % args.batch,
+                       "batch_images": args.batch, "num_classes": NUM_CLASSES, "crf_config": list(CRF_CFG),
+                       "parallelism": "image-sharded x%d, no collective" % world},
+            "roofline": roofline,
+            "stages": stages,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

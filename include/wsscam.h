@@ -56,7 +56,8 @@ typedef enum wsc_arch {
 /* arithmetic of the conv stack */
 typedef enum wsc_precision {
     WSC_PREC_BF16 = 0,  /* bf16 operands, fp32 MFMA accumulation, bf16 activations in HBM */
-    WSC_PREC_BF16X3 = 1 /* split-bf16 (hi+lo) operands, 3 MFMA products: fp32-class accuracy */
+    WSC_PREC_BF16X3 = 1, /* split-bf16 (hi+lo) operands, 3 MFMA products: fp32-class accuracy */
+    WSC_PREC_F16 = 2     /* IEEE half operands (11-bit significand, saturating), fp32 accumulation */
 } wsc_precision;
 
 typedef struct wsc_ctx wsc_ctx; /* device + stream + workspace arena */
@@ -158,6 +159,14 @@ int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h,
                         const int32_t *size_hw_host /*[B][2]*/, const int32_t *keys_host,
                         const int32_t *key_off_host /*[B+1]*/, const int64_t *strided_off_host /*[B]*/,
                         const int64_t *highres_off_host /*[B]*/, float *strided_dev, float *highres_dev);
+
+/* Probabilities -> CRF unaries for a [background | class maps] stack:
+ *   v_0 = bg_value, v_{c+1} = maps[b][c][p];  U[b][m][p] = -log(clip(v_m / sum_m v_m, 1e-5, 1))
+ * i.e. eval_cam.py:49-51 (np.pad(high_res, constant_values=cam_eval_thres)) followed by
+ * pydensecrf.utils.unary_from_softmax (03c_hsn/utilities.py:431).
+ *   maps_dev float32 [B][C][N]  ->  unary_dev float32 [B][C+1][N] */
+int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N, float bg_value,
+                        float *unary_dev);
 
 /* F.interpolate(mode='bilinear', align_corners=False) on float32 [C][h][w] -> [C][H][W]
  * (make_cam.py:64-69; also resize_stack 02_cues/utilities.py:20-40 up to the

@@ -15,6 +15,12 @@ def bf16_round(a):
     return u.astype(np.uint32).view(np.float32).reshape(a.shape)
 
 
+def f16_round(a):
+    """Round float32 array to IEEE half (RNE, saturating like the kernels) and back."""
+    a = np.clip(np.ascontiguousarray(a, dtype=np.float32), -65504.0, 65504.0)
+    return a.astype(np.float16).astype(np.float32)
+
+
 _crf_lib = None
 
 

@@ -1,0 +1,97 @@
+"""GPU: single conv layers through the production implicit-GEMM kernel (wsc_conv2d_nchw) against
+torch fp32 conv2d, over the conv shape classes of the CAM networks.
+
+Tolerances (stated per the north star):
+  bf16 mode   -- operands are rounded to bf16, so the oracle is fed the same bf16-rounded operands
+                 and the comparison isolates the kernel: |err| <= 2^-8 |ref| (output rounding to
+                 bf16) + 2e-3 max|ref| (fp32 accumulation order).
+  f16 mode    -- same scheme with IEEE-half rounding: 2^-11 |ref| + 3e-4 max|ref|.
+  bf16x3 mode -- split operands, fp32-class: |err| <= 1e-4 max|ref| against the unrounded oracle.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import bf16_round, f16_round
+from wsscam import _lib
+
+pytestmark = pytest.mark.gpu
+
+# (N, Cin, H, W, Cout, k, stride, pad)
+SHAPES = [
+    (2, 3, 65, 65, 64, 7, 2, 3),      # ResNet stem (small-Cin path, 7x7 s2)
+    (2, 3, 33, 37, 64, 3, 1, 1),      # VGG first layer (small-Cin path, 3x3)
+    (3, 64, 21, 21, 64, 1, 1, 0),     # 1x1 64->64
+    (2, 64, 21, 23, 256, 1, 1, 0),    # 1x1 64->256
+    (2, 256, 17, 17, 64, 1, 1, 0),    # 1x1 256->64
+    (2, 64, 19, 19, 64, 3, 1, 1),     # 3x3 s1
+    (2, 128, 21, 21, 128, 3, 2, 1),   # 3x3 s2 (odd -> 11)
+    (2, 256, 16, 16, 512, 1, 2, 0),   # downsample 1x1 s2
+    (1, 512, 9, 9, 512, 3, 1, 1),     # deep 3x3
+    (2, 2048, 5, 5, 512, 1, 1, 0),    # K = 2048
+    (5, 128, 7, 9, 136, 1, 1, 0),     # Cout not a multiple of the tile (136 -> pad 256), ragged M
+]
+
+
+def _run(ctx, x, w, stride, pad, scale, shift, res, relu, precision):
+    N, Cin, H, W = x.shape
+    x_dev = ctx.to_device(x)
+    r_dev = ctx.to_device(res) if res is not None else None
+    y_dev, shp = _lib.conv2d_nchw(ctx, x_dev, N, Cin, H, W, w, stride, pad, scale, shift, r_dev, relu, precision)
+    return ctx.to_host(y_dev, shp, np.float32)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("precision", [_lib.PREC_BF16, _lib.PREC_F16, _lib.PREC_BF16X3])
+def test_conv_layer(ctx, shape, precision):
+    N, Cin, H, W, Cout, k, stride, pad = shape
+    rng = np.random.default_rng(abs(hash(shape)) % (2 ** 31))
+    x = rng.normal(0, 1, (N, Cin, H, W)).astype(np.float32)
+    # asymmetric weights (transpose-detecting): distinct scale per output channel and tap
+    w = (rng.normal(0, 1, (Cout, Cin, k, k)) * np.sqrt(2.0 / (Cin * k * k))).astype(np.float32)
+    w *= (1.0 + 0.5 * np.arange(Cout, dtype=np.float32) / Cout)[:, None, None, None]
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.normal(0, 0.2, Cout).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = rng.normal(0, 1, (N, Cout, Ho, Wo)).astype(np.float32)
+
+    for use_res, relu in ((False, False), (True, True)):
+        y = _run(ctx, x, w, stride, pad, scale, shift, res if use_res else None, relu, precision)
+        if precision == _lib.PREC_BF16:
+            xr, wr, rr = bf16_round(x), bf16_round(w), bf16_round(res)
+        elif precision == _lib.PREC_F16:
+            xr, wr, rr = f16_round(x), f16_round(w), f16_round(res)
+        else:
+            xr, wr, rr = x, w, res
+        ref = F.conv2d(torch.from_numpy(xr).double(), torch.from_numpy(wr).double(), stride=stride, padding=pad)
+        ref = ref * torch.from_numpy(scale).double()[None, :, None, None] + \
+            torch.from_numpy(shift).double()[None, :, None, None]
+        if use_res:
+            ref = ref + torch.from_numpy(rr).double()
+        if relu:
+            ref = torch.relu(ref)
+        ref = ref.numpy()
+        assert y.shape == ref.shape
+        mx = np.abs(ref).max()
+        err = np.abs(y - ref)
+        if precision == _lib.PREC_BF16:
+            bound = 2.0 ** -8 * np.abs(ref) + 2e-3 * mx
+        elif precision == _lib.PREC_F16:
+            bound = 2.0 ** -11 * np.abs(ref) + 3e-4 * mx
+        else:
+            bound = np.full_like(ref, 1e-4 * mx)
+        bad = err > bound
+        assert not bad.any(), "shape %s prec %d res %s: %d bad, max err %.4g (max|ref| %.3g) at %s" % (
+            shape, precision, use_res, bad.sum(), err.max(), mx, np.unravel_index(err.argmax(), err.shape))
+
+
+def test_conv_identity_weights_detect_transposes(ctx):
+    """A = asymmetric ramp, B = identity-like 1x1 kernel: output must equal the input channel map."""
+    N, C, H, W = 1, 64, 8, 8
+    x = (np.arange(N * C * H * W, dtype=np.float32).reshape(N, C, H, W) % 251) / 16.0
+    w = np.zeros((64, 64, 1, 1), np.float32)
+    perm = (np.arange(64) * 7 + 3) % 64
+    w[np.arange(64), perm, 0, 0] = 1.0
+    y = _run(ctx, x, w, 1, 0, None, None, None, False, _lib.PREC_BF16)
+    assert np.array_equal(y, bf16_round(x)[:, perm])

@@ -1,0 +1,136 @@
+"""GPU: permutohedral dense-CRF (wsc_crf_*) against the C restatement oracle/densecrf_ref.c.
+
+Stated tolerances: arg-max label agreement >= 99.5 %, max|dQ| <= 1e-3.  The
+lattice build is integer/index work and must match the oracle exactly: identical vertex counts.
+"""
+import numpy as np
+import pytest
+
+from tests import helpers
+from wsscam import _lib
+from wsscam.hsn import utilities as hsn_utilities
+from wsscam.misc import imutils
+
+pytestmark = pytest.mark.gpu
+
+CFGS = [(1.5, 3, 40, 13, 10, 10), (3, 3, 50, 5, 10, 10), (3 / 12, 3, 80 / 12, 13, 10, 5)]
+
+
+def _gpu_crf(ctx, rgbs, Us, cfg):
+    B = len(rgbs)
+    H, W, _ = rgbs[0].shape
+    M = Us[0].shape[0]
+    rgb_dev = ctx.to_device(np.stack(rgbs))
+    u_dev = ctx.to_device(np.stack(Us))
+    q_dev = ctx.alloc(B * M * H * W * 4)
+    a_dev = ctx.alloc(B * H * W * 4)
+    crf = _lib.Crf(ctx, rgb_dev, B, H, W, cfg[0], cfg[2], cfg[3])
+    vg, vb = crf.lattice_sizes()
+    crf.inference(u_dev, M, cfg[1], cfg[4], int(cfg[5]), q_dev, a_dev)
+    q = ctx.to_host(q_dev, (B, M, H * W), np.float32)
+    a = ctx.to_host(a_dev, (B, H * W), np.int32)
+    crf.close()
+    return q, a, vg, vb
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+@pytest.mark.parametrize("M", [1, 2, 3, 6, 21, 32])
+def test_crf_vs_oracle(ctx, cfg, M):
+    rng = np.random.default_rng(100 + M)
+    H, W = 57, 75
+    cases = [helpers.synth_crf_case(rng, H, W, M) for _ in range(3)]
+    q, a, vg, vb = _gpu_crf(ctx, [c[0] for c in cases], [c[1] for c in cases], cfg)
+    for b, (rgb, U, _) in enumerate(cases):
+        qr, ar, ls = helpers.crf_oracle(rgb, U, cfg)
+        assert (vg[b], vb[b]) == (ls[0], ls[1]), "lattice vertex counts differ: %s vs %s" % ((vg[b], vb[b]), ls)
+        assert np.abs(q[b] - qr).max() <= 1e-3, np.abs(q[b] - qr).max()
+        assert (a[b] == ar).mean() >= 0.995
+        assert np.abs(q[b].sum(0) - 1).max() <= 1e-5
+        assert np.array_equal(a[b], q[b].argmax(0))
+
+
+def test_crf_321_config3(ctx):
+    """BASELINE config 3 size: 321x321, M=21, 10 iterations, one image (oracle takes ~1 s)."""
+    rng = np.random.default_rng(7)
+    rgb, U, _ = helpers.synth_crf_case(rng, 321, 321, 21)
+    cfg = (1.5, 3, 40, 13, 10, 10)
+    q, a, vg, vb = _gpu_crf(ctx, [rgb], [U], cfg)
+    qr, ar, ls = helpers.crf_oracle(rgb, U, cfg)
+    assert (vg[0], vb[0]) == (ls[0], ls[1])
+    assert np.abs(q[0] - qr).max() <= 1e-3
+    assert (a[0] == ar).mean() >= 0.995
+
+
+def test_crf_invariants(ctx):
+    rng = np.random.default_rng(8)
+    rgb, U, _ = helpers.synth_crf_case(rng, 40, 52, 5)
+    sm = np.exp(-U - (-U).max(0, keepdims=True))
+    sm /= sm.sum(0, keepdims=True)
+    q, _, _, _ = _gpu_crf(ctx, [rgb], [U], (1.5, 0, 40, 13, 0, 5))     # zero compat
+    assert np.abs(q[0] - sm).max() <= 1e-6
+    q, _, _, _ = _gpu_crf(ctx, [rgb], [U], (1.5, 3, 40, 13, 10, 0))    # zero iterations
+    assert np.abs(q[0] - sm).max() <= 1e-6
+    # a batch is the same as its images one by one (no cross-image leakage through the shared rows)
+    rgb2, U2, _ = helpers.synth_crf_case(rng, 40, 52, 5)
+    cfg = (3, 3, 50, 5, 10, 4)
+    qb, ab, _, _ = _gpu_crf(ctx, [rgb, rgb2], [U, U2], cfg)
+    q1, a1, _, _ = _gpu_crf(ctx, [rgb], [U], cfg)
+    q2, a2, _, _ = _gpu_crf(ctx, [rgb2], [U2], cfg)
+    assert np.array_equal(qb[0], q1[0]) and np.array_equal(qb[1], q2[0])
+    # run-to-run bit reproducibility (sorted splat lists, no float atomics)
+    qb2, _, _, _ = _gpu_crf(ctx, [rgb, rgb2], [U, U2], cfg)
+    assert np.array_equal(qb, qb2)
+
+
+def test_crf_flat_image_long_rows(ctx):
+    """A constant image puts thousands of pixels on one bilateral vertex (long splat rows)."""
+    H, W, M = 96, 96, 3
+    rgb = np.full((H, W, 3), 200, np.uint8)
+    rng = np.random.default_rng(12)
+    _, U, _ = helpers.synth_crf_case(rng, H, W, M)
+    cfg = (3, 3, 80, 13, 10, 5)
+    q, a, vg, vb = _gpu_crf(ctx, [rgb], [U], cfg)
+    qr, ar, ls = helpers.crf_oracle(rgb, U, cfg)
+    assert (vg[0], vb[0]) == (ls[0], ls[1])
+    assert np.abs(q[0] - qr).max() <= 1e-3 and (a[0] == ar).mean() >= 0.995
+
+
+def test_dcrf_process_mirror(ctx):
+    """03c_hsn/utilities.py:399-445 semantics: per-image pass classes, scatter back, argmax over all."""
+    rng = np.random.default_rng(13)
+    B, C, H, W = 3, 6, 33, 41
+    probs = np.zeros((B, C, H, W))
+    imgs = np.zeros((B, H, W, 3), np.uint8)
+    pass_sets = [[0, 2, 5], [1, 3, 4], [0, 2, 5]]
+    for b in range(B):
+        rgb, _, p = helpers.synth_crf_case(rng, H, W, 3)
+        imgs[b] = rgb
+        probs[b, pass_sets[b]] = p
+    cfg = [1.5, 3, 40, 13, 10, 10]
+    out = hsn_utilities.dcrf_process(probs, imgs, cfg, ctx=ctx)
+    assert out.shape == (B, H, W) and out.dtype == np.int64
+    for b in range(B):
+        U = imutils.unary_from_softmax(probs[b, pass_sets[b]])
+        qr, ar, _ = helpers.crf_oracle(imgs[b], U, cfg)
+        ref = np.asarray(pass_sets[b])[ar].reshape(H, W)
+        assert (out[b] == ref).mean() >= 0.995
+
+
+def test_crf_inference_label_mirror(ctx):
+    rng = np.random.default_rng(14)
+    H, W, n_labels = 45, 38, 4
+    rgb, _, p = helpers.synth_crf_case(rng, H, W, n_labels)
+    labels = p.argmax(0)
+    out = imutils.crf_inference_label(rgb, labels, "voc12", n_labels=n_labels, ctx=ctx)
+    U = imutils.unary_from_labels(labels, n_labels, 0.7, zero_unsure=False)
+    _, ar, _ = helpers.crf_oracle(rgb, U, (3, 3, 50, 5, 10, 10))
+    assert out.shape == (H, W) and (out.reshape(-1) == ar).mean() >= 0.995
+
+
+def test_crf_key_range_error(ctx):
+    """Bilateral kernel widths so small that lattice coordinates leave the 12-bit packed range."""
+    rgb = np.zeros((64, 64, 3), np.uint8)
+    rgb[..., 0] = 255
+    with pytest.raises(_lib.WscError) as ei:
+        _lib.Crf(ctx, ctx.to_device(rgb), 1, 64, 64, 1.0, 0.02, 0.05)
+    assert ei.value.status == _lib.WSC_ERR_KEY_RANGE

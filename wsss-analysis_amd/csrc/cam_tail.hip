@@ -118,9 +118,41 @@ __global__ void bilinear_kernel(const float *__restrict__ src, int C, int h, int
     }
 }
 
+// U[b][m][p] = -log(clip(v_m / sum_m v_m, 1e-5, 1)),  v_0 = bg_value, v_{c+1} = maps[b][c][p]
+// (eval_cam.py:49-51 pads the max-normalised CAMs with a constant background channel;
+//  pydensecrf.utils.unary_from_softmax, 03c_hsn/utilities.py:431, turns probabilities into unaries)
+__global__ void unary_from_maps_kernel(const float *__restrict__ maps, float bg, int C, int N, long long total,
+                                       float *__restrict__ unary) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / N;
+        const int p = (int)(i - b * N);
+        const float *src = maps + b * C * N + p;
+        float sum = bg;
+        for (int c = 0; c < C; ++c) sum += src[(long long)c * N];
+        float *dst = unary + b * (C + 1) * N + p;
+        const float inv = 1.f / sum;
+        dst[0] = -logf(fminf(fmaxf(bg * inv, 1e-5f), 1.f));
+        for (int c = 0; c < C; ++c) dst[(long long)(c + 1) * N] = -logf(fminf(fmaxf(src[(long long)c * N] * inv, 1e-5f), 1.f));
+    }
+}
+
 } // namespace
 
 extern "C" {
+
+int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N, float bg_value, float *unary_dev) {
+    WSC_CHECK(ctx && maps_dev && unary_dev, WSC_ERR_INVALID, "wsc_unary_from_maps: null argument");
+    WSC_CHECK(B > 0 && C > 0 && N > 0 && bg_value > 0.f, WSC_ERR_INVALID, "wsc_unary_from_maps: bad argument");
+    WSC_HIP(hipSetDevice(ctx->device));
+    const long long total = (long long)B * N;
+    long long g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(unary_from_maps_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, maps_dev, bg_value, C, N,
+                       total, unary_dev);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
 
 int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w,
                         const int32_t *size_hw_host, const int32_t *keys_host, const int32_t *key_off_host,

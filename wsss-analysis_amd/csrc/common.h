@@ -10,6 +10,7 @@
 typedef uint16_t bf16_t; // raw bfloat16 bits
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -27,6 +28,53 @@ __host__ __device__ inline float bf16_to_f32(bf16_t h) {
     v.u = ((uint32_t)h) << 16;
     return v.f;
 }
+
+// ---- IEEE half helpers: round-to-nearest-even, SATURATING at +-65504 (no infinities) -------
+__host__ __device__ inline uint16_t f32_to_f16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const _Float16 h = (_Float16)fminf(fmaxf(f, -65504.f), 65504.f);
+    return __builtin_bit_cast(uint16_t, h);
+#else
+    union { float f; uint32_t u; } v, magic;
+    v.f = f;
+    const uint32_t sign = v.u & 0x80000000u;
+    v.u ^= sign;
+    uint16_t o;
+    if (v.u >= ((127u + 16u) << 23)) {
+        o = v.u > (255u << 23) ? 0x7e00 : 0x7bff; // NaN stays NaN, overflow saturates
+    } else if (v.u < (113u << 23)) { // subnormal half or zero
+        magic.u = ((127u - 15u) + (23u - 10u) + 1u) << 23;
+        v.f += magic.f;
+        o = (uint16_t)(v.u - magic.u);
+    } else {
+        const uint32_t mant_odd = (v.u >> 13) & 1u;
+        v.u += ((15u - 127u) << 23) + 0xfffu;
+        v.u += mant_odd;
+        o = (uint16_t)(v.u >> 13);
+        if (o >= 0x7c00) o = 0x7bff;
+    }
+    return (uint16_t)(o | (sign >> 16));
+#endif
+}
+__host__ __device__ inline float f16_to_f32(uint16_t h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (float)__builtin_bit_cast(_Float16, h);
+#else
+    union { float f; uint32_t u; } o, magic;
+    magic.u = 113u << 23;
+    const uint32_t shifted_exp = 0x7c00u << 13;
+    o.u = ((uint32_t)h & 0x7fffu) << 13;
+    const uint32_t exp = shifted_exp & o.u;
+    o.u += (127u - 15u) << 23;
+    if (exp == shifted_exp) o.u += (128u - 16u) << 23;
+    else if (exp == 0) { o.u += 1u << 23; o.f -= magic.f; }
+    o.u |= ((uint32_t)h & 0x8000u) << 16;
+    return o.f;
+#endif
+}
+// 16-bit storage format of activations / weights: 0 = bfloat16, 1 = IEEE half
+__host__ __device__ inline uint16_t f32_to_h16(float f, int fmt) { return fmt ? f32_to_f16(f) : f32_to_bf16(f); }
+__host__ __device__ inline float h16_to_f32(uint16_t h, int fmt) { return fmt ? f16_to_f32(h) : bf16_to_f32(h); }
 
 // ---- error plumbing -----------------------------------------------------------
 void wsc_set_error(const char *fmt, ...);
@@ -85,18 +133,19 @@ struct ConvLaunch {
     int relu;
     int small_cin; // 0: generic (Cin % 64 == 0); else log2(slots per kernel row): 2 = 7x7 stem, 1 = 3x3 Cin<=4
     int split;     // 1: bf16x3
+    int fmt;       // 16-bit operand format: 0 bf16, 1 f16 (split requires bf16)
 };
 int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p);
 
 // ---- misc kernels ---------------------------------------------------------------------
-int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo);
+int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo, int fmt);
 int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, int C, int k,
-                   int stride, int pad, int Ho, int Wo, bf16_t *y, bf16_t *y_lo);
+                   int stride, int pad, int Ho, int Wo, bf16_t *y, bf16_t *y_lo, int fmt);
 // cam[b][c][y][x] = relu(head[2b][y][x][c]) + relu(head[2b+1][y][w-1-x][c])   (head fp32 NHWC, stride Cs)
 int launch_flip_add(wsc_ctx *ctx, const float *head, int B, int h, int w, int C, int Cs, float *cam);
 // score[b][c] = sigmoid(sum_f mean_hw(feat[2b])[f] * Wc[c][f] + bias[c])
 int launch_gap_linear_sigmoid(wsc_ctx *ctx, const bf16_t *feat, const bf16_t *feat_lo, int B, int hw, int F,
-                              const float *Wc, const float *bias, int C, float *score);
-int launch_bf16_to_f32(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, size_t n, float *y);
-int launch_nchw_to_nhwc(wsc_ctx *ctx, const float *x, int N, int C, int HW, bf16_t *y, bf16_t *y_lo);
-int launch_nhwc_to_nchw(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int C, int HW, float *y);
+                              const float *Wc, const float *bias, int C, float *score, int fmt);
+int launch_bf16_to_f32(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, size_t n, float *y, int fmt);
+int launch_nchw_to_nhwc(wsc_ctx *ctx, const float *x, int N, int C, int HW, bf16_t *y, bf16_t *y_lo, int fmt);
+int launch_nhwc_to_nchw(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int C, int HW, float *y, int fmt);

@@ -9,7 +9,7 @@
 // GEMM view:  M = N*Ho*Wo output pixels, N = Cout, K = kh*kw*Cin.
 //   A[m][k]  gathered on the fly from the NHWC bf16 activation (zero padding by predicate)
 //   B[n][k]  packed weights, K contiguous
-//   C        fp32 accumulators in registers (v_mfma_f32_32x32x16_bf16)
+//   C        fp32 accumulators in registers (v_mfma_f32_32x32x16_bf16 / _f16)
 // Block tile 128 x BN x 64, 4 waves (2x2), each wave 64 x BN/2 as 32x32 MFMA tiles.
 // LDS tiles are [row][64 k] bf16 (128 B rows) with the 16-byte slot XOR-swizzled by
 // (row>>1)&7 so both the ds_write_b128 staging stores and the ds_read_b128 fragment
@@ -51,7 +51,7 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
     return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int BN, int MODE, bool SPLIT>
+template <int BN, int MODE, bool SPLIT, int ET>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
     constexpr int WN = BN / 2;
     constexpr int NI = WN / 32;
@@ -176,22 +176,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int sl = ks * 2 + kgrp;
-            bf16x8_t af[2], bfr[NI];
+            uint4 af[2], bfr[NI];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                uint4 v = *reinterpret_cast<const uint4 *>(sa + lds_off(wm * 64 + mi * 32 + l31, sl));
-                af[mi] = __builtin_bit_cast(bf16x8_t, v);
-            }
+            for (int mi = 0; mi < 2; ++mi)
+                af[mi] = *reinterpret_cast<const uint4 *>(sa + lds_off(wm * 64 + mi * 32 + l31, sl));
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                uint4 v = *reinterpret_cast<const uint4 *>(sb + lds_off(wn * WN + ni * 32 + l31, sl));
-                bfr[ni] = __builtin_bit_cast(bf16x8_t, v);
-            }
+            for (int ni = 0; ni < NI; ++ni)
+                bfr[ni] = *reinterpret_cast<const uint4 *>(sb + lds_off(wn * WN + ni * 32 + l31, sl));
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (ET == 0)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8_t, af[mi]), __builtin_bit_cast(bf16x8_t, bfr[ni]), acc[mi][ni], 0,
+                            0, 0);
+                    else
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8_t, af[mi]), __builtin_bit_cast(f16x8_t, bfr[ni]), acc[mi][ni], 0, 0,
+                            0);
+                }
         }
     };
 
@@ -264,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
                 const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    v[2 * j] += bf16_to_f32((bf16_t)(rw[j] & 0xffffu));
-                    v[2 * j + 1] += bf16_to_f32((bf16_t)(rw[j] >> 16));
+                    v[2 * j] += h16_to_f32((bf16_t)(rw[j] & 0xffffu), ET);
+                    v[2 * j + 1] += h16_to_f32((bf16_t)(rw[j] >> 16), ET);
                 }
                 if (SPLIT) {
                     const uint4 lv = *reinterpret_cast<const uint4 *>(p.res_lo + o);
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
                 uint32_t hw[4], lw[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bf16_t h0 = f32_to_bf16(v[2 * j]), h1 = f32_to_bf16(v[2 * j + 1]);
+                    const bf16_t h0 = f32_to_h16(v[2 * j], ET), h1 = f32_to_h16(v[2 * j + 1], ET);
                     hw[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
                     if (SPLIT) {
                         const bf16_t l0 = f32_to_bf16(v[2 * j] - bf16_to_f32(h0));
@@ -313,14 +317,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
     }
 }
 
-template <int BN, int MODE, bool SPLIT>
+template <int BN, int MODE, bool SPLIT, int ET>
 int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int PIPE = 2 * (A_BYTES + B_BYTES);
     constexpr int EPI = BM * (BN + 4) * 4;
     constexpr int LDS = PIPE > EPI ? PIPE : EPI;
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<BN, MODE, SPLIT>;
+    auto kern = conv_igemm_kernel<BN, MODE, SPLIT, ET>;
     if (!attr_set) {
         WSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -332,15 +336,20 @@ int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
 }
 
 template <int BN>
-int launch_bn(wsc_ctx *ctx, const ConvKArgs &a, int small_cin, int split) {
+int launch_bn(wsc_ctx *ctx, const ConvKArgs &a, int small_cin, int split, int fmt) {
     if (split) {
-        if (small_cin == 0) return launch_variant<BN, 0, true>(ctx, a);
-        if (small_cin == 1) return launch_variant<BN, 1, true>(ctx, a);
-        return launch_variant<BN, 2, true>(ctx, a);
+        if (small_cin == 0) return launch_variant<BN, 0, true, 0>(ctx, a);
+        if (small_cin == 1) return launch_variant<BN, 1, true, 0>(ctx, a);
+        return launch_variant<BN, 2, true, 0>(ctx, a);
     }
-    if (small_cin == 0) return launch_variant<BN, 0, false>(ctx, a);
-    if (small_cin == 1) return launch_variant<BN, 1, false>(ctx, a);
-    return launch_variant<BN, 2, false>(ctx, a);
+    if (fmt) {
+        if (small_cin == 0) return launch_variant<BN, 0, false, 1>(ctx, a);
+        if (small_cin == 1) return launch_variant<BN, 1, false, 1>(ctx, a);
+        return launch_variant<BN, 2, false, 1>(ctx, a);
+    }
+    if (small_cin == 0) return launch_variant<BN, 0, false, 0>(ctx, a);
+    if (small_cin == 1) return launch_variant<BN, 1, false, 0>(ctx, a);
+    return launch_variant<BN, 2, false, 0>(ctx, a);
 }
 
 } // namespace
@@ -373,6 +382,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     a.ntiles_n = p.CoutPad / BN;
     a.nblocks = ((a.M + BM - 1) / BM) * a.ntiles_n;
     if (a.M == 0) return WSC_OK;
-    if (BN == 128) return launch_bn<128>(ctx, a, p.small_cin, p.split);
-    return launch_bn<64>(ctx, a, p.small_cin, p.split);
+    WSC_CHECK(!(p.split && p.fmt), WSC_ERR_INVALID, "conv: split precision requires bf16 planes");
+    if (BN == 128) return launch_bn<128>(ctx, a, p.small_cin, p.split, p.fmt);
+    return launch_bn<64>(ctx, a, p.small_cin, p.split, p.fmt);
 }

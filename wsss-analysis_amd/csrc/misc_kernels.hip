@@ -6,7 +6,7 @@ namespace {
 // float32 NCHW [N][3][H][W] -> bf16 NHWC4 [N][H][W][4] (4th channel zero), optional lo plane.
 // Replaces img.cuda() + the layout torch/cuDNN picks internally (make_cam.py:48).
 __global__ void nchw_to_nhwc4_kernel(const float *__restrict__ x, int N, int HW, bf16_t *__restrict__ y,
-                                     bf16_t *__restrict__ y_lo) {
+                                     bf16_t *__restrict__ y_lo, int fmt) {
     const long long total = (long long)N * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -14,11 +14,11 @@ __global__ void nchw_to_nhwc4_kernel(const float *__restrict__ x, int N, int HW,
         const int p = (int)(i - n * HW);
         const float *s = x + n * 3 * HW + p;
         const float c0 = s[0], c1 = s[HW], c2 = s[2 * HW];
-        const bf16_t h0 = f32_to_bf16(c0), h1 = f32_to_bf16(c1), h2 = f32_to_bf16(c2);
+        const bf16_t h0 = f32_to_h16(c0, fmt), h1 = f32_to_h16(c1, fmt), h2 = f32_to_h16(c2, fmt);
         reinterpret_cast<uint2 *>(y)[i] = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2);
         if (y_lo != nullptr) {
-            const bf16_t l0 = f32_to_bf16(c0 - bf16_to_f32(h0)), l1 = f32_to_bf16(c1 - bf16_to_f32(h1)),
-                         l2 = f32_to_bf16(c2 - bf16_to_f32(h2));
+            const bf16_t l0 = f32_to_bf16(c0 - h16_to_f32(h0, fmt)), l1 = f32_to_bf16(c1 - h16_to_f32(h1, fmt)),
+                         l2 = f32_to_bf16(c2 - h16_to_f32(h2, fmt));
             reinterpret_cast<uint2 *>(y_lo)[i] = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2);
         }
     }
@@ -28,7 +28,7 @@ __global__ void nchw_to_nhwc4_kernel(const float *__restrict__ x, int N, int HW,
 // resnet50.py:64 (3x3 s2 p1), common_cnn.py:131-132 (2x2 s2).
 __global__ void maxpool_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ x_lo, int N, int H,
                                int W, int C, int k, int stride, int pad, int Ho, int Wo,
-                               bf16_t *__restrict__ y, bf16_t *__restrict__ y_lo) {
+                               bf16_t *__restrict__ y, bf16_t *__restrict__ y_lo, int fmt) {
     const int C8 = C >> 3;
     const long long total = (long long)N * Ho * Wo * C8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -54,8 +54,8 @@ __global__ void maxpool_kernel(const bf16_t *__restrict__ x, const bf16_t *__res
                 float f[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    f[2 * j] = bf16_to_f32((bf16_t)(vw[j] & 0xffffu));
-                    f[2 * j + 1] = bf16_to_f32((bf16_t)(vw[j] >> 16));
+                    f[2 * j] = h16_to_f32((bf16_t)(vw[j] & 0xffffu), fmt);
+                    f[2 * j + 1] = h16_to_f32((bf16_t)(vw[j] >> 16), fmt);
                 }
                 if (x_lo != nullptr) {
                     const uint4 l = *reinterpret_cast<const uint4 *>(x_lo + o);
@@ -73,10 +73,10 @@ __global__ void maxpool_kernel(const bf16_t *__restrict__ x, const bf16_t *__res
         uint32_t hw[4], lw[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bf16_t h0 = f32_to_bf16(best[2 * j]), h1 = f32_to_bf16(best[2 * j + 1]);
+            const bf16_t h0 = f32_to_h16(best[2 * j], fmt), h1 = f32_to_h16(best[2 * j + 1], fmt);
             hw[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            const bf16_t l0 = f32_to_bf16(best[2 * j] - bf16_to_f32(h0));
-            const bf16_t l1 = f32_to_bf16(best[2 * j + 1] - bf16_to_f32(h1));
+            const bf16_t l0 = f32_to_bf16(best[2 * j] - h16_to_f32(h0, fmt));
+            const bf16_t l1 = f32_to_bf16(best[2 * j + 1] - h16_to_f32(h1, fmt));
             lw[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
         }
         const long long oo = (((long long)n * Ho + ho) * Wo + wo) * C + c8 * 8;
@@ -110,7 +110,8 @@ __global__ void flip_add_kernel(const float *__restrict__ head, int B, int h, in
 // (m7_cam.py:32-35: MaxPool 2x2 then AdaptiveMaxPool2d((1,1))).
 __global__ void gap_linear_sigmoid_kernel(const bf16_t *__restrict__ feat, const bf16_t *__restrict__ feat_lo,
                                           int hw, int F, const float *__restrict__ Wc,
-                                          const float *__restrict__ bias, int C, float *__restrict__ score) {
+                                          const float *__restrict__ bias, int C, float *__restrict__ score,
+                                          int fmt) {
     extern __shared__ float gap[]; // F floats
     const int b = blockIdx.x;
     const long long img = (long long)(2 * b) * (hw < 0 ? -hw : hw) * F;
@@ -121,7 +122,7 @@ __global__ void gap_linear_sigmoid_kernel(const bf16_t *__restrict__ feat, const
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
         float s = use_max ? -3.0e38f : 0.f;
         for (int p = 0; p < npix; ++p) {
-            float v = bf16_to_f32(f0[(long long)p * F + f]);
+            float v = h16_to_f32(f0[(long long)p * F + f], fmt);
             if (l0) v += bf16_to_f32(l0[(long long)p * F + f]);
             s = use_max ? fmaxf(s, v) : s + v;
         }
@@ -138,9 +139,9 @@ __global__ void gap_linear_sigmoid_kernel(const bf16_t *__restrict__ feat, const
 }
 
 __global__ void bf16_to_f32_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ x_lo, size_t n,
-                                   float *__restrict__ y) {
+                                   float *__restrict__ y, int fmt) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float v = bf16_to_f32(x[i]);
+        float v = h16_to_f32(x[i], fmt);
         if (x_lo) v += bf16_to_f32(x_lo[i]);
         y[i] = v;
     }
@@ -148,7 +149,7 @@ __global__ void bf16_to_f32_kernel(const bf16_t *__restrict__ x, const bf16_t *_
 
 // generic layout changes for the single-layer entry point (wsc_conv2d_nchw)
 __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, int N, int C, int HW, bf16_t *__restrict__ y,
-                                    bf16_t *__restrict__ y_lo) {
+                                    bf16_t *__restrict__ y_lo, int fmt) {
     const long long total = (long long)N * C * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -157,13 +158,13 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, int N, int C, i
         const int p = (int)(r % HW);
         const long long n = r / HW;
         const float v = x[(n * C + c) * HW + p];
-        const bf16_t h = f32_to_bf16(v);
+        const bf16_t h = f32_to_h16(v, fmt);
         y[i] = h;
-        if (y_lo) y_lo[i] = f32_to_bf16(v - bf16_to_f32(h));
+        if (y_lo) y_lo[i] = f32_to_bf16(v - h16_to_f32(h, fmt));
     }
 }
 __global__ void nhwc_to_nchw_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ x_lo, int N, int C,
-                                    int HW, float *__restrict__ y) {
+                                    int HW, float *__restrict__ y, int fmt) {
     const long long total = (long long)N * C * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -172,7 +173,7 @@ __global__ void nhwc_to_nchw_kernel(const bf16_t *__restrict__ x, const bf16_t *
         const int c = (int)(r % C);
         const long long n = r / C;
         const long long src = (n * HW + p) * C + c;
-        float v = bf16_to_f32(x[src]);
+        float v = h16_to_f32(x[src], fmt);
         if (x_lo) v += bf16_to_f32(x_lo[src]);
         y[i] = v;
     }
@@ -187,20 +188,20 @@ inline int grid_for(long long total, int block = 256, int cap = 256 * 16) {
 
 } // namespace
 
-int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo) {
+int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo, int fmt) {
     const long long total = (long long)N * H * W;
     hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, N, H * W, y,
-                       y_lo);
+                       y_lo, fmt);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
 
 int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, int C, int k,
-                   int stride, int pad, int Ho, int Wo, bf16_t *y, bf16_t *y_lo) {
+                   int stride, int pad, int Ho, int Wo, bf16_t *y, bf16_t *y_lo, int fmt) {
     WSC_CHECK(C % 8 == 0, WSC_ERR_INVALID, "maxpool: C=%d not a multiple of 8", C);
     const long long total = (long long)N * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, x_lo, N, H, W, C, k,
-                       stride, pad, Ho, Wo, y, y_lo);
+                       stride, pad, Ho, Wo, y, y_lo, fmt);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
@@ -214,30 +215,30 @@ int launch_flip_add(wsc_ctx *ctx, const float *head, int B, int h, int w, int C,
 }
 
 int launch_gap_linear_sigmoid(wsc_ctx *ctx, const bf16_t *feat, const bf16_t *feat_lo, int B, int hw, int F,
-                              const float *Wc, const float *bias, int C, float *score) {
+                              const float *Wc, const float *bias, int C, float *score, int fmt) {
     hipLaunchKernelGGL(gap_linear_sigmoid_kernel, dim3(B), dim3(256), F * sizeof(float), ctx->stream, feat,
-                       feat_lo, hw, F, Wc, bias, C, score);
+                       feat_lo, hw, F, Wc, bias, C, score, fmt);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
 
-int launch_bf16_to_f32(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, size_t n, float *y) {
+int launch_bf16_to_f32(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, size_t n, float *y, int fmt) {
     hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for((long long)n)), dim3(256), 0, ctx->stream, x, x_lo, n,
-                       y);
+                       y, fmt);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
 
-int launch_nchw_to_nhwc(wsc_ctx *ctx, const float *x, int N, int C, int HW, bf16_t *y, bf16_t *y_lo) {
+int launch_nchw_to_nhwc(wsc_ctx *ctx, const float *x, int N, int C, int HW, bf16_t *y, bf16_t *y_lo, int fmt) {
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)N * C * HW)), dim3(256), 0, ctx->stream, x, N, C,
-                       HW, y, y_lo);
+                       HW, y, y_lo, fmt);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
 
-int launch_nhwc_to_nchw(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int C, int HW, float *y) {
+int launch_nhwc_to_nchw(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int C, int HW, float *y, int fmt) {
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)N * C * HW)), dim3(256), 0, ctx->stream, x, x_lo,
-                       N, C, HW, y);
+                       N, C, HW, y, fmt);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }

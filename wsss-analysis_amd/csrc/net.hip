@@ -46,7 +46,7 @@ struct Op {
 
 struct wsc_net {
     wsc_ctx *ctx = nullptr;
-    int arch = 0, C = 0, split = 0, F = 0;
+    int arch = 0, C = 0, split = 0, fmt = 0, F = 0;
     std::vector<ConvW> convs;
     std::vector<Op> ops;
     int final_buf = 0;
@@ -128,7 +128,7 @@ int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, 
     for (int co = 0; co < Cout; ++co) {
         bf16_t *row = wp.data() + (size_t)co * Kw;
         auto put = [&](int k, float v) {
-            const bf16_t h = f32_to_bf16(v);
+            const bf16_t h = f32_to_h16(v, net->fmt);
             row[k] = h;
             if (net->split) row[Kbase + k] = f32_to_bf16(v - bf16_to_f32(h));
         };
@@ -399,7 +399,7 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
     }
     *extra = (void *)p;
 
-    WSC_TRY(launch_nchw_to_nhwc4(ctx, x_dev, N, S, S, xin, xin_lo));
+    WSC_TRY(launch_nchw_to_nhwc4(ctx, x_dev, N, S, S, xin, xin_lo, net->fmt));
     int bh[4] = {0, 0, 0, 0}, bw[4] = {0, 0, 0, 0}, bc[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < net->ops.size(); ++i) {
         const Op &op = net->ops[i];
@@ -418,11 +418,11 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
             L.N = N; L.H = H; L.W = W; L.Cin = c.Cin; L.Ho = pl.H[i]; L.Wo = pl.W[i];
             L.Cout = c.Cout; L.CoutPad = c.CoutPad;
             L.kh = c.kh; L.kw = c.kw; L.stride = c.stride; L.pad = c.pad; L.relu = c.relu;
-            L.small_cin = c.small_cin; L.split = net->split;
+            L.small_cin = c.small_cin; L.split = net->split; L.fmt = net->fmt;
             WSC_TRY(conv_igemm_launch(ctx, L));
         } else {
             WSC_TRY(launch_maxpool(ctx, src, src_lo, N, H, W, C, op.pk, op.ps, op.pp, pl.H[i], pl.W[i], buf[op.out],
-                                   buf_lo[op.out]));
+                                   buf_lo[op.out], net->fmt));
         }
         bh[op.out] = pl.H[i]; bw[op.out] = pl.W[i]; bc[op.out] = pl.C[i];
     }
@@ -443,8 +443,8 @@ int wsc_net_create(wsc_ctx *ctx, int arch, const wsc_tensor_desc *weights, int n
                    int precision, wsc_net **out) {
     WSC_CHECK(ctx && weights && out && n_weights > 0, WSC_ERR_INVALID, "wsc_net_create: null argument");
     WSC_CHECK(num_classes > 0 && num_classes <= 64, WSC_ERR_INVALID, "num_classes=%d outside [1,64]", num_classes);
-    WSC_CHECK(precision == WSC_PREC_BF16 || precision == WSC_PREC_BF16X3, WSC_ERR_INVALID, "unknown precision %d",
-              precision);
+    WSC_CHECK(precision == WSC_PREC_BF16 || precision == WSC_PREC_BF16X3 || precision == WSC_PREC_F16,
+              WSC_ERR_INVALID, "unknown precision %d", precision);
     WSC_HIP(hipSetDevice(ctx->device));
     Dict d;
     for (int i = 0; i < n_weights; ++i) {
@@ -463,6 +463,7 @@ int wsc_net_create(wsc_ctx *ctx, int arch, const wsc_tensor_desc *weights, int n
     net->arch = arch;
     net->C = num_classes;
     net->split = precision == WSC_PREC_BF16X3 ? 1 : 0;
+    net->fmt = precision == WSC_PREC_F16 ? 1 : 0;
     int st;
     switch (arch) {
     case WSC_ARCH_RESNET50_CAM: st = build_resnet50(net, d); break;
@@ -522,12 +523,12 @@ int wsc_net_forward_cam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, in
     L.x = feat; L.x_lo = feat_lo; L.w = c.w; L.s1 = c.s1; L.b1 = c.b1;
     L.y_f32 = head_out;
     L.N = N; L.H = hf; L.W = wf; L.Cin = c.Cin; L.Ho = hf; L.Wo = wf; L.Cout = c.Cout; L.CoutPad = c.CoutPad;
-    L.kh = 1; L.kw = 1; L.stride = 1; L.pad = 0; L.relu = 0; L.small_cin = 0; L.split = net->split;
+    L.kh = 1; L.kw = 1; L.stride = 1; L.pad = 0; L.relu = 0; L.small_cin = 0; L.split = net->split; L.fmt = net->fmt;
     WSC_TRY(conv_igemm_launch(ctx, L));
     WSC_TRY(launch_flip_add(ctx, head_out, B, hf, wf, net->C, net->C, cam_dev));
     if (score_dev != nullptr)
         WSC_TRY(launch_gap_linear_sigmoid(ctx, feat, feat_lo, B, net->cls_max ? -(hf * wf) : hf * wf, net->F,
-                                          net->cls_w, net->cls_b, net->Ccls, score_dev));
+                                          net->cls_w, net->cls_b, net->Ccls, score_dev, net->fmt));
     return WSC_OK;
 }
 
@@ -539,7 +540,7 @@ int wsc_net_forward_features(wsc_ctx *ctx, const wsc_net *net, const float *x_de
     int hf, wf;
     void *extra;
     WSC_TRY(run_backbone(ctx, net, x_dev, N, S, 0, &feat, &feat_lo, &hf, &wf, &extra));
-    return launch_bf16_to_f32(ctx, feat, feat_lo, (size_t)N * hf * wf * net->F, feat_dev);
+    return launch_bf16_to_f32(ctx, feat, feat_lo, (size_t)N * hf * wf * net->F, feat_dev, net->fmt);
 }
 
 // One convolution layer through the production kernel, NCHW fp32 in / out (layout changes and
@@ -553,6 +554,7 @@ int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int
     wsc_net tmp;
     tmp.ctx = ctx;
     tmp.split = precision == WSC_PREC_BF16X3 ? 1 : 0;
+    tmp.fmt = precision == WSC_PREC_F16 ? 1 : 0;
     HostTensor wt;
     wt.data = w_host; wt.ndim = 4; wt.shape[0] = Cout; wt.shape[1] = Cin; wt.shape[2] = kh; wt.shape[3] = kw;
     std::vector<float> s1(Cout, 1.f), b1(Cout, 0.f);
@@ -581,9 +583,9 @@ int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int
     bf16_t *yo_lo = nullptr; if (tmp.split) { yo_lo = (bf16_t *)p; p += al(out_e * 2); }
     bf16_t *ri = nullptr, *ri_lo = nullptr;
     if (residual_dev) { ri = (bf16_t *)p; p += al(out_e * 2); if (tmp.split) { ri_lo = (bf16_t *)p; p += al(out_e * 2); } }
-    if (small) st = launch_nchw_to_nhwc4(ctx, x_dev, N, H, W, xi, xi_lo);
-    else st = launch_nchw_to_nhwc(ctx, x_dev, N, Cin, H * W, xi, xi_lo);
-    if (st == WSC_OK && residual_dev) st = launch_nchw_to_nhwc(ctx, residual_dev, N, Cout, Ho * Wo, ri, ri_lo);
+    if (small) st = launch_nchw_to_nhwc4(ctx, x_dev, N, H, W, xi, xi_lo, tmp.fmt);
+    else st = launch_nchw_to_nhwc(ctx, x_dev, N, Cin, H * W, xi, xi_lo, tmp.fmt);
+    if (st == WSC_OK && residual_dev) st = launch_nchw_to_nhwc(ctx, residual_dev, N, Cout, Ho * Wo, ri, ri_lo, tmp.fmt);
     if (st == WSC_OK) {
         ConvLaunch L;
         memset(&L, 0, sizeof(L));
@@ -591,9 +593,10 @@ int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int
         L.y = yo; L.y_lo = yo_lo;
         L.N = N; L.H = H; L.W = W; L.Cin = c.Cin; L.Ho = Ho; L.Wo = Wo; L.Cout = Cout; L.CoutPad = c.CoutPad;
         L.kh = kh; L.kw = kw; L.stride = stride; L.pad = pad; L.relu = relu; L.small_cin = small; L.split = tmp.split;
+        L.fmt = tmp.fmt;
         st = conv_igemm_launch(ctx, L);
     }
-    if (st == WSC_OK) st = launch_nhwc_to_nchw(ctx, yo, yo_lo, N, Cout, Ho * Wo, y_dev);
+    if (st == WSC_OK) st = launch_nhwc_to_nchw(ctx, yo, yo_lo, N, Cout, Ho * Wo, y_dev, tmp.fmt);
     cleanup();
     return st;
 }

@@ -29,6 +29,7 @@ ARCH_M7_CAM = 2
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
+PREC_F16 = 2
 
 
 class WscError(RuntimeError):
@@ -76,6 +77,7 @@ _SIGNATURES = {
     "wsc_net_forward_features": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "wsc_conv2d_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "wsc_cam_postprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wsc_unary_from_maps": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     "wsc_crf_create": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _f, ctypes.POINTER(_vp)]),
     "wsc_crf_destroy": (None, [_vp]),
@@ -334,6 +336,10 @@ def conv2d_nchw(ctx, x_dev, N, Cin, H, W, w, stride, pad, scale=None, shift=None
                                    None if sc is None else sc.ctypes.data, None if sh is None else sh.ctypes.data,
                                    _ptr(residual_dev), int(relu), precision, _ptr(y_dev)))
     return y_dev, (N, Cout, Ho, Wo)
+
+
+def unary_from_maps(ctx, maps_dev, B, C, N, bg_value, unary_dev):
+    check(ctx._lib.wsc_unary_from_maps(ctx.h, _ptr(maps_dev), B, C, N, float(bg_value), _ptr(unary_dev)))
 
 
 def bilinear_resize(ctx, src_dev, C, h, w, dst_dev, H, W):
