@@ -1,0 +1,64 @@
+"""__graft_entry__.smoke(): one small invocation of the hot path on cuda:0, checked against the oracle.
+
+ResNet50-CAM (2 images, 97x97 network input) -> make_cam tail -> [bg | maps] unaries -> dense-CRF,
+all through the C ABI; compared with the torch fp32 restatement and the C CRF restatement."""
+import numpy as np
+import torch
+
+from oracle import cnn_ref
+from tests import helpers
+from wsscam import _lib
+from wsscam.net import resnet50_cam
+from wsscam.step import make_cam
+
+
+def run():
+    S, C = 97, 20
+    sd = cnn_ref.make_resnet50_cam_state_dict(C, seed=0)
+    rng = np.random.default_rng(1)
+    sizes = [(120, 150), (97, 97)]
+    imgs = [cnn_ref.synth_image(rng, *sz) for sz in sizes]
+    labels = [np.zeros(C, np.float32), np.zeros(C, np.float32)]
+    labels[0][[2, 9]] = 1
+    labels[1][[14]] = 1
+    packs = [{"name": "smoke%d" % i, "img": cnn_ref.msf_pack(im, (S, S)), "size": sz, "label": lb}
+             for i, (im, sz, lb) in enumerate(zip(imgs, sizes, labels))]
+
+    class Args:
+        split = "train_aug"
+        dataset = "voc12"
+        cam_out_dir = None
+
+    model = resnet50_cam.CAM(None, "voc12", "", C, None, precision=_lib.PREC_F16)
+    model.load_state_dict(sd)
+    model.eval().cuda(0)
+    arch, cus = model.ctx.device_info()
+    outs = make_cam.process_batch(model, packs, Args, save=False)
+    worst = 0.0
+    for p, o in zip(packs, outs):
+        ref = cnn_ref.make_cam_image(torch.from_numpy(p["img"]), sd, p["size"], torch.from_numpy(p["label"]))
+        assert np.array_equal(o["keys"], ref["keys"])
+        worst = max(worst, float(np.abs(o["high_res"] - ref["high_res"]).max()),
+                    float(np.abs(o["cam"] - ref["cam"]).max()))
+    assert worst <= 2e-2, "CAM parity %.3g > 2e-2" % worst
+
+    # CRF on the second image at its native 97x97 with [bg | the GT class map] probabilities
+    ctx = model.ctx
+    hi = outs[1]["high_res"]  # (1, 97, 97)
+    v = np.concatenate([np.full((1, 97 * 97), 0.15, np.float32), hi.reshape(1, -1)], 0)
+    p = v / v.sum(0, keepdims=True)
+    U = np.ascontiguousarray(-np.log(np.clip(p, 1e-5, 1.0)).astype(np.float32))
+    cfg = (1.5, 3, 40, 13, 10, 10)
+    crf = _lib.Crf(ctx, ctx.to_device(imgs[1]), 1, 97, 97, cfg[0], cfg[2], cfg[3])
+    q_dev = ctx.alloc(2 * 97 * 97 * 4)
+    a_dev = ctx.alloc(97 * 97 * 4)
+    crf.inference(ctx.to_device(U), 2, cfg[1], cfg[4], cfg[5], q_dev, a_dev)
+    q = ctx.to_host(q_dev, (2, 97 * 97), np.float32)
+    a = ctx.to_host(a_dev, (97 * 97,), np.int32)
+    crf.close()
+    qr, ar, _ = helpers.crf_oracle(imgs[1], U, cfg)
+    dq = float(np.abs(q - qr).max())
+    agree = float((a == ar).mean())
+    assert dq <= 1e-3 and agree >= 0.995, (dq, agree)
+    print("smoke ok on %s (%d CUs): CAM max|d| %.2e (f16), CRF max|dQ| %.2e, label agreement %.4f"
+          % (arch, cus, worst, dq, agree))

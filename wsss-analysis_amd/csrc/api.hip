@@ -33,6 +33,63 @@ int wsc_ctx_workspace(wsc_ctx *ctx, size_t bytes, void **out) {
     return WSC_OK;
 }
 
+int wsc_ctx_cached_alloc(wsc_ctx *ctx, size_t bytes, void **out) {
+    size_t want = bytes < 256 ? 256 : bytes;
+    want = want <= (1u << 20) ? (want + 4095) / 4096 * 4096 : (want + (2u << 20) - 1) / (2u << 20) * (2u << 20);
+    auto it = ctx->free_blocks.lower_bound(want);
+    if (it != ctx->free_blocks.end() && it->first <= 2 * want + (1u << 20)) {
+        *out = it->second;
+        ctx->live_blocks[it->second] = it->first;
+        ctx->free_blocks.erase(it);
+        return WSC_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
+        ctx->free_blocks.clear();
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        wsc_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        return WSC_ERR_NOMEM;
+    }
+    ctx->live_blocks[p] = want;
+    *out = p;
+    return WSC_OK;
+}
+
+void wsc_ctx_cached_free(wsc_ctx *ctx, void *p) {
+    if (!p) return;
+    auto it = ctx->live_blocks.find(p);
+    if (it == ctx->live_blocks.end()) return;
+    ctx->free_blocks.emplace(it->second, p);
+    ctx->live_blocks.erase(it);
+}
+
+int wsc_ctx_upload_small(wsc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    if (bytes == 0) return WSC_OK;
+    if (ctx->pinned_busy) {
+        WSC_HIP(hipEventSynchronize(ctx->pinned_ev));
+        ctx->pinned_busy = false;
+    }
+    if (bytes > ctx->pinned_bytes) {
+        if (ctx->pinned) WSC_HIP(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        const size_t want = bytes * 2 < (64u << 10) ? (64u << 10) : bytes * 2;
+        WSC_HIP(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    memcpy(ctx->pinned, src_host, bytes);
+    WSC_HIP(hipMemcpyAsync(dst_dev, ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    WSC_HIP(hipEventRecord(ctx->pinned_ev, ctx->stream));
+    ctx->pinned_busy = true;
+    return WSC_OK;
+}
+
 extern "C" {
 
 int wsc_version(void) { return WSC_VERSION; }
@@ -66,6 +123,7 @@ int wsc_ctx_create(int device, void *stream, wsc_ctx **out) {
         WSC_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->own_stream = true;
     }
+    WSC_HIP(hipEventCreateWithFlags(&ctx->pinned_ev, hipEventDisableTiming));
     WSC_HIP(hipEventCreate(&ctx->ev0));
     WSC_HIP(hipEventCreate(&ctx->ev1));
     *out = ctx;
@@ -77,7 +135,10 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
+    for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_ev) (void)hipEventDestroy(ctx->pinned_ev);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

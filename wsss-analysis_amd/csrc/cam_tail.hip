@@ -189,14 +189,12 @@ int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h,
     if (jobs.empty()) return WSC_OK;
     WSC_CHECK(strided_dev && highres_dev, WSC_ERR_INVALID, "wsc_cam_postprocess: null output");
     WSC_CHECK(jobs.size() <= 65535, WSC_ERR_INVALID, "too many (image, class) jobs in one call: %zu", jobs.size());
-    // descriptor + maxima live in a small per-call device allocation released on the stream
+    // descriptor + maxima live in a small block of the ctx's stream-ordered cache
     const size_t jb = jobs.size() * sizeof(TailJob), mb = jobs.size() * 2 * sizeof(unsigned int);
     char *d = nullptr;
-    WSC_HIP(hipMallocAsync((void **)&d, jb + mb, ctx->stream));
-    WSC_HIP(hipMemcpyAsync(d, jobs.data(), jb, hipMemcpyHostToDevice, ctx->stream));
+    WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + mb, (void **)&d));
+    WSC_TRY(wsc_ctx_upload_small(ctx, d, jobs.data(), jb)); // through pinned staging: no host sync
     WSC_HIP(hipMemsetAsync(d + jb, 0, mb, ctx->stream));
-    // jobs is pageable host memory: make sure the copy has consumed it before it goes away
-    WSC_HIP(hipStreamSynchronize(ctx->stream));
     const dim3 grid((max_pix + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, (unsigned)jobs.size());
     const size_t lds = (size_t)h * w * sizeof(float);
     hipLaunchKernelGGL(cam_tail_kernel<false>, grid, dim3(256), lds, ctx->stream, cam_dev, (const TailJob *)d, h, w,
@@ -204,7 +202,7 @@ int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h,
     hipLaunchKernelGGL(cam_tail_kernel<true>, grid, dim3(256), lds, ctx->stream, cam_dev, (const TailJob *)d, h, w,
                        (unsigned int *)(d + jb), strided_dev, highres_dev);
     WSC_HIP(hipGetLastError());
-    WSC_HIP(hipFreeAsync(d, ctx->stream));
+    wsc_ctx_cached_free(ctx, d); // stream-ordered reuse
     return WSC_OK;
 }
 

@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/wsscam.h"
@@ -113,9 +115,20 @@ struct wsc_ctx {
     // small pinned staging buffer for descriptor uploads
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    hipEvent_t pinned_ev = nullptr; // completion of the last copy out of `pinned`
+    bool pinned_busy = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // stream-ordered caching allocator: blocks released by wsc_ctx_cached_free are reused by later
+    // requests of the same ctx (all work of a ctx is on one stream, so reuse is ordered after the
+    // previous user) instead of going through hipFree/hipMalloc (both synchronise the device).
+    std::multimap<size_t, void *> free_blocks;
+    std::unordered_map<void *, size_t> live_blocks;
 };
 int wsc_ctx_workspace(wsc_ctx *ctx, size_t bytes, void **out);
+int wsc_ctx_cached_alloc(wsc_ctx *ctx, size_t bytes, void **out);
+void wsc_ctx_cached_free(wsc_ctx *ctx, void *p);
+// copies `bytes` of host data to dst_dev through the ctx's pinned staging buffer, asynchronously
+int wsc_ctx_upload_small(wsc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 
 // ---- conv (implicit GEMM) -----------------------------------------------------------
 // One conv layer as the kernel sees it.  Activations are NHWC bf16; in split

@@ -44,6 +44,11 @@ struct LatticeDev {
     int32_t *csr_pix = nullptr;   // [B*N*(d+1)]  global pixel index
     float *csr_w = nullptr;       // [B*N*(d+1)]
     int2 *nbr = nullptr;          // [(d+1)][rows]
+    // splat work items: every row is cut into chunks of <= SPLAT_CHUNK gathered pixels
+    int32_t *chunk_base = nullptr; // [rows + 1] first chunk of each row
+    int32_t *chunk_row = nullptr;  // [n_chunks] owning row
+    int32_t *long_rows = nullptr;  // [n_long] rows with more than one chunk
+    int n_chunks = 0, n_long = 0;
     float alpha = 0.f;
     std::vector<int32_t> v_per_image;
 };
@@ -496,33 +501,84 @@ __global__ void neighbors_kernel(const unsigned long long *__restrict__ rowkey, 
 // ---- iteration kernels ------------------------------------------------------------------
 
 // Splat in gather form: val[row][m] = sum over the row's pixels of w * (norm[p] * Q[p][m]).
-// MP lanes cooperate on one row (lane m < M active); the pixel list is read once per group.
-// NORM_IN = false: splat of the all-ones vector (M = 1) for the normalisation pass.
+// Work item = one chunk (<= SPLAT_CHUNK consecutive entries of one row's sorted pixel list) x MP
+// lanes (lane m < M active).  Rows of flat image regions gather thousands of pixels; cutting
+// them bounds the serial chain per work item.  Entries are fetched 8 at a time so that 8
+// independent Q-row gathers are in flight per lane; the sum itself stays in list order.
+// A single-chunk row writes val directly; chunks of long rows write partials that
+// splat_combine_kernel adds up in chunk order (fixed order: bit-reproducible).
+// ONES: splat of the all-ones vector (M = 1) for the normalisation pass.
+constexpr int SPLAT_CHUNK = 32;
+
 template <int MP, bool ONES>
 __global__ __launch_bounds__(256) void splat_kernel(const unsigned *__restrict__ start,
+                                                    const int32_t *__restrict__ chunk_base,
+                                                    const int32_t *__restrict__ chunk_row,
                                                     const int32_t *__restrict__ csr_pix,
                                                     const float *__restrict__ csr_w, const float *__restrict__ norm,
-                                                    const float *__restrict__ q, int M, int rows,
-                                                    float *__restrict__ val) {
+                                                    const float *__restrict__ q, int M, int n_chunks,
+                                                    float *__restrict__ val, float *__restrict__ part) {
     constexpr int GPB = 256 / MP; // groups per block
     const int m = threadIdx.x % MP;
     const int g = threadIdx.x / MP;
-    for (long long row = (long long)blockIdx.x * GPB + g; row < rows; row += (long long)gridDim.x * GPB) {
-        if (row == 0) {
-            if (m < M) val[m] = 0.f;
-            continue;
-        }
-        const unsigned s = start[row], e = start[row + 1];
+    for (long long c = (long long)blockIdx.x * GPB + g; c < n_chunks; c += (long long)gridDim.x * GPB) {
+        const int row = chunk_row[c];
+        const int cb = chunk_base[row];
+        const bool single = chunk_base[row + 1] - cb == 1;
+        const unsigned s = start[row] + (unsigned)(c - cb) * SPLAT_CHUNK;
+        const unsigned e = min(s + SPLAT_CHUNK, start[row + 1]);
+        if (m >= M) continue;
         float acc = 0.f;
-        if (m < M) {
-            for (unsigned i = s; i < e; ++i) {
-                const int p = csr_pix[i];
-                const float w = csr_w[i];
-                const float in = ONES ? 1.f : q[(long long)p * M + m] * norm[p];
-                acc += w * in;
+        for (unsigned i = s; i < e; i += 8) {
+            int p[8];
+            float w[8], in[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned idx = min(i + j, e - 1);
+                p[j] = csr_pix[idx];
+                w[j] = i + j < e ? csr_w[idx] : 0.f;
             }
-            val[row * M + m] = acc;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) in[j] = ONES ? 1.f : q[(long long)p[j] * M + m] * norm[p[j]];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += w[j] * in[j];
         }
+        if (single) val[(long long)row * M + m] = acc;
+        else part[c * M + m] = acc;
+    }
+}
+
+template <int MP>
+__global__ __launch_bounds__(256) void splat_combine_kernel(const int32_t *__restrict__ long_rows, int n_long,
+                                                            const int32_t *__restrict__ chunk_base,
+                                                            const float *__restrict__ part, int M,
+                                                            float *__restrict__ val) {
+    constexpr int GPB = 256 / MP;
+    const int m = threadIdx.x % MP;
+    const int g = threadIdx.x / MP;
+    if (m >= M) return;
+    for (int i = blockIdx.x * GPB + g; i < n_long; i += gridDim.x * GPB) {
+        const int row = long_rows[i];
+        const int cb = chunk_base[row], ce = chunk_base[row + 1];
+        float acc = 0.f;
+        for (int c = cb; c < ce; ++c) acc += part[(long long)c * M + m];
+        val[(long long)row * M + m] = acc;
+    }
+}
+
+// chunk bookkeeping (lattice build)
+__global__ void count_chunks_kernel(const unsigned *__restrict__ start, int rows, unsigned *__restrict__ nch) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+        const unsigned len = start[row + 1] - start[row];
+        nch[row] = len <= SPLAT_CHUNK ? 1u : (len + SPLAT_CHUNK - 1) / SPLAT_CHUNK;
+    }
+}
+__global__ void fill_chunks_kernel(const int32_t *__restrict__ chunk_base, int rows, int32_t *__restrict__ chunk_row,
+                                   unsigned *__restrict__ n_long, int32_t *__restrict__ long_rows) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+        const int cb = chunk_base[row], ce = chunk_base[row + 1];
+        for (int c = cb; c < ce; ++c) chunk_row[c] = row;
+        if (ce - cb > 1) long_rows[atomicAdd(n_long, 1u)] = row;
     }
 }
 
@@ -688,53 +744,53 @@ inline int grid1d(long long total, int per_block = 256, int cap = 256 * 32) {
 
 int crf_alloc(wsc_crf *crf, size_t bytes, void **out) {
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-    if (e != hipSuccess) {
-        wsc_set_error("CRF hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        return WSC_ERR_NOMEM;
-    }
+    WSC_TRY(wsc_ctx_cached_alloc(crf->ctx, bytes, &p));
     crf->allocs.push_back(p);
     *out = p;
     return WSC_OK;
 }
 
-struct TempBuf { // build-time scratch released at the end of wsc_crf_create
+struct TempBuf { // build-time scratch handed back to the ctx cache at the end of a lattice build
+    wsc_ctx *ctx;
     std::vector<void *> ptrs;
+    explicit TempBuf(wsc_ctx *c) : ctx(c) {}
     int alloc(size_t bytes, void **out) {
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-        if (e != hipSuccess) {
-            wsc_set_error("CRF scratch hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-            return WSC_ERR_NOMEM;
-        }
+        WSC_TRY(wsc_ctx_cached_alloc(ctx, bytes, &p));
         ptrs.push_back(p);
         *out = p;
         return WSC_OK;
     }
     ~TempBuf() {
-        for (void *p : ptrs) (void)hipFree(p);
+        for (void *p : ptrs) wsc_ctx_cached_free(ctx, p); // stream-ordered reuse: no sync needed
     }
 };
 
 template <int MP>
-void launch_splat(wsc_ctx *ctx, const LatticeDev &L, const float *q, int M, float *val, bool ones) {
+void launch_splat(wsc_ctx *ctx, const LatticeDev &L, const float *q, int M, float *val, float *part, bool ones) {
     const int gpb = 256 / MP;
-    const int grid = grid1d(L.rows, gpb, 256 * 64);
+    const int grid = grid1d(L.n_chunks, gpb, 256 * 64);
     if (ones)
         hipLaunchKernelGGL((splat_kernel<MP, true>), dim3(grid), dim3(256), 0, ctx->stream,
-                           (const unsigned *)L.csr_start, L.csr_pix, L.csr_w, L.norm, q, M, L.rows, val);
+                           (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_pix, L.csr_w, L.norm, q, M,
+                           L.n_chunks, val, part);
     else
         hipLaunchKernelGGL((splat_kernel<MP, false>), dim3(grid), dim3(256), 0, ctx->stream,
-                           (const unsigned *)L.csr_start, L.csr_pix, L.csr_w, L.norm, q, M, L.rows, val);
+                           (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_pix, L.csr_w, L.norm, q, M,
+                           L.n_chunks, val, part);
+    if (L.n_long > 0)
+        hipLaunchKernelGGL(splat_combine_kernel<MP>, dim3(grid1d(L.n_long, gpb, 4096)), dim3(256), 0, ctx->stream,
+                           L.long_rows, L.n_long, L.chunk_base, part, M, val);
 }
 
-void splat_dispatch(wsc_ctx *ctx, const LatticeDev &L, const float *q, int M, float *val, bool ones) {
-    if (M <= 1) launch_splat<1>(ctx, L, q, M, val, ones);
-    else if (M <= 2) launch_splat<2>(ctx, L, q, M, val, ones);
-    else if (M <= 4) launch_splat<4>(ctx, L, q, M, val, ones);
-    else if (M <= 8) launch_splat<8>(ctx, L, q, M, val, ones);
-    else if (M <= 16) launch_splat<16>(ctx, L, q, M, val, ones);
-    else launch_splat<32>(ctx, L, q, M, val, ones);
+// part: scratch of n_chunks * M floats (partials of multi-chunk rows)
+void splat_dispatch(wsc_ctx *ctx, const LatticeDev &L, const float *q, int M, float *val, float *part, bool ones) {
+    if (M <= 1) launch_splat<1>(ctx, L, q, M, val, part, ones);
+    else if (M <= 2) launch_splat<2>(ctx, L, q, M, val, part, ones);
+    else if (M <= 4) launch_splat<4>(ctx, L, q, M, val, part, ones);
+    else if (M <= 8) launch_splat<8>(ctx, L, q, M, val, part, ones);
+    else if (M <= 16) launch_splat<16>(ctx, L, q, M, val, part, ones);
+    else launch_splat<32>(ctx, L, q, M, val, part, ones);
 }
 
 // d+1 blur passes, ping-pong between a and b; returns the buffer holding the result
@@ -761,7 +817,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     while (cap < 2ll * N * dp1) cap <<= 1;
     WSC_CHECK(B * cap < (1ll << 31), WSC_ERR_CAPACITY, "CRF batch too large for the hash tables");
 
-    TempBuf tmp;
+    TempBuf tmp(ctx);
     unsigned long long *table;
     int32_t *first, *eslot, *slot2row, *rowimg;
     unsigned *flag, *prefix, *sums, *count, *cursor;
@@ -855,17 +911,42 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     hipLaunchKernelGGL(neighbors_kernel<D>, dim3(grid1d((long long)L.rows * dp1)), dim3(256), 0, ctx->stream, rowkey,
                        rowimg, table, slot2row, cap, (unsigned)(cap - 1), L.rows, L.nbr);
     WSC_HIP(hipGetLastError());
+    {   // splat chunk tables
+        unsigned *nch, *sums3, *n_long_dev;
+        const int nb3 = (L.rows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&nch));
+        WSC_TRY(tmp.alloc(sizeof(unsigned) * (nb3 + 2), (void **)&sums3));
+        WSC_TRY(tmp.alloc(sizeof(unsigned), (void **)&n_long_dev));
+        WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (L.rows + 2), (void **)&L.chunk_base));
+        WSC_HIP(hipMemsetAsync(nch, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
+        WSC_HIP(hipMemsetAsync(n_long_dev, 0, sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(count_chunks_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream,
+                           (const unsigned *)L.csr_start, L.rows, nch);
+        WSC_TRY(exclusive_scan(ctx, nch, L.rows + 1, (unsigned *)L.chunk_base, sums3));
+        unsigned tc = 0;
+        WSC_HIP(hipMemcpyAsync(&tc, sums3 + nb3, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        WSC_HIP(hipStreamSynchronize(ctx->stream));
+        L.n_chunks = (int)tc;
+        WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (size_t)L.n_chunks, (void **)&L.chunk_row));
+        WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (size_t)L.rows, (void **)&L.long_rows));
+        hipLaunchKernelGGL(fill_chunks_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream, L.chunk_base, L.rows,
+                           L.chunk_row, n_long_dev, L.long_rows);
+        unsigned nl = 0;
+        WSC_HIP(hipMemcpyAsync(&nl, n_long_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        WSC_HIP(hipStreamSynchronize(ctx->stream));
+        L.n_long = (int)nl;
+    }
 
     // norm = 1/sqrt(Lattice(1) + 1e-20)
-    float *va, *vb;
+    float *va, *vb, *vp;
     WSC_TRY(tmp.alloc(sizeof(float) * L.rows, (void **)&va));
     WSC_TRY(tmp.alloc(sizeof(float) * L.rows, (void **)&vb));
-    splat_dispatch(ctx, L, nullptr, 1, va, true);
+    WSC_TRY(tmp.alloc(sizeof(float) * L.n_chunks, (void **)&vp));
+    splat_dispatch(ctx, L, nullptr, 1, va, vp, true);
     float *res = blur_all(ctx, L, 1, va, vb);
     hipLaunchKernelGGL(slice_norm_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1,
                        L.alpha, res, npix, L.norm);
     WSC_HIP(hipGetLastError());
-    WSC_HIP(hipStreamSynchronize(ctx->stream)); // scratch is freed by ~TempBuf
     return WSC_OK;
 }
 
@@ -900,8 +981,7 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
 
 void wsc_crf_destroy(wsc_crf *crf) {
     if (!crf) return;
-    (void)hipStreamSynchronize(crf->ctx->stream);
-    for (void *p : crf->allocs) (void)hipFree(p);
+    for (void *p : crf->allocs) wsc_ctx_cached_free(crf->ctx, p); // reused in stream order
     delete crf;
 }
 
@@ -926,8 +1006,9 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t qb = al(sizeof(float) * npix * M);
     const size_t vg = al(sizeof(float) * (size_t)G.rows * M), vb = al(sizeof(float) * (size_t)Bl.rows * M);
+    const size_t pg = al(sizeof(float) * (size_t)G.n_chunks * M), pb = al(sizeof(float) * (size_t)Bl.n_chunks * M);
     void *ws;
-    WSC_TRY(wsc_ctx_workspace(ctx, 2 * qb + 2 * vg + 2 * vb, &ws));
+    WSC_TRY(wsc_ctx_workspace(ctx, 2 * qb + 2 * vg + 2 * vb + pg + pb, &ws));
     char *p = (char *)ws;
     float *u = (float *)p; p += qb;
     float *q = (float *)p; p += qb;
@@ -935,14 +1016,16 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     float *vg1 = (float *)p; p += vg;
     float *vb0 = (float *)p; p += vb;
     float *vb1 = (float *)p; p += vb;
+    float *partg = (float *)p; p += pg;
+    float *partb = (float *)p; p += pb;
 
     const dim3 tgrid((N + TP - 1) / TP, B);
     hipLaunchKernelGGL(init_q_kernel, tgrid, dim3(TP), 2 * (size_t)M * (TP + 1) * sizeof(float), ctx->stream,
                        unary_dev, M, N, u, q);
     for (int it = 0; it < n_iters; ++it) {
-        splat_dispatch(ctx, G, q, M, vg0, false);
+        splat_dispatch(ctx, G, q, M, vg0, partg, false);
         float *rg = blur_all(ctx, G, M, vg0, vg1);
-        splat_dispatch(ctx, Bl, q, M, vb0, false);
+        splat_dispatch(ctx, Bl, q, M, vb0, partb, false);
         float *rb = blur_all(ctx, Bl, M, vb0, vb1);
         UpdateArgs a;
         a.off_g = G.offset; a.off_b = Bl.offset; a.bary_g = G.bary; a.bary_b = Bl.bary;
