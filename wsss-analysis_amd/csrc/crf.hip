@@ -121,6 +121,44 @@ __device__ __forceinline__ int hash_lookup(const unsigned long long *table, unsi
     }
 }
 
+// ---- wave-aggregated atomics ---------------------------------------------------------------
+// Neighbouring pixels share lattice vertices (57 pixels per bilateral vertex on the bench images),
+// so the lanes of a wave mostly hit the same few table slots / rows.  wave_match returns, for
+// every active lane, the mask of active lanes holding the same (key, tag); the lowest lane of
+// a mask acts for the group: one CAS / atomic per distinct key per wave instead of one per lane.
+__device__ __forceinline__ unsigned long long wave_match(unsigned long long key, int tag) {
+    unsigned long long remaining = __ballot(1);
+    unsigned long long mine = 0;
+    while (remaining) {
+        const int leader = __ffsll((long long)remaining) - 1;
+        const unsigned klo = __shfl((unsigned)key, leader, 64);
+        const unsigned khi = __shfl((unsigned)(key >> 32), leader, 64);
+        const int t = __shfl(tag, leader, 64);
+        const bool same = (unsigned)key == klo && (unsigned)(key >> 32) == khi && tag == t;
+        const unsigned long long m = __ballot(same);
+        if (same) mine = m;
+        remaining &= ~m;
+    }
+    return mine;
+}
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// XCD-contiguous work split for the gather kernels.  Blocks are dispatched round-robin over the 8
+// XCDs (block b -> XCD b % 8); a plain grid-stride loop therefore makes every XCD touch every
+// image, and the lattice rows a pixel gathers never stay in that XCD's 4 MB L2.  Here block b gets
+// the logical id that puts the blocks of one XCD next to each other, and each block owns ONE
+// contiguous range of items, so an XCD sweeps a contiguous window of pixels / lattice rows whose
+// neighbours are in its own L2 (and, within a block, in the CU's L1).  Pure speed: any placement
+// computes the same result.
+__device__ __forceinline__ void xcd_range(long long total, long long &begin, long long &end) {
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nb >> 3, r = nb & 7;
+    const long long lb = (xcd < r ? (long long)xcd * (q + 1) : (long long)r * (q + 1) + (long long)(xcd - r) * q) + (bid >> 3);
+    const long long per = (total + nb - 1) / nb;
+    begin = lb * per;
+    end = begin + per < total ? begin + per : total;
+}
+
 struct EmbedArgs {
     const uint8_t *rgb; // [B][N][3]
     int B, H, W, N;
@@ -231,10 +269,23 @@ __global__ __launch_bounds__(256) void lattice_embed_kernel(EmbedArgs a) {
         }
         unsigned long long pk;
         if (!pack_key<D>(key, pk)) *a.err = 1;
-        const int slot = hash_insert(table, a.cap_mask, pk);
+        int slot;
+        if (true) {
+            // lanes = consecutive pixels: the group leader (lowest lane = lowest pixel) inserts for all
+            const unsigned long long grp = wave_match(pk, b);
+            const int leader = __ffsll((long long)grp) - 1;
+            slot = 0;
+            if (lane_id() == leader) {
+                slot = hash_insert(table, a.cap_mask, pk);
+                atomicMin(&first[slot], n * (D + 1) + r);
+            }
+            slot = __shfl(slot, leader, 64);
+        } else {
+            slot = hash_insert(table, a.cap_mask, pk);
+            atomicMin(&first[slot], n * (D + 1) + r);
+        }
         a.eslot[e0 + r] = slot;
         a.bary[e0 + r] = bary[r];
-        atomicMin(&first[slot], n * (D + 1) + r);
     }
 }
 
@@ -349,105 +400,43 @@ __global__ void assign_ids_kernel(const int32_t *__restrict__ eslot, const unsig
     }
 }
 
-// offset[e] = row of entry e; count entries per row
-__global__ void remap_count_kernel(const int32_t *__restrict__ eslot, const int32_t *__restrict__ slot2row,
-                                   long long cap, int N, int dp1, long long total, int32_t *__restrict__ offset,
-                                   unsigned *__restrict__ count) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(e / ((long long)N * dp1));
+// offset[e] = row of entry e; count entries per row.  One thread per pixel, r in the loop, so the
+// lanes of a wave are neighbouring pixels and share rows: one atomicAdd per distinct row per wave.
+__global__ __launch_bounds__(256) void remap_count_kernel(const int32_t *__restrict__ eslot,
+                                                          const int32_t *__restrict__ slot2row, long long cap, int N,
+                                                          int dp1, long long npix, int32_t *__restrict__ offset,
+                                                          unsigned *__restrict__ count) {
+    const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gp >= npix) return;
+    const int b = (int)(gp / N);
+    for (int r = 0; r < dp1; ++r) {
+        const long long e = gp * dp1 + r;
         const int row = slot2row[(long long)b * cap + eslot[e]];
         offset[e] = row;
-        atomicAdd(&count[row], 1u);
+        const unsigned long long grp = wave_match((unsigned long long)(unsigned)row, 0);
+        if (lane_id() == __ffsll((long long)grp) - 1) atomicAdd(&count[row], (unsigned)__popcll(grp));
     }
 }
 
-__global__ void csr_fill_kernel(const int32_t *__restrict__ offset, const float *__restrict__ bary, int dp1,
-                                long long total, const unsigned *__restrict__ start, unsigned *__restrict__ cursor,
-                                int32_t *__restrict__ csr_pix, float *__restrict__ csr_w) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t *__restrict__ offset,
+                                                       const float *__restrict__ bary, int dp1, long long npix,
+                                                       const unsigned *__restrict__ start,
+                                                       unsigned *__restrict__ cursor, int32_t *__restrict__ csr_pix,
+                                                       float *__restrict__ csr_w) {
+    const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gp >= npix) return;
+    const int lane = lane_id();
+    for (int r = 0; r < dp1; ++r) {
+        const long long e = gp * dp1 + r;
         const int row = offset[e];
-        const unsigned pos = start[row] + atomicAdd(&cursor[row], 1u);
-        csr_pix[pos] = (int32_t)(e / dp1);
+        const unsigned long long grp = wave_match((unsigned long long)(unsigned)row, 0);
+        const int leader = __ffsll((long long)grp) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[row], (unsigned)__popcll(grp));
+        base = __shfl(base, leader, 64);
+        const unsigned pos = start[row] + base + (unsigned)__popcll(grp & ((1ull << lane) - 1ull));
+        csr_pix[pos] = (int32_t)gp;
         csr_w[pos] = bary[e];
-    }
-}
-
-// Within a row, order the gathered pixels ascending (the CPU reference's splat order): the
-// atomic cursor of csr_fill_kernel fills a row in arbitrary order, and a fixed order makes
-// the fp32 sums of the iteration loop bit-reproducible from run to run.
-// Short rows: one thread each, insertion sort.  Long rows are queued for the block sort.
-constexpr int SORT_SHORT = 32;
-constexpr int SORT_LDS_MAX = 8192; // rows longer than this keep their fill order
-
-__global__ void csr_sort_short_kernel(const unsigned *__restrict__ start, int rows, int32_t *__restrict__ csr_pix,
-                                      float *__restrict__ csr_w, unsigned *__restrict__ n_long,
-                                      int32_t *__restrict__ long_rows) {
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
-        const unsigned s = start[row], e = start[row + 1];
-        const int len = (int)(e - s);
-        if (len > SORT_SHORT) {
-            if (len <= SORT_LDS_MAX) long_rows[atomicAdd(n_long, 1u)] = row;
-            continue;
-        }
-        int32_t *p = csr_pix + s;
-        float *w = csr_w + s;
-        for (int i = 1; i < len; ++i) {
-            const int32_t kp = p[i];
-            const float kw = w[i];
-            int j = i - 1;
-            while (j >= 0 && p[j] > kp) {
-                p[j + 1] = p[j];
-                w[j + 1] = w[j];
-                --j;
-            }
-            p[j + 1] = kp;
-            w[j + 1] = kw;
-        }
-    }
-}
-
-// one block per queued long row: bitonic sort of (pixel, weight) pairs in LDS
-__global__ __launch_bounds__(256) void csr_sort_long_kernel(const unsigned *__restrict__ start,
-                                                            const unsigned *__restrict__ n_long,
-                                                            const int32_t *__restrict__ long_rows,
-                                                            int32_t *__restrict__ csr_pix, float *__restrict__ csr_w) {
-    extern __shared__ __attribute__((aligned(16))) char sort_lds[];
-    int32_t *kp = reinterpret_cast<int32_t *>(sort_lds);
-    float *kw = reinterpret_cast<float *>(sort_lds + SORT_LDS_MAX * sizeof(int32_t));
-    const unsigned nl = *n_long;
-    for (unsigned li = blockIdx.x; li < nl; li += gridDim.x) {
-        const int row = long_rows[li];
-        const unsigned s = start[row];
-        const int len = (int)(start[row + 1] - s);
-        int n2 = 64;
-        while (n2 < len) n2 <<= 1;
-        for (int i = threadIdx.x; i < n2; i += 256) {
-            kp[i] = i < len ? csr_pix[s + i] : 0x7fffffff;
-            kw[i] = i < len ? csr_w[s + i] : 0.f;
-        }
-        __syncthreads();
-        for (int k = 2; k <= n2; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = threadIdx.x; i < n2; i += 256) {
-                    const int ixj = i ^ j;
-                    if (ixj > i) {
-                        const bool up = (i & k) == 0;
-                        const int32_t a = kp[i], b = kp[ixj];
-                        if ((a > b) == up) {
-                            kp[i] = b; kp[ixj] = a;
-                            const float t = kw[i]; kw[i] = kw[ixj]; kw[ixj] = t;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        for (int i = threadIdx.x; i < len; i += 256) {
-            csr_pix[s + i] = kp[i];
-            csr_w[s + i] = kw[i];
-        }
-        __syncthreads();
     }
 }
 
@@ -501,37 +490,75 @@ __global__ void neighbors_kernel(const unsigned long long *__restrict__ rowkey, 
 // ---- iteration kernels ------------------------------------------------------------------
 
 // Splat in gather form: val[row][m] = sum over the row's pixels of w * (norm[p] * Q[p][m]).
-// Work item = one chunk (<= SPLAT_CHUNK consecutive entries of one row's sorted pixel list) x MP
-// lanes (lane m < M active).  Rows of flat image regions gather thousands of pixels; cutting
-// them bounds the serial chain per work item.  Entries are fetched 8 at a time so that 8
-// independent Q-row gathers are in flight per lane; the sum itself stays in list order.
-// A single-chunk row writes val directly; chunks of long rows write partials that
-// splat_combine_kernel adds up in chunk order (fixed order: bit-reproducible).
+// Work item = one chunk (<= SPLAT_CHUNK consecutive entries of one row's pixel list) x M lanes;
+// a wave carries floor(64/M) chunks (M = 21 -> 63 of 64 lanes busy).  Rows of flat image regions
+// gather thousands of pixels; cutting them bounds the serial chain per work item.  Entries are
+// fetched 8 at a time so that 8 independent Q-row gathers are in flight per lane.
+//
+// The sum is accumulated in 64-bit FIXED POINT: every fp32 term w*norm*Q is rounded to a multiple
+// of 2^-28 (|term| <= 2.5 because norm <= 1/sqrt(alpha/(d+1)), so it fits an int32) and added as
+// an integer.  Integer addition is associative, so the result does not depend on the order in
+// which csr_fill's atomic cursors laid the row out -- the iteration loop is bit-reproducible from
+// run to run without sorting the lists and without float atomics.  Quantisation error per term is
+// <= 1.9e-9 absolute, far inside the 1e-3 parity budget on Q.
+// A single-chunk row writes val directly; chunks of long rows write int64 partials that
+// splat_combine_kernel adds up.
 // ONES: splat of the all-ones vector (M = 1) for the normalisation pass.
 constexpr int SPLAT_CHUNK = 32;
+constexpr float FIX_SCALE = 268435456.0f;        // 2^28
+constexpr float FIX_INV = 1.0f / 268435456.0f;   // 2^-28 (exact)
 
-template <int MP, bool ONES>
-__global__ __launch_bounds__(256) void splat_kernel(const unsigned *__restrict__ start,
-                                                    const int32_t *__restrict__ chunk_base,
-                                                    const int32_t *__restrict__ chunk_row,
-                                                    const int32_t *__restrict__ csr_pix,
-                                                    const float *__restrict__ csr_w, const float *__restrict__ norm,
-                                                    const float *__restrict__ q, int M, int n_chunks,
-                                                    float *__restrict__ val, float *__restrict__ part) {
-    constexpr int GPB = 256 / MP; // groups per block
-    const int m = threadIdx.x % MP;
-    const int g = threadIdx.x / MP;
-    for (long long c = (long long)blockIdx.x * GPB + g; c < n_chunks; c += (long long)gridDim.x * GPB) {
+// Scalar form, used for the normalisation pass only (splat of the all-ones vector, M = 1).
+__global__ __launch_bounds__(256) void splat_ones_kernel(const unsigned *__restrict__ start,
+                                                         const int32_t *__restrict__ chunk_base,
+                                                         const int32_t *__restrict__ chunk_row,
+                                                         const float *__restrict__ csr_w, int n_chunks,
+                                                         float *__restrict__ val, long long *__restrict__ part) {
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks;
+         c += (long long)gridDim.x * blockDim.x) {
         const int row = chunk_row[c];
         const int cb = chunk_base[row];
         const bool single = chunk_base[row + 1] - cb == 1;
         const unsigned s = start[row] + (unsigned)(c - cb) * SPLAT_CHUNK;
         const unsigned e = min(s + SPLAT_CHUNK, start[row + 1]);
-        if (m >= M) continue;
-        float acc = 0.f;
+        long long acc = 0;
+        for (unsigned i = s; i < e; ++i) acc += (long long)__float2int_rn(csr_w[i] * FIX_SCALE);
+        if (single) val[row] = (float)acc * FIX_INV;
+        else part[c] = acc;
+    }
+}
+
+// Iteration form.  Q / U / val rows are padded to Mp = 4*LP floats (16-byte aligned rows) and a
+// lane owns 4 consecutive classes: every gather is a 16-byte load.  (The L1 serves one access per
+// clock whatever its width; with 4-byte lanes the gathers of this kernel ran at 1.04 L1 accesses
+// per clock per CU -- L1-issue bound -- for 3.8 useful bytes each: profiles/r01_pmc_crf.txt.)
+// LP lanes per chunk, floor(64/LP) chunks per wave.
+__global__ __launch_bounds__(256) void splat4_kernel(const unsigned *__restrict__ start,
+                                                     const int32_t *__restrict__ chunk_base,
+                                                     const int32_t *__restrict__ chunk_row,
+                                                     const int32_t *__restrict__ csr_pix,
+                                                     const float *__restrict__ csr_w, const float *__restrict__ norm,
+                                                     const float *__restrict__ q, int LP, int n_chunks,
+                                                     float *__restrict__ val, long long *__restrict__ part) {
+    const int gpw = 64 / LP;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / LP;
+    const int l = lane - g * LP;
+    if (g >= gpw) return;
+    const f32x4_t *q4 = reinterpret_cast<const f32x4_t *>(q);
+    long long cbeg, cend;
+    xcd_range(n_chunks, cbeg, cend);
+    for (long long c = cbeg + (threadIdx.x >> 6) * gpw + g; c < cend; c += 4 * gpw) {
+        const int row = chunk_row[c];
+        const int cb = chunk_base[row];
+        const bool single = chunk_base[row + 1] - cb == 1;
+        const unsigned s = start[row] + (unsigned)(c - cb) * SPLAT_CHUNK;
+        const unsigned e = min(s + SPLAT_CHUNK, start[row + 1]);
+        long long acc[4] = {0, 0, 0, 0};
         for (unsigned i = s; i < e; i += 8) {
             int p[8];
-            float w[8], in[8];
+            float w[8];
+            f32x4_t in[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const unsigned idx = min(i + j, e - 1);
@@ -539,30 +566,44 @@ __global__ __launch_bounds__(256) void splat_kernel(const unsigned *__restrict__
                 w[j] = i + j < e ? csr_w[idx] : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) in[j] = ONES ? 1.f : q[(long long)p[j] * M + m] * norm[p[j]];
+            for (int j = 0; j < 8; ++j) {
+                in[j] = q4[(unsigned)p[j] * (unsigned)LP + l];
+                w[j] *= 1.f; // keep (q*norm) then *w order below
+                const float nr = norm[p[j]];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += w[j] * in[j];
+                for (int k = 0; k < 4; ++k) in[j][k] = in[j][k] * nr;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += (long long)__float2int_rn((w[j] * in[j][k]) * FIX_SCALE);
         }
-        if (single) val[(long long)row * M + m] = acc;
-        else part[c * M + m] = acc;
+        if (single) {
+            f32x4_t o = {(float)acc[0] * FIX_INV, (float)acc[1] * FIX_INV, (float)acc[2] * FIX_INV,
+                         (float)acc[3] * FIX_INV};
+            reinterpret_cast<f32x4_t *>(val)[(unsigned)row * (unsigned)LP + l] = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) part[(c * LP + l) * 4 + k] = acc[k];
+        }
     }
 }
 
-template <int MP>
+// sums the int64 partials of multi-chunk rows; Mp = values per row (1 for the ones pass)
 __global__ __launch_bounds__(256) void splat_combine_kernel(const int32_t *__restrict__ long_rows, int n_long,
                                                             const int32_t *__restrict__ chunk_base,
-                                                            const float *__restrict__ part, int M,
+                                                            const long long *__restrict__ part, int Mp,
                                                             float *__restrict__ val) {
-    constexpr int GPB = 256 / MP;
-    const int m = threadIdx.x % MP;
-    const int g = threadIdx.x / MP;
-    if (m >= M) return;
-    for (int i = blockIdx.x * GPB + g; i < n_long; i += gridDim.x * GPB) {
-        const int row = long_rows[i];
+    const long long total = (long long)n_long * Mp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int li = (int)(i / Mp);
+        const int m = (int)(i - (long long)li * Mp);
+        const int row = long_rows[li];
         const int cb = chunk_base[row], ce = chunk_base[row + 1];
-        float acc = 0.f;
-        for (int c = cb; c < ce; ++c) acc += part[(long long)c * M + m];
-        val[(long long)row * M + m] = acc;
+        long long acc = 0;
+        for (int c = cb; c < ce; ++c) acc += part[(long long)c * Mp + m];
+        val[(long long)row * Mp + m] = (float)acc * FIX_INV;
     }
 }
 
@@ -582,21 +623,53 @@ __global__ void fill_chunks_kernel(const int32_t *__restrict__ chunk_base, int r
     }
 }
 
-// One blur pass along one lattice axis: out[row][m] = in[row][m] + 0.5*(in[n1][m] + in[n2][m]).
-// Flat over rows*M elements: perfectly coalesced reads of `in` and writes of `out`; the two
-// neighbour rows are gathered as M-float runs.
-__global__ __launch_bounds__(256) void blur_kernel(const float *__restrict__ in, const int2 *__restrict__ nbr, int M,
-                                                   long long total, float *__restrict__ out) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(i / M);
-        const int m = (int)(i - (long long)row * M);
-        if (row == 0) {
-            out[i] = 0.f;
-            continue;
-        }
+// One blur pass along one lattice axis: out[row] = in[row] + 0.5*(in[n1] + in[n2]).
+// Scalar form for the normalisation pass (one value per row).
+__global__ __launch_bounds__(256) void blur1_kernel(const float *__restrict__ in, const int2 *__restrict__ nbr,
+                                                    int rows, float *__restrict__ out) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
         const int2 nb = nbr[row];
-        out[i] = in[i] + 0.5f * (in[(long long)nb.x * M + m] + in[(long long)nb.y * M + m]);
+        out[row] = row == 0 ? 0.f : in[row] + 0.5f * (in[nb.x] + in[nb.y]);
+    }
+}
+
+// Iteration form on padded rows: a lane owns one float4 of a row, a block covers floor(256/LP)
+// consecutive rows (one contiguous run of `in` / `out`), the two neighbour rows are gathered as
+// 16-byte loads.  Each block owns an XCD-contiguous range of rows.
+__global__ __launch_bounds__(256) void blur4_kernel(const f32x4_t *__restrict__ in, const int2 *__restrict__ nbr,
+                                                    int LP, int rows, f32x4_t *__restrict__ out) {
+    const int rpb = 256 / LP;
+    const int tr = threadIdx.x / LP;
+    const int l = threadIdx.x - tr * LP;
+    if (tr >= rpb) return;
+    constexpr int U = 2;
+    long long rbeg, rend;
+    xcd_range(rows, rbeg, rend);
+    for (long long row0 = rbeg + tr; row0 < rend; row0 += U * rpb) {
+        int2 nb[U];
+        f32x4_t c[U], a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long row = row0 + u * rpb;
+            nb[u] = row < rend ? nbr[row] : make_int2(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long row = row0 + u * rpb;
+            c[u] = in[(unsigned)(row < rend ? row : 0) * (unsigned)LP + l];
+            a[u] = in[(unsigned)nb[u].x * (unsigned)LP + l];
+            b[u] = in[(unsigned)nb[u].y * (unsigned)LP + l];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long row = row0 + u * rpb;
+            if (row < rend) {
+                f32x4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = row == 0 ? 0.f : c[u][k] + 0.5f * (a[u][k] + b[u][k]);
+                out[(unsigned)row * (unsigned)LP + l] = o;
+            }
+        }
     }
 }
 
@@ -617,53 +690,98 @@ struct UpdateArgs {
     const float *bary_g, *bary_b;
     const float *norm_g, *norm_b;
     const float *val_g, *val_b;
-    const float *u; // [pixel][M]
-    float *q;       // [pixel][M]
+    const float *u; // [pixel][Mp]
+    float *q;       // [pixel][Mp]
     float alpha_g, alpha_b, compat_g, compat_b;
-    int M;
+    int M, LP;
     long long npix;
 };
 
 // Slice both lattices, add the unary, softmax over classes (DenseCRF::inference loop body):
 //   E = -U - (-wG * normG * sliceG) - (-wB * normB * sliceB);  Q = expAndNormalize(E)
-// MP lanes per pixel; reductions by xor-shuffles inside the group.
-template <int MP>
+// LP lanes per pixel (4 classes each, 16-byte gathers), floor(64/LP) pixels per wave; the max / sum
+// over a pixel's classes are reduced inside the lane, then across the pixel's LP lanes by
+// shuffle-down with a segment bound and a broadcast from the segment's first lane.
 __global__ __launch_bounds__(256) void slice_update_kernel(UpdateArgs a) {
-    constexpr int GPB = 256 / MP;
-    const int m = threadIdx.x % MP;
-    const int g = threadIdx.x / MP;
-    const bool act = m < a.M;
-    for (long long p = (long long)blockIdx.x * GPB + g; p < a.npix; p += (long long)gridDim.x * GPB) {
-        float sg = 0.f, sb = 0.f;
-        if (act) {
+    const int LP = a.LP;
+    const int gpw = 64 / LP;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / LP;
+    const int l = lane - g * LP;
+    const bool act = g < gpw;
+    const int seg0 = g * LP;
+    const f32x4_t *vg4 = reinterpret_cast<const f32x4_t *>(a.val_g);
+    const f32x4_t *vb4 = reinterpret_cast<const f32x4_t *>(a.val_b);
+    const f32x4_t *u4 = reinterpret_cast<const f32x4_t *>(a.u);
+    f32x4_t *q4 = reinterpret_cast<f32x4_t *>(a.q);
+    long long pbeg, pend;
+    xcd_range(a.npix, pbeg, pend);
+    for (long long p0 = pbeg + (long long)(threadIdx.x >> 6) * gpw; p0 < pend; p0 += 4ll * gpw) {
+        const long long pp = p0 + g;
+        const bool ok = act && pp < pend;
+        const long long p = ok ? pp : pbeg;
+        int og[3], ob[6];
+        float bg[3], bb[6];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-                sg += a.bary_g[p * 3 + r] * a.val_g[(long long)a.off_g[p * 3 + r] * a.M + m] * a.alpha_g;
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-                sb += a.bary_b[p * 6 + r] * a.val_b[(long long)a.off_b[p * 6 + r] * a.M + m] * a.alpha_b;
+        for (int r = 0; r < 3; ++r) {
+            og[r] = a.off_g[p * 3 + r];
+            bg[r] = a.bary_g[p * 3 + r];
         }
-        float e = -3.0e38f;
-        if (act) {
-            e = -a.u[p * a.M + m];
-            e -= -a.compat_g * (sg * a.norm_g[p]);
-            e -= -a.compat_b * (sb * a.norm_b[p]);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            ob[r] = a.off_b[p * 6 + r];
+            bb[r] = a.bary_b[p * 6 + r];
         }
-        float mx = e;
+        f32x4_t vg[3], vb[6];
 #pragma unroll
-        for (int o = MP / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float ex = act ? expf(e - mx) : 0.f;
-        float sum = ex;
+        for (int r = 0; r < 3; ++r) vg[r] = vg4[(unsigned)og[r] * (unsigned)LP + l];
 #pragma unroll
-        for (int o = MP / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        if (act) a.q[p * a.M + m] = ex / sum;
+        for (int r = 0; r < 6; ++r) vb[r] = vb4[(unsigned)ob[r] * (unsigned)LP + l];
+        const f32x4_t un = u4[p * LP + l];
+        const float ng = a.norm_g[p], nb = a.norm_b[p];
+        float e[4];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sg = 0.f, sb = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) sg += bg[r] * vg[r][k] * a.alpha_g;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) sb += bb[r] * vb[r][k] * a.alpha_b;
+            float ek = -un[k];
+            ek -= -a.compat_g * (sg * ng);
+            ek -= -a.compat_b * (sb * nb);
+            const bool valid = ok && 4 * l + k < a.M;
+            e[k] = valid ? ek : -3.0e38f;
+            mx = fmaxf(mx, e[k]);
+        }
+        for (int o = 4; o > 0; o >>= 1) {
+            const float other = __shfl_down(mx, o, 64);
+            if (l + o < LP) mx = fmaxf(mx, other);
+        }
+        mx = __shfl(mx, seg0, 64);
+        float ex[4], sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ex[k] = (ok && 4 * l + k < a.M) ? expf(e[k] - mx) : 0.f;
+            sum += ex[k];
+        }
+        for (int o = 4; o > 0; o >>= 1) {
+            const float other = __shfl_down(sum, o, 64);
+            if (l + o < LP) sum += other;
+        }
+        sum = __shfl(sum, seg0, 64);
+        if (ok) {
+            f32x4_t o4 = {ex[0] / sum, ex[1] / sum, ex[2] / sum, ex[3] / sum};
+            q4[pp * LP + l] = o4;
+        }
     }
 }
 
 constexpr int TP = 128; // pixels per block of the layout-changing kernels
 
 // unary [B][M][N] (class-major) -> U [pixel][M] and Q = softmax(-U); TP pixels per block.
-__global__ __launch_bounds__(TP) void init_q_kernel(const float *__restrict__ unary, int M, int N,
+__global__ __launch_bounds__(TP) void init_q_kernel(const float *__restrict__ unary, int M, int Mp, int N,
                                                      float *__restrict__ u, float *__restrict__ q) {
     extern __shared__ float tile[]; // [M][TP+1] twice
     float *tu = tile, *tq = tile + (size_t)M * (TP + 1);
@@ -686,25 +804,25 @@ __global__ __launch_bounds__(TP) void init_q_kernel(const float *__restrict__ un
         for (int m = 0; m < M; ++m) tq[m * (TP + 1) + threadIdx.x] = tq[m * (TP + 1) + threadIdx.x] / s;
     }
     __syncthreads();
-    const long long obase = ((long long)b * N + n0) * M;
-    for (int i = threadIdx.x; i < np * M; i += TP) {
-        const int n = i / M, m = i - n * M;
-        u[obase + i] = tu[m * (TP + 1) + n];
-        q[obase + i] = tq[m * (TP + 1) + n];
+    const long long obase = ((long long)b * N + n0) * Mp;
+    for (int i = threadIdx.x; i < np * Mp; i += TP) {
+        const int n = i / Mp, m = i - n * Mp;
+        u[obase + i] = m < M ? tu[m * (TP + 1) + n] : 0.f; // padding classes: masked in slice_update
+        q[obase + i] = m < M ? tq[m * (TP + 1) + n] : 0.f;
     }
 }
 
 // Q [pixel][M] -> q_out [B][M][N] and/or argmax [B][N]
-__global__ __launch_bounds__(TP) void finish_kernel(const float *__restrict__ q, int M, int N,
+__global__ __launch_bounds__(TP) void finish_kernel(const float *__restrict__ q, int M, int Mp, int N,
                                                     float *__restrict__ q_out, int32_t *__restrict__ argmax) {
     extern __shared__ float tile[]; // [M][TP+1]
     const int b = blockIdx.y;
     const int n0 = blockIdx.x * TP;
     const int np = min(TP, N - n0);
-    const long long ibase = ((long long)b * N + n0) * M;
-    for (int i = threadIdx.x; i < np * M; i += TP) {
-        const int n = i / M, m = i - n * M;
-        tile[m * (TP + 1) + n] = q[ibase + i];
+    const long long ibase = ((long long)b * N + n0) * Mp;
+    for (int i = threadIdx.x; i < np * Mp; i += TP) {
+        const int n = i / Mp, m = i - n * Mp;
+        if (m < M) tile[m * (TP + 1) + n] = q[ibase + i];
     }
     __syncthreads();
     if ((int)threadIdx.x < np) {
@@ -766,39 +884,39 @@ struct TempBuf { // build-time scratch handed back to the ctx cache at the end o
     }
 };
 
-template <int MP>
-void launch_splat(wsc_ctx *ctx, const LatticeDev &L, const float *q, int M, float *val, float *part, bool ones) {
-    const int gpb = 256 / MP;
-    const int grid = grid1d(L.n_chunks, gpb, 256 * 64);
-    if (ones)
-        hipLaunchKernelGGL((splat_kernel<MP, true>), dim3(grid), dim3(256), 0, ctx->stream,
-                           (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_pix, L.csr_w, L.norm, q, M,
-                           L.n_chunks, val, part);
-    else
-        hipLaunchKernelGGL((splat_kernel<MP, false>), dim3(grid), dim3(256), 0, ctx->stream,
-                           (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_pix, L.csr_w, L.norm, q, M,
-                           L.n_chunks, val, part);
+// the normalisation pass: val = Lattice-splat of the all-ones vector (one value per row)
+void splat_ones(wsc_ctx *ctx, const LatticeDev &L, float *val, long long *part) {
+    hipLaunchKernelGGL(splat_ones_kernel, dim3(grid1d(L.n_chunks)), dim3(256), 0, ctx->stream,
+                       (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_w, L.n_chunks, val, part);
     if (L.n_long > 0)
-        hipLaunchKernelGGL(splat_combine_kernel<MP>, dim3(grid1d(L.n_long, gpb, 4096)), dim3(256), 0, ctx->stream,
-                           L.long_rows, L.n_long, L.chunk_base, part, M, val);
+        hipLaunchKernelGGL(splat_combine_kernel, dim3(grid1d(L.n_long, 256, 4096)), dim3(256), 0, ctx->stream,
+                           L.long_rows, L.n_long, L.chunk_base, part, 1, val);
 }
 
-// part: scratch of n_chunks * M floats (partials of multi-chunk rows)
-void splat_dispatch(wsc_ctx *ctx, const LatticeDev &L, const float *q, int M, float *val, float *part, bool ones) {
-    if (M <= 1) launch_splat<1>(ctx, L, q, M, val, part, ones);
-    else if (M <= 2) launch_splat<2>(ctx, L, q, M, val, part, ones);
-    else if (M <= 4) launch_splat<4>(ctx, L, q, M, val, part, ones);
-    else if (M <= 8) launch_splat<8>(ctx, L, q, M, val, part, ones);
-    else if (M <= 16) launch_splat<16>(ctx, L, q, M, val, part, ones);
-    else launch_splat<32>(ctx, L, q, M, val, part, ones);
+// part: scratch of n_chunks * Mp int64 (partials of multi-chunk rows)
+void splat4(wsc_ctx *ctx, const LatticeDev &L, const float *q, int LP, float *val, long long *part) {
+    const int gpw = 64 / LP;
+    hipLaunchKernelGGL(splat4_kernel, dim3(grid1d(L.n_chunks, 4 * gpw, 256 * 64)), dim3(256), 0, ctx->stream,
+                       (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_pix, L.csr_w, L.norm, q, LP,
+                       L.n_chunks, val, part);
+    if (L.n_long > 0)
+        hipLaunchKernelGGL(splat_combine_kernel, dim3(grid1d((long long)L.n_long * 4 * LP, 256, 4096)), dim3(256), 0,
+                           ctx->stream, L.long_rows, L.n_long, L.chunk_base, part, 4 * LP, val);
 }
 
 // d+1 blur passes, ping-pong between a and b; returns the buffer holding the result
-float *blur_all(wsc_ctx *ctx, const LatticeDev &L, int M, float *a, float *b) {
-    const long long total = (long long)L.rows * M;
+float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
     for (int j = 0; j <= L.d; ++j) {
-        hipLaunchKernelGGL(blur_kernel, dim3(grid1d(total, 256, 256 * 64)), dim3(256), 0, ctx->stream, a,
-                           L.nbr + (long long)j * L.rows, M, total, b);
+        hipLaunchKernelGGL(blur1_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream, a,
+                           L.nbr + (long long)j * L.rows, L.rows, b);
+        float *t = a; a = b; b = t;
+    }
+    return a;
+}
+float *blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, float *a, float *b) {
+    for (int j = 0; j <= L.d; ++j) {
+        hipLaunchKernelGGL(blur4_kernel, dim3(grid1d(L.rows, (256 / LP) * 2, 256 * 64)), dim3(256), 0, ctx->stream,
+                           (const f32x4_t *)a, L.nbr + (long long)j * L.rows, LP, L.rows, (f32x4_t *)b);
         float *t = a; a = b; b = t;
     }
     return a;
@@ -886,28 +1004,16 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
 
     hipLaunchKernelGGL(assign_ids_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, flag, prefix, table,
                        cap, N, dp1, total, slot2row, rowkey, rowimg);
-    hipLaunchKernelGGL(remap_count_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, slot2row, cap, N,
-                       dp1, total, L.offset, count);
+    hipLaunchKernelGGL(remap_count_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, eslot,
+                       slot2row, cap, N, dp1, npix, L.offset, count);
     {
         unsigned *sums2;
         const int nb2 = (L.rows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
         WSC_TRY(tmp.alloc(sizeof(unsigned) * (nb2 + 2), (void **)&sums2));
         WSC_TRY(exclusive_scan(ctx, count, L.rows + 1, (unsigned *)L.csr_start, sums2));
     }
-    hipLaunchKernelGGL(csr_fill_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1, total,
-                       (const unsigned *)L.csr_start, cursor, L.csr_pix, L.csr_w);
-    {
-        unsigned *n_long;
-        int32_t *long_rows;
-        WSC_TRY(tmp.alloc(sizeof(unsigned), (void **)&n_long));
-        WSC_TRY(tmp.alloc(sizeof(int32_t) * L.rows, (void **)&long_rows));
-        WSC_HIP(hipMemsetAsync(n_long, 0, sizeof(unsigned), ctx->stream));
-        hipLaunchKernelGGL(csr_sort_short_kernel, dim3(grid1d(L.rows, 64)), dim3(64), 0, ctx->stream,
-                           (const unsigned *)L.csr_start, L.rows, L.csr_pix, L.csr_w, n_long, long_rows);
-        hipLaunchKernelGGL(csr_sort_long_kernel, dim3(2048), dim3(256), SORT_LDS_MAX * 8, ctx->stream,
-                           (const unsigned *)L.csr_start, (const unsigned *)n_long, (const int32_t *)long_rows,
-                           L.csr_pix, L.csr_w);
-    }
+    hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, L.offset,
+                       L.bary, dp1, npix, (const unsigned *)L.csr_start, cursor, L.csr_pix, L.csr_w);
     hipLaunchKernelGGL(neighbors_kernel<D>, dim3(grid1d((long long)L.rows * dp1)), dim3(256), 0, ctx->stream, rowkey,
                        rowimg, table, slot2row, cap, (unsigned)(cap - 1), L.rows, L.nbr);
     WSC_HIP(hipGetLastError());
@@ -938,22 +1044,22 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     }
 
     // norm = 1/sqrt(Lattice(1) + 1e-20)
-    float *va, *vb, *vp;
+    float *va, *vb;
+    long long *vp;
     WSC_TRY(tmp.alloc(sizeof(float) * L.rows, (void **)&va));
     WSC_TRY(tmp.alloc(sizeof(float) * L.rows, (void **)&vb));
-    WSC_TRY(tmp.alloc(sizeof(float) * L.n_chunks, (void **)&vp));
-    splat_dispatch(ctx, L, nullptr, 1, va, vp, true);
-    float *res = blur_all(ctx, L, 1, va, vb);
+    WSC_TRY(tmp.alloc(sizeof(long long) * L.n_chunks, (void **)&vp));
+    splat_ones(ctx, L, va, vp);
+    float *res = blur_all1(ctx, L, va, vb);
     hipLaunchKernelGGL(slice_norm_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1,
                        L.alpha, res, npix, L.norm);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
 
-template <int MP>
 void launch_update(wsc_ctx *ctx, const UpdateArgs &a) {
-    const int gpb = 256 / MP;
-    hipLaunchKernelGGL(slice_update_kernel<MP>, dim3(grid1d(a.npix, gpb, 256 * 64)), dim3(256), 0, ctx->stream, a);
+    const int gpw = 64 / a.LP;
+    hipLaunchKernelGGL(slice_update_kernel, dim3(grid1d(a.npix, 4 * gpw, 256 * 64)), dim3(256), 0, ctx->stream, a);
 }
 
 } // namespace
@@ -1003,10 +1109,13 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     const int B = crf->B, N = crf->N;
     const long long npix = (long long)B * N;
     const LatticeDev &G = crf->lat[0], &Bl = crf->lat[1];
+    const int LP = (M + 3) / 4, Mp = 4 * LP; // rows padded to 16-byte multiples
+    WSC_CHECK(npix * Mp < (1ll << 31) && (long long)G.rows * Mp < (1ll << 31) && (long long)Bl.rows * Mp < (1ll << 31),
+              WSC_ERR_CAPACITY, "CRF batch too large for 32-bit element indices (B*N*Mp = %lld)", npix * Mp);
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t qb = al(sizeof(float) * npix * M);
-    const size_t vg = al(sizeof(float) * (size_t)G.rows * M), vb = al(sizeof(float) * (size_t)Bl.rows * M);
-    const size_t pg = al(sizeof(float) * (size_t)G.n_chunks * M), pb = al(sizeof(float) * (size_t)Bl.n_chunks * M);
+    const size_t qb = al(sizeof(float) * npix * Mp);
+    const size_t vg = al(sizeof(float) * (size_t)G.rows * Mp), vb = al(sizeof(float) * (size_t)Bl.rows * Mp);
+    const size_t pg = al(sizeof(long long) * (size_t)G.n_chunks * Mp), pb = al(sizeof(long long) * (size_t)Bl.n_chunks * Mp);
     void *ws;
     WSC_TRY(wsc_ctx_workspace(ctx, 2 * qb + 2 * vg + 2 * vb + pg + pb, &ws));
     char *p = (char *)ws;
@@ -1016,33 +1125,28 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     float *vg1 = (float *)p; p += vg;
     float *vb0 = (float *)p; p += vb;
     float *vb1 = (float *)p; p += vb;
-    float *partg = (float *)p; p += pg;
-    float *partb = (float *)p; p += pb;
+    long long *partg = (long long *)p; p += pg;
+    long long *partb = (long long *)p; p += pb;
 
     const dim3 tgrid((N + TP - 1) / TP, B);
     hipLaunchKernelGGL(init_q_kernel, tgrid, dim3(TP), 2 * (size_t)M * (TP + 1) * sizeof(float), ctx->stream,
-                       unary_dev, M, N, u, q);
+                       unary_dev, M, Mp, N, u, q);
     for (int it = 0; it < n_iters; ++it) {
-        splat_dispatch(ctx, G, q, M, vg0, partg, false);
-        float *rg = blur_all(ctx, G, M, vg0, vg1);
-        splat_dispatch(ctx, Bl, q, M, vb0, partb, false);
-        float *rb = blur_all(ctx, Bl, M, vb0, vb1);
+        splat4(ctx, G, q, LP, vg0, partg);
+        float *rg = blur_all4(ctx, G, LP, vg0, vg1);
+        splat4(ctx, Bl, q, LP, vb0, partb);
+        float *rb = blur_all4(ctx, Bl, LP, vb0, vb1);
         UpdateArgs a;
         a.off_g = G.offset; a.off_b = Bl.offset; a.bary_g = G.bary; a.bary_b = Bl.bary;
         a.norm_g = G.norm; a.norm_b = Bl.norm; a.val_g = rg; a.val_b = rb;
         a.u = u; a.q = q;
         a.alpha_g = G.alpha; a.alpha_b = Bl.alpha; a.compat_g = g_compat; a.compat_b = bi_compat;
-        a.M = M; a.npix = npix;
-        if (M <= 1) launch_update<1>(ctx, a);
-        else if (M <= 2) launch_update<2>(ctx, a);
-        else if (M <= 4) launch_update<4>(ctx, a);
-        else if (M <= 8) launch_update<8>(ctx, a);
-        else if (M <= 16) launch_update<16>(ctx, a);
-        else launch_update<32>(ctx, a);
+        a.M = M; a.LP = LP; a.npix = npix;
+        launch_update(ctx, a);
     }
     if (q_dev || argmax_dev)
-        hipLaunchKernelGGL(finish_kernel, tgrid, dim3(TP), (size_t)M * (TP + 1) * sizeof(float), ctx->stream, q, M, N,
-                           q_dev, argmax_dev);
+        hipLaunchKernelGGL(finish_kernel, tgrid, dim3(TP), (size_t)M * (TP + 1) * sizeof(float), ctx->stream, q, M, Mp,
+                           N, q_dev, argmax_dev);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
