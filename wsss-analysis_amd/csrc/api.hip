@@ -123,6 +123,8 @@ int wsc_ctx_create(int device, void *stream, wsc_ctx **out) {
         WSC_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->own_stream = true;
     }
+    WSC_HIP(hipMalloc(&ctx->zero_page, 256));
+    WSC_HIP(hipMemset(ctx->zero_page, 0, 256));
     WSC_HIP(hipEventCreateWithFlags(&ctx->pinned_ev, hipEventDisableTiming));
     WSC_HIP(hipEventCreate(&ctx->ev0));
     WSC_HIP(hipEventCreate(&ctx->ev1));
@@ -135,6 +137,7 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->zero_page) (void)hipFree(ctx->zero_page);
     for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
     for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -115,6 +115,7 @@ struct wsc_ctx {
     // small pinned staging buffer for descriptor uploads
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    void *zero_page = nullptr; // 256 bytes of zeros in HBM (source of padded conv taps)
     hipEvent_t pinned_ev = nullptr; // completion of the last copy out of `pinned`
     bool pinned_busy = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

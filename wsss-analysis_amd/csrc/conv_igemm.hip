@@ -13,8 +13,12 @@
 // Block tile 128 x BN x 64, 4 waves (2x2), each wave 64 x BN/2 as 32x32 MFMA tiles.
 // LDS tiles are [row][64 k] bf16 (128 B rows) with the 16-byte slot XOR-swizzled by
 // (row>>1)&7 so both the ds_write_b128 staging stores and the ds_read_b128 fragment
-// loads are bank-conflict free.  Global -> register -> LDS staging is software
-// pipelined one K-step ahead (double-buffered LDS, one barrier per K-step).
+// loads are bank-conflict free.  Staging is double-buffered, one barrier per K-step, one K-step
+// ahead: generic layers use the LDS DMA (global_load_lds_dwordx4: no staging VGPRs, no
+// ds_write pass -- the ds_write_b128 path tops out at ~79 B/clk/CU and together with the fragment
+// reads made the first version of this kernel LDS-bound at ~300 TFLOP/s); the swizzle is applied
+// to the per-lane SOURCE address because a DMA's LDS destination is lane-linear, and padded taps
+// read a zero page.  The small-Cin layers (stem) keep global -> register -> LDS staging.
 // Epilogue: accumulators go through LDS as an fp32 tile so that each thread owns 8
 // consecutive channels of one pixel: folded-BN scale/shift, residual add, ReLU,
 // optional post-ReLU affine, then one 16-byte coalesced store.
@@ -45,13 +49,14 @@ struct ConvKArgs {
     int Kw;          // packed weight row length in elements
     int Kbase;       // elements of one weight plane per row
     int ntiles_n, nblocks;
+    const bf16_t *zero; // >= 16 bytes of zeros in HBM: source of padded taps for the LDS-DMA path
 };
 
 __device__ __forceinline__ int lds_off(int row, int slot) {
     return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int BN, int MODE, bool SPLIT, int ET>
+template <int BN, int MODE, bool SPLIT, int ET, bool GLDS>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
     constexpr int WN = BN / 2;
     constexpr int NI = WN / 32;
@@ -82,13 +87,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
     const int n0 = nt * BN;
 
     // ---- per-thread A gather state: 4 rows, one 16-byte slot each -------------
+    // Staging ownership.  Register path: thread t stages rows (t>>3) + 32 i, k-slot t&7.
+    // LDS-DMA path (GLDS): one global_load_lds_dwordx4 wave-instruction fills 1 KiB of LDS in lane
+    // order = 8 tile rows x 8 slot positions, so wave w's i-th instruction owns rows
+    // w*32 + i*8 + (lane>>3) and lane position lane&7; the XOR swizzle is applied to the SOURCE
+    // k-slot (the LDS destination of a DMA is always lane-linear).
     const int slot = t & 7;
-    const int lrow = t >> 3; // 0..31
+    const int lrow = GLDS ? (wv * 32 + (lane >> 3)) : (t >> 3);
+    constexpr int RSTEP = GLDS ? 8 : 32;
     int hb[4], wb[4];
     long long base[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + RSTEP * i;
         if (m < p.M) {
             const int n = m / p.HoWo;
             const int rem = m - n * p.HoWo;
@@ -103,11 +114,49 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
             base[i] = 0;
         }
     }
+    // B rows: register path (t>>3) + 32 i; DMA path wave w owns rows w*(BN/4) + i*8 + (lane>>3)
+    const int brow0 = GLDS ? (wv * (BN / 4) + (lane >> 3)) : (t >> 3);
     const bf16_t *wrow[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) wrow[i] = p.w + (long long)(n0 + lrow + 32 * i) * p.Kw + slot * 8;
+    for (int i = 0; i < NB; ++i) {
+        const int r = brow0 + RSTEP * i;
+        const int ks = GLDS ? (slot ^ ((r >> 1) & 7)) : slot;
+        wrow[i] = p.w + (long long)(n0 + r) * p.Kw + ks * 8;
+    }
 
     uint4 ra[4], rb[NB];
+
+    // LDS-DMA issue of one K-step's A and B tiles into buffer `buf` (MODE 0 only)
+    auto issue_dma = [&](int kt, int buf) {
+        int seg = 0, ktl = kt;
+        if (SPLIT) {
+            seg = kt / p.ksteps_base;
+            ktl = kt - seg * p.ksteps_base;
+        }
+        const bf16_t *src = (SPLIT && seg == 1) ? p.x_lo : p.x;
+        const int tap = ktl / p.cchunks;
+        const int cc = ktl - tap * p.cchunks;
+        const int khi = tap / p.kw;
+        const int kwi = tap - khi * p.kw;
+        const long long tap_off = ((long long)khi * p.W + kwi) * p.Cin + cc * 64;
+        char *sa = smem + buf * A_BYTES + wv * 4096;
+        char *sb = smem + 2 * A_BYTES + buf * B_BYTES + wv * (NB * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lrow + RSTEP * i;
+            const int ks = slot ^ ((r >> 1) & 7);
+            const int hi = hb[i] + khi, wi = wb[i] + kwi;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const bf16_t *g = ok ? src + base[i] + tap_off + ks * 8 : p.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(sa + i * 1024), 16, 0, 0);
+        }
+        const int wk = ((SPLIT && seg == 2) ? p.Kbase : 0) + ktl * 64;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wrow[i] + wk),
+                                             (__attribute__((address_space(3))) void *)(sb + i * 1024), 16, 0, 0);
+    };
 
     auto load_tile = [&](int kt) {
         int seg = 0, ktl = kt;
@@ -201,16 +250,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
 
     // ---- main loop ------------------------------------------------------------------
     const int nk = p.nk;
-    load_tile(0);
-    store_lds(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tile(kt + 1);
-        compute(cur);
-        if (more) store_lds(cur ^ 1);
+    if (GLDS && MODE == 0) {
+        // the DMA for K-step kt+1 is issued before the MFMAs of K-step kt and has landed when the
+        // barrier (which carries the vmcnt(0) for the in-flight DMA) releases
+        issue_dma(0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) issue_dma(kt + 1, cur ^ 1);
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+        load_tile(0);
+        store_lds(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nk;
+            if (more) load_tile(kt + 1);
+            compute(cur);
+            if (more) store_lds(cur ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue --------------------------------------------------------------------
@@ -319,12 +381,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
 
 template <int BN, int MODE, bool SPLIT, int ET>
 int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
+    constexpr bool GLDS = MODE == 0; // LDS-DMA staging for every generic layer; small-Cin layers stage via registers
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int PIPE = 2 * (A_BYTES + B_BYTES);
     constexpr int EPI = BM * (BN + 4) * 4;
     constexpr int LDS = PIPE > EPI ? PIPE : EPI;
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<BN, MODE, SPLIT, ET>;
+    auto kern = conv_igemm_kernel<BN, MODE, SPLIT, ET, GLDS>;
     if (!attr_set) {
         WSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -380,6 +443,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     const int BN = p.CoutPad % 128 == 0 ? 128 : 64;
     WSC_CHECK(p.CoutPad % 64 == 0, WSC_ERR_INVALID, "conv: CoutPad=%d not a multiple of 64", p.CoutPad);
     a.ntiles_n = p.CoutPad / BN;
+    a.zero = (const bf16_t *)ctx->zero_page;
     a.nblocks = ((a.M + BM - 1) / BM) * a.ntiles_n;
     if (a.M == 0) return WSC_OK;
     WSC_CHECK(!(p.split && p.fmt), WSC_ERR_INVALID, "conv: split precision requires bf16 planes");

@@ -43,6 +43,7 @@ struct LatticeDev {
     int32_t *csr_start = nullptr; // [rows + 1]
     int32_t *csr_pix = nullptr;   // [B*N*(d+1)]  global pixel index
     float *csr_w = nullptr;       // [B*N*(d+1)]
+    uint2 *csr_ent = nullptr;     // [B*N*(d+1)] {pixel, bits(w * norm[pixel])}: one 8-byte load per gathered pixel
     int2 *nbr = nullptr;          // [(d+1)][rows]
     // splat work items: every row is cut into chunks of <= SPLAT_CHUNK gathered pixels
     int32_t *chunk_base = nullptr; // [rows + 1] first chunk of each row
@@ -59,6 +60,8 @@ struct wsc_crf {
     wsc_ctx *ctx = nullptr;
     int B = 0, H = 0, W = 0, N = 0;
     LatticeDev lat[2]; // 0: Gaussian (d=2), 1: bilateral (d=5)
+    // per pixel, 20 dwords = five 16-byte loads: offG[3] offB[6] baryG[3] baryB[6] normG normB
+    uint4 *pix_rec = nullptr;
     std::vector<void *> allocs;
 };
 
@@ -536,8 +539,7 @@ __global__ __launch_bounds__(256) void splat_ones_kernel(const unsigned *__restr
 __global__ __launch_bounds__(256) void splat4_kernel(const unsigned *__restrict__ start,
                                                      const int32_t *__restrict__ chunk_base,
                                                      const int32_t *__restrict__ chunk_row,
-                                                     const int32_t *__restrict__ csr_pix,
-                                                     const float *__restrict__ csr_w, const float *__restrict__ norm,
+                                                     const uint2 *__restrict__ csr_ent,
                                                      const float *__restrict__ q, int LP, int n_chunks,
                                                      float *__restrict__ val, long long *__restrict__ part) {
     const int gpw = 64 / LP;
@@ -556,23 +558,16 @@ __global__ __launch_bounds__(256) void splat4_kernel(const unsigned *__restrict_
         const unsigned e = min(s + SPLAT_CHUNK, start[row + 1]);
         long long acc[4] = {0, 0, 0, 0};
         for (unsigned i = s; i < e; i += 8) {
-            int p[8];
+            uint2 en[8];
             float w[8];
             f32x4_t in[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const unsigned idx = min(i + j, e - 1);
-                p[j] = csr_pix[idx];
-                w[j] = i + j < e ? csr_w[idx] : 0.f;
+                en[j] = csr_ent[min(i + j, e - 1)];
+                w[j] = i + j < e ? __uint_as_float(en[j].y) : 0.f; // w * norm[pixel]
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                in[j] = q4[(unsigned)p[j] * (unsigned)LP + l];
-                w[j] *= 1.f; // keep (q*norm) then *w order below
-                const float nr = norm[p[j]];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) in[j][k] = in[j][k] * nr;
-            }
+            for (int j = 0; j < 8; ++j) in[j] = q4[en[j].x * (unsigned)LP + l];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -685,10 +680,35 @@ __global__ void slice_norm_kernel(const int32_t *__restrict__ offset, const floa
     }
 }
 
+// csr_ent[i] = {pixel, w * norm[pixel]}: the splat then needs one 8-byte load per gathered pixel
+__global__ void pack_entries_kernel(const int32_t *__restrict__ csr_pix, const float *__restrict__ csr_w,
+                                    const float *__restrict__ norm, long long total, uint2 *__restrict__ ent) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int p = csr_pix[i];
+        ent[i] = make_uint2((unsigned)p, __float_as_uint(csr_w[i] * norm[p]));
+    }
+}
+
+// everything slice_update needs to know about a pixel in 80 contiguous bytes
+__global__ void pack_pixels_kernel(const int32_t *__restrict__ off_g, const float *__restrict__ bary_g,
+                                   const float *__restrict__ norm_g, const int32_t *__restrict__ off_b,
+                                   const float *__restrict__ bary_b, const float *__restrict__ norm_b, long long npix,
+                                   uint32_t *__restrict__ rec) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * blockDim.x) {
+        uint32_t *r = rec + p * 20;
+        for (int i = 0; i < 3; ++i) r[i] = (uint32_t)off_g[p * 3 + i];
+        for (int i = 0; i < 6; ++i) r[3 + i] = (uint32_t)off_b[p * 6 + i];
+        for (int i = 0; i < 3; ++i) r[9 + i] = __float_as_uint(bary_g[p * 3 + i]);
+        for (int i = 0; i < 6; ++i) r[12 + i] = __float_as_uint(bary_b[p * 6 + i]);
+        r[18] = __float_as_uint(norm_g[p]);
+        r[19] = __float_as_uint(norm_b[p]);
+    }
+}
+
 struct UpdateArgs {
-    const int32_t *off_g, *off_b;
-    const float *bary_g, *bary_b;
-    const float *norm_g, *norm_b;
+    const uint4 *pix_rec; // [pixel][5]
     const float *val_g, *val_b;
     const float *u; // [pixel][Mp]
     float *q;       // [pixel][Mp]
@@ -720,25 +740,32 @@ __global__ __launch_bounds__(256) void slice_update_kernel(UpdateArgs a) {
         const long long pp = p0 + g;
         const bool ok = act && pp < pend;
         const long long p = ok ? pp : pbeg;
-        int og[3], ob[6];
+        // the pixel's record: 5 x 16 bytes, identical for the LP lanes of the pixel (broadcast loads)
+        uint32_t rc[20];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint4 t = a.pix_rec[p * 5 + i];
+            rc[4 * i] = t.x; rc[4 * i + 1] = t.y; rc[4 * i + 2] = t.z; rc[4 * i + 3] = t.w;
+        }
+        unsigned og[3], ob[6];
         float bg[3], bb[6];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            og[r] = a.off_g[p * 3 + r];
-            bg[r] = a.bary_g[p * 3 + r];
+            og[r] = rc[r];
+            bg[r] = __uint_as_float(rc[9 + r]);
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            ob[r] = a.off_b[p * 6 + r];
-            bb[r] = a.bary_b[p * 6 + r];
+            ob[r] = rc[3 + r];
+            bb[r] = __uint_as_float(rc[12 + r]);
         }
         f32x4_t vg[3], vb[6];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) vg[r] = vg4[(unsigned)og[r] * (unsigned)LP + l];
+        for (int r = 0; r < 3; ++r) vg[r] = vg4[og[r] * (unsigned)LP + l];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) vb[r] = vb4[(unsigned)ob[r] * (unsigned)LP + l];
+        for (int r = 0; r < 6; ++r) vb[r] = vb4[ob[r] * (unsigned)LP + l];
         const f32x4_t un = u4[p * LP + l];
-        const float ng = a.norm_g[p], nb = a.norm_b[p];
+        const float ng = __uint_as_float(rc[18]), nb = __uint_as_float(rc[19]);
         float e[4];
         float mx = -3.0e38f;
 #pragma unroll
@@ -897,8 +924,8 @@ void splat_ones(wsc_ctx *ctx, const LatticeDev &L, float *val, long long *part) 
 void splat4(wsc_ctx *ctx, const LatticeDev &L, const float *q, int LP, float *val, long long *part) {
     const int gpw = 64 / LP;
     hipLaunchKernelGGL(splat4_kernel, dim3(grid1d(L.n_chunks, 4 * gpw, 256 * 64)), dim3(256), 0, ctx->stream,
-                       (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_pix, L.csr_w, L.norm, q, LP,
-                       L.n_chunks, val, part);
+                       (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_ent, q, LP, L.n_chunks, val,
+                       part);
     if (L.n_long > 0)
         hipLaunchKernelGGL(splat_combine_kernel, dim3(grid1d((long long)L.n_long * 4 * LP, 256, 4096)), dim3(256), 0,
                            ctx->stream, L.long_rows, L.n_long, L.chunk_base, part, 4 * LP, val);
@@ -1053,6 +1080,9 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     float *res = blur_all1(ctx, L, va, vb);
     hipLaunchKernelGGL(slice_norm_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1,
                        L.alpha, res, npix, L.norm);
+    WSC_TRY(crf_alloc(crf, sizeof(uint2) * total, (void **)&L.csr_ent));
+    hipLaunchKernelGGL(pack_entries_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, L.csr_pix, L.csr_w, L.norm,
+                       total, L.csr_ent);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
@@ -1077,6 +1107,13 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
     crf->ctx = ctx; crf->B = B; crf->H = H; crf->W = W; crf->N = H * W;
     int st = build_lattice<2>(crf, crf->lat[0], rgb_dev, g_sxy, 1.f);
     if (st == WSC_OK) st = build_lattice<5>(crf, crf->lat[1], rgb_dev, bi_sxy, bi_srgb);
+    if (st == WSC_OK) st = crf_alloc(crf, sizeof(uint4) * 5 * (size_t)B * crf->N, (void **)&crf->pix_rec);
+    if (st == WSC_OK) {
+        const long long npix = (long long)B * crf->N;
+        hipLaunchKernelGGL(pack_pixels_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, crf->lat[0].offset,
+                           crf->lat[0].bary, crf->lat[0].norm, crf->lat[1].offset, crf->lat[1].bary, crf->lat[1].norm,
+                           npix, (uint32_t *)crf->pix_rec);
+    }
     if (st != WSC_OK) {
         wsc_crf_destroy(crf);
         return st;
@@ -1137,8 +1174,7 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
         splat4(ctx, Bl, q, LP, vb0, partb);
         float *rb = blur_all4(ctx, Bl, LP, vb0, vb1);
         UpdateArgs a;
-        a.off_g = G.offset; a.off_b = Bl.offset; a.bary_g = G.bary; a.bary_b = Bl.bary;
-        a.norm_g = G.norm; a.norm_b = Bl.norm; a.val_g = rg; a.val_b = rb;
+        a.pix_rec = crf->pix_rec; a.val_g = rg; a.val_b = rb;
         a.u = u; a.q = q;
         a.alpha_g = G.alpha; a.alpha_b = Bl.alpha; a.compat_g = g_compat; a.compat_b = bi_compat;
         a.M = M; a.LP = LP; a.npix = npix;
