@@ -9,7 +9,8 @@ in HBM (BASELINE config 2/3: ResNet50 CAM + dense-CRF, 321x321, batch 32 images 
                            (strided /4 map + high-res map, per-class max-normalised)
   wsc_cam_postprocess      all 20 class maps at 321x321 (the CRF's probability stack)
   wsc_unary_from_maps      [bg=0.15 | maps] -> -log(clip(p)) unaries, M = 21
-  wsc_crf_create           Gaussian + bilateral permutohedral lattices of the 32 images
+  wsc_crf_create           Gaussian + bilateral permutohedral lattices of the 32 images (second
+                           context/stream: overlaps the conv stack, joined by wsc_ctx_wait)
   wsc_crf_inference        10 mean-field iterations -> arg-max label map
 
 N > 1: one process per GPU (torch.distributed.run), every rank owns its own batch (the dataset is
@@ -74,6 +75,9 @@ class Workload:
         self.np, self._lib = np, _lib
         self.B, self.workload = batch, workload
         self.ctx = _lib.Context(device)
+        # second context (own stream) for the lattice build: it needs only the RGB images, so it runs
+        # concurrently with the CNN forward pass of the same batch and joins before the inference
+        self.ctx_build = _lib.Context(device)
         prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3}[precision]
         sd = {k: v.numpy() for k, v in cnn_ref.make_resnet50_cam_state_dict(NUM_CLASSES, seed=0).items()}
         self.net = _lib.Net(self.ctx, _lib.ARCH_RESNET50_CAM, sd, NUM_CLASSES, prec)
@@ -125,22 +129,29 @@ class Workload:
         self._lib.unary_from_maps(self.ctx, self.maps_dev, self.B, NUM_CLASSES, S * S, 0.15, self.unary_dev)
 
     def crf_create(self):
-        return self._lib.Crf(self.ctx, self.rgb_dev, self.B, S, S, CRF_CFG[0], CRF_CFG[2], CRF_CFG[3])
+        return self._lib.Crf(self.ctx_build, self.rgb_dev, self.B, S, S, CRF_CFG[0], CRF_CFG[2], CRF_CFG[3])
 
     def crf_infer(self, crf):
-        crf.inference(self.unary_dev, NUM_CLASSES + 1, CRF_CFG[1], CRF_CFG[4], CRF_CFG[5], None, self.label_dev)
+        crf.inference(self.unary_dev, NUM_CLASSES + 1, CRF_CFG[1], CRF_CFG[4], CRF_CFG[5], None, self.label_dev,
+                      ctx=self.ctx)
 
     def step(self):
+        # stream 1: conv stack (enqueued asynchronously, returns at once)
         self.run_cnn()
+        if self.workload != "cam_crf":
+            self.run_tail()
+            return
+        # stream 2: lattice build of the same batch (needs only the RGB images) while the conv stack runs
+        crf = self.crf_create()
+        if self.vg is None:
+            self.vg, self.vb = crf.lattice_sizes()
+        # stream 1 again: tail + unaries, then join and run the mean-field loop
         self.run_tail()
-        if self.workload == "cam_crf":
-            self.run_unary()
-            crf = self.crf_create()
-            if self.vg is None:
-                self.vg, self.vb = crf.lattice_sizes()
-            self.crf_infer(crf)
-            self.ctx.sync()
-            crf.close()
+        self.run_unary()
+        self.ctx.wait_for(self.ctx_build)
+        self.crf_infer(crf)
+        self.ctx.sync()  # the lattice memory goes back to the build ctx's cache only when inference is done
+        crf.close()
 
     def timed(self, fn, reps):
         """Average device time of fn() over reps, HIP events on the ctx stream."""
@@ -271,8 +282,9 @@ def main():
         t_un = wl.timed(wl.run_unary, reps)
         t0c = time.perf_counter()
         crf = wl.crf_create()
-        wl.ctx.sync()
+        wl.ctx_build.sync()
         t_create = (time.perf_counter() - t0c) * 1e3
+        wl.ctx.wait_for(wl.ctx_build)
         t_inf = wl.timed(lambda: wl.crf_infer(crf), 3)
         crf.close()
         vg, vb = float(wl.vg.mean()), float(wl.vb.mean())

@@ -84,6 +84,11 @@ const char *wsc_last_error(void);
 int wsc_ctx_create(int device, void *stream, wsc_ctx **out);
 void wsc_ctx_destroy(wsc_ctx *ctx);
 int wsc_sync(wsc_ctx *ctx);
+/* Make all work enqueued on `ctx` after this call wait (on the device, without blocking the host) for
+ * everything enqueued so far on `other`: lets one process overlap independent stages on two contexts
+ * of the same device (e.g. the lattice build of a batch, which needs only the RGB images, with its
+ * CNN forward pass) and join them before the stage that needs both. */
+int wsc_ctx_wait(wsc_ctx *ctx, wsc_ctx *other);
 /* name of the device's gcnArchName ("gfx950...") and CU count */
 int wsc_device_info(wsc_ctx *ctx, char *arch_name, size_t arch_name_len, int *num_cus);
 

@@ -126,6 +126,7 @@ int wsc_ctx_create(int device, void *stream, wsc_ctx **out) {
     WSC_HIP(hipMalloc(&ctx->zero_page, 256));
     WSC_HIP(hipMemset(ctx->zero_page, 0, 256));
     WSC_HIP(hipEventCreateWithFlags(&ctx->pinned_ev, hipEventDisableTiming));
+    WSC_HIP(hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming));
     WSC_HIP(hipEventCreate(&ctx->ev0));
     WSC_HIP(hipEventCreate(&ctx->ev1));
     *out = ctx;
@@ -142,6 +143,7 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
     for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_ev) (void)hipEventDestroy(ctx->pinned_ev);
+    if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -151,6 +153,15 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
 int wsc_sync(wsc_ctx *ctx) {
     WSC_CHECK(ctx, WSC_ERR_INVALID, "wsc_sync: null ctx");
     WSC_HIP(hipStreamSynchronize(ctx->stream));
+    return WSC_OK;
+}
+
+int wsc_ctx_wait(wsc_ctx *ctx, wsc_ctx *other) {
+    WSC_CHECK(ctx && other, WSC_ERR_INVALID, "wsc_ctx_wait: null ctx");
+    WSC_CHECK(ctx->device == other->device, WSC_ERR_INVALID, "wsc_ctx_wait: contexts are on different devices");
+    if (ctx == other) return WSC_OK;
+    WSC_HIP(hipEventRecord(other->join_ev, other->stream));
+    WSC_HIP(hipStreamWaitEvent(ctx->stream, other->join_ev, 0));
     return WSC_OK;
 }
 

@@ -119,6 +119,7 @@ struct wsc_ctx {
     hipEvent_t pinned_ev = nullptr; // completion of the last copy out of `pinned`
     bool pinned_busy = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t join_ev = nullptr; // wsc_ctx_wait
     // stream-ordered caching allocator: blocks released by wsc_ctx_cached_free are reused by later
     // requests of the same ctx (all work of a ctx is on one stream, so reuse is ordered after the
     // previous user) instead of going through hipFree/hipMalloc (both synchronise the device).

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "wsc_ctx_create": (_i, [_i, _vp, ctypes.POINTER(_vp)]),
     "wsc_ctx_destroy": (None, [_vp]),
     "wsc_sync": (_i, [_vp]),
+    "wsc_ctx_wait": (_i, [_vp, _vp]),
     "wsc_device_info": (_i, [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(_i)]),
     "wsc_malloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     "wsc_free": (_i, [_vp, _vp]),
@@ -168,6 +169,10 @@ class Context:
 
     def sync(self):
         check(self._lib.wsc_sync(self.h))
+
+    def wait_for(self, other):
+        """Device-side join: later work on this ctx waits for everything enqueued so far on `other`."""
+        check(self._lib.wsc_ctx_wait(self.h, other.h))
 
     def device_info(self):
         buf = ctypes.create_string_buffer(128)
@@ -374,6 +379,9 @@ class Crf:
         check(self.ctx._lib.wsc_crf_lattice_sizes(self.ctx.h, self.h, vg.ctypes.data, vb.ctypes.data))
         return vg, vb
 
-    def inference(self, unary_dev, M, g_compat, bi_compat, n_iters, q_dev=None, argmax_dev=None):
-        check(self.ctx._lib.wsc_crf_inference(self.ctx.h, self.h, _ptr(unary_dev), M, float(g_compat),
+    def inference(self, unary_dev, M, g_compat, bi_compat, n_iters, q_dev=None, argmax_dev=None, ctx=None):
+        """ctx: the context (stream, workspace) to run the mean-field loop on; defaults to the one the
+        lattices were built on.  When it differs, the caller orders the two with ctx.wait_for(build_ctx)."""
+        run = ctx or self.ctx
+        check(self.ctx._lib.wsc_crf_inference(run.h, self.h, _ptr(unary_dev), M, float(g_compat),
                                               float(bi_compat), int(n_iters), _ptr(q_dev), _ptr(argmax_dev)))
