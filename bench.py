@@ -272,12 +272,8 @@ def main():
     reps = 5
     t_cnn = wl.timed(wl.run_cnn, reps)
     t_tail = wl.timed(wl.run_tail, reps)
-    stages = {"cnn_ms": round(t_cnn, 4), "tail_ms": round(t_tail, 4)}
-    roof_mfma = {"bound": "mfma", "achieved": round(GFLOP_PER_IMAGE * wl.B / t_cnn, 2),
-                 "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s", "traffic": None,
-                 "kernel": "conv_igemm_kernel (whole conv stack, %d launches)" % 55}
-    roof_mfma["frac"] = round(roof_mfma["achieved"] / roof_mfma["peak"], 4)
-    roofline = roof_mfma
+    stages = {"cnn_ms": round(t_cnn, 4), "tail_ms": round(t_tail, 4),
+              "conv_stack_tflops": round(GFLOP_PER_IMAGE * wl.B / t_cnn, 2)}
     if args.workload == "cam_crf":
         t_un = wl.timed(wl.run_unary, reps)
         t0c = time.perf_counter()
@@ -290,16 +286,35 @@ def main():
         vg, vb = float(wl.vg.mean()), float(wl.vb.mean())
         by = crf_bytes_per_image(S * S, NUM_CLASSES + 1, CRF_CFG[5], vg, vb)
         stages.update({"unary_ms": round(t_un, 4), "crf_create_ms": round(t_create, 4), "crf_infer_ms": round(t_inf, 4),
-                       "lattice_vertices_gauss": round(vg, 1), "lattice_vertices_bilat": round(vb, 1)})
-        roof_hbm = {"bound": "hbm", "achieved": round(by * wl.B / (t_inf * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "traffic": None,
-                    "kernel": "CRF mean-field loop (splat/blur/slice, %d iterations)" % CRF_CFG[5]}
-        roof_hbm["frac"] = round(roof_hbm["achieved"] / roof_hbm["peak"], 4)
-        if t_inf > t_cnn:
-            roofline = roof_hbm
-            stages["roofline_mfma"] = roof_mfma
-        else:
-            stages["roofline_hbm"] = roof_hbm
+                       "lattice_vertices_gauss": round(vg, 1), "lattice_vertices_bilat": round(vb, 1),
+                       "crf_loop_algorithmic_GBps": round(by * wl.B / (t_inf * 1e-3) / 1e9, 2)})
+
+    # ---- per-kernel roofline: every launch of one more step bracketed by HIP events on its stream ----
+    wl.ctx.profile_begin()
+    wl.ctx_build.profile_begin()
+    for _ in range(2):
+        wl.step()
+    prof = wl.ctx.profile_end()
+    prof.update(wl.ctx_build.profile_end())
+    kernels = {}
+    for name, (calls, ms, work) in prof.items():
+        is_conv = name.startswith("conv_igemm")
+        rate = work / (ms * 1e-3) / (1e12 if is_conv else 1e9) if ms > 0 else 0.0
+        kernels[name] = {"launches_per_step": calls // 2, "avg_us": round(ms / calls * 1e3, 2),
+                         "ms_per_step": round(ms / 2, 4), ("TFLOP/s" if is_conv else "GB/s"): round(rate, 2)}
+    dom = max((n for n in prof if n != "crf_build(all)"), key=lambda n: prof[n][1])
+    calls, ms, work = prof[dom]
+    if dom.startswith("conv_igemm"):
+        roofline = {"bound": "mfma", "achieved": round(work / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[args.precision],
+                    "unit": "TFLOP/s", "traffic": None}
+    else:
+        roofline = {"bound": "hbm", "achieved": round(work / (ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "traffic": None}
+    roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
+    roofline["kernel"] = dom
+    roofline["avg_launch_us"] = round(ms / calls * 1e3, 2)
+    roofline["launches_per_step"] = calls // 2
+    stages["kernels"] = kernels
 
     if rank == 0:
         images = args.batch * args.steps * world

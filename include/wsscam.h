@@ -105,6 +105,15 @@ int wsc_memset(wsc_ctx *ctx, void *dst_dev, int value, size_t bytes);
 int wsc_timer_begin(wsc_ctx *ctx);
 int wsc_timer_end(wsc_ctx *ctx, float *ms_out);
 
+/* Per-kernel-class timing with HIP events on the ctx stream (bench.py's roofline object): between
+ * _begin and _end every kernel launch of the ctx is bracketed by an event pair; _end synchronises and
+ * returns, per class, the number of launches, their summed duration and their summed algorithmic
+ * work (FLOPs for the conv classes, bytes otherwise).  Arrays hold max_classes entries. */
+int wsc_profile_begin(wsc_ctx *ctx);
+int wsc_profile_end(wsc_ctx *ctx, int max_classes, int32_t *calls_out, float *total_ms_out, double *work_out,
+                    int *n_classes_out);
+const char *wsc_profile_class_name(int cls);
+
 /* ---- CNN + CAM head --------------------------------------------------- */
 
 /* Build a network from a state_dict.  Replaces model construction +

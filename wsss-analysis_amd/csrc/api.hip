@@ -90,7 +90,79 @@ int wsc_ctx_upload_small(wsc_ctx *ctx, void *dst_dev, const void *src_host, size
     return WSC_OK;
 }
 
+static hipEvent_t prof_event(wsc_ctx *ctx) {
+    if (!ctx->prof_pool.empty()) {
+        hipEvent_t e = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+WscKernelTimer::WscKernelTimer(wsc_ctx *c, int cls, double work) : ctx(c) {
+    if (!ctx->profiling) return;
+    WscProfRecord r;
+    r.cls = cls;
+    r.work = work;
+    r.e0 = prof_event(ctx);
+    r.e1 = prof_event(ctx);
+    (void)hipEventRecord(r.e0, ctx->stream);
+    ctx->prof.push_back(r);
+    idx = (int)ctx->prof.size() - 1;
+}
+WscKernelTimer::~WscKernelTimer() {
+    if (idx >= 0) (void)hipEventRecord(ctx->prof[idx].e1, ctx->stream);
+}
+
+static const char *kClassNames[WSC_K_COUNT] = {
+    "conv_igemm_kernel<128x128,glds>", "conv_igemm_kernel<128x64,glds>", "conv_igemm_kernel<small-Cin>",
+    "pool/layout/flip-add", "cam_tail+unary", "crf_build(all)", "splat4+combine", "blur4_kernel",
+    "slice_update_kernel", "crf init/finish"};
+
 extern "C" {
+
+int wsc_profile_begin(wsc_ctx *ctx) {
+    WSC_CHECK(ctx, WSC_ERR_INVALID, "wsc_profile_begin: null ctx");
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->prof) {
+        ctx->prof_pool.push_back(r.e0);
+        ctx->prof_pool.push_back(r.e1);
+    }
+    ctx->prof.clear();
+    ctx->profiling = true;
+    return WSC_OK;
+}
+
+int wsc_profile_end(wsc_ctx *ctx, int max_classes, int32_t *calls_out, float *total_ms_out, double *work_out,
+                    int *n_classes_out) {
+    WSC_CHECK(ctx && calls_out && total_ms_out && work_out, WSC_ERR_INVALID, "wsc_profile_end: null argument");
+    ctx->profiling = false;
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    const int n = max_classes < WSC_K_COUNT ? max_classes : (int)WSC_K_COUNT;
+    for (int i = 0; i < n; ++i) {
+        calls_out[i] = 0;
+        total_ms_out[i] = 0.f;
+        work_out[i] = 0.0;
+    }
+    for (auto &r : ctx->prof) {
+        float ms = 0.f;
+        WSC_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        if (r.cls < n) {
+            calls_out[r.cls] += 1;
+            total_ms_out[r.cls] += ms;
+            work_out[r.cls] += r.work;
+        }
+        ctx->prof_pool.push_back(r.e0);
+        ctx->prof_pool.push_back(r.e1);
+    }
+    ctx->prof.clear();
+    if (n_classes_out) *n_classes_out = n;
+    return WSC_OK;
+}
+
+const char *wsc_profile_class_name(int cls) { return cls >= 0 && cls < WSC_K_COUNT ? kClassNames[cls] : ""; }
 
 int wsc_version(void) { return WSC_VERSION; }
 const char *wsc_last_error(void) { return g_err; }
@@ -144,6 +216,8 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_ev) (void)hipEventDestroy(ctx->pinned_ev);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
+    for (auto &r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -148,6 +148,7 @@ int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N
     const long long total = (long long)B * N;
     long long g = (total + 255) / 256;
     if (g > 8192) g = 8192;
+    WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, (double)B * N * (2.0 * C + 1) * 4);
     hipLaunchKernelGGL(unary_from_maps_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, maps_dev, bg_value, C, N,
                        total, unary_dev);
     WSC_HIP(hipGetLastError());
@@ -197,6 +198,9 @@ int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h,
     WSC_HIP(hipMemsetAsync(d + jb, 0, mb, ctx->stream));
     const dim3 grid((max_pix + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, (unsigned)jobs.size());
     const size_t lds = (size_t)h * w * sizeof(float);
+    double out_bytes = 0;
+    for (const TailJob &t : jobs) out_bytes += ((double)t.H0 * t.W0 + (double)t.h4 * t.w4) * 4;
+    WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, out_bytes);
     hipLaunchKernelGGL(cam_tail_kernel<false>, grid, dim3(256), lds, ctx->stream, cam_dev, (const TailJob *)d, h, w,
                        (unsigned int *)(d + jb), strided_dev, highres_dev);
     hipLaunchKernelGGL(cam_tail_kernel<true>, grid, dim3(256), lds, ctx->stream, cam_dev, (const TailJob *)d, h, w,

@@ -102,6 +102,26 @@ void wsc_set_error(const char *fmt, ...);
         if (_s != WSC_OK) return _s;                                                           \
     } while (0)
 
+// ---- per-kernel-class timing (wsc_profile_begin / _end) --------------------------------------------
+enum WscKernelClass {
+    WSC_K_CONV128 = 0,   // conv_igemm_kernel, 128x128 tile, LDS-DMA staging
+    WSC_K_CONV64,        // conv_igemm_kernel, 128x64 tile
+    WSC_K_CONV_SMALLCIN, // conv_igemm_kernel, stem / first layer (register staging)
+    WSC_K_POOL_MISC,     // maxpool, layout changes, flip-add, classifier branch
+    WSC_K_CAM_TAIL,      // cam_tail_kernel (both passes) + unary_from_maps
+    WSC_K_CRF_BUILD,     // every kernel of wsc_crf_create
+    WSC_K_SPLAT,         // splat4_kernel + splat_combine_kernel
+    WSC_K_BLUR,          // blur4_kernel
+    WSC_K_SLICE_UPDATE,  // slice_update_kernel
+    WSC_K_CRF_MISC,      // init_q / finish
+    WSC_K_COUNT
+};
+struct WscProfRecord {
+    int cls;
+    double work; // algorithmic FLOPs (conv classes) or bytes (everything else) of this launch
+    hipEvent_t e0, e1;
+};
+
 // ---- context --------------------------------------------------------------------
 struct wsc_ctx {
     int device = 0;
@@ -120,6 +140,9 @@ struct wsc_ctx {
     bool pinned_busy = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t join_ev = nullptr; // wsc_ctx_wait
+    bool profiling = false;
+    std::vector<WscProfRecord> prof;
+    std::vector<hipEvent_t> prof_pool;
     // stream-ordered caching allocator: blocks released by wsc_ctx_cached_free are reused by later
     // requests of the same ctx (all work of a ctx is on one stream, so reuse is ordered after the
     // previous user) instead of going through hipFree/hipMalloc (both synchronise the device).
@@ -127,6 +150,14 @@ struct wsc_ctx {
     std::unordered_map<void *, size_t> live_blocks;
 };
 int wsc_ctx_workspace(wsc_ctx *ctx, size_t bytes, void **out);
+// Brackets the launches enqueued during its lifetime with a pair of HIP events on the ctx stream
+// when profiling is on (no-op otherwise).
+struct WscKernelTimer {
+    wsc_ctx *ctx;
+    int idx = -1;
+    WscKernelTimer(wsc_ctx *c, int cls, double work);
+    ~WscKernelTimer();
+};
 int wsc_ctx_cached_alloc(wsc_ctx *ctx, size_t bytes, void **out);
 void wsc_ctx_cached_free(wsc_ctx *ctx, void *p);
 // copies `bytes` of host data to dst_dev through the ctx's pinned staging buffer, asynchronously

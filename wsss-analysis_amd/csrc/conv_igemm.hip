@@ -393,6 +393,9 @@ int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
+    // algorithmic FLOPs: 2 * M * Cout * (kh*kw*Cin_real), x1 regardless of the precision mode
+    const double flops = 2.0 * a.M * a.Cout * (MODE == 0 ? (double)a.kh * a.kw * a.Cin : (double)a.kh * a.kw * 3);
+    WscKernelTimer timer(ctx, MODE != 0 ? WSC_K_CONV_SMALLCIN : (BN == 128 ? WSC_K_CONV128 : WSC_K_CONV64), flops);
     hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), LDS, ctx->stream, a);
     WSC_HIP(hipGetLastError());
     return WSC_OK;

@@ -50,6 +50,8 @@ struct LatticeDev {
     int32_t *chunk_row = nullptr;  // [n_chunks] owning row
     int32_t *long_rows = nullptr;  // [n_long] rows with more than one chunk
     int n_chunks = 0, n_long = 0;
+    long long n_pix = 0; // B*N
+    int M_cur = 0;       // class count of the inference in flight (algorithmic byte accounting)
     float alpha = 0.f;
     std::vector<int32_t> v_per_image;
 };
@@ -923,6 +925,9 @@ void splat_ones(wsc_ctx *ctx, const LatticeDev &L, float *val, long long *part) 
 // part: scratch of n_chunks * Mp int64 (partials of multi-chunk rows)
 void splat4(wsc_ctx *ctx, const LatticeDev &L, const float *q, int LP, float *val, long long *part) {
     const int gpw = 64 / LP;
+    // algorithmic bytes: read the batch's Q once + (pixel index, weight) per gathered pixel + write the rows
+    WscKernelTimer timer(ctx, WSC_K_SPLAT, (double)L.n_pix * L.M_cur * 4 + (double)L.n_pix * (L.d + 1) * 8 +
+                                              (double)L.rows * L.M_cur * 4);
     hipLaunchKernelGGL(splat4_kernel, dim3(grid1d(L.n_chunks, 4 * gpw, 256 * 64)), dim3(256), 0, ctx->stream,
                        (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_ent, q, LP, L.n_chunks, val,
                        part);
@@ -942,6 +947,7 @@ float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
 }
 float *blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, float *a, float *b) {
     for (int j = 0; j <= L.d; ++j) {
+        WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.M_cur * 4); // read + write every row once
         hipLaunchKernelGGL(blur4_kernel, dim3(grid1d(L.rows, (256 / LP) * 2, 256 * 64)), dim3(256), 0, ctx->stream,
                            (const f32x4_t *)a, L.nbr + (long long)j * L.rows, LP, L.rows, (f32x4_t *)b);
         float *t = a; a = b; b = t;
@@ -957,6 +963,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     const long long total = npix * dp1;
     WSC_CHECK(total < (1ll << 31), WSC_ERR_CAPACITY, "CRF batch too large: %lld lattice entries", total);
     L.d = D;
+    L.n_pix = npix;
     L.alpha = 1.0f / (1.0f + powf(2.0f, -(float)D));
     long long cap = 1;
     while (cap < 2ll * N * dp1) cap <<= 1;
@@ -1089,6 +1096,9 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
 
 void launch_update(wsc_ctx *ctx, const UpdateArgs &a) {
     const int gpw = 64 / a.LP;
+    // algorithmic bytes: slice index+weight of both lattices, read U, write Q (+ the two
+    // messages the reference materialises: N*M*4 each)
+    WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, (double)a.npix * (9 * 8 + 4.0 * a.M * 4));
     hipLaunchKernelGGL(slice_update_kernel, dim3(grid1d(a.npix, 4 * gpw, 256 * 64)), dim3(256), 0, ctx->stream, a);
 }
 
@@ -1105,6 +1115,7 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
     WSC_HIP(hipSetDevice(ctx->device));
     wsc_crf *crf = new wsc_crf();
     crf->ctx = ctx; crf->B = B; crf->H = H; crf->W = W; crf->N = H * W;
+    WscKernelTimer timer(ctx, WSC_K_CRF_BUILD, (double)B * H * W * (3.0 * 16 + 6.0 * 16));
     int st = build_lattice<2>(crf, crf->lat[0], rgb_dev, g_sxy, 1.f);
     if (st == WSC_OK) st = build_lattice<5>(crf, crf->lat[1], rgb_dev, bi_sxy, bi_srgb);
     if (st == WSC_OK) st = crf_alloc(crf, sizeof(uint4) * 5 * (size_t)B * crf->N, (void **)&crf->pix_rec);
@@ -1165,9 +1176,14 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     long long *partg = (long long *)p; p += pg;
     long long *partb = (long long *)p; p += pb;
 
+    crf->lat[0].M_cur = M;
+    crf->lat[1].M_cur = M;
     const dim3 tgrid((N + TP - 1) / TP, B);
-    hipLaunchKernelGGL(init_q_kernel, tgrid, dim3(TP), 2 * (size_t)M * (TP + 1) * sizeof(float), ctx->stream,
-                       unary_dev, M, Mp, N, u, q);
+    {
+        WscKernelTimer timer(ctx, WSC_K_CRF_MISC, (double)npix * M * 12);
+        hipLaunchKernelGGL(init_q_kernel, tgrid, dim3(TP), 2 * (size_t)M * (TP + 1) * sizeof(float), ctx->stream,
+                           unary_dev, M, Mp, N, u, q);
+    }
     for (int it = 0; it < n_iters; ++it) {
         splat4(ctx, G, q, LP, vg0, partg);
         float *rg = blur_all4(ctx, G, LP, vg0, vg1);
@@ -1180,6 +1196,7 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
         a.M = M; a.LP = LP; a.npix = npix;
         launch_update(ctx, a);
     }
+    WscKernelTimer ftimer(ctx, WSC_K_CRF_MISC, (double)npix * M * 8);
     if (q_dev || argmax_dev)
         hipLaunchKernelGGL(finish_kernel, tgrid, dim3(TP), (size_t)M * (TP + 1) * sizeof(float), ctx->stream, q, M, Mp,
                            N, q_dev, argmax_dev);

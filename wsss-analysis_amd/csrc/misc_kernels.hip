@@ -190,6 +190,7 @@ inline int grid_for(long long total, int block = 256, int cap = 256 * 16) {
 
 int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo, int fmt) {
     const long long total = (long long)N * H * W;
+    WscKernelTimer timer(ctx, WSC_K_POOL_MISC, (double)total * (12 + 8));
     hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, N, H * W, y,
                        y_lo, fmt);
     WSC_HIP(hipGetLastError());
@@ -200,6 +201,7 @@ int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int
                    int stride, int pad, int Ho, int Wo, bf16_t *y, bf16_t *y_lo, int fmt) {
     WSC_CHECK(C % 8 == 0, WSC_ERR_INVALID, "maxpool: C=%d not a multiple of 8", C);
     const long long total = (long long)N * Ho * Wo * (C / 8);
+    WscKernelTimer timer(ctx, WSC_K_POOL_MISC, ((double)N * H * W * C + (double)N * Ho * Wo * C) * 2);
     hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, x_lo, N, H, W, C, k,
                        stride, pad, Ho, Wo, y, y_lo, fmt);
     WSC_HIP(hipGetLastError());
@@ -208,6 +210,7 @@ int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int
 
 int launch_flip_add(wsc_ctx *ctx, const float *head, int B, int h, int w, int C, int Cs, float *cam) {
     const long long total = (long long)B * C * h * w;
+    WscKernelTimer timer(ctx, WSC_K_POOL_MISC, (double)total * 12);
     hipLaunchKernelGGL(flip_add_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, head, B, h, w, C, Cs,
                        cam);
     WSC_HIP(hipGetLastError());

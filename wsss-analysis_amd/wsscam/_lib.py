@@ -68,6 +68,9 @@ _SIGNATURES = {
     "wsc_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "wsc_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "wsc_memset": (_i, [_vp, _vp, _i, _sz]),
+    "wsc_profile_begin": (_i, [_vp]),
+    "wsc_profile_end": (_i, [_vp, _i, _vp, _vp, _vp, ctypes.POINTER(_i)]),
+    "wsc_profile_class_name": (ctypes.c_char_p, [_i]),
     "wsc_timer_begin": (_i, [_vp]),
     "wsc_timer_end": (_i, [_vp, ctypes.POINTER(_f)]),
     "wsc_net_create": (_i, [_vp, _i, ctypes.POINTER(TensorDesc), _i, _i, _i, ctypes.POINTER(_vp)]),
@@ -194,6 +197,20 @@ class Context:
         out = np.empty(shape, dtype=dtype)
         check(self._lib.wsc_memcpy_d2h(self.h, out.ctypes.data, _ptr(buf) + offset_bytes, out.nbytes))
         return out
+
+    def profile_begin(self):
+        check(self._lib.wsc_profile_begin(self.h))
+
+    def profile_end(self):
+        """-> {class name: (launches, total_ms, algorithmic work)} for the launches since profile_begin."""
+        n = 16
+        calls = np.zeros(n, np.int32)
+        ms = np.zeros(n, np.float32)
+        work = np.zeros(n, np.float64)
+        k = _i()
+        check(self._lib.wsc_profile_end(self.h, n, calls.ctypes.data, ms.ctypes.data, work.ctypes.data, ctypes.byref(k)))
+        return {self._lib.wsc_profile_class_name(i).decode(): (int(calls[i]), float(ms[i]), float(work[i]))
+                for i in range(k.value) if calls[i] > 0}
 
     def timer_begin(self):
         check(self._lib.wsc_timer_begin(self.h))
