@@ -147,6 +147,15 @@ int wsc_net_forward_cam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, in
 int wsc_net_forward_features(wsc_ctx *ctx, const wsc_net *net, const float *x_dev /*[N][3][S][S]*/,
                              int N, int S, float *feat_dev);
 
+/* Grad-CAM for a plain batch of N samples (02_cues/utilities.py:128-133, 03c_hsn/utilities.py:258-263):
+ *   cams[n][y][x][c] = [relu]( sum_f feat[n][y][x][f] * alpha[f][c] )      ('ijkl,lm->ijkm')
+ * with alpha the `gradcam_weights` tensor given to wsc_net_create (vgg16 / m7).  One CNN pass
+ * yields both the maps and, if score_dev != NULL, sigmoid classifier scores [N][C] -- the
+ * reference runs the network twice (model.predict + K.function).
+ *   x_dev float32 [N][3][S][S];  cams_dev float32 [N][h][w][C] (NHWC as numpy's einsum result). */
+int wsc_net_forward_gradcam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, int S, int relu,
+                            float *cams_dev, float *score_dev);
+
 /* One nn.Conv2d (+ per-channel scale/shift, residual add, ReLU) through the production
  * implicit-GEMM kernel with NCHW float32 tensors on the device -- the unit the per-layer
  * numerics tests drive (conv shape classes of SURVEY.md section 8 a4/a6).  w_host is OIHW.

@@ -179,3 +179,110 @@ def test_state_dict_errors(ctx, resnet_sd):
     with pytest.raises(_lib.WscError) as ei:
         _lib.Net(ctx, _lib.ARCH_RESNET50_CAM, bad, 20)
     assert ei.value.status == _lib.WSC_ERR_SHAPE
+
+
+# ---- 02_cues / 03c_hsn Grad-CAM mirrors -------------------------------------------------------------
+def _vgg_model(C, seed):
+    sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, True, seed=seed)
+    return _model(vgg16_cam.CAM, sd, C, _lib.PREC_BF16X3), sd
+
+
+def test_get_grad_cam_weights_closed_form_vs_autograd():
+    """02_cues/utilities.py:60-99 on the GAP+Linear VGG16: closed form == torch autograd on a zeros image."""
+    from wsscam.cues import utilities as cues
+
+    C = 20
+    model, sd = _vgg_model(C, seed=3)
+    alpha = cues.get_grad_cam_weights(model, cues.find_final_layer(model), np.zeros((1, 65, 65, 3), np.float32))
+    ref = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 65, C)
+    assert alpha.shape == ref.shape == (1024, C)
+    assert np.abs(alpha - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_cues_grad_cam_and_resize_stack():
+    """02_cues/utilities.py:101-144 (einsum + relu, keep_inds, threshold mask) and :20-40 (resize_stack)."""
+    from wsscam.cues import utilities as cues
+
+    C = 20
+    model, sd = _vgg_model(C, seed=4)
+    rng = np.random.default_rng(6)
+    imgs = np.stack([cnn_ref.normalize_int(cnn_ref.resize_bilinear_f64(cnn_ref.synth_image(rng, 70, 80), (65, 65)))
+                     for _ in range(3)])                                  # (B, S, S, 3) NHWC as read_batch gives
+    alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 65, C)
+    keep = np.array([0, 2, 5, 19])
+    is_pass = rng.random((3, len(keep))) > 0.3
+    out = cues.grad_cam(model, alpha, imgs, is_pass, "x", keep)
+    with torch.no_grad():
+        feat = cnn_ref.plain_features(torch.from_numpy(np.transpose(imgs, (0, 3, 1, 2)).copy()), sd, "vgg16",
+                                      cnn_ref.VGG16_CFG).numpy()
+    conv_val = np.transpose(feat, (0, 2, 3, 1)).astype(np.float64)
+    ref = np.maximum(np.einsum("ijkl,lm->ijkm", conv_val, alpha), 0)[:, :, :, keep] * is_pass[:, None, None, :]
+    assert out.shape == ref.shape == (3, 8, 8, 4)
+    assert np.abs(out - ref).max() <= 2e-4 * ref.max()
+    # resize_stack to the 41x41 seed size vs torch bilinear (cv2 INTER_LINEAR has the same half-pixel centres)
+    st = np.transpose(ref, (0, 3, 1, 2))
+    rs = cues.resize_stack(st, (41, 41), ctx=model.ctx)
+    tr = torch.nn.functional.interpolate(torch.from_numpy(st), (41, 41), mode="bilinear", align_corners=False).numpy()
+    assert rs.shape == (3, 4, 41, 41) and np.abs(rs - tr).max() <= 1e-5 * max(tr.max(), 1)
+
+
+def test_hsn_grad_cam_and_postprocessing():
+    """03c_hsn/utilities.py:231-278 (grad_cam), :306-364 (modify_by_htt), :367-397 (get_cs_gradcam)."""
+    from wsscam.hsn import utilities as hsn
+
+    C = 20
+    model, sd = _vgg_model(C, seed=5)
+    rng = np.random.default_rng(7)
+    raw = [cnn_ref.synth_image(rng, 70, 80) for _ in range(2)]
+    imgs = np.stack([cnn_ref.normalize_int(cnn_ref.resize_bilinear_f64(im, (65, 65))) for im in raw])
+    alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 65, C)
+    scores = rng.random((2, C))
+    is_pass = scores > 0.4
+    out = hsn.grad_cam(model, alpha, imgs, is_pass, "x", scores, orig_sz=[65, 65], should_upsample=True)
+    with torch.no_grad():
+        feat = cnn_ref.plain_features(torch.from_numpy(np.transpose(imgs, (0, 3, 1, 2)).copy()), sd, "vgg16",
+                                      cnn_ref.VGG16_CFG).numpy()
+    cams = np.einsum("ijkl,lm->ijkm", np.transpose(feat, (0, 2, 3, 1)).astype(np.float64), alpha)
+    up = torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cams, (0, 3, 1, 2))), (65, 65), mode="bilinear",
+                                         align_corners=False).numpy()
+    up = np.maximum(np.transpose(up, (0, 2, 3, 1)), 0)
+    ref = up / np.maximum(up.max(axis=(1, 2, 3), keepdims=True), 1e-7) * (scores * is_pass)[:, None, None, :]
+    assert out.shape == ref.shape == (2, 65, 65, C)
+    assert np.abs(out - ref).max() <= 5e-4
+
+    # get_cs_gradcam: margin on the arg-max class only; 'Other' passes through for func
+    g = rng.random((2, 4, 5, 6))
+    classes = ["Background", "Other", "G.O", "T"]
+    cs = hsn.get_cs_gradcam(g.copy(), classes, "func")
+    srt = np.sort(g, axis=1)
+    for c in range(4):
+        exp = g[:, c] if c == 1 else (srt[:, -1] - srt[:, -2]) * (g.argmax(1) == c)
+        assert np.allclose(cs[:, c], exp)
+    # modify_by_htt (morph): background = smoothed 0.75*sigmoid(4(mean-240)) minus max exception CAM
+    import scipy.ndimage
+    import scipy.special
+    classes_m = ["Background", "E", "A.W", "A.B", "A.M"]
+    gm = rng.random((2, 5, 9, 9))
+    ims = rng.integers(200, 256, (2, 9, 9, 3)).astype(np.float64)
+    outm = hsn.modify_by_htt(gm.copy(), ims, classes_m)
+    bg = np.stack([scipy.ndimage.gaussian_filter(0.75 * scipy.special.expit(4 * (ims[i].mean(-1) - 240)), sigma=2)
+                   for i in range(2)])
+    assert np.allclose(outm[:, 0], bg - gm[:, 2:5].max(1))
+    assert np.array_equal(outm[:, 1:], gm[:, 1:])
+
+
+def test_crf_inference_mirror(ctx):
+    """lib.crf.crf_inference (03a_sec-dsrg call sites): marginals (H, W, C) vs the C oracle."""
+    from tests import helpers
+    from wsscam.misc import imutils
+
+    rng = np.random.default_rng(15)
+    H, W, C = 41, 41, 5
+    rgb, _, p = helpers.synth_crf_case(rng, H, W, C)
+    fm = np.transpose(p, (1, 2, 0)).astype(np.float32)
+    cfg = {"g_sxy": 3 / 12, "g_compat": 3, "bi_sxy": 80 / 12, "bi_srgb": 13, "bi_compat": 10, "iterations": 5}
+    out = imutils.crf_inference(rgb, cfg, C, fm, use_log=True, ctx=ctx)
+    U = np.ascontiguousarray(-np.log(np.transpose(fm, (2, 0, 1)).reshape(C, -1)))
+    qr, _, _ = helpers.crf_oracle(rgb, U, (cfg["g_sxy"], 3, cfg["bi_sxy"], 13, 10, 5))
+    assert out.shape == (H, W, C) and out.dtype == np.float32
+    assert np.abs(out - np.transpose(qr.reshape(C, H, W), (1, 2, 0))).max() <= 1e-3

@@ -191,7 +191,8 @@ int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int
 int launch_flip_add(wsc_ctx *ctx, const float *head, int B, int h, int w, int C, int Cs, float *cam);
 // score[b][c] = sigmoid(sum_f mean_hw(feat[2b])[f] * Wc[c][f] + bias[c])
 int launch_gap_linear_sigmoid(wsc_ctx *ctx, const bf16_t *feat, const bf16_t *feat_lo, int B, int hw, int F,
-                              const float *Wc, const float *bias, int C, float *score, int fmt);
+                              const float *Wc, const float *bias, int C, float *score, int fmt,
+                              int sample_stride);
 int launch_bf16_to_f32(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, size_t n, float *y, int fmt);
 int launch_nchw_to_nhwc(wsc_ctx *ctx, const float *x, int N, int C, int HW, bf16_t *y, bf16_t *y_lo, int fmt);
 int launch_nhwc_to_nchw(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int C, int HW, float *y, int fmt);

@@ -105,16 +105,16 @@ __global__ void flip_add_kernel(const float *__restrict__ head, int B, int h, in
 }
 
 // Classifier branch of vgg16_cam.py:34-36 on sample 0 of each image:
-// score[b][c] = sigmoid(bias[c] + sum_f Wc[c][f] * mean_hw feat[2b][.][f])
+// score[b][c] = sigmoid(bias[c] + sum_f Wc[c][f] * mean_hw feat[sample_stride*b][.][f])
 // one block per image; feat NHWC bf16 (+ lo plane).  hw < 0 selects the global max of m7
 // (m7_cam.py:32-35: MaxPool 2x2 then AdaptiveMaxPool2d((1,1))).
 __global__ void gap_linear_sigmoid_kernel(const bf16_t *__restrict__ feat, const bf16_t *__restrict__ feat_lo,
                                           int hw, int F, const float *__restrict__ Wc,
                                           const float *__restrict__ bias, int C, float *__restrict__ score,
-                                          int fmt) {
+                                          int fmt, int sample_stride) {
     extern __shared__ float gap[]; // F floats
     const int b = blockIdx.x;
-    const long long img = (long long)(2 * b) * (hw < 0 ? -hw : hw) * F;
+    const long long img = (long long)(sample_stride * b) * (hw < 0 ? -hw : hw) * F;
     const bf16_t *f0 = feat + img;
     const bf16_t *l0 = feat_lo ? feat_lo + img : nullptr;
     const bool use_max = hw < 0; // m7: AdaptiveMaxPool2d((1,1)) instead of the average
@@ -218,9 +218,9 @@ int launch_flip_add(wsc_ctx *ctx, const float *head, int B, int h, int w, int C,
 }
 
 int launch_gap_linear_sigmoid(wsc_ctx *ctx, const bf16_t *feat, const bf16_t *feat_lo, int B, int hw, int F,
-                              const float *Wc, const float *bias, int C, float *score, int fmt) {
+                              const float *Wc, const float *bias, int C, float *score, int fmt, int sample_stride) {
     hipLaunchKernelGGL(gap_linear_sigmoid_kernel, dim3(B), dim3(256), F * sizeof(float), ctx->stream, feat,
-                       feat_lo, hw, F, Wc, bias, C, score, fmt);
+                       feat_lo, hw, F, Wc, bias, C, score, fmt, sample_stride);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }

@@ -290,10 +290,22 @@ int build_vgg16(wsc_net *net, const Dict &d) {
     WSC_TRY(get(d, "vgg16.classifier.0.weight", 2, &lw));
     WSC_CHECK(lw->shape[0] >= net->C && lw->shape[1] == net->F, WSC_ERR_SHAPE,
               "vgg16.classifier.0.weight must be [>=%d][%d]", net->C, net->F);
-    // CAM head = the Linear weight as a 1x1 kernel: vgg16_cam.py:48
+    // CAM head = the Linear weight as a 1x1 kernel: vgg16_cam.py:48 -- or, when the state dict carries
+    // `gradcam_weights` (F x C), the Grad-CAM alpha of 02_cues/utilities.py:60-99 (einsum 'ijkl,lm->ijkm')
     HostTensor hw = *lw;
     hw.ndim = 4; hw.shape[0] = net->C; hw.shape[2] = 1; hw.shape[3] = 1;
     std::vector<float> one(net->C, 1.f), zero(net->C, 0.f);
+    std::vector<float> wt;
+    if (has(d, "gradcam_weights")) {
+        const HostTensor *gw;
+        WSC_TRY(get(d, "gradcam_weights", 2, &gw));
+        WSC_CHECK(gw->shape[0] == net->F && gw->shape[1] == net->C, WSC_ERR_SHAPE,
+                  "gradcam_weights must be [%d][%d]", net->F, net->C);
+        wt.resize((size_t)net->C * net->F);
+        for (int f = 0; f < net->F; ++f)
+            for (int c = 0; c < net->C; ++c) wt[(size_t)c * net->F + f] = gw->data[(size_t)f * net->C + c];
+        hw.data = wt.data();
+    }
     WSC_TRY(make_conv(net, &hw, 1, 0, 0, 0, one, zero, nullptr, nullptr, &net->head));
     net->Ccls = net->C;
     net->cls_max = 0;
@@ -528,7 +540,33 @@ int wsc_net_forward_cam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, in
     WSC_TRY(launch_flip_add(ctx, head_out, B, hf, wf, net->C, net->C, cam_dev));
     if (score_dev != nullptr)
         WSC_TRY(launch_gap_linear_sigmoid(ctx, feat, feat_lo, B, net->cls_max ? -(hf * wf) : hf * wf, net->F,
-                                          net->cls_w, net->cls_b, net->Ccls, score_dev, net->fmt));
+                                          net->cls_w, net->cls_b, net->Ccls, score_dev, net->fmt, 2));
+    return WSC_OK;
+}
+
+int wsc_net_forward_gradcam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, int S, int relu,
+                            float *cams_dev, float *score_dev) {
+    WSC_CHECK(ctx && net && x_dev && cams_dev, WSC_ERR_INVALID, "wsc_net_forward_gradcam: null argument");
+    WSC_CHECK(N > 0 && S > 0, WSC_ERR_INVALID, "wsc_net_forward_gradcam: N=%d S=%d", N, S);
+    WSC_CHECK(score_dev == nullptr || net->cls_w != nullptr, WSC_ERR_INVALID,
+              "this architecture has no classifier branch (score_dev must be NULL)");
+    WSC_HIP(hipSetDevice(ctx->device));
+    const bf16_t *feat, *feat_lo;
+    int hf, wf;
+    void *extra;
+    WSC_TRY(run_backbone(ctx, net, x_dev, N, S, 0, &feat, &feat_lo, &hf, &wf, &extra));
+    ConvLaunch L;
+    memset(&L, 0, sizeof(L));
+    const ConvW &c = net->head;
+    L.x = feat; L.x_lo = feat_lo; L.w = c.w; L.s1 = c.s1; L.b1 = c.b1;
+    L.y_f32 = cams_dev; // fp32 NHWC [N][h][w][C]: the layout of np.einsum('ijkl,lm->ijkm')
+    L.N = N; L.H = hf; L.W = wf; L.Cin = c.Cin; L.Ho = hf; L.Wo = wf; L.Cout = c.Cout; L.CoutPad = c.CoutPad;
+    L.kh = 1; L.kw = 1; L.stride = 1; L.pad = 0; L.relu = relu ? 1 : 0; L.small_cin = 0; L.split = net->split;
+    L.fmt = net->fmt;
+    WSC_TRY(conv_igemm_launch(ctx, L));
+    if (score_dev != nullptr)
+        WSC_TRY(launch_gap_linear_sigmoid(ctx, feat, feat_lo, N, net->cls_max ? -(hf * wf) : hf * wf, net->F,
+                                          net->cls_w, net->cls_b, net->Ccls, score_dev, net->fmt, 1));
     return WSC_OK;
 }
 

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "wsc_net_cam_size": (_i, [_vp, _i, ctypes.POINTER(_i)]),
     "wsc_net_feat_channels": (_i, [_vp, ctypes.POINTER(_i)]),
     "wsc_net_forward_cam": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "wsc_net_forward_gradcam": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "wsc_net_forward_features": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "wsc_conv2d_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "wsc_cam_postprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -302,6 +303,10 @@ class Net:
     def forward_cam(self, x_dev, B, S, cam_dev, score_dev=None):
         check(self.ctx._lib.wsc_net_forward_cam(self.ctx.h, self.h, _ptr(x_dev), B, S, _ptr(cam_dev),
                                                 _ptr(score_dev)))
+
+    def forward_gradcam(self, x_dev, N, S, relu, cams_dev, score_dev=None):
+        check(self.ctx._lib.wsc_net_forward_gradcam(self.ctx.h, self.h, _ptr(x_dev), N, S, int(relu), _ptr(cams_dev),
+                                                    _ptr(score_dev)))
 
     def forward_features(self, x_dev, N, S, feat_dev):
         check(self.ctx._lib.wsc_net_forward_features(self.ctx.h, self.h, _ptr(x_dev), N, S, _ptr(feat_dev)))

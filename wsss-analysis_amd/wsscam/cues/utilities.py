@@ -1,0 +1,93 @@
+"""Grad-CAM cue generation on the device -- mirror of 02_cues/utilities.py.
+
+`input_model` is a wsscam CAM wrapper (wsscam.net.vgg16_cam.CAM / m7_cam.CAM holding a torch-style
+state dict) where the reference passes a Keras Sequential model; every other argument keeps its
+meaning.  The conv stack and the `einsum('ijkl,lm->ijkm')` contraction run in ONE pass of libwsscam
+(wsc_net_forward_gradcam); the reference evaluates the CNN twice per batch."""
+import numpy as np
+
+from .. import _lib
+
+
+def find_final_layer(model):
+    """02_cues/utilities.py:42-58: name of the layer after the last Conv2D.  The device networks expose
+    exactly one such tap (the last conv feature map), identified by this constant."""
+    return "final_conv_activation"
+
+
+def get_grad_cam_weights(input_model, final_layer, dummy_image, should_normalize=True):
+    """02_cues/utilities.py:60-99: alpha[:, c] = mean_{h,w} normalize(d y_c / d A) on `dummy_image`.
+
+    For the GAP + Linear classifier of the modified VGG16 the gradient of the pre-sigmoid logit y_c with
+    respect to the final feature map A (h x w x F) is the constant W[c, f] / (h w) at every position and
+    for every input image, so alpha has the closed form below (identical to K.gradients up to round-off).
+    Networks whose classifier pools with a max (M7 / X1.7) need a framework's tie-breaking on the
+    all-zeros image; pass their precomputed alpha instead."""
+    sd = input_model._sd
+    root = input_model.root
+    if getattr(input_model, "arch", None) != _lib.ARCH_VGG16_CAM:
+        raise NotImplementedError("get_grad_cam_weights: closed form only for GAP+Linear classifiers (vgg16)")
+    W = np.asarray(sd[root + ".classifier.0.weight"], dtype=np.float64)  # (C, F)
+    S = int(dummy_image.shape[1])
+    h = input_model.cam_size(S)
+    g = W / float(h * h)  # d y_c / d A[h, w, f], constant over (h, w)
+    if should_normalize:
+        rms = np.sqrt(np.mean(np.float32(g) ** 2, axis=1, keepdims=True, dtype=np.float64))
+        g = g / (rms + 1e-5)
+    return np.ascontiguousarray(g.T)  # (F, C); the spatial mean of a constant map is the constant
+
+
+def _to_nchw(images):
+    x = np.asarray(images, dtype=np.float32)
+    assert x.ndim == 4 and x.shape[-1] == 3, "images must be (B, H, W, 3)"
+    return np.ascontiguousarray(np.transpose(x, (0, 3, 1, 2)))
+
+
+def conv_and_cams(input_model, weights, images, relu, want_scores=False):
+    """One device pass: (cams (B,h,w,C) float32 = [relu] einsum(conv_val, weights), scores (B,C) or None)."""
+    net, ctx = input_model.gradcam_net(weights)
+    x = _to_nchw(images)
+    B, S = x.shape[0], x.shape[2]
+    h = net.cam_size(S)
+    C = weights.shape[1]
+    x_dev = ctx.to_device(x)
+    cams_dev = ctx.alloc(B * h * h * C * 4)
+    score_dev = ctx.alloc(B * C * 4) if want_scores else None
+    net.forward_gradcam(x_dev, B, S, relu, cams_dev, score_dev)
+    cams = ctx.to_host(cams_dev, (B, h, h, C), np.float32)
+    scores = ctx.to_host(score_dev, (B, C), np.float32) if want_scores else None
+    return cams, scores
+
+
+def _upsample_nhwc(ctx, cams, size):
+    """cv2.resize(cams[i, :, :, j], size) for every (i, j): bilinear, half-pixel centres."""
+    B, h, w, C = cams.shape
+    src = np.ascontiguousarray(np.transpose(cams, (0, 3, 1, 2)).reshape(B * C, h, w), dtype=np.float32)
+    dst = ctx.alloc(B * C * size[0] * size[1] * 4)
+    _lib.bilinear_resize(ctx, ctx.to_device(src), B * C, h, w, dst, size[0], size[1])
+    out = ctx.to_host(dst, (B, C, size[0], size[1]), np.float32)
+    return np.transpose(out, (0, 2, 3, 1))
+
+
+def grad_cam(input_model, weights, images, is_pass_threshold, final_layer, keep_inds, orig_sz=[224, 224],
+             should_upsample=False):
+    """02_cues/utilities.py:101-144 -> (B, h, w, C_keep) thresholded Grad-CAMs (float64 like the reference)."""
+    cams, _ = conv_and_cams(input_model, np.asarray(weights), images, relu=True)
+    cams = cams[:, :, :, keep_inds]
+    if should_upsample:
+        cams = _upsample_nhwc(input_model.ctx, cams, (int(orig_sz[0]), int(orig_sz[1])))
+    cams = cams.astype(np.float64)
+    return cams * np.expand_dims(np.expand_dims(is_pass_threshold, axis=1), axis=2)
+
+
+def resize_stack(stack, size, ctx=None):
+    """02_cues/utilities.py:20-40: bilinear resize of every (i, j) map of a (B, C, h, w) stack."""
+    from ..misc.imutils import default_context
+
+    ctx = ctx or default_context()
+    stack = np.asarray(stack)
+    B, C, h, w = stack.shape
+    src = np.ascontiguousarray(stack.reshape(B * C, h, w), dtype=np.float32)
+    dst = ctx.alloc(B * C * size[0] * size[1] * 4)
+    _lib.bilinear_resize(ctx, ctx.to_device(src), B * C, h, w, dst, int(size[0]), int(size[1]))
+    return ctx.to_host(dst, (B, C, int(size[0]), int(size[1])), np.float32).astype(np.float64)

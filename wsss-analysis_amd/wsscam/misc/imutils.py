@@ -73,3 +73,25 @@ def crf_inference_label(img, labels, dataset=None, t=10, n_labels=21, gt_prob=0.
     out = ctx.to_host(am_dev, (h, w), np.int32)
     crf.close()
     return out.astype(np.int64)
+
+
+def crf_inference(img, crf_config, num_classes, featmap, use_log=True, ctx=None):
+    """lib.crf.crf_inference of 03a_sec-dsrg (call sites SEC.py:275, DSRG.py:328, model.py:689-693; the file
+    itself is not in the reference tree -- upstream SEC/DSRG semantics): unary = -log(featmap) (or -featmap),
+    Gaussian + bilateral pairwise terms from crf_config {g_sxy, g_compat, bi_sxy, bi_srgb, bi_compat,
+    iterations}; returns the marginals as (H, W, C) float32."""
+    ctx = ctx or default_context()
+    img = np.ascontiguousarray(np.asarray(img, dtype=np.uint8))
+    h, w = img.shape[:2]
+    fm = np.asarray(featmap, dtype=np.float32).reshape(h, w, num_classes)
+    U = -np.log(fm) if use_log else -fm
+    U = np.ascontiguousarray(np.transpose(U, (2, 0, 1)).reshape(num_classes, -1), dtype=np.float32)
+    rgb_dev = ctx.to_device(img)
+    u_dev = ctx.to_device(U)
+    q_dev = ctx.alloc(num_classes * h * w * 4)
+    crf = _lib.Crf(ctx, rgb_dev, 1, h, w, crf_config["g_sxy"], crf_config["bi_sxy"], crf_config["bi_srgb"])
+    crf.inference(u_dev, num_classes, crf_config["g_compat"], crf_config["bi_compat"], int(crf_config["iterations"]),
+                  q_dev, None)
+    Q = ctx.to_host(q_dev, (num_classes, h, w), np.float32)
+    crf.close()
+    return np.ascontiguousarray(np.transpose(Q, (1, 2, 0)))

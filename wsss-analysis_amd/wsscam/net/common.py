@@ -74,6 +74,19 @@ class DeviceCAMBase:
     def cam_size(self, S):
         return self._ensure_net().cam_size(S)
 
+    def gradcam_net(self, weights):
+        """(wsc_net with `weights` (F x C Grad-CAM alpha) as its 1x1 head, ctx); cached per alpha."""
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        key = (w.shape, hash(w.tobytes()))
+        cache = self.__dict__.setdefault("_gradcam_nets", {})
+        if key not in cache:
+            if self._ctx is None:
+                self._ctx = _lib.Context(self._device)
+            sd = dict(self._sd)
+            sd["gradcam_weights"] = w
+            cache[key] = _lib.Net(self._ctx, self.arch, sd, w.shape[1], self.precision)
+        return cache[key], self._ctx
+
     # -- batched device forward ---------------------------------------------------------------
     def forward_batch_device(self, x_dev, B, S, cam_dev, score_dev=None):
         """x_dev float32 [B][2][3][S][S] -> cam_dev float32 [B][C][h][w] (device pointers/buffers)."""
