@@ -1,0 +1,63 @@
+"""CPU: host-side seed logic of 02_cues (utilities.py:183-278) and the localization_cues layout SEC/DSRG read."""
+import pickle
+
+import numpy as np
+
+from wsscam.cues import utilities as cues
+
+
+def _brute(loc):
+    """Independent per-pixel statement: the label of a pixel is the covering class with the smallest mask
+    (visiting order = np.argsort(-area), later classes overwrite)."""
+    B, C, H, W = loc.shape
+    out = np.zeros((B, H, W), np.int64)
+    for b in range(B):
+        area = loc[b].sum(axis=(1, 2))
+        order = np.argsort(-area)
+        for y in range(H):
+            for x in range(W):
+                for c in order:
+                    if loc[b, c, y, x]:
+                        out[b, y, x] = c + 1
+    return out
+
+
+def test_fg_cues_layout_and_overlap():
+    rng = np.random.default_rng(0)
+    H_fg = rng.random((3, 4, 7, 6))
+    H_fg[:, 1, :3] += 1.0  # a dominant region
+    d = cues.get_fg_cues({}, H_fg, [np.array([1, 2]), np.array([0]), np.array([3])], [10, 11, 12], 0.5)
+    assert sorted(d) == ["10_cues", "10_labels", "11_cues", "11_labels", "12_cues", "12_labels"]
+    loc = np.stack([H_fg[:, c] > 0.5 * H_fg[:, c].max() for c in range(4)], 1).astype(np.int64)
+    ref = _brute(loc)
+    for i, x in enumerate([10, 11, 12]):
+        c = d["%d_cues" % x]
+        assert c.dtype == np.int64 and c.shape[0] == 3
+        lab = np.zeros((7, 6), np.int64)
+        lab[c[1], c[2]] = c[0] + 1
+        assert np.array_equal(lab, ref[i])
+    # round-trips through pickle like localization_cues.pickle (02_cues/demo.py:217-222)
+    d2 = pickle.loads(pickle.dumps(d))
+    assert np.array_equal(d2["11_cues"], d["11_cues"])
+
+
+def test_fgbg_cues_background_channel():
+    rng = np.random.default_rng(1)
+    H_fg = rng.random((2, 3, 9, 9))
+    H_bg = rng.random((2, 2, 9, 9))
+    d = cues.get_fgbg_cues({}, H_fg, H_bg, [np.array([2]), np.array([1, 3])], [0, 1], 0.6)
+    import scipy.ndimage
+
+    for b in range(2):
+        grad = scipy.ndimage.median_filter(H_bg[b].sum(0), 3)
+        thr = np.sort(grad.ravel())[int(0.1 * 81)]
+        c = d["%d_cues" % b]
+        bg_pixels = set(zip(c[1][c[0] == 0], c[2][c[0] == 0]))
+        # every background cue pixel is below the 10th-percentile threshold
+        assert all(grad[y, x] < thr for (y, x) in bg_pixels)
+        assert c[0].max() <= 3 and c[0].min() >= 0
+    # batch-level max (Q7): scaling one image's activations changes the other image's cues
+    H2 = H_fg.copy()
+    H2[0] *= 10
+    d2 = cues.get_fgbg_cues({}, H2, H_bg, [np.array([2]), np.array([1, 3])], [0, 1], 0.6)
+    assert d2["1_cues"].shape[1] < d["1_cues"].shape[1]

@@ -91,3 +91,54 @@ def resize_stack(stack, size, ctx=None):
     dst = ctx.alloc(B * C * size[0] * size[1] * 4)
     _lib.bilinear_resize(ctx, ctx.to_device(src), B * C, h, w, dst, int(size[0]), int(size[1]))
     return ctx.to_host(dst, (B, C, int(size[0]), int(size[1])), np.float32).astype(np.float64)
+
+
+# ---- seed (localization cue) generation: 02_cues/utilities.py:183-278 -------------------------------------
+def _resolve_and_store(cues, localization, class_inds, indices):
+    """Overlap resolution by mask area and the pickle layout SEC/DSRG read (03a_sec-dsrg/model.py:238-246).
+
+    Classes are visited from the largest mask to the smallest; each paints its pixels over what is there,
+    so a pixel ends up with the SMALLEST mask that covers it.  `'%d_cues'` is np.where of the one-hot
+    result: int64 (3, n) rows (class, row, col); `'%d_labels'` the image's class indices."""
+    area = localization.sum(axis=(2, 3))
+    order = np.argsort(-area)  # per image, largest mask first (same call as the reference: same tie order)
+    B, C, H, W = localization.shape
+    label = np.zeros((B, H, W), dtype=np.int64)
+    rows = np.arange(B)
+    for k in range(C):
+        cls = order[:, k]
+        mask = localization[rows, cls]
+        label = np.where(mask != 0, (cls + 1)[:, None, None], label)
+    onehot = np.zeros_like(localization)
+    for c in range(C):
+        onehot[:, c] = label == c + 1
+    for i, x in enumerate(indices):
+        cues["%d_labels" % x] = class_inds[i]
+        cues["%d_cues" % x] = np.array(np.where(onehot[i]))
+    return cues
+
+
+def get_fgbg_cues(cues, H_fg, H_bg, class_inds, indices, thresh):
+    """02_cues/utilities.py:183-235: channel 0 = background (3x3-median-filtered summed background activation
+    below its 10th-percentile value), channels 1.. = foreground maps above thresh x (max over the BATCH of
+    that class -- SURVEY.md Q7)."""
+    import scipy.ndimage
+
+    B, C, H, W = H_fg.shape
+    loc = np.zeros((B, C + 1, H, W), dtype="int64")
+    for b in range(B):
+        grad = scipy.ndimage.median_filter(np.sum(H_bg[b], axis=0), 3)
+        thr = np.sort(grad.ravel())[int(0.1 * H * W)]
+        loc[b, 0] = grad < thr
+    for c in range(C):
+        loc[:, c + 1] = H_fg[:, c] > thresh * np.max(H_fg[:, c])
+    return _resolve_and_store(cues, loc, class_inds, indices)
+
+
+def get_fg_cues(cues, H_fg, class_inds, indices, thresh):
+    """02_cues/utilities.py:237-278: foreground-only variant (no background channel)."""
+    B, C, H, W = H_fg.shape
+    loc = np.zeros((B, C, H, W), dtype="int64")
+    for c in range(C):
+        loc[:, c] = H_fg[:, c] > thresh * np.max(H_fg[:, c])
+    return _resolve_and_store(cues, loc, class_inds, indices)
