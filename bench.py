@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "bf16x3"])
     ap.add_argument("--workload", default="cam_crf", choices=["cam_crf", "cam"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="finish each step before starting the next (default: the mean-field loop of step i "
+                         "overlaps the conv stack + lattice build of step i+1 on separate streams)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -78,6 +81,10 @@ class Workload:
         # second context (own stream) for the lattice build: it needs only the RGB images, so it runs
         # concurrently with the CNN forward pass of the same batch and joins before the inference
         self.ctx_build = _lib.Context(device)
+        # third context: the mean-field loop.  With --pipeline (default) step i's loop runs here while
+        # step i+1's conv stack (self.ctx) and lattice build (self.ctx_build) are already under way.
+        self.ctx_crf = _lib.Context(device)
+        self.pending = None  # lattices of the step whose mean-field loop is still in flight
         prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3}[precision]
         sd = {k: v.numpy() for k, v in cnn_ref.make_resnet50_cam_state_dict(NUM_CLASSES, seed=0).items()}
         self.net = _lib.Net(self.ctx, _lib.ARCH_RESNET50_CAM, sd, NUM_CLASSES, prec)
@@ -111,8 +118,11 @@ class Workload:
         self.all_keys = [np.arange(NUM_CLASSES, dtype=np.int32)] * batch
         self.maps_dev = ctx.alloc(batch * NUM_CLASSES * N * 4)
         self.maps_s_dev = ctx.alloc(batch * NUM_CLASSES * ((S - 1) // 4 + 1) ** 2 * 4)
-        self.unary_dev = ctx.alloc(batch * (NUM_CLASSES + 1) * N * 4)
-        self.label_dev = ctx.alloc(batch * N * 4)
+        # unaries / labels are double-buffered: step i+1 writes its unaries while step i's loop reads its own
+        self.unary_bufs = [ctx.alloc(batch * (NUM_CLASSES + 1) * N * 4) for _ in range(2)]
+        self.label_bufs = [ctx.alloc(batch * N * 4) for _ in range(2)]
+        self.unary_dev, self.label_dev = self.unary_bufs[0], self.label_bufs[0]
+        self.parity = 0
         self.vg = self.vb = None
 
     # -- pieces ------------------------------------------------------------------------------
@@ -131,9 +141,36 @@ class Workload:
     def crf_create(self):
         return self._lib.Crf(self.ctx_build, self.rgb_dev, self.B, S, S, CRF_CFG[0], CRF_CFG[2], CRF_CFG[3])
 
-    def crf_infer(self, crf):
+    def crf_infer(self, crf, ctx=None):
         crf.inference(self.unary_dev, NUM_CLASSES + 1, CRF_CFG[1], CRF_CFG[4], CRF_CFG[5], None, self.label_dev,
-                      ctx=self.ctx)
+                      ctx=ctx or self.ctx)
+
+    def drain(self):
+        """Wait for the mean-field loop still in flight (pipelined mode) and release its lattices."""
+        if self.pending is not None:
+            self.ctx_crf.sync()
+            self.pending.close()
+            self.pending = None
+
+    def step_pipelined(self):
+        """Same work per step as step(), issued so that consecutive steps overlap:
+        stream A (ctx)       conv stack, tail, unaries of step i
+        stream B (ctx_build) lattice build of step i
+        stream C (ctx_crf)   mean-field loop of step i, after A and B  -- still running while the host
+                             already enqueues step i+1 on A and B."""
+        self.parity ^= 1
+        self.unary_dev, self.label_dev = self.unary_bufs[self.parity], self.label_bufs[self.parity]
+        self.run_cnn()
+        crf = self.crf_create()          # host blocks on the build stream only; A and C keep running
+        if self.vg is None:
+            self.vg, self.vb = crf.lattice_sizes()
+        self.run_tail()
+        self.run_unary()
+        self.drain()                     # step i-1's loop must be done before its workspace is reused
+        self.ctx_crf.wait_for(self.ctx)
+        self.ctx_crf.wait_for(self.ctx_build)
+        self.crf_infer(crf, ctx=self.ctx_crf)
+        self.pending = crf
 
     def step(self):
         # stream 1: conv stack (enqueued asynchronously, returns at once)
@@ -249,16 +286,22 @@ def main():
 
     def barrier():
         wl.ctx.sync()
+        wl.ctx_build.sync()
+        wl.ctx_crf.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
+    pipelined = args.workload == "cam_crf" and not args.no_pipeline
+    do_step = wl.step_pipelined if pipelined else wl.step
     for _ in range(args.warmup):
-        wl.step()
+        do_step()
+    wl.drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wl.step()
+        do_step()
+    wl.drain()
     wl.ctx.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -336,7 +379,9 @@ def main():
                        if args.workload == "cam_crf" else
                        "ResNet50 CAM (make_cam), 321x321, batch %d images per GPU" % args.batch,
                        "batch_images": args.batch, "num_classes": NUM_CLASSES, "crf_config": list(CRF_CFG),
-                       "parallelism": "image-sharded x%d, no collective" % world},
+                       "parallelism": "image-sharded x%d, no collective" % world,
+                       "step_overlap": "mean-field loop of step i overlaps conv stack + lattice build of step i+1 "
+                                       "(3 HIP streams)" if pipelined else "none"},
             "roofline": roofline,
             "stages": stages,
         }
