@@ -48,6 +48,7 @@ struct LatticeDev {
     // splat work items: every row is cut into chunks of <= SPLAT_CHUNK gathered pixels
     int32_t *chunk_base = nullptr; // [rows + 1] first chunk of each row
     int32_t *chunk_row = nullptr;  // [n_chunks] owning row
+    int4 *chunk_desc = nullptr;    // [n_chunks] {first entry, entry count, row, 1 if the row's only chunk}
     int32_t *long_rows = nullptr;  // [n_long] rows with more than one chunk
     int n_chunks = 0, n_long = 0;
     long long n_pix = 0; // B*N
@@ -538,9 +539,7 @@ __global__ __launch_bounds__(256) void splat_ones_kernel(const unsigned *__restr
 // clock whatever its width; with 4-byte lanes the gathers of this kernel ran at 1.04 L1 accesses
 // per clock per CU -- L1-issue bound -- for 3.8 useful bytes each: profiles/r01_pmc_crf.txt.)
 // LP lanes per chunk, floor(64/LP) chunks per wave.
-__global__ __launch_bounds__(256) void splat4_kernel(const unsigned *__restrict__ start,
-                                                     const int32_t *__restrict__ chunk_base,
-                                                     const int32_t *__restrict__ chunk_row,
+__global__ __launch_bounds__(256) void splat4_kernel(const int4 *__restrict__ chunk_desc,
                                                      const uint2 *__restrict__ csr_ent,
                                                      const float *__restrict__ q, int LP, int n_chunks,
                                                      float *__restrict__ val, long long *__restrict__ part) {
@@ -552,36 +551,57 @@ __global__ __launch_bounds__(256) void splat4_kernel(const unsigned *__restrict_
     const f32x4_t *q4 = reinterpret_cast<const f32x4_t *>(q);
     long long cbeg, cend;
     xcd_range(n_chunks, cbeg, cend);
-    for (long long c = cbeg + (threadIdx.x >> 6) * gpw + g; c < cend; c += 4 * gpw) {
-        const int row = chunk_row[c];
-        const int cb = chunk_base[row];
-        const bool single = chunk_base[row + 1] - cb == 1;
-        const unsigned s = start[row] + (unsigned)(c - cb) * SPLAT_CHUNK;
-        const unsigned e = min(s + SPLAT_CHUNK, start[row + 1]);
-        long long acc[4] = {0, 0, 0, 0};
-        for (unsigned i = s; i < e; i += 8) {
-            uint2 en[8];
-            float w[8];
-            f32x4_t in[8];
+    // two chunks per lane group per trip: descriptor -> entries -> Q rows is a chain of three dependent
+    // memory latencies, so the only way to keep the memory system busy is more independent chains
+    constexpr int CU_ = 4;
+    for (long long c0 = cbeg + (threadIdx.x >> 6) * gpw * CU_ + g; c0 < cend; c0 += 4 * gpw * CU_) {
+        int4 d[CU_];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                en[j] = csr_ent[min(i + j, e - 1)];
-                w[j] = i + j < e ? __uint_as_float(en[j].y) : 0.f; // w * norm[pixel]
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) in[j] = q4[en[j].x * (unsigned)LP + l];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] += (long long)__float2int_rn((w[j] * in[j][k]) * FIX_SCALE);
+        for (int u = 0; u < CU_; ++u) {
+            const long long c = c0 + (long long)u * gpw;
+            d[u] = c < cend ? chunk_desc[c] : make_int4(0, 0, 0, 1);
         }
-        if (single) {
-            f32x4_t o = {(float)acc[0] * FIX_INV, (float)acc[1] * FIX_INV, (float)acc[2] * FIX_INV,
-                         (float)acc[3] * FIX_INV};
-            reinterpret_cast<f32x4_t *>(val)[(unsigned)row * (unsigned)LP + l] = o;
-        } else {
+        long long acc[CU_][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) part[(c * LP + l) * 4 + k] = acc[k];
+        for (int u = 0; u < CU_; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[u][k] = 0;
+        int maxlen = 0;
+#pragma unroll
+        for (int u = 0; u < CU_; ++u) maxlen = max(maxlen, d[u].y);
+        for (int i = 0; i < maxlen; i += 8) {
+            uint2 en[CU_][8];
+            f32x4_t in[CU_][8];
+#pragma unroll
+            for (int u = 0; u < CU_; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    en[u][j] = i + j < d[u].y ? csr_ent[(unsigned)d[u].x + i + j] : make_uint2(0, 0); // weight 0
+#pragma unroll
+            for (int u = 0; u < CU_; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) in[u][j] = q4[en[u][j].x * (unsigned)LP + l];
+#pragma unroll
+            for (int u = 0; u < CU_; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = __uint_as_float(en[u][j].y); // w * norm[pixel]
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[u][k] += (long long)__float2int_rn((w * in[u][j][k]) * FIX_SCALE);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < CU_; ++u) {
+            const long long c = c0 + (long long)u * gpw;
+            if (c >= cend) continue;
+            if (d[u].w) {
+                f32x4_t o = {(float)acc[u][0] * FIX_INV, (float)acc[u][1] * FIX_INV, (float)acc[u][2] * FIX_INV,
+                             (float)acc[u][3] * FIX_INV};
+                reinterpret_cast<f32x4_t *>(val)[(unsigned)d[u].z * (unsigned)LP + l] = o;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) part[(c * LP + l) * 4 + k] = acc[u][k];
+            }
         }
     }
 }
@@ -611,11 +631,17 @@ __global__ void count_chunks_kernel(const unsigned *__restrict__ start, int rows
         nch[row] = len <= SPLAT_CHUNK ? 1u : (len + SPLAT_CHUNK - 1) / SPLAT_CHUNK;
     }
 }
-__global__ void fill_chunks_kernel(const int32_t *__restrict__ chunk_base, int rows, int32_t *__restrict__ chunk_row,
+__global__ void fill_chunks_kernel(const unsigned *__restrict__ start, const int32_t *__restrict__ chunk_base,
+                                   int rows, int32_t *__restrict__ chunk_row, int4 *__restrict__ chunk_desc,
                                    unsigned *__restrict__ n_long, int32_t *__restrict__ long_rows) {
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
         const int cb = chunk_base[row], ce = chunk_base[row + 1];
-        for (int c = cb; c < ce; ++c) chunk_row[c] = row;
+        const unsigned s = start[row], e = start[row + 1];
+        for (int c = cb; c < ce; ++c) {
+            chunk_row[c] = row;
+            const unsigned b = s + (unsigned)(c - cb) * SPLAT_CHUNK;
+            chunk_desc[c] = make_int4((int)b, (int)(min(b + SPLAT_CHUNK, e) - b), row, ce - cb == 1 ? 1 : 0);
+        }
         if (ce - cb > 1) long_rows[atomicAdd(n_long, 1u)] = row;
     }
 }
@@ -639,7 +665,7 @@ __global__ __launch_bounds__(256) void blur4_kernel(const f32x4_t *__restrict__ 
     const int tr = threadIdx.x / LP;
     const int l = threadIdx.x - tr * LP;
     if (tr >= rpb) return;
-    constexpr int U = 2;
+    constexpr int U = 4;
     long long rbeg, rend;
     xcd_range(rows, rbeg, rend);
     for (long long row0 = rbeg + tr; row0 < rend; row0 += U * rpb) {
@@ -738,71 +764,72 @@ __global__ __launch_bounds__(256) void slice_update_kernel(UpdateArgs a) {
     f32x4_t *q4 = reinterpret_cast<f32x4_t *>(a.q);
     long long pbeg, pend;
     xcd_range(a.npix, pbeg, pend);
-    for (long long p0 = pbeg + (long long)(threadIdx.x >> 6) * gpw; p0 < pend; p0 += 4ll * gpw) {
-        const long long pp = p0 + g;
-        const bool ok = act && pp < pend;
-        const long long p = ok ? pp : pbeg;
-        // the pixel's record: 5 x 16 bytes, identical for the LP lanes of the pixel (broadcast loads)
-        uint32_t rc[20];
+    constexpr int U = 1; // pixels per lane group per trip (2 measured slower: 362 vs 332 us)
+    for (long long p0 = pbeg + (long long)(threadIdx.x >> 6) * gpw * U; p0 < pend; p0 += 4ll * gpw * U) {
+        long long pp[U];
+        bool ok[U];
+        uint32_t rc[U][20];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const uint4 t = a.pix_rec[p * 5 + i];
-            rc[4 * i] = t.x; rc[4 * i + 1] = t.y; rc[4 * i + 2] = t.z; rc[4 * i + 3] = t.w;
+        for (int u = 0; u < U; ++u) {
+            pp[u] = p0 + (long long)u * gpw + g;
+            ok[u] = act && pp[u] < pend;
+            const long long p = ok[u] ? pp[u] : pbeg;
+            // the pixel's record: 5 x 16 bytes, identical for the LP lanes of the pixel (broadcast loads)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const uint4 t = a.pix_rec[p * 5 + i];
+                rc[u][4 * i] = t.x; rc[u][4 * i + 1] = t.y; rc[u][4 * i + 2] = t.z; rc[u][4 * i + 3] = t.w;
+            }
         }
-        unsigned og[3], ob[6];
-        float bg[3], bb[6];
+        f32x4_t vg[U][3], vb[U][6], un[U];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            og[r] = rc[r];
-            bg[r] = __uint_as_float(rc[9 + r]);
+        for (int u = 0; u < U; ++u) {
+            const long long p = ok[u] ? pp[u] : pbeg;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) vg[u][r] = vg4[rc[u][r] * (unsigned)LP + l];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) vb[u][r] = vb4[rc[u][3 + r] * (unsigned)LP + l];
+            un[u] = u4[p * LP + l];
         }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            ob[r] = rc[3 + r];
-            bb[r] = __uint_as_float(rc[12 + r]);
-        }
-        f32x4_t vg[3], vb[6];
+        for (int u = 0; u < U; ++u) {
+            const float ng = __uint_as_float(rc[u][18]), nb = __uint_as_float(rc[u][19]);
+            float e[4];
+            float mx = -3.0e38f;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) vg[r] = vg4[og[r] * (unsigned)LP + l];
+            for (int k = 0; k < 4; ++k) {
+                float sg = 0.f, sb = 0.f;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) vb[r] = vb4[ob[r] * (unsigned)LP + l];
-        const f32x4_t un = u4[p * LP + l];
-        const float ng = __uint_as_float(rc[18]), nb = __uint_as_float(rc[19]);
-        float e[4];
-        float mx = -3.0e38f;
+                for (int r = 0; r < 3; ++r) sg += __uint_as_float(rc[u][9 + r]) * vg[u][r][k] * a.alpha_g;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float sg = 0.f, sb = 0.f;
+                for (int r = 0; r < 6; ++r) sb += __uint_as_float(rc[u][12 + r]) * vb[u][r][k] * a.alpha_b;
+                float ek = -un[u][k];
+                ek -= -a.compat_g * (sg * ng);
+                ek -= -a.compat_b * (sb * nb);
+                const bool valid = ok[u] && 4 * l + k < a.M;
+                e[k] = valid ? ek : -3.0e38f;
+                mx = fmaxf(mx, e[k]);
+            }
+            for (int o = 4; o > 0; o >>= 1) {
+                const float other = __shfl_down(mx, o, 64);
+                if (l + o < LP) mx = fmaxf(mx, other);
+            }
+            mx = __shfl(mx, seg0, 64);
+            float ex[4], sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) sg += bg[r] * vg[r][k] * a.alpha_g;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) sb += bb[r] * vb[r][k] * a.alpha_b;
-            float ek = -un[k];
-            ek -= -a.compat_g * (sg * ng);
-            ek -= -a.compat_b * (sb * nb);
-            const bool valid = ok && 4 * l + k < a.M;
-            e[k] = valid ? ek : -3.0e38f;
-            mx = fmaxf(mx, e[k]);
-        }
-        for (int o = 4; o > 0; o >>= 1) {
-            const float other = __shfl_down(mx, o, 64);
-            if (l + o < LP) mx = fmaxf(mx, other);
-        }
-        mx = __shfl(mx, seg0, 64);
-        float ex[4], sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            ex[k] = (ok && 4 * l + k < a.M) ? expf(e[k] - mx) : 0.f;
-            sum += ex[k];
-        }
-        for (int o = 4; o > 0; o >>= 1) {
-            const float other = __shfl_down(sum, o, 64);
-            if (l + o < LP) sum += other;
-        }
-        sum = __shfl(sum, seg0, 64);
-        if (ok) {
-            f32x4_t o4 = {ex[0] / sum, ex[1] / sum, ex[2] / sum, ex[3] / sum};
-            q4[pp * LP + l] = o4;
+            for (int k = 0; k < 4; ++k) {
+                ex[k] = (ok[u] && 4 * l + k < a.M) ? expf(e[k] - mx) : 0.f;
+                sum += ex[k];
+            }
+            for (int o = 4; o > 0; o >>= 1) {
+                const float other = __shfl_down(sum, o, 64);
+                if (l + o < LP) sum += other;
+            }
+            sum = __shfl(sum, seg0, 64);
+            if (ok[u]) {
+                f32x4_t o4 = {ex[0] / sum, ex[1] / sum, ex[2] / sum, ex[3] / sum};
+                q4[pp[u] * LP + l] = o4;
+            }
         }
     }
 }
@@ -928,9 +955,8 @@ void splat4(wsc_ctx *ctx, const LatticeDev &L, const float *q, int LP, float *va
     // algorithmic bytes: read the batch's Q once + (pixel index, weight) per gathered pixel + write the rows
     WscKernelTimer timer(ctx, WSC_K_SPLAT, (double)L.n_pix * L.M_cur * 4 + (double)L.n_pix * (L.d + 1) * 8 +
                                               (double)L.rows * L.M_cur * 4);
-    hipLaunchKernelGGL(splat4_kernel, dim3(grid1d(L.n_chunks, 4 * gpw, 256 * 64)), dim3(256), 0, ctx->stream,
-                       (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_ent, q, LP, L.n_chunks, val,
-                       part);
+    hipLaunchKernelGGL(splat4_kernel, dim3(grid1d(L.n_chunks, 16 * gpw, 256 * 64)), dim3(256), 0, ctx->stream,
+                       L.chunk_desc, L.csr_ent, q, LP, L.n_chunks, val, part);
     if (L.n_long > 0)
         hipLaunchKernelGGL(splat_combine_kernel, dim3(grid1d((long long)L.n_long * 4 * LP, 256, 4096)), dim3(256), 0,
                            ctx->stream, L.long_rows, L.n_long, L.chunk_base, part, 4 * LP, val);
@@ -948,7 +974,7 @@ float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
 float *blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, float *a, float *b) {
     for (int j = 0; j <= L.d; ++j) {
         WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.M_cur * 4); // read + write every row once
-        hipLaunchKernelGGL(blur4_kernel, dim3(grid1d(L.rows, (256 / LP) * 2, 256 * 64)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(blur4_kernel, dim3(grid1d(L.rows, (256 / LP) * 4, 256 * 64)), dim3(256), 0, ctx->stream,
                            (const f32x4_t *)a, L.nbr + (long long)j * L.rows, LP, L.rows, (f32x4_t *)b);
         float *t = a; a = b; b = t;
     }
@@ -1068,9 +1094,11 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
         WSC_HIP(hipStreamSynchronize(ctx->stream));
         L.n_chunks = (int)tc;
         WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (size_t)L.n_chunks, (void **)&L.chunk_row));
+        WSC_TRY(crf_alloc(crf, sizeof(int4) * (size_t)L.n_chunks, (void **)&L.chunk_desc));
         WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (size_t)L.rows, (void **)&L.long_rows));
-        hipLaunchKernelGGL(fill_chunks_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream, L.chunk_base, L.rows,
-                           L.chunk_row, n_long_dev, L.long_rows);
+        hipLaunchKernelGGL(fill_chunks_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream,
+                           (const unsigned *)L.csr_start, L.chunk_base, L.rows, L.chunk_row, L.chunk_desc, n_long_dev,
+                           L.long_rows);
         unsigned nl = 0;
         WSC_HIP(hipMemcpyAsync(&nl, n_long_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         WSC_HIP(hipStreamSynchronize(ctx->stream));
