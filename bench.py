@@ -52,6 +52,9 @@ def parse():
                     help="finish each step before starting the next (default: the mean-field loop of step i "
                          "overlaps the conv stack + lattice build of step i+1 on separate streams)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the timing barrier (nccl = RCCL; gloo only to exercise the "
+                         "N>1 code path on a box with fewer GPUs than ranks, together with WSC_BENCH_DEVICE)")
     return ap.parse_args()
 
 
@@ -275,14 +278,18 @@ def main():
     import torch
 
     dist = None
+    device = int(os.environ.get("WSC_BENCH_DEVICE", local_rank))  # override only for single-GPU dry runs
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend="gloo")
 
-    wl = Workload(local_rank, args.batch, args.precision, args.workload, seed=rank)
+    wl = Workload(device, args.batch, args.precision, args.workload, seed=rank)
 
     def barrier():
         wl.ctx.sync()
@@ -306,7 +313,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
