@@ -104,7 +104,8 @@ void wsc_set_error(const char *fmt, ...);
 
 // ---- per-kernel-class timing (wsc_profile_begin / _end) --------------------------------------------
 enum WscKernelClass {
-    WSC_K_CONV128 = 0,   // conv_igemm_kernel, 128x128 tile, LDS-DMA staging
+    WSC_K_CONV256 = 0,   // conv_igemm_kernel, 256x128 tile, 3-stage LDS-DMA pipeline
+    WSC_K_CONV128,       // conv_igemm_kernel, 128x128 tile, LDS-DMA staging
     WSC_K_CONV64,        // conv_igemm_kernel, 128x64 tile
     WSC_K_CONV_SMALLCIN, // conv_igemm_kernel, stem / first layer (register staging)
     WSC_K_POOL_MISC,     // maxpool, layout changes, flip-add, classifier branch

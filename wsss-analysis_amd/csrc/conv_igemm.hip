@@ -29,9 +29,10 @@
 // MFMA instruction.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 64;
 
 struct ConvKArgs {
@@ -50,20 +51,30 @@ struct ConvKArgs {
     int Kbase;       // elements of one weight plane per row
     int ntiles_n, nblocks;
     const bf16_t *zero; // >= 16 bytes of zeros in HBM: source of padded taps for the LDS-DMA path
+    int debug;          // WSC_CONV_DEBUG ablations (timing only, results are wrong): 1 = no DMA after the
+                        // first two stages, 2 = no fragment reads / MFMAs
 };
 
 __device__ __forceinline__ int lds_off(int row, int slot) {
     return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int BN, int MODE, bool SPLIT, int ET, bool GLDS>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
+// BM x BN x 64 tile, BM/32 waves (BM/64 along M x 2 along N, 64 x BN/2 per wave), STAGES LDS buffers.
+//   128-row tile: 4 waves, 2 stages, 2 blocks per CU.
+//   256-row tile: 8 waves, 3 stages (144 KB), 1 block per CU: 0.73x the L2->LDS bytes per FLOP and a
+//   prefetch distance of two K-steps, with counted s_waitcnt vmcnt + raw s_barrier so a stage stays in
+//   flight across the barrier (a __syncthreads() would drain the LDS DMA every K-step).
+template <int BM, int BN, int MODE, bool SPLIT, int ET, bool GLDS, int STAGES>
+__global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
+    constexpr int NT = BM * 2;   // threads
+    constexpr int NW = BM / 32;  // waves
     constexpr int WN = BN / 2;
     constexpr int NI = WN / 32;
-    constexpr int NB = BN / 32; // B rows per thread
+    constexpr int NB = BN * 8 / NT; // B 16-byte slots per thread per K-step
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int B_BYTES = BN * BK * 2;
     constexpr int CT_STRIDE = BN + 4;
+    static_assert(GLDS || (BM == 128 && STAGES == 2), "register staging exists for the 128-row tile only");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -114,8 +125,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
             base[i] = 0;
         }
     }
-    // B rows: register path (t>>3) + 32 i; DMA path wave w owns rows w*(BN/4) + i*8 + (lane>>3)
-    const int brow0 = GLDS ? (wv * (BN / 4) + (lane >> 3)) : (t >> 3);
+    // B rows: register path (t>>3) + 32 i; DMA path wave w owns rows w*(BN/NW) + i*8 + (lane>>3)
+    const int brow0 = GLDS ? (wv * (BN / NW) + (lane >> 3)) : (t >> 3);
     const bf16_t *wrow[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
         const int kwi = tap - khi * p.kw;
         const long long tap_off = ((long long)khi * p.W + kwi) * p.Cin + cc * 64;
         char *sa = smem + buf * A_BYTES + wv * 4096;
-        char *sb = smem + 2 * A_BYTES + buf * B_BYTES + wv * (NB * 1024);
+        char *sb = smem + STAGES * A_BYTES + buf * B_BYTES + wv * (NB * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = lrow + RSTEP * i;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
 
     auto store_lds = [&](int buf) {
         char *sa = smem + buf * A_BYTES;
-        char *sb = smem + 2 * A_BYTES + buf * B_BYTES;
+        char *sb = smem + STAGES * A_BYTES + buf * B_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(sa + lds_off(lrow + 32 * i, slot)) = ra[i];
 #pragma unroll
@@ -219,46 +230,109 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
     const int l31 = lane & 31;
     const int kgrp = lane >> 5;
 
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    auto mfma = [&](const u32x4_t &a, const u32x4_t &b, f32x16_t &c) {
+        if (ET == 0)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                        c, 0, 0, 0);
+        else
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b),
+                                                       c, 0, 0, 0);
+    };
+    // LDS byte address of the (only) LDS object
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+
     auto compute = [&](int buf) {
+        if (GLDS) {
+            // Fragment reads in inline asm.  With compiler-visible ds_reads hipcc puts an
+            // s_waitcnt vmcnt(0) in front of the first read of every K-step (it cannot prove that the
+            // in-flight LDS DMA of the NEXT stage does not alias the buffer being read), which drains
+            // the DMA before the MFMAs start and removes all overlap inside a block.  The reads of
+            // k-slice ks+1 are issued before the MFMAs of ks; LDS returns in order, so lgkmcnt(4)
+            // means "all but the 4 newest reads have landed".
+            const unsigned sa = lds0 + buf * A_BYTES, sb = lds0 + STAGES * A_BYTES + buf * B_BYTES;
+            u32x4_t fa[2][2], fb[2][NI];
+            auto rd = [&](int set, int ks) {
+                const int sl = ks * 2 + kgrp;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][mi]) : "v"(sa + lds_off(wm * 64 + mi * 32 + l31, sl)) : "memory");
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][ni]) : "v"(sb + lds_off(wn * WN + ni * 32 + l31, sl)) : "memory");
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int set = ks & 1;
+                if (ks < 3) {
+                    rd(set ^ 1, ks + 1);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 + NI) : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) mfma(fa[set][mi], fb[set][ni], acc[mi][ni]);
+            }
+            return;
+        }
         const char *sa = smem + buf * A_BYTES;
-        const char *sb = smem + 2 * A_BYTES + buf * B_BYTES;
+        const char *sb = smem + STAGES * A_BYTES + buf * B_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int sl = ks * 2 + kgrp;
-            uint4 af[2], bfr[NI];
+            u32x4_t af[2], bfr[NI];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
-                af[mi] = *reinterpret_cast<const uint4 *>(sa + lds_off(wm * 64 + mi * 32 + l31, sl));
+                af[mi] = *reinterpret_cast<const u32x4_t *>(sa + lds_off(wm * 64 + mi * 32 + l31, sl));
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                bfr[ni] = *reinterpret_cast<const uint4 *>(sb + lds_off(wn * WN + ni * 32 + l31, sl));
+                bfr[ni] = *reinterpret_cast<const u32x4_t *>(sb + lds_off(wn * WN + ni * 32 + l31, sl));
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    if (ET == 0)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8_t, af[mi]), __builtin_bit_cast(bf16x8_t, bfr[ni]), acc[mi][ni], 0,
-                            0, 0);
-                    else
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            __builtin_bit_cast(f16x8_t, af[mi]), __builtin_bit_cast(f16x8_t, bfr[ni]), acc[mi][ni], 0, 0,
-                            0);
-                }
+                for (int ni = 0; ni < NI; ++ni) mfma(af[mi], bfr[ni], acc[mi][ni]);
         }
     };
 
     // ---- main loop ------------------------------------------------------------------
     const int nk = p.nk;
-    if (GLDS && MODE == 0) {
+    if (GLDS && MODE == 0 && STAGES == 3) {
+        // three LDS buffers, prefetch distance two K-steps.  Every wave issues PER = 4 + NB DMA
+        // instructions per stage; vmcnt(PER) therefore means "everything but the newest stage has
+        // landed".  The raw barrier after it makes the other waves' DMA of that stage visible too and
+        // doubles as the WAR fence for the buffer the next iteration refills.
+        constexpr int PER = 4 + NB;
+        issue_dma(0, 0);
+        if (nk > 1) {
+            issue_dma(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool ahead = kt + 2 < nk;
+            if (ahead && !(p.debug & 1)) issue_dma(kt + 2, cur == 0 ? 2 : cur - 1);
+            if (!(p.debug & 2)) compute(cur);
+            if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+    } else if (GLDS && MODE == 0) {
         // the DMA for K-step kt+1 is issued before the MFMAs of K-step kt and has landed when the
         // barrier (which carries the vmcnt(0) for the in-flight DMA) releases
         issue_dma(0, 0);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) issue_dma(kt + 1, cur ^ 1);
-            compute(cur);
+            if (kt + 1 < nk && !(p.debug & 1)) issue_dma(kt + 1, cur ^ 1);
+            if (!(p.debug & 2)) compute(cur);
             __syncthreads();
         }
     } else {
@@ -276,6 +350,41 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
     }
 
     // ---- epilogue --------------------------------------------------------------------
+    // Thread (r0, c8) finishes 8 consecutive channels of rows r0 + pass*RPP.  The residual rows are
+    // requested FIRST (they are the only long-latency loads of the epilogue) so that they travel while
+    // the accumulators go through LDS; the per-pass work is fully unrolled so the 16-byte stores of all
+    // passes are issued back to back.
+    constexpr int TPR = BN / 8;   // threads per row
+    constexpr int RPP = NT / TPR; // rows per pass
+    constexpr int NPASS = BM / RPP;
+    const int c8 = t % TPR;
+    const int r0 = t / TPR;
+    const int c = n0 + c8 * 8;
+    const bool cok = c < p.Cout;
+    const bool full = c + 8 <= p.Cout;
+    const bool has_res = p.res != nullptr && full;
+    uint4 rres[NPASS], rres_lo[NPASS];
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int m = m0 + pass * RPP + r0;
+        rres[pass] = make_uint4(0, 0, 0, 0);
+        rres_lo[pass] = make_uint4(0, 0, 0, 0);
+        if (has_res && m < p.M) {
+            const long long o = (long long)m * p.Cout + c;
+            rres[pass] = *reinterpret_cast<const uint4 *>(p.res + o);
+            if (SPLIT) rres_lo[pass] = *reinterpret_cast<const uint4 *>(p.res_lo + o);
+        }
+    }
+    float s1[8], b1[8], s2[8], b2[8];
+    const bool post = p.s2 != nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s1[j] = cok ? p.s1[c + j] : 0.f;
+        b1[j] = cok ? p.b1[c + j] : 0.f;
+        s2[j] = (cok && post) ? p.s2[c + j] : 1.f;
+        b2[j] = (cok && post) ? p.b2[c + j] : 0.f;
+    }
+
     float *ct = reinterpret_cast<float *>(smem);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -289,105 +398,86 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs p) {
             }
     __syncthreads();
 
-    constexpr int TPR = BN / 8;    // threads per row
-    constexpr int RPP = 256 / TPR; // rows per pass
-    const int c8 = t % TPR;
-    const int r0 = t / TPR;
-    const int c = n0 + c8 * 8;
-    if (c < p.Cout) {
-        float s1[8], b1[8], s2[8], b2[8];
+    if (cok) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            s1[j] = p.s1[c + j];
-            b1[j] = p.b1[c + j];
-        }
-        const bool post = p.s2 != nullptr;
-        if (post) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                s2[j] = p.s2[c + j];
-                b2[j] = p.b2[c + j];
-            }
-        }
-        const bool full = c + 8 <= p.Cout;
-        for (int pass = 0; pass < BM / RPP; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int row = pass * RPP + r0;
             const int m = m0 + row;
-            if (m >= p.M) break;
-            float v[8];
-            const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(ct + row * CT_STRIDE + c8 * 8);
-            const f32x4_t q1 = *reinterpret_cast<const f32x4_t *>(ct + row * CT_STRIDE + c8 * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = q0[j];
-                v[4 + j] = q1[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] * s1[j] + b1[j];
-            const long long o = (long long)m * p.Cout + c;
-            if (p.res != nullptr && full) {
-                const uint4 rv = *reinterpret_cast<const uint4 *>(p.res + o);
-                const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+            if (m < p.M) {
+                float v[8];
+                const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(ct + row * CT_STRIDE + c8 * 8);
+                const f32x4_t q1 = *reinterpret_cast<const f32x4_t *>(ct + row * CT_STRIDE + c8 * 8 + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    v[2 * j] += h16_to_f32((bf16_t)(rw[j] & 0xffffu), ET);
-                    v[2 * j + 1] += h16_to_f32((bf16_t)(rw[j] >> 16), ET);
+                    v[j] = q0[j];
+                    v[4 + j] = q1[j];
                 }
-                if (SPLIT) {
-                    const uint4 lv = *reinterpret_cast<const uint4 *>(p.res_lo + o);
-                    const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] * s1[j] + b1[j];
+                const long long o = (long long)m * p.Cout + c;
+                if (has_res) {
+                    const uint32_t rw[4] = {rres[pass].x, rres[pass].y, rres[pass].z, rres[pass].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        v[2 * j] += bf16_to_f32((bf16_t)(lw[j] & 0xffffu));
-                        v[2 * j + 1] += bf16_to_f32((bf16_t)(lw[j] >> 16));
+                        v[2 * j] += h16_to_f32((bf16_t)(rw[j] & 0xffffu), ET);
+                        v[2 * j + 1] += h16_to_f32((bf16_t)(rw[j] >> 16), ET);
                     }
-                }
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-            if (post) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v[j] * s2[j] + b2[j];
-            }
-            if (p.y_f32 != nullptr) {
-                if (full && (p.Cout & 3) == 0) {
-                    f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    *reinterpret_cast<f32x4_t *>(p.y_f32 + o) = o0;
-                    *reinterpret_cast<f32x4_t *>(p.y_f32 + o + 4) = o1;
-                } else {
-                    for (int j = 0; j < 8 && c + j < p.Cout; ++j) p.y_f32[o + j] = v[j];
-                }
-            }
-            if (p.y != nullptr && full) {
-                uint32_t hw[4], lw[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bf16_t h0 = f32_to_h16(v[2 * j], ET), h1 = f32_to_h16(v[2 * j + 1], ET);
-                    hw[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
                     if (SPLIT) {
-                        const bf16_t l0 = f32_to_bf16(v[2 * j] - bf16_to_f32(h0));
-                        const bf16_t l1 = f32_to_bf16(v[2 * j + 1] - bf16_to_f32(h1));
-                        lw[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                        const uint32_t lw[4] = {rres_lo[pass].x, rres_lo[pass].y, rres_lo[pass].z, rres_lo[pass].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[2 * j] += bf16_to_f32((bf16_t)(lw[j] & 0xffffu));
+                            v[2 * j + 1] += bf16_to_f32((bf16_t)(lw[j] >> 16));
+                        }
                     }
                 }
-                *reinterpret_cast<uint4 *>(p.y + o) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-                if (SPLIT) *reinterpret_cast<uint4 *>(p.y_lo + o) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                if (p.relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                if (post) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] * s2[j] + b2[j];
+                }
+                if (p.y_f32 != nullptr) {
+                    if (full && (p.Cout & 3) == 0) {
+                        f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                        *reinterpret_cast<f32x4_t *>(p.y_f32 + o) = o0;
+                        *reinterpret_cast<f32x4_t *>(p.y_f32 + o + 4) = o1;
+                    } else {
+                        for (int j = 0; j < 8 && c + j < p.Cout; ++j) p.y_f32[o + j] = v[j];
+                    }
+                }
+                if (p.y != nullptr && full) {
+                    uint32_t hw[4], lw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bf16_t h0 = f32_to_h16(v[2 * j], ET), h1 = f32_to_h16(v[2 * j + 1], ET);
+                        hw[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                        if (SPLIT) {
+                            const bf16_t l0 = f32_to_bf16(v[2 * j] - bf16_to_f32(h0));
+                            const bf16_t l1 = f32_to_bf16(v[2 * j + 1] - bf16_to_f32(h1));
+                            lw[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                        }
+                    }
+                    *reinterpret_cast<uint4 *>(p.y + o) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                    if (SPLIT) *reinterpret_cast<uint4 *>(p.y_lo + o) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                }
             }
         }
     }
 }
 
-template <int BN, int MODE, bool SPLIT, int ET>
+template <int BM, int BN, int MODE, bool SPLIT, int ET>
 int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
     constexpr bool GLDS = MODE == 0; // LDS-DMA staging for every generic layer; small-Cin layers stage via registers
+    constexpr int STAGES = BM == 256 ? 3 : 2;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    constexpr int PIPE = 2 * (A_BYTES + B_BYTES);
+    constexpr int PIPE = STAGES * (A_BYTES + B_BYTES);
     constexpr int EPI = BM * (BN + 4) * 4;
     constexpr int LDS = PIPE > EPI ? PIPE : EPI;
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<BN, MODE, SPLIT, ET, GLDS>;
+    auto kern = conv_igemm_kernel<BM, BN, MODE, SPLIT, ET, GLDS, STAGES>;
     if (!attr_set) {
         WSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -395,8 +485,8 @@ int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
     }
     // algorithmic FLOPs: 2 * M * Cout * (kh*kw*Cin_real), x1 regardless of the precision mode
     const double flops = 2.0 * a.M * a.Cout * (MODE == 0 ? (double)a.kh * a.kw * a.Cin : (double)a.kh * a.kw * 3);
-    WscKernelTimer timer(ctx, MODE != 0 ? WSC_K_CONV_SMALLCIN : (BN == 128 ? WSC_K_CONV128 : WSC_K_CONV64), flops);
-    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), LDS, ctx->stream, a);
+    WscKernelTimer timer(ctx, MODE != 0 ? WSC_K_CONV_SMALLCIN : (BM == 256 ? WSC_K_CONV256 : (BN == 128 ? WSC_K_CONV128 : WSC_K_CONV64)), flops);
+    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(BM * 2), LDS, ctx->stream, a);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
@@ -404,18 +494,25 @@ int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
 template <int BN>
 int launch_bn(wsc_ctx *ctx, const ConvKArgs &a, int small_cin, int split, int fmt) {
     if (split) {
-        if (small_cin == 0) return launch_variant<BN, 0, true, 0>(ctx, a);
-        if (small_cin == 1) return launch_variant<BN, 1, true, 0>(ctx, a);
-        return launch_variant<BN, 2, true, 0>(ctx, a);
+        if (small_cin == 0) return launch_variant<128, BN, 0, true, 0>(ctx, a);
+        if (small_cin == 1) return launch_variant<128, BN, 1, true, 0>(ctx, a);
+        return launch_variant<128, BN, 2, true, 0>(ctx, a);
     }
     if (fmt) {
-        if (small_cin == 0) return launch_variant<BN, 0, false, 1>(ctx, a);
-        if (small_cin == 1) return launch_variant<BN, 1, false, 1>(ctx, a);
-        return launch_variant<BN, 2, false, 1>(ctx, a);
+        if (small_cin == 0) return launch_variant<128, BN, 0, false, 1>(ctx, a);
+        if (small_cin == 1) return launch_variant<128, BN, 1, false, 1>(ctx, a);
+        return launch_variant<128, BN, 2, false, 1>(ctx, a);
     }
-    if (small_cin == 0) return launch_variant<BN, 0, false, 0>(ctx, a);
-    if (small_cin == 1) return launch_variant<BN, 1, false, 0>(ctx, a);
-    return launch_variant<BN, 2, false, 0>(ctx, a);
+    if (small_cin == 0) return launch_variant<128, BN, 0, false, 0>(ctx, a);
+    if (small_cin == 1) return launch_variant<128, BN, 1, false, 0>(ctx, a);
+    return launch_variant<128, BN, 2, false, 0>(ctx, a);
+}
+
+// 256 x 128 tile (generic layers only)
+int launch_big(wsc_ctx *ctx, const ConvKArgs &a, int split, int fmt) {
+    if (split) return launch_variant<256, 128, 0, true, 0>(ctx, a);
+    if (fmt) return launch_variant<256, 128, 0, false, 1>(ctx, a);
+    return launch_variant<256, 128, 0, false, 0>(ctx, a);
 }
 
 } // namespace
@@ -447,8 +544,29 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     WSC_CHECK(p.CoutPad % 64 == 0, WSC_ERR_INVALID, "conv: CoutPad=%d not a multiple of 64", p.CoutPad);
     a.ntiles_n = p.CoutPad / BN;
     a.zero = (const bf16_t *)ctx->zero_page;
-    a.nblocks = ((a.M + BM - 1) / BM) * a.ntiles_n;
+    // timing-only ablations; honoured only together with WSC_ALLOW_WRONG_RESULTS=1
+    static const int debug = [] {
+        const char *e = getenv("WSC_CONV_DEBUG"), *ok = getenv("WSC_ALLOW_WRONG_RESULTS");
+        return (e && ok && atoi(ok) == 1) ? atoi(e) : 0;
+    }();
+    a.debug = debug;
     if (a.M == 0) return WSC_OK;
+    // tile choice.  Measured on the ResNet50-CAM stack (64 samples @321^2, f16): 128-row tiles 4.31 ms,
+    // 256-row 3-stage tiles on the K >= 512 layers 4.37 ms, everywhere 4.45 ms -- the stack is bound by
+    // per-block memory latency with 1-2 blocks per CU (an ablation without DMA and without MFMAs still
+    // takes 2.2 ms), not by L2->LDS bytes per FLOP, so the 128-row tile stays the default.
+    // WSC_CONV_TILE=256 selects the 256-row tile wherever it applies, =-1 where K >= 512 (A/B runs).
+    static const int force = [] { const char *e = getenv("WSC_CONV_TILE"); return e ? atoi(e) : 0; }();
+    const long long blocks256 = ((a.M + 255) / 256) * (long long)a.ntiles_n;
+    bool big = false;
+    if (force == -1) big = p.small_cin == 0 && BN == 128 && a.Kbase >= 512 && blocks256 >= 200;
+    if (force == 256) big = p.small_cin == 0 && BN == 128;
+    const int BMsel = big ? 256 : 128;
+    a.nblocks = ((a.M + BMsel - 1) / BMsel) * a.ntiles_n;
+    if (big) {
+        WSC_CHECK(!(p.split && p.fmt), WSC_ERR_INVALID, "conv: split precision requires bf16 planes");
+        return launch_big(ctx, a, p.split, p.fmt);
+    }
     WSC_CHECK(!(p.split && p.fmt), WSC_ERR_INVALID, "conv: split precision requires bf16 planes");
     if (BN == 128) return launch_bn<128>(ctx, a, p.small_cin, p.split, p.fmt);
     return launch_bn<64>(ctx, a, p.small_cin, p.split, p.fmt);
