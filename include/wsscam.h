@@ -183,6 +183,18 @@ int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h,
                         const int32_t *key_off_host /*[B+1]*/, const int64_t *strided_off_host /*[B]*/,
                         const int64_t *highres_off_host /*[B]*/, float *strided_dev, float *highres_dev);
 
+/* eval_cam for a batch straight from the packed high_res maps of wsc_cam_postprocess
+ * (03b_irn/step/eval_cam.py:48-62 and chainercv.evaluations.calc_semantic_segmentation_confusion):
+ *   cams = np.pad(high_res, ((1,0),...), constant_values=bg_thres); keys' = np.pad(keys + 1, (1,0))
+ *   pred = keys'[np.argmax(cams, axis=0)];  confusion[gt][pred] += 1 where gt != ignore_label
+ * gt_dev / pred_dev: uint8, images packed back to back (H0*W0 each, in batch order); pred_dev may be
+ * NULL; gt_dev may be NULL (labels only).  confusion_dev int64 [n_class][n_class] is ACCUMULATED into, so
+ * one matrix can be carried over a whole dataset (zero it first with wsc_memset). */
+int wsc_cam_eval_confusion(wsc_ctx *ctx, const float *highres_dev, int B, const int32_t *size_hw_host,
+                           const int32_t *keys_host, const int32_t *key_off_host,
+                           const int64_t *highres_off_host, float bg_thres, const uint8_t *gt_dev, int n_class,
+                           int ignore_label, uint8_t *pred_dev, int64_t *confusion_dev);
+
 /* Probabilities -> CRF unaries for a [background | class maps] stack:
  *   v_0 = bg_value, v_{c+1} = maps[b][c][p];  U[b][m][p] = -log(clip(v_m / sum_m v_m, 1e-5, 1))
  * i.e. eval_cam.py:49-51 (np.pad(high_res, constant_values=cam_eval_thres)) followed by

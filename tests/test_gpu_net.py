@@ -286,3 +286,44 @@ def test_crf_inference_mirror(ctx):
     qr, _, _ = helpers.crf_oracle(rgb, U, (cfg["g_sxy"], 3, cfg["bi_sxy"], 13, 10, 5))
     assert out.shape == (H, W, C) and out.dtype == np.float32
     assert np.abs(out - np.transpose(qr.reshape(C, H, W), (1, 2, 0))).max() <= 1e-3
+
+
+def test_eval_cam_confusion_exact(ctx, tmp_path):
+    """eval_cam on the device (eval_cam.py:48-62 + chainercv confusion): integer work, bit-exact vs numpy."""
+    from wsscam.step import eval_cam
+
+    rng = np.random.default_rng(21)
+    C, h = 20, 21
+    cam = np.maximum(rng.normal(0.3, 1.0, (3, C, h, h)), 0).astype(np.float32)
+    sizes = [(37, 50), (64, 41), (1, 7)]
+    keys = [[2, 9, 19], [], [0]]
+    cam_dev = ctx.to_device(cam)
+    s_dev, h_dev, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, 3, C, h, h, sizes, keys)
+    gts = [rng.integers(0, 21, sz).astype(np.uint8) for sz in sizes]
+    for g in gts:
+        g[rng.random(g.shape) < 0.1] = 255  # ignore label
+    acc = eval_cam.ConfusionAccumulator(ctx, n_class=21, cam_eval_thres=0.15)
+    preds = acc.add_batch(h_dev, sizes, keys, h_off, gts, want_pred=True)
+    acc.add_batch(h_dev, sizes, keys, h_off, gts)  # accumulates: second pass doubles the counts
+    conf = acc.confusion()
+    hi_all = ctx.to_host(h_dev, (max(sum(k * a * b for k, _, _, a, b in shapes), 1),), np.float32)
+    ref = np.zeros((21, 21), np.int64)
+    for b, (sz, ks, gt) in enumerate(zip(sizes, keys, gts)):
+        K, _, _, H0, W0 = shapes[b]
+        hr = hi_all[h_off[b]:h_off[b] + K * H0 * W0].reshape(K, H0, W0)
+        cams = np.pad(hr, ((1, 0), (0, 0), (0, 0)), mode="constant", constant_values=0.15)  # eval_cam.py:50
+        kk = np.pad(np.asarray(ks, dtype=np.int64) + 1, (1, 0), mode="constant")              # eval_cam.py:51
+        cls = kk[np.argmax(cams, axis=0)]
+        assert np.array_equal(preds[b], cls.astype(np.uint8))
+        m = gt != 255
+        ref += np.bincount(21 * gt[m].astype(np.int64) + cls[m], minlength=441).reshape(21, 21)
+    assert np.array_equal(conf, 2 * ref)
+    s = eval_cam.scores_from_confusion(conf)
+    assert 0 <= s["miou"] <= 1
+
+    class Args:
+        eval_dir = str(tmp_path); run_name = "r"; split = "val"; logfile = str(tmp_path / "log.txt")
+
+    eval_cam.write_report(Args, conf, ["c%d" % i for i in range(21)])
+    assert "[eval_cam, val] miou: " in open(Args.logfile).read()
+    assert open(tmp_path / "r_val_cam_iou.csv").readline().strip() == ",iou,precision,recall"

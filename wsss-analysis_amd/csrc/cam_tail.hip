@@ -14,6 +14,9 @@
 //   out = lh0*(lw0*a + lw1*b) + lh1*(lw0*c + lw1*d)
 #include "common.h"
 
+#include <algorithm>
+#include <cstring>
+
 namespace {
 
 struct TailJob {
@@ -137,9 +140,90 @@ __global__ void unary_from_maps_kernel(const float *__restrict__ maps, float bg,
     }
 }
 
+// eval_cam (03b_irn/step/eval_cam.py:48-62 + chainercv's calc_semantic_segmentation_confusion):
+//   cams = pad(high_res, bg channel = thres); cls = pad(keys+1, 0)[argmax(cams, 0)]
+//   confusion[gt][cls] += 1 for every pixel whose gt != ignore_label
+// Integer work: per-block LDS histogram, one 64-bit global atomic per touched cell.
+struct EvalJob {
+    long long highres_off; // float offset of this image's [K][H0*W0] block
+    long long pix_off;     // offset of this image in the packed gt / pred arrays
+    int npix, K, key_base;
+};
+
+__global__ __launch_bounds__(256) void cam_eval_kernel(const float *__restrict__ highres,
+                                                       const EvalJob *__restrict__ jobs,
+                                                       const int32_t *__restrict__ keys, float thres,
+                                                       const uint8_t *__restrict__ gt, int n_class, int ignore_label,
+                                                       uint8_t *__restrict__ pred,
+                                                       unsigned long long *__restrict__ confusion) {
+    extern __shared__ unsigned hist[]; // n_class * n_class
+    const EvalJob job = jobs[blockIdx.y];
+    const int cells = n_class * n_class;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < job.npix; p += gridDim.x * blockDim.x) {
+        float best = thres;
+        int idx = 0;
+        for (int k = 0; k < job.K; ++k) {
+            const float v = highres[job.highres_off + (long long)k * job.npix + p];
+            if (v > best) { // strict: np.argmax keeps the first maximum (the background channel comes first)
+                best = v;
+                idx = k + 1;
+            }
+        }
+        const int cls = idx == 0 ? 0 : keys[job.key_base + idx - 1] + 1;
+        if (pred != nullptr) pred[job.pix_off + p] = (uint8_t)cls;
+        const int g = gt != nullptr ? (int)gt[job.pix_off + p] : ignore_label;
+        if (g != ignore_label && g < n_class && cls < n_class) atomicAdd(&hist[g * n_class + cls], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells; i += blockDim.x)
+        if (hist[i]) atomicAdd(&confusion[i], (unsigned long long)hist[i]);
+}
+
 } // namespace
 
 extern "C" {
+
+int wsc_cam_eval_confusion(wsc_ctx *ctx, const float *highres_dev, int B, const int32_t *size_hw_host,
+                           const int32_t *keys_host, const int32_t *key_off_host, const int64_t *highres_off_host,
+                           float bg_thres, const uint8_t *gt_dev, int n_class, int ignore_label, uint8_t *pred_dev,
+                           int64_t *confusion_dev) {
+    WSC_CHECK(ctx && highres_dev && size_hw_host && key_off_host && highres_off_host && confusion_dev, WSC_ERR_INVALID,
+              "wsc_cam_eval_confusion: null argument");
+    WSC_CHECK(B > 0 && n_class > 0 && n_class <= 64, WSC_ERR_INVALID, "wsc_cam_eval_confusion: B=%d n_class=%d", B,
+              n_class);
+    WSC_HIP(hipSetDevice(ctx->device));
+    std::vector<EvalJob> jobs(B);
+    long long pix = 0;
+    int max_pix = 0;
+    for (int b = 0; b < B; ++b) {
+        const int H0 = size_hw_host[2 * b], W0 = size_hw_host[2 * b + 1];
+        WSC_CHECK(H0 > 0 && W0 > 0, WSC_ERR_INVALID, "image %d has size %dx%d", b, H0, W0);
+        jobs[b].highres_off = highres_off_host[b];
+        jobs[b].pix_off = pix;
+        jobs[b].npix = H0 * W0;
+        jobs[b].K = key_off_host[b + 1] - key_off_host[b];
+        jobs[b].key_base = key_off_host[b];
+        pix += (long long)H0 * W0;
+        max_pix = std::max(max_pix, H0 * W0);
+    }
+    const int nkeys = key_off_host[B];
+    const size_t jb = (jobs.size() * sizeof(EvalJob) + 15) / 16 * 16, kb = (size_t)std::max(nkeys, 1) * sizeof(int32_t);
+    char *d = nullptr;
+    WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + kb, (void **)&d));
+    std::vector<char> stage(jb + kb, 0);
+    memcpy(stage.data(), jobs.data(), jobs.size() * sizeof(EvalJob));
+    if (nkeys > 0) memcpy(stage.data() + jb, keys_host, (size_t)nkeys * sizeof(int32_t));
+    WSC_TRY(wsc_ctx_upload_small(ctx, d, stage.data(), stage.size()));
+    const dim3 grid((unsigned)std::min((max_pix + 255) / 256, 64), (unsigned)B);
+    hipLaunchKernelGGL(cam_eval_kernel, grid, dim3(256), (size_t)n_class * n_class * sizeof(unsigned), ctx->stream,
+                       highres_dev, (const EvalJob *)d, (const int32_t *)(d + jb), bg_thres, gt_dev, n_class,
+                       ignore_label, pred_dev, (unsigned long long *)confusion_dev);
+    WSC_HIP(hipGetLastError());
+    wsc_ctx_cached_free(ctx, d);
+    return WSC_OK;
+}
 
 int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N, float bg_value, float *unary_dev) {
     WSC_CHECK(ctx && maps_dev && unary_dev, WSC_ERR_INVALID, "wsc_unary_from_maps: null argument");

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "wsc_net_forward_features": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "wsc_conv2d_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "wsc_cam_postprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wsc_cam_eval_confusion": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _vp]),
     "wsc_unary_from_maps": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     "wsc_crf_create": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _f, ctypes.POINTER(_vp)]),
@@ -363,6 +364,23 @@ def conv2d_nchw(ctx, x_dev, N, Cin, H, W, w, stride, pad, scale=None, shift=None
                                    None if sc is None else sc.ctypes.data, None if sh is None else sh.ctypes.data,
                                    _ptr(residual_dev), int(relu), precision, _ptr(y_dev)))
     return y_dev, (N, Cout, Ho, Wo)
+
+
+def cam_eval_confusion(ctx, highres_dev, sizes, keys_per_image, highres_off, bg_thres, gt_dev, n_class, confusion_dev,
+                       pred_dev=None, ignore_label=255):
+    """Accumulates the eval_cam confusion matrix of a batch into confusion_dev (int64 [n_class][n_class])."""
+    B = len(sizes)
+    size_hw = np.asarray(sizes, dtype=np.int32).reshape(B, 2)
+    key_off = np.zeros(B + 1, dtype=np.int32)
+    for b in range(B):
+        key_off[b + 1] = key_off[b] + len(keys_per_image[b])
+    keys = np.zeros(max(int(key_off[-1]), 1), dtype=np.int32)
+    for b in range(B):
+        keys[key_off[b]:key_off[b + 1]] = np.asarray(keys_per_image[b], dtype=np.int32)
+    h_off = np.ascontiguousarray(highres_off, dtype=np.int64)
+    check(ctx._lib.wsc_cam_eval_confusion(ctx.h, _ptr(highres_dev), B, size_hw.ctypes.data, keys.ctypes.data,
+                                          key_off.ctypes.data, h_off.ctypes.data, float(bg_thres), _ptr(gt_dev),
+                                          int(n_class), int(ignore_label), _ptr(pred_dev), _ptr(confusion_dev)))
 
 
 def unary_from_maps(ctx, maps_dev, B, C, N, bg_value, unary_dev):
