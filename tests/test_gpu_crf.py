@@ -134,3 +134,30 @@ def test_crf_key_range_error(ctx):
     with pytest.raises(_lib.WscError) as ei:
         _lib.Crf(ctx, ctx.to_device(rgb), 1, 64, 64, 1.0, 0.02, 0.05)
     assert ei.value.status == _lib.WSC_ERR_KEY_RANGE
+
+
+def test_cam_to_ir_label_mirror(ctx):
+    """03b_irn/step/cam_to_ir_label.py:42-58 (VOC branch): two label-unary CRF runs on one lattice pair."""
+    from wsscam.step import cam_to_ir_label
+
+    rng = np.random.default_rng(16)
+    H, W = 47, 59
+    rgb, _, p = helpers.synth_crf_case(rng, H, W, 3)
+    hi = (p[:2] / p[:2].max(axis=(1, 2), keepdims=True)).astype(np.float32)  # two max-normalised "CAMs"
+    cam_dict = {"keys": np.array([4, 11]), "cam": None, "high_res": hi}
+    out = cam_to_ir_label.ir_label_voc12(rgb, cam_dict, 0.30, 0.05, ctx=ctx)
+    keys = np.array([0, 5, 12])
+
+    def oracle_conf(thres):
+        lab = np.argmax(np.pad(hi, ((1, 0), (0, 0), (0, 0)), mode="constant", constant_values=thres), axis=0)
+        U = imutils.unary_from_labels(lab, 3, 0.7, zero_unsure=False)
+        _, ar, _ = helpers.crf_oracle(rgb, U, (3, 3, 50, 5, 10, 10))
+        return keys[ar.reshape(H, W)]
+
+    fg, bg = oracle_conf(0.30), oracle_conf(0.05)
+    ref = fg.copy()
+    ref[fg == 0] = 255
+    ref[bg + fg == 0] = 0
+    assert out.shape == (H, W) and out.dtype == np.uint8
+    assert (out == ref).mean() >= 0.995
+    assert set(np.unique(out)) <= {0, 5, 12, 255}
