@@ -39,17 +39,51 @@ class CAM(DeviceCAMBase):
             y = y[ADP_INDS_X17]
         return y
 
+    # ---- ADP background / other-tissue channels: common_cam.py:31-92 ------------------------------------
+    def _adp_background(self, cam, img_orig):
+        """0.75 * sigmoid(4 * (mean_rgb - 240)) of the ORIGINAL (un-normalised, un-flipped) image, Gaussian
+        smoothed (sigma 2), resized to the CAM size (cv2.resize bilinear)."""
+        import scipy.ndimage
+        import scipy.special
+
+        from ..cues.utilities import resize_stack
+
+        mean_img = np.mean(np.asarray(img_orig[0], dtype=np.float32), axis=2)
+        bg = 0.75 * scipy.special.expit(4 * (mean_img - 240))
+        bg = scipy.ndimage.gaussian_filter(bg, sigma=2)
+        if bg.shape != cam.shape[1:]:
+            bg = resize_stack(bg[None, None], cam.shape[1:], ctx=self.ctx)[0, 0]
+        return bg.astype(np.float32)
+
+    def _adp_modify_morph(self, cam, img_orig):
+        """common_cam.py:31-55: background = relu(bg - max adipose CAM), prepended to cam[use_cls]."""
+        bg = self._adp_background(cam, img_orig)
+        background = np.maximum(bg - np.max(cam[[18, 19, 20]], axis=0), 0)
+        return np.concatenate((background[None], cam[self.use_cls]), axis=0)
+
+    def _adp_modify_func(self, cam, img_orig):
+        """common_cam.py:57-92: background = bg - max exception CAM (no relu), then an 'other' channel
+        max(0.05 * (1 - max_c modified), max adipose CAM) inserted after it."""
+        bg = self._adp_background(cam, img_orig)
+        background = bg - np.max(cam[[28, 29, 30]], axis=0)
+        modified = np.concatenate((background[None], cam[self.use_cls]), axis=0)
+        other = np.maximum(0.05 * (1 - np.max(modified, axis=0)), np.max(cam[[18, 19, 20]], axis=0))
+        return np.concatenate((modified[:1], other[None], modified[1:]), axis=0)
+
     def forward(self, x, x_orig=None):
-        """-> (cam (C,h,w), y bool (C,)).  The ADP background/other-channel synthesis of
-        common_cam.py:31-92 (x_orig branch) is not part of this round."""
-        if self.dataset in ("adp_morph", "adp_func"):
-            raise NotImplementedError("ADP CAM modifications (common_cam.py:31-92) are not implemented yet")
+        """-> (cam (C,h,w), y bool (C,)) as vgg16_cam.py:24-60 / m7_cam.py:22-57; for the ADP datasets
+        `x_orig` is the (2,H0,W0,3) uint8 image pair of the ADP dataloader."""
+        assert (self.dataset in ("adp_morph", "adp_func")) ^ (x_orig is None)
         is_torch = hasattr(x, "detach")
         xn = x.detach().cpu().numpy() if is_torch else np.asarray(x)
         cam, score = self.forward_batch(xn[None], want_score=True)
         cam, y = cam[0], self.predict_labels(score[0])
         if "X1.7" in self.tag:
             cam = cam[ADP_INDS_X17]
+        if self.dataset == "adp_morph":
+            cam = self._adp_modify_morph(cam, x_orig.detach().cpu().numpy() if hasattr(x_orig, "detach") else x_orig)
+        elif self.dataset == "adp_func":
+            cam = self._adp_modify_func(cam, x_orig.detach().cpu().numpy() if hasattr(x_orig, "detach") else x_orig)
         if is_torch:
             import torch
 
