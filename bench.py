@@ -175,12 +175,17 @@ class Workload:
         self.crf_infer(crf, ctx=self.ctx_crf)
         self.pending = crf
 
-    def step(self):
+    def step(self, sequential=False):
+        """One step, finished before it returns.  sequential=True additionally keeps the stages from
+        overlapping each other (used for the per-kernel HIP-event measurement, where a kernel's duration
+        must not include time shared with another stream's kernels)."""
         # stream 1: conv stack (enqueued asynchronously, returns at once)
         self.run_cnn()
         if self.workload != "cam_crf":
             self.run_tail()
             return
+        if sequential:
+            self.ctx.sync()
         # stream 2: lattice build of the same batch (needs only the RGB images) while the conv stack runs
         crf = self.crf_create()
         if self.vg is None:
@@ -339,11 +344,12 @@ def main():
                        "lattice_vertices_gauss": round(vg, 1), "lattice_vertices_bilat": round(vb, 1),
                        "crf_loop_algorithmic_GBps": round(by * wl.B / (t_inf * 1e-3) / 1e9, 2)})
 
-    # ---- per-kernel roofline: every launch of one more step bracketed by HIP events on its stream ----
+    # ---- per-kernel roofline: every launch of two more steps bracketed by HIP events on its stream; the
+    # stages of these steps do not overlap, so a duration is the kernel's own ----
     wl.ctx.profile_begin()
     wl.ctx_build.profile_begin()
     for _ in range(2):
-        wl.step()
+        wl.step(sequential=True)
     prof = wl.ctx.profile_end()
     prof.update(wl.ctx_build.profile_end())
     kernels = {}
