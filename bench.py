@@ -31,7 +31,10 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-GFLOP_PER_IMAGE = 54.923  # ResNet50-CAM, 2 samples of 321x321 incl. head
+# algorithmic GFLOP per image = 2 samples (orig + flip) through the conv stack incl. the 1x1 head
+GFLOP_PER_IMAGE_BY_ARCH = {"resnet50": 54.923, "vgg16": 249.95, "m7": 37.34}
+INPUT_SIZE_BY_ARCH = {"resnet50": 321, "vgg16": 321, "m7": 224}
+GFLOP_PER_IMAGE = 54.923
 S = 321
 NUM_CLASSES = 20
 CRF_CFG = (1.5, 3.0, 40.0, 13.0, 10.0, 10)  # 03c_hsn/demo.py:157-165 VOC-VGG16 / DeepGlobe
@@ -47,6 +50,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="images per step per GPU")
     ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "bf16x3"])
     ap.add_argument("--workload", default="cam_crf", choices=["cam_crf", "cam"])
+    ap.add_argument("--arch", default="resnet50", choices=["resnet50", "vgg16", "m7"],
+                    help="CAM network (resnet50 is the BASELINE.json configuration; vgg16 / m7 are extra "
+                         "measurements of the other conv stacks of the reference, 03b_irn/net/{vgg16,m7}.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish each step before starting the next (default: the mean-field loop of step i "
@@ -72,11 +78,15 @@ def crf_bytes_per_image(N, M, T, vg, vb):
 
 
 class Workload:
-    def __init__(self, device, batch, precision, workload, seed):
+    def __init__(self, device, batch, precision, workload, seed, arch="resnet50"):
         import numpy as np
 
         from oracle import cnn_ref  # synthetic-input generator only (no compute of the product path)
         from wsscam import _lib
+
+        global S, GFLOP_PER_IMAGE
+        S = INPUT_SIZE_BY_ARCH[arch]
+        GFLOP_PER_IMAGE = GFLOP_PER_IMAGE_BY_ARCH[arch]
 
         self.np, self._lib = np, _lib
         self.B, self.workload = batch, workload
@@ -89,8 +99,20 @@ class Workload:
         self.ctx_crf = _lib.Context(device)
         self.pending = None  # lattices of the step whose mean-field loop is still in flight
         prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3}[precision]
-        sd = {k: v.numpy() for k, v in cnn_ref.make_resnet50_cam_state_dict(NUM_CLASSES, seed=0).items()}
-        self.net = _lib.Net(self.ctx, _lib.ARCH_RESNET50_CAM, sd, NUM_CLASSES, prec)
+        if arch == "resnet50":
+            sd = {k: v.numpy() for k, v in cnn_ref.make_resnet50_cam_state_dict(NUM_CLASSES, seed=0).items()}
+            self.net = _lib.Net(self.ctx, _lib.ARCH_RESNET50_CAM, sd, NUM_CLASSES, prec)
+        elif arch == "vgg16":
+            sd = {k: v.numpy() for k, v in cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, NUM_CLASSES, True,
+                                                                       seed=0).items()}
+            self.net = _lib.Net(self.ctx, _lib.ARCH_VGG16_CAM, sd, NUM_CLASSES, prec)
+        else:
+            sd = {k: v.numpy() for k, v in cnn_ref.make_plain_state_dict("m7", cnn_ref.M7_CFG, NUM_CLASSES, True,
+                                                                       seed=0).items()}
+            rngw = np.random.default_rng(5)
+            sd["gradcam_weights"] = rngw.normal(0, 0.05, (256, NUM_CLASSES)).astype(np.float32)
+            self.net = _lib.Net(self.ctx, _lib.ARCH_M7_CAM, sd, NUM_CLASSES, prec)
+        self.arch = arch
         self.h = self.net.cam_size(S)
         rng = np.random.default_rng(20121 + seed)
         gold = np.load(os.path.join(ROOT, "tests", "golden", "resnet50_cam.npz"))
@@ -294,7 +316,7 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
-    wl = Workload(device, args.batch, args.precision, args.workload, seed=rank)
+    wl = Workload(device, args.batch, args.precision, args.workload, seed=rank, arch=args.arch)
 
     def barrier():
         wl.ctx.sync()
@@ -387,10 +409,11 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": "ResNet50 CAM + dense-CRF (M=21, 10 mean-field iters), 321x321, batch %d "
-                                   "images (=%d samples) per GPU, image-sharded" % (args.batch, 2 * args.batch)
+            "config": {"workload": "%s CAM + dense-CRF (M=21, 10 mean-field iters), %dx%d, batch %d "
+                                   "images (=%d samples) per GPU, image-sharded" % (args.arch, S, S, args.batch,
+                                                                                   2 * args.batch)
                        if args.workload == "cam_crf" else
-                       "ResNet50 CAM (make_cam), 321x321, batch %d images per GPU" % args.batch,
+                       "%s CAM (make_cam), %dx%d, batch %d images per GPU" % (args.arch, S, S, args.batch),
                        "batch_images": args.batch, "num_classes": NUM_CLASSES, "crf_config": list(CRF_CFG),
                        "parallelism": "image-sharded x%d, no collective" % world,
                        "step_overlap": "mean-field loop of step i overlaps conv stack + lattice build of step i+1 "
@@ -398,7 +421,7 @@ def main():
             "roofline": roofline,
             "stages": stages,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.arch == "resnet50":
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
         print(json.dumps(out))
     if dist is not None:
