@@ -1,0 +1,148 @@
+"""GPU: edge cases of the hot path -- tiny / ragged / empty inputs, native VOC sizes, the end-to-end
+make_cam.run drop-in with its on-disk format."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cnn_ref
+from tests import helpers
+from wsscam import _lib
+from wsscam.hsn import utilities as hsn_utilities
+from wsscam.step import make_cam
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tiny_network_input_single_image():
+    """B = 1, S = 33: every layer has fewer output pixels than one 128-row tile by the end (3x3 maps)."""
+    sd = cnn_ref.make_resnet50_cam_state_dict(20, seed=0)
+    from wsscam.net import resnet50_cam
+
+    m = resnet50_cam.CAM(None, "voc12", "", 20, None, precision=_lib.PREC_BF16X3)
+    m.load_state_dict(sd)
+    m.cuda(0)
+    rng = np.random.default_rng(1)
+    x = cnn_ref.msf_pack(cnn_ref.synth_image(rng, 40, 50), (33, 33))
+    cam = m.forward(x)
+    with torch.no_grad():
+        ref = cnn_ref.resnet50_cam_forward(torch.from_numpy(x), sd).numpy()
+    assert cam.shape == ref.shape == (20, 3, 3)
+    assert np.abs(cam - ref).max() <= 2e-4 * ref.max()
+
+
+def test_make_cam_run_end_to_end(tmp_path):
+    """step.make_cam.run(args) with the reference's Namespace fields: one .npy per image in the
+    reference's three layouts (make_cam.py:80-88), values vs the oracle's make_cam_image."""
+    sd = cnn_ref.make_resnet50_cam_state_dict(20, seed=0)
+    rng = np.random.default_rng(2)
+    sizes = [(60, 80), (97, 64), (64, 64), (33, 47), (80, 60)]
+    labels = [np.zeros(20, np.float32) for _ in sizes]
+    labels[0][[1, 4]] = 1
+    labels[1][[7]] = 1
+    # labels[2] stays empty: the reference writes three empty arrays
+    labels[3][[0, 19]] = 1
+    labels[4][[12]] = 1
+    data = [{"name": "2007_%06d" % i, "img": cnn_ref.msf_pack(cnn_ref.synth_image(rng, *sz), (65, 65)), "size": sz,
+             "label": lb} for i, (sz, lb) in enumerate(zip(sizes, labels))]
+    args = types.SimpleNamespace(cam_network="net.resnet50_cam", model_dir=None, dataset="voc12", tag="", num_classes=20,
+                                 use_cls=None, model_id="resnet50", cam_weights_name=None, state_dict=sd,
+                                 dataset_obj=data, split="train_aug", cam_out_dir=str(tmp_path), n_gpus=1,
+                                 cam_batch_images=2,  # 5 images in batches of 2: a ragged last batch
+                                 cam_precision=_lib.PREC_BF16X3)  # 5x5 CAMs at S=65: check the plumbing tightly
+    make_cam.run(args)
+    files = sorted(os.listdir(tmp_path))
+    assert files == [d["name"] + ".npy" for d in data]
+    for d in data:
+        rec = np.load(os.path.join(tmp_path, d["name"] + ".npy"), allow_pickle=True).item()
+        ref = cnn_ref.make_cam_image(torch.from_numpy(d["img"]), sd, d["size"], torch.from_numpy(d["label"]))
+        assert list(rec) == ["keys", "cam", "high_res"]
+        if d["label"].sum() == 0:
+            assert all(rec[k].shape == (0,) for k in rec)
+            continue
+        assert rec["keys"].dtype == np.int64 and np.array_equal(rec["keys"], ref["keys"])
+        assert rec["cam"].shape == ref["cam"].shape and rec["high_res"].shape == ref["high_res"].shape
+        assert np.abs(rec["high_res"] - ref["high_res"]).max() <= 2e-4
+        assert np.abs(rec["cam"] - ref["cam"]).max() <= 2e-4
+
+
+def test_cam_tail_large_native_size(ctx):
+    """ADP evaluation size 1088x1088 (eval_cam.py:28): 1.18 M pixels per class map."""
+    rng = np.random.default_rng(3)
+    cam = np.maximum(rng.normal(0.4, 1.0, (1, 5, 40, 40)), 0).astype(np.float32)
+    s_dev, h_dev, s_off, h_off, shapes = _lib.cam_postprocess(ctx, ctx.to_device(cam), 1, 5, 40, 40, [(1088, 1088)],
+                                                              [[1, 3]])
+    K, h4, w4, H0, W0 = shapes[0]
+    hi = ctx.to_host(h_dev, (K, H0, W0), np.float32)
+    rs, rh = cnn_ref.make_cam_tail(torch.from_numpy(cam[0]), (1088, 1088), torch.tensor([1, 3]))
+    assert np.abs(hi - rh.numpy()).max() <= 2e-6
+
+
+def _gpu_crf(ctx, rgb, U, cfg):
+    H, W, _ = rgb.shape
+    M = U.shape[0]
+    crf = _lib.Crf(ctx, ctx.to_device(rgb), 1, H, W, cfg[0], cfg[2], cfg[3])
+    q_dev, a_dev = ctx.alloc(M * H * W * 4), ctx.alloc(H * W * 4)
+    crf.inference(ctx.to_device(U), M, cfg[1], cfg[4], int(cfg[5]), q_dev, a_dev)
+    q = ctx.to_host(q_dev, (M, H * W), np.float32)
+    a = ctx.to_host(a_dev, (H * W,), np.int32)
+    vg, vb = crf.lattice_sizes()
+    crf.close()
+    return q, a, (int(vg[0]), int(vb[0]))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 37), (29, 1), (3, 5)])
+def test_crf_degenerate_sizes(ctx, shape):
+    rng = np.random.default_rng(4)
+    H, W = shape
+    rgb = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+    p = rng.random((3, H * W)).astype(np.float32) + 0.05
+    U = np.ascontiguousarray(-np.log(p / p.sum(0, keepdims=True)))
+    cfg = (1.5, 3, 40, 13, 10, 3)
+    q, a, v = _gpu_crf(ctx, rgb, U, cfg)
+    qr, ar, ls = helpers.crf_oracle(rgb, U, cfg)
+    assert v == (ls[0], ls[1])
+    assert np.abs(q - qr).max() <= 1e-3 and np.array_equal(a, ar)
+
+
+def test_crf_native_voc_size_label_unaries(ctx):
+    """cam_to_ir_label's regime: native 375x500, M = K+1 = 3, label unaries, irn CRF parameters."""
+    from wsscam.misc import imutils
+
+    rng = np.random.default_rng(5)
+    H, W = 375, 500
+    rgb, _, p = helpers.synth_crf_case(rng, H, W, 3)
+    U = np.ascontiguousarray(imutils.unary_from_labels(p.argmax(0), 3, 0.7, zero_unsure=False))
+    cfg = (3, 3, 50, 5, 10, 10)
+    q, a, v = _gpu_crf(ctx, rgb, U, cfg)
+    qr, ar, ls = helpers.crf_oracle(rgb, U, cfg)
+    assert v == (ls[0], ls[1])
+    assert np.abs(q - qr).max() <= 1e-3 and (a == ar).mean() >= 0.995
+
+
+def test_dcrf_process_image_without_mass(ctx):
+    """An image whose probabilities are all zero has no pass classes: its CRF output stays zero -> label 0."""
+    rng = np.random.default_rng(6)
+    H, W = 21, 25
+    rgb, _, p = helpers.synth_crf_case(rng, H, W, 2)
+    probs = np.zeros((2, 4, H, W))
+    probs[0, [1, 3]] = p
+    imgs = np.stack([rgb, rgb])
+    out = hsn_utilities.dcrf_process(probs, imgs, [1.5, 3, 40, 13, 10, 5], ctx=ctx)
+    assert np.array_equal(out[1], np.zeros((H, W), np.int64))
+    assert set(np.unique(out[0])) <= {1, 3}
+
+
+def test_argument_errors(ctx):
+    with pytest.raises(_lib.WscError) as ei:
+        _lib.Crf(ctx, ctx.to_device(np.zeros((4, 4, 3), np.uint8)), 1, 4, 4, -1.0, 40, 13)
+    assert ei.value.status == _lib.WSC_ERR_INVALID
+    crf = _lib.Crf(ctx, ctx.to_device(np.zeros((4, 4, 3), np.uint8)), 1, 4, 4, 1.5, 40, 13)
+    with pytest.raises(_lib.WscError) as ei:
+        crf.inference(ctx.alloc(33 * 16 * 4), 33, 3, 10, 1, None, None)  # M > 32
+    assert ei.value.status == _lib.WSC_ERR_INVALID
+    crf.close()
+    with pytest.raises(_lib.WscError):
+        _lib.cam_postprocess(ctx, ctx.alloc(4 * 21 * 21 * 4), 1, 4, 21, 21, [(10, 10)], [[7]])  # key out of range

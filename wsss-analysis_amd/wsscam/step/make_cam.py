@@ -116,6 +116,8 @@ def run(args):
         mod = "wsscam." + mod  # the reference passes 'net.resnet50_cam'
     model = getattr(importlib.import_module(mod), "CAM")(args.model_dir, args.dataset, args.tag,
                                                          args.num_classes, args.use_cls)
+    if getattr(args, "cam_precision", None) is not None:  # optional: _lib.PREC_F16 (default) / BF16 / BF16X3
+        model.precision = args.cam_precision
     if getattr(args, "state_dict", None) is not None:
         model.load_state_dict(args.state_dict, strict=True)
     else:
