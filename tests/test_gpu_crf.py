@@ -82,6 +82,36 @@ def test_crf_invariants(ctx):
     assert np.array_equal(qb, qb2)
 
 
+def test_crf_shared_gaussian_lattice_cache():
+    """The Gaussian lattice is built once per (H, W, sxy) and ctx and shared by every image of a batch:
+    a ctx that has served other sizes / widths / batch sizes gives bit-identical results to a fresh one."""
+    rng = np.random.default_rng(21)
+    M = 4
+    small = [helpers.synth_crf_case(rng, 33, 47, M) for _ in range(3)]
+    other = [helpers.synth_crf_case(rng, 47, 33, M) for _ in range(2)]
+    cfg_a, cfg_b = (1.5, 3, 40, 13, 10, 3), (3, 3, 50, 5, 10, 3)
+
+    def run(c, cases, cfg):
+        return _gpu_crf(c, [k[0] for k in cases], [k[1] for k in cases], cfg)
+
+    fresh = {}
+    for name, cases, cfg in (("a3", small, cfg_a), ("b3", small, cfg_b), ("a1", small[1:2], cfg_a),
+                             ("o2", other, cfg_a)):
+        c = _lib.Context(0)
+        fresh[name] = run(c, cases, cfg)
+        c.close()
+    c = _lib.Context(0)
+    for name, cases, cfg in (("a3", small, cfg_a), ("o2", other, cfg_a), ("b3", small, cfg_b),
+                             ("a1", small[1:2], cfg_a), ("a3", small, cfg_a), ("o2", other, cfg_a)):
+        q, a, vg, vb = run(c, cases, cfg)
+        assert np.array_equal(q, fresh[name][0]) and np.array_equal(a, fresh[name][1]), name
+        assert list(vg) == list(fresh[name][2]) and list(vb) == list(fresh[name][3])
+        assert len(set(vg)) == 1  # position-only lattice: same vertex count for every image
+    c.close()
+    qr, ar, ls = helpers.crf_oracle(small[2][0], small[2][1], cfg_a)
+    assert fresh["a3"][2][2] == ls[0] and np.abs(fresh["a3"][0][2] - qr).max() <= 1e-3
+
+
 def test_crf_flat_image_long_rows(ctx):
     """A constant image puts thousands of pixels on one bilateral vertex (long splat rows)."""
     H, W, M = 96, 96, 3

@@ -209,6 +209,7 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto &a : ctx->attachments) a.second(a.first);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->zero_page) (void)hipFree(ctx->zero_page);
     for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);

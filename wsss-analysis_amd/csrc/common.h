@@ -149,6 +149,9 @@ struct wsc_ctx {
     // previous user) instead of going through hipFree/hipMalloc (both synchronise the device).
     std::multimap<size_t, void *> free_blocks;
     std::unordered_map<void *, size_t> live_blocks;
+    // host-side objects owned by the ctx (crf.hip keeps its per-image-size Gaussian lattices here);
+    // their device arrays are cached-alloc blocks, released with everything else at destroy
+    std::vector<std::pair<void *, void (*)(void *)>> attachments;
 };
 int wsc_ctx_workspace(wsc_ctx *ctx, size_t bytes, void **out);
 // Brackets the launches enqueued during its lifetime with a pair of HIP events on the ctx stream

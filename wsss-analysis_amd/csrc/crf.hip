@@ -36,7 +36,12 @@ constexpr unsigned long long EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
 
 struct LatticeDev {
     int d = 0;
-    int rows = 0;               // total rows incl. the zero row (Vtot + 1)
+    // rep > 1: the index arrays below describe ONE image and are shared by `rep` images whose value
+    // rows / pixels are laid out back to back (replica k uses rows [k*rows, (k+1)*rows) and pixels
+    // [k*n_pix, (k+1)*n_pix)).  The Gaussian lattice depends on (H, W, sxy) only, so the whole batch
+    // shares one copy; the bilateral lattice is per image content (rep = 1, arrays cover the batch).
+    int rep = 1;
+    int rows = 0;               // rows of one replica incl. its zero row (V + 1)
     int32_t *offset = nullptr;  // [B*N*(d+1)]
     float *bary = nullptr;      // [B*N*(d+1)]
     float *norm = nullptr;      // [B*N]
@@ -51,7 +56,7 @@ struct LatticeDev {
     int4 *chunk_desc = nullptr;    // [n_chunks] {first entry, entry count, row, 1 if the row's only chunk}
     int32_t *long_rows = nullptr;  // [n_long] rows with more than one chunk
     int n_chunks = 0, n_long = 0;
-    long long n_pix = 0; // B*N
+    long long n_pix = 0; // pixels of one replica (B*N when rep == 1)
     int M_cur = 0;       // class count of the inference in flight (algorithmic byte accounting)
     float alpha = 0.f;
     std::vector<int32_t> v_per_image;
@@ -66,6 +71,7 @@ struct wsc_crf {
     // per pixel, 20 dwords = five 16-byte loads: offG[3] offB[6] baryG[3] baryB[6] normG normB
     uint4 *pix_rec = nullptr;
     std::vector<void *> allocs;
+    bool persist = false; // allocations made while set belong to the ctx (cached Gaussian lattice)
 };
 
 namespace {
@@ -163,6 +169,21 @@ __device__ __forceinline__ void xcd_range(long long total, long long &begin, lon
     const long long per = (total + nb - 1) / nb;
     begin = lb * per;
     end = begin + per < total ? begin + per : total;
+}
+
+// Replicated form: the grid is `rep` equal groups of blocks (gridDim.x % rep == 0); group k works on
+// replica k's [0, n_local) items.  The replica is uniform over the block, so its pointer offsets are
+// scalar and the loop bodies are the same as in the unreplicated case (rep = 1 reduces to xcd_range).
+__device__ __forceinline__ void xcd_range_rep(long long n_local, int rep, int &k, long long &begin, long long &end) {
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nb >> 3, r = nb & 7;
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int bpr = nb / rep;
+    k = lb / bpr;
+    const int j = lb - k * bpr;
+    const long long per = (n_local + bpr - 1) / bpr;
+    begin = (long long)j * per;
+    end = begin + per < n_local ? begin + per : n_local;
 }
 
 struct EmbedArgs {
@@ -541,16 +562,21 @@ __global__ __launch_bounds__(256) void splat_ones_kernel(const unsigned *__restr
 // LP lanes per chunk, floor(64/LP) chunks per wave.
 __global__ __launch_bounds__(256) void splat4_kernel(const int4 *__restrict__ chunk_desc,
                                                      const uint2 *__restrict__ csr_ent,
-                                                     const float *__restrict__ q, int LP, int n_chunks,
+                                                     const float *__restrict__ q, int LP, int n_local,
+                                                     int rep, unsigned pix_stride, unsigned row_stride,
                                                      float *__restrict__ val, long long *__restrict__ part) {
+    // n_local chunks per replica; replica k reads pixels + k*pix_stride and writes rows + k*row_stride
     const int gpw = 64 / LP;
     const int lane = threadIdx.x & 63;
     const int g = lane / LP;
     const int l = lane - g * LP;
     if (g >= gpw) return;
-    const f32x4_t *q4 = reinterpret_cast<const f32x4_t *>(q);
     long long cbeg, cend;
-    xcd_range(n_chunks, cbeg, cend);
+    int rk;
+    xcd_range_rep(n_local, rep, rk, cbeg, cend);
+    const f32x4_t *q4 = reinterpret_cast<const f32x4_t *>(q) + (size_t)rk * pix_stride * LP;
+    val += (size_t)rk * row_stride * LP * 4;
+    part += (size_t)rk * n_local * LP * 4;
     // two chunks per lane group per trip: descriptor -> entries -> Q rows is a chain of three dependent
     // memory latencies, so the only way to keep the memory system busy is more independent chains
     constexpr int CU_ = 4;
@@ -609,18 +635,21 @@ __global__ __launch_bounds__(256) void splat4_kernel(const int4 *__restrict__ ch
 // sums the int64 partials of multi-chunk rows; Mp = values per row (1 for the ones pass)
 __global__ __launch_bounds__(256) void splat_combine_kernel(const int32_t *__restrict__ long_rows, int n_long,
                                                             const int32_t *__restrict__ chunk_base,
-                                                            const long long *__restrict__ part, int Mp,
+                                                            const long long *__restrict__ part, int Mp, int rep,
+                                                            int chunk_stride, int row_stride,
                                                             float *__restrict__ val) {
-    const long long total = (long long)n_long * Mp;
+    const long long total = (long long)n_long * rep * Mp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int li = (int)(i / Mp);
-        const int m = (int)(i - (long long)li * Mp);
-        const int row = long_rows[li];
+        const int gi = (int)(i / Mp);
+        const int m = (int)(i - (long long)gi * Mp);
+        const int k = gi / n_long; // replica
+        const int row = long_rows[gi - k * n_long];
         const int cb = chunk_base[row], ce = chunk_base[row + 1];
+        const long long pbase = (long long)k * chunk_stride;
         long long acc = 0;
-        for (int c = cb; c < ce; ++c) acc += part[(long long)c * Mp + m];
-        val[(long long)row * Mp + m] = (float)acc * FIX_INV;
+        for (int c = cb; c < ce; ++c) acc += part[(pbase + c) * Mp + m];
+        val[((long long)k * row_stride + row) * Mp + m] = (float)acc * FIX_INV;
     }
 }
 
@@ -660,14 +689,17 @@ __global__ __launch_bounds__(256) void blur1_kernel(const float *__restrict__ in
 // consecutive rows (one contiguous run of `in` / `out`), the two neighbour rows are gathered as
 // 16-byte loads.  Each block owns an XCD-contiguous range of rows.
 __global__ __launch_bounds__(256) void blur4_kernel(const f32x4_t *__restrict__ in, const int2 *__restrict__ nbr,
-                                                    int LP, int rows, f32x4_t *__restrict__ out) {
+                                                    int LP, int rows_local, int rep, f32x4_t *__restrict__ out) {
     const int rpb = 256 / LP;
     const int tr = threadIdx.x / LP;
     const int l = threadIdx.x - tr * LP;
     if (tr >= rpb) return;
     constexpr int U = 4;
     long long rbeg, rend;
-    xcd_range(rows, rbeg, rend);
+    int rk; // replica k: rows [k*rows_local, (k+1)*rows_local) of in / out, shared neighbour table
+    xcd_range_rep(rows_local, rep, rk, rbeg, rend);
+    in += (size_t)rk * rows_local * LP;
+    out += (size_t)rk * rows_local * LP;
     for (long long row0 = rbeg + tr; row0 < rend; row0 += U * rpb) {
         int2 nb[U];
         f32x4_t c[U], a[U], b[U];
@@ -722,15 +754,16 @@ __global__ void pack_entries_kernel(const int32_t *__restrict__ csr_pix, const f
 __global__ void pack_pixels_kernel(const int32_t *__restrict__ off_g, const float *__restrict__ bary_g,
                                    const float *__restrict__ norm_g, const int32_t *__restrict__ off_b,
                                    const float *__restrict__ bary_b, const float *__restrict__ norm_b, long long npix,
-                                   uint32_t *__restrict__ rec) {
+                                   long long g_pix, uint32_t *__restrict__ rec) {
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
          p += (long long)gridDim.x * blockDim.x) {
         uint32_t *r = rec + p * 20;
-        for (int i = 0; i < 3; ++i) r[i] = (uint32_t)off_g[p * 3 + i];
+        const long long pg = p % g_pix; // the Gaussian lattice arrays describe one image
+        for (int i = 0; i < 3; ++i) r[i] = (uint32_t)off_g[pg * 3 + i];
         for (int i = 0; i < 6; ++i) r[3 + i] = (uint32_t)off_b[p * 6 + i];
-        for (int i = 0; i < 3; ++i) r[9 + i] = __float_as_uint(bary_g[p * 3 + i]);
+        for (int i = 0; i < 3; ++i) r[9 + i] = __float_as_uint(bary_g[pg * 3 + i]);
         for (int i = 0; i < 6; ++i) r[12 + i] = __float_as_uint(bary_b[p * 6 + i]);
-        r[18] = __float_as_uint(norm_g[p]);
+        r[18] = __float_as_uint(norm_g[pg]);
         r[19] = __float_as_uint(norm_b[p]);
     }
 }
@@ -743,6 +776,7 @@ struct UpdateArgs {
     float alpha_g, alpha_b, compat_g, compat_b;
     int M, LP;
     long long npix;
+    unsigned g_pix, g_rows; // shared Gaussian lattice: pixels / rows per replica (g_rows = 0: not shared)
 };
 
 // Slice both lattices, add the unary, softmax over classes (DenseCRF::inference loop body):
@@ -785,8 +819,9 @@ __global__ __launch_bounds__(256) void slice_update_kernel(UpdateArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long p = ok[u] ? pp[u] : pbeg;
+            const unsigned gofs = a.g_rows ? ((unsigned)p / a.g_pix) * a.g_rows : 0u;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) vg[u][r] = vg4[rc[u][r] * (unsigned)LP + l];
+            for (int r = 0; r < 3; ++r) vg[u][r] = vg4[(rc[u][r] + gofs) * (unsigned)LP + l];
 #pragma unroll
             for (int r = 0; r < 6; ++r) vb[u][r] = vb4[rc[u][3 + r] * (unsigned)LP + l];
             un[u] = u4[p * LP + l];
@@ -916,10 +951,16 @@ inline int grid1d(long long total, int per_block = 256, int cap = 256 * 32) {
     return (int)g;
 }
 
+// grid of the replicated kernels: a multiple of rep (xcd_range_rep), at most 256*64 blocks
+inline int grid_rep(long long total, int per_block, int rep) {
+    const int g = grid1d(total, per_block, 256 * 64);
+    return g <= rep ? rep : g / rep * rep;
+}
+
 int crf_alloc(wsc_crf *crf, size_t bytes, void **out) {
     void *p = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(crf->ctx, bytes, &p));
-    crf->allocs.push_back(p);
+    if (!crf->persist) crf->allocs.push_back(p);
     *out = p;
     return WSC_OK;
 }
@@ -946,20 +987,22 @@ void splat_ones(wsc_ctx *ctx, const LatticeDev &L, float *val, long long *part) 
                        (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_w, L.n_chunks, val, part);
     if (L.n_long > 0)
         hipLaunchKernelGGL(splat_combine_kernel, dim3(grid1d(L.n_long, 256, 4096)), dim3(256), 0, ctx->stream,
-                           L.long_rows, L.n_long, L.chunk_base, part, 1, val);
+                           L.long_rows, L.n_long, L.chunk_base, part, 1, 1, 0, 0, val);
 }
 
 // part: scratch of n_chunks * Mp int64 (partials of multi-chunk rows)
 void splat4(wsc_ctx *ctx, const LatticeDev &L, const float *q, int LP, float *val, long long *part) {
     const int gpw = 64 / LP;
     // algorithmic bytes: read the batch's Q once + (pixel index, weight) per gathered pixel + write the rows
-    WscKernelTimer timer(ctx, WSC_K_SPLAT, (double)L.n_pix * L.M_cur * 4 + (double)L.n_pix * (L.d + 1) * 8 +
-                                              (double)L.rows * L.M_cur * 4);
-    hipLaunchKernelGGL(splat4_kernel, dim3(grid1d(L.n_chunks, 16 * gpw, 256 * 64)), dim3(256), 0, ctx->stream,
-                       L.chunk_desc, L.csr_ent, q, LP, L.n_chunks, val, part);
+    const double npix = (double)L.n_pix * L.rep, rows = (double)L.rows * L.rep;
+    WscKernelTimer timer(ctx, WSC_K_SPLAT, npix * L.M_cur * 4 + npix * (L.d + 1) * 8 + rows * L.M_cur * 4);
+    hipLaunchKernelGGL(splat4_kernel, dim3(grid_rep((long long)L.n_chunks * L.rep, 16 * gpw, L.rep)), dim3(256), 0,
+                       ctx->stream, L.chunk_desc, L.csr_ent, q, LP, L.n_chunks, L.rep, (unsigned)L.n_pix,
+                       (unsigned)L.rows, val, part);
     if (L.n_long > 0)
-        hipLaunchKernelGGL(splat_combine_kernel, dim3(grid1d((long long)L.n_long * 4 * LP, 256, 4096)), dim3(256), 0,
-                           ctx->stream, L.long_rows, L.n_long, L.chunk_base, part, 4 * LP, val);
+        hipLaunchKernelGGL(splat_combine_kernel, dim3(grid1d((long long)L.n_long * L.rep * 4 * LP, 256, 4096)),
+                           dim3(256), 0, ctx->stream, L.long_rows, L.n_long, L.chunk_base, part, 4 * LP, L.rep,
+                           L.n_chunks, L.rows, val);
 }
 
 // d+1 blur passes, ping-pong between a and b; returns the buffer holding the result
@@ -973,18 +1016,21 @@ float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
 }
 float *blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, float *a, float *b) {
     for (int j = 0; j <= L.d; ++j) {
-        WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.M_cur * 4); // read + write every row once
-        hipLaunchKernelGGL(blur4_kernel, dim3(grid1d(L.rows, (256 / LP) * 4, 256 * 64)), dim3(256), 0, ctx->stream,
-                           (const f32x4_t *)a, L.nbr + (long long)j * L.rows, LP, L.rows, (f32x4_t *)b);
+        WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.rep * L.M_cur * 4); // read + write every row once
+        hipLaunchKernelGGL(blur4_kernel, dim3(grid_rep((long long)L.rows * L.rep, (256 / LP) * 4, L.rep)), dim3(256),
+                           0, ctx->stream, (const f32x4_t *)a, L.nbr + (long long)j * L.rows, LP, L.rows, L.rep,
+                           (f32x4_t *)b);
         float *t = a; a = b; b = t;
     }
     return a;
 }
 
 template <int D>
-int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy, float srgb) {
+int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy, float srgb, bool shared) {
     wsc_ctx *ctx = crf->ctx;
-    const int B = crf->B, N = crf->N, dp1 = D + 1;
+    // shared: build the lattice of ONE image and let all crf->B images use it (position-only features)
+    const int B = shared ? 1 : crf->B, N = crf->N, dp1 = D + 1;
+    L.rep = shared ? crf->B : 1;
     const long long npix = (long long)B * N;
     const long long total = npix * dp1;
     WSC_CHECK(total < (1ll << 31), WSC_ERR_CAPACITY, "CRF batch too large: %lld lattice entries", total);
@@ -1050,8 +1096,11 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
               "CRF lattice coordinate outside the packed-key range (sxy=%g srgb=%g too small for this image size)",
               (double)sxy, (double)srgb);
     L.rows = (int)vtot + 1;
-    L.v_per_image.resize(B);
-    for (int b = 0; b < B; ++b) L.v_per_image[b] = (int)((b + 1 < B ? bound[b + 1] : vtot) - bound[b]);
+    L.v_per_image.resize(crf->B);
+    if (shared)
+        for (int b = 0; b < crf->B; ++b) L.v_per_image[b] = (int)vtot;
+    else
+        for (int b = 0; b < B; ++b) L.v_per_image[b] = (int)((b + 1 < B ? bound[b + 1] : vtot) - bound[b]);
 
     WSC_TRY(tmp.alloc(sizeof(unsigned long long) * L.rows, (void **)&rowkey));
     WSC_TRY(tmp.alloc(sizeof(int32_t) * L.rows, (void **)&rowimg));
@@ -1122,6 +1171,14 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     return WSC_OK;
 }
 
+struct GaussCache {
+    int H, W;
+    float sxy;
+    LatticeDev L;
+};
+constexpr int GAUSS_CACHE_MAX = 16; // distinct image sizes kept per ctx; later sizes are rebuilt per call
+void gauss_cache_delete(void *p) { delete static_cast<GaussCache *>(p); }
+
 void launch_update(wsc_ctx *ctx, const UpdateArgs &a) {
     const int gpw = 64 / a.LP;
     // algorithmic bytes: slice index+weight of both lattices, read U, write Q (+ the two
@@ -1144,14 +1201,39 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
     wsc_crf *crf = new wsc_crf();
     crf->ctx = ctx; crf->B = B; crf->H = H; crf->W = W; crf->N = H * W;
     WscKernelTimer timer(ctx, WSC_K_CRF_BUILD, (double)B * H * W * (3.0 * 16 + 6.0 * 16));
-    int st = build_lattice<2>(crf, crf->lat[0], rgb_dev, g_sxy, 1.f);
-    if (st == WSC_OK) st = build_lattice<5>(crf, crf->lat[1], rgb_dev, bi_sxy, bi_srgb);
+    // The Gaussian lattice is a function of (H, W, sxy) alone: one copy per ctx serves every batch of
+    // that image size (the reference rebuilds it per image, addPairwiseGaussian in dcrf_process /
+    // crf_inference_label, and gets the same table every time).
+    int st = WSC_OK;
+    GaussCache *hit = nullptr;
+    int n_cached = 0;
+    for (auto &a : ctx->attachments)
+        if (a.second == &gauss_cache_delete) {
+            ++n_cached;
+            GaussCache *g = static_cast<GaussCache *>(a.first);
+            if (g->H == H && g->W == W && g->sxy == g_sxy) hit = g;
+        }
+    if (hit) {
+        crf->lat[0] = hit->L;
+    } else {
+        crf->persist = n_cached < GAUSS_CACHE_MAX;
+        st = build_lattice<2>(crf, crf->lat[0], rgb_dev, g_sxy, 1.f, true);
+        if (st == WSC_OK && crf->persist) {
+            GaussCache *g = new GaussCache{H, W, g_sxy, crf->lat[0]};
+            ctx->attachments.emplace_back(g, &gauss_cache_delete);
+        }
+        // on failure the partially built arrays stay with the ctx and are released at wsc_ctx_destroy
+        crf->persist = false;
+    }
+    crf->lat[0].rep = B;
+    crf->lat[0].v_per_image.assign(B, crf->lat[0].rows - 1);
+    if (st == WSC_OK) st = build_lattice<5>(crf, crf->lat[1], rgb_dev, bi_sxy, bi_srgb, false);
     if (st == WSC_OK) st = crf_alloc(crf, sizeof(uint4) * 5 * (size_t)B * crf->N, (void **)&crf->pix_rec);
     if (st == WSC_OK) {
         const long long npix = (long long)B * crf->N;
         hipLaunchKernelGGL(pack_pixels_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, crf->lat[0].offset,
                            crf->lat[0].bary, crf->lat[0].norm, crf->lat[1].offset, crf->lat[1].bary, crf->lat[1].norm,
-                           npix, (uint32_t *)crf->pix_rec);
+                           npix, (long long)crf->lat[0].n_pix, (uint32_t *)crf->pix_rec);
     }
     if (st != WSC_OK) {
         wsc_crf_destroy(crf);
@@ -1186,12 +1268,13 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     const long long npix = (long long)B * N;
     const LatticeDev &G = crf->lat[0], &Bl = crf->lat[1];
     const int LP = (M + 3) / 4, Mp = 4 * LP; // rows padded to 16-byte multiples
-    WSC_CHECK(npix * Mp < (1ll << 31) && (long long)G.rows * Mp < (1ll << 31) && (long long)Bl.rows * Mp < (1ll << 31),
+    const long long g_rows = (long long)G.rows * G.rep, g_chunks = (long long)G.n_chunks * G.rep;
+    WSC_CHECK(npix * Mp < (1ll << 31) && g_rows * Mp < (1ll << 31) && (long long)Bl.rows * Mp < (1ll << 31),
               WSC_ERR_CAPACITY, "CRF batch too large for 32-bit element indices (B*N*Mp = %lld)", npix * Mp);
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t qb = al(sizeof(float) * npix * Mp);
-    const size_t vg = al(sizeof(float) * (size_t)G.rows * Mp), vb = al(sizeof(float) * (size_t)Bl.rows * Mp);
-    const size_t pg = al(sizeof(long long) * (size_t)G.n_chunks * Mp), pb = al(sizeof(long long) * (size_t)Bl.n_chunks * Mp);
+    const size_t vg = al(sizeof(float) * (size_t)g_rows * Mp), vb = al(sizeof(float) * (size_t)Bl.rows * Mp);
+    const size_t pg = al(sizeof(long long) * (size_t)g_chunks * Mp), pb = al(sizeof(long long) * (size_t)Bl.n_chunks * Mp);
     void *ws;
     WSC_TRY(wsc_ctx_workspace(ctx, 2 * qb + 2 * vg + 2 * vb + pg + pb, &ws));
     char *p = (char *)ws;
@@ -1222,6 +1305,7 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
         a.u = u; a.q = q;
         a.alpha_g = G.alpha; a.alpha_b = Bl.alpha; a.compat_g = g_compat; a.compat_b = bi_compat;
         a.M = M; a.LP = LP; a.npix = npix;
+        a.g_pix = (unsigned)G.n_pix; a.g_rows = G.rep > 1 ? (unsigned)G.rows : 0u;
         launch_update(ctx, a);
     }
     WscKernelTimer ftimer(ctx, WSC_K_CRF_MISC, (double)npix * M * 8);
