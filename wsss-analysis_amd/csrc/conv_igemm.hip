@@ -75,6 +75,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     constexpr int B_BYTES = BN * BK * 2;
     constexpr int CT_STRIDE = BN + 4;
     static_assert(GLDS || (BM == 128 && STAGES == 2), "register staging exists for the 128-row tile only");
+    static_assert(STAGES >= 1 && STAGES <= 3, "1 (single K-step layers), 2 or 3 LDS buffers");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -385,28 +386,43 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
         b2[j] = (cok && post) ? p.b2[c + j] : 0.f;
     }
 
+    // fp32 transpose through LDS.  Multi-K-step variants move the whole BM x BN tile at once (one barrier).
+    // The single-buffer variant (one-K-step layers: 1x1 convs with 64 input channels, bound by bytes in
+    // flight, not by MFMA) moves it 64 rows at a time so that a block needs 34 KB of LDS instead of 68 KB
+    // and a third block fits the CU: layer1.conv3 of the ResNet50 stack went from 190-205 us to 128 us.
+    // (Splitting everywhere costs more than it gains: stem 179 -> 219 us, layer2.0.conv1 88 -> 105 us.)
     float *ct = reinterpret_cast<float *>(smem);
+    constexpr int NHALF = STAGES == 1 ? BM / 64 : 1;
+    constexpr int GR = BM / NHALF;     // tile rows per group
+    constexpr int PPH = NPASS / NHALF; // passes per group
+    static_assert(NPASS % NHALF == 0 && PPH * RPP == GR, "epilogue pass layout");
+    const int grp = (wm * 64) / GR, roff = wm * 64 - grp * GR;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int half = 0; half < NHALF; ++half) {
+        if (half > 0) __syncthreads(); // the previous group's reads are done
+        if (grp == half) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
-                const int col = wn * WN + ni * 32 + l31;
-                ct[row * CT_STRIDE + col] = acc[mi][ni][r];
-            }
-    __syncthreads();
-
-    if (cok) {
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int row = pass * RPP + r0;
-            const int m = m0 + row;
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = roff + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+                        const int col = wn * WN + ni * 32 + l31;
+                        ct[row * CT_STRIDE + col] = acc[mi][ni][r];
+                    }
+        }
+        __syncthreads();
+        if (!cok) continue;
+#pragma unroll
+        for (int pp = 0; pp < PPH; ++pp) {
+            const int pass = half * PPH + pp;
+            const int lrow_e = pp * RPP + r0; // row inside the group
+            const int m = m0 + half * GR + lrow_e;
             if (m < p.M) {
                 float v[8];
-                const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(ct + row * CT_STRIDE + c8 * 8);
-                const f32x4_t q1 = *reinterpret_cast<const f32x4_t *>(ct + row * CT_STRIDE + c8 * 8 + 4);
+                const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(ct + lrow_e * CT_STRIDE + c8 * 8);
+                const f32x4_t q1 = *reinterpret_cast<const f32x4_t *>(ct + lrow_e * CT_STRIDE + c8 * 8 + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     v[j] = q0[j];
@@ -468,13 +484,12 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     }
 }
 
-template <int BM, int BN, int MODE, bool SPLIT, int ET>
-int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
+template <int BM, int BN, int MODE, bool SPLIT, int ET, int STAGES>
+int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     constexpr bool GLDS = MODE == 0; // LDS-DMA staging for every generic layer; small-Cin layers stage via registers
-    constexpr int STAGES = BM == 256 ? 3 : 2;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int PIPE = STAGES * (A_BYTES + B_BYTES);
-    constexpr int EPI = BM * (BN + 4) * 4;
+    constexpr int EPI = (STAGES == 1 ? 64 : BM) * (BN + 4) * 4; // fp32 transpose (64-row groups in the single-buffer variant)
     constexpr int LDS = PIPE > EPI ? PIPE : EPI;
     static bool attr_set = false;
     auto kern = conv_igemm_kernel<BM, BN, MODE, SPLIT, ET, GLDS, STAGES>;
@@ -489,6 +504,19 @@ int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
     hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(BM * 2), LDS, ctx->stream, a);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
+}
+
+template <int BM, int BN, int MODE, bool SPLIT, int ET>
+int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
+    if constexpr (BM == 256) {
+        return launch_stages<BM, BN, MODE, SPLIT, ET, 3>(ctx, a);
+    } else if constexpr (MODE == 0) {
+        // a one-K-step layer (1x1 conv, 64 input channels) needs one LDS buffer: 34 KB per block, 4 blocks per CU
+        if (a.nk == 1) return launch_stages<BM, BN, MODE, SPLIT, ET, 1>(ctx, a);
+        return launch_stages<BM, BN, MODE, SPLIT, ET, 2>(ctx, a);
+    } else {
+        return launch_stages<BM, BN, MODE, SPLIT, ET, 2>(ctx, a);
+    }
 }
 
 template <int BN>
@@ -554,7 +582,9 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     // tile choice.  Measured on the ResNet50-CAM stack (64 samples @321^2, f16): 128-row tiles 4.31 ms,
     // 256-row 3-stage tiles on the K >= 512 layers 4.37 ms, everywhere 4.45 ms -- the stack is bound by
     // per-block memory latency with 1-2 blocks per CU (an ablation without DMA and without MFMAs still
-    // takes 2.2 ms), not by L2->LDS bytes per FLOP, so the 128-row tile stays the default.
+    // takes 2.2 ms), not by L2->LDS bytes per FLOP, so the 128-row tile stays the default.  128x64 tiles
+    // (3 blocks per CU) on the K <= 128 / 256 / 512 layers were also measured: no layer gained, layer1.conv3
+    // lost 10 %.
     // WSC_CONV_TILE=256 selects the 256-row tile wherever it applies, =-1 where K >= 512 (A/B runs).
     static const int force = [] { const char *e = getenv("WSC_CONV_TILE"); return e ? atoi(e) : 0; }();
     const long long blocks256 = ((a.M + 255) / 256) * (long long)a.ntiles_n;
