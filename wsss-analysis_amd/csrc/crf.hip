@@ -532,6 +532,7 @@ __global__ void neighbors_kernel(const unsigned long long *__restrict__ rowkey, 
 // splat_combine_kernel adds up.
 // ONES: splat of the all-ones vector (M = 1) for the normalisation pass.
 constexpr int SPLAT_CHUNK = 64;
+constexpr int SPLAT_CU = 1; // chunks per lane group per trip of splat4_kernel
 constexpr float FIX_SCALE = 268435456.0f;        // 2^28
 constexpr float FIX_INV = 1.0f / 268435456.0f;   // 2^-28 (exact)
 
@@ -577,9 +578,13 @@ __global__ __launch_bounds__(256) void splat4_kernel(const int4 *__restrict__ ch
     const f32x4_t *q4 = reinterpret_cast<const f32x4_t *>(q) + (size_t)rk * pix_stride * LP;
     val += (size_t)rk * row_stride * LP * 4;
     part += (size_t)rk * n_local * LP * 4;
-    // two chunks per lane group per trip: descriptor -> entries -> Q rows is a chain of three dependent
-    // memory latencies, so the only way to keep the memory system busy is more independent chains
-    constexpr int CU_ = 4;
+    // descriptor -> entries -> Q rows is a chain of three dependent memory latencies; it is hidden by
+    // occupancy, not by per-wave parallelism: one chunk per lane group per trip keeps the kernel at 63
+    // VGPRs = 8 waves per SIMD.  Measured splat + combine per iteration (G + B, 32 images, M = 21):
+    // 1 chunk 273 us, 2 chunks 278 us, 3 chunks 289 us, 4 chunks (161 VGPRs, 3 waves) 296 us.  16 entries
+    // per batch (288 us) and 32-bit accumulators at 2^-23 (272 us) change nothing: the kernel is bound by
+    // the gather path (L1/L2 requests), neither by VALU nor by exposed latency.
+    constexpr int CU_ = SPLAT_CU;
     for (long long c0 = cbeg + (threadIdx.x >> 6) * gpw * CU_ + g; c0 < cend; c0 += 4 * gpw * CU_) {
         int4 d[CU_];
 #pragma unroll
@@ -996,7 +1001,7 @@ void splat4(wsc_ctx *ctx, const LatticeDev &L, const float *q, int LP, float *va
     // algorithmic bytes: read the batch's Q once + (pixel index, weight) per gathered pixel + write the rows
     const double npix = (double)L.n_pix * L.rep, rows = (double)L.rows * L.rep;
     WscKernelTimer timer(ctx, WSC_K_SPLAT, npix * L.M_cur * 4 + npix * (L.d + 1) * 8 + rows * L.M_cur * 4);
-    hipLaunchKernelGGL(splat4_kernel, dim3(grid_rep((long long)L.n_chunks * L.rep, 16 * gpw, L.rep)), dim3(256), 0,
+    hipLaunchKernelGGL(splat4_kernel, dim3(grid_rep((long long)L.n_chunks * L.rep, 4 * SPLAT_CU * gpw, L.rep)), dim3(256), 0,
                        ctx->stream, L.chunk_desc, L.csr_ent, q, LP, L.n_chunks, L.rep, (unsigned)L.n_pix,
                        (unsigned)L.rows, val, part);
     if (L.n_long > 0)
