@@ -390,6 +390,18 @@ def main():
                     "unit": "GB/s", "traffic": None}
     roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
     roofline["kernel"] = dom
+    roofline["algorithmic_bytes_per_launch" if roofline["bound"] == "hbm" else "flop_per_launch"] = round(work / calls)
+    # HBM bytes per launch of that kernel class from the committed PMC passes (profiles/collect.sh ->
+    # profiles/hbm_traffic.json; FETCH_SIZE / WRITE_SIZE cannot be read from inside the process).  Only the
+    # default workload is profiled there; anything else reports null.
+    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    default_wl = (args.workload == "cam_crf" and args.arch == "resnet50" and args.batch == 32 and args.precision == "f16")
+    if default_wl and os.path.exists(tj):
+        with open(tj) as fh:
+            cls = json.load(fh).get("classes", {}).get(dom)
+        if cls:
+            roofline["traffic"] = cls["bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
     roofline["avg_launch_us"] = round(ms / calls * 1e3, 2)
     roofline["launches_per_step"] = calls // 2
     stages["kernels"] = kernels

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects every round artifact under profiles/ in ONE gpurun call:
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r01'
+# Outputs land in gpurun_out/<tag>_* (merged back by gpurun); copy the ones to keep into profiles/.
+tag=${1:-rXX}
+out=gpurun_out
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/${tag}_pytest_gpu.txt
+timeout 300 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+timeout 300 python bench.py --no-cpu-baseline --no-pipeline > $out/${tag}_bench_nopipeline.json 2>> $out/${tag}_bench.err
+rm -rf $out/prof_stats $out/pmc_f $out/pmc_w
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline > $out/${tag}_prof_stats.log 2>&1
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline"; python profiles/summarize_rocpd.py $out/prof_stats/*/*_results.db; } > $out/${tag}_kernel_stats_bench.txt 2>&1
+{ echo "# one ResNet50-CAM forward (64 samples @321^2, f16) out of the same trace"; python profiles/conv_layer_table.py $out/prof_stats/*/*_results.db; } > $out/${tag}_conv_layers.txt 2>&1
+RX='splat4_kernel|splat_combine|slice_update|blur4_kernel|conv_igemm'
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$RX" -d $out/pmc_f -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > $out/${tag}_pmc_f.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$RX" -d $out/pmc_w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > $out/${tag}_pmc_w.log 2>&1
+{ echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-include-regex '$RX' -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline"
+  echo "# KiB per dispatch summed over the XCD instances; FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md, HBM section)"
+  python profiles/summarize_pmc.py $out/pmc_f/*/*_results.db $out/pmc_w/*/*_results.db; } > $out/${tag}_pmc_hbm_traffic.txt 2>&1
+python profiles/make_traffic_json.py $out/pmc_f/*/*_results.db $out/pmc_w/*/*_results.db > $out/${tag}_hbm_traffic.json 2>> $out/${tag}_bench.err
+ls -la $out | grep ${tag}_

@@ -1,0 +1,51 @@
+"""HBM traffic per launch of a kernel class from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+    python profiles/make_traffic_json.py <fetch_results.db> <write_results.db> > profiles/hbm_traffic.json
+
+Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KiB
+summed over the XCD instances of a dispatch, and FETCH_SIZE under-reports by 2x on gfx950 (doubled here).
+bench.py copies `classes[<roofline kernel>].bytes_per_launch` into `roofline.traffic`.
+"""
+import json
+import sqlite3
+import sys
+from collections import defaultdict
+
+CLASSES = {  # bench.py kernel-class label -> (kernel-name substrings, substring whose dispatches count as launches)
+    "splat4+combine": (("splat4_kernel", "splat_combine_kernel"), "splat4_kernel"),
+    "blur4_kernel": (("blur4_kernel",), "blur4_kernel"),
+    "slice_update_kernel": (("slice_update_kernel",), "slice_update_kernel"),
+}
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    tot = defaultdict(float)
+    disp = defaultdict(set)
+    for name, d, cn, cv in c.execute("select name, dispatch_id, counter_name, counter_value from pmc_events"):
+        if cn == counter:
+            tot[name] += cv
+            disp[name].add(d)
+    return tot, {k: len(v) for k, v in disp.items()}
+
+
+def main(fetch_db, write_db):
+    f, fd = per_kernel(fetch_db, "FETCH_SIZE")
+    w, wd = per_kernel(write_db, "WRITE_SIZE")
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 "
+                     "--no-cpu-baseline --no-pipeline; FETCH_SIZE doubled (gfx950 correction)", "classes": {}}
+    for label, (subs, launch_sub) in CLASSES.items():
+        fb = sum(v for k, v in f.items() if any(s in k for s in subs)) * 1024.0 * 2.0
+        wb = sum(v for k, v in w.items() if any(s in k for s in subs)) * 1024.0
+        nf = sum(v for k, v in fd.items() if launch_sub in k)
+        nw = sum(v for k, v in wd.items() if launch_sub in k)
+        if nf == 0 or nw == 0:
+            continue
+        out["classes"][label] = {"read_bytes_per_launch": round(fb / nf), "write_bytes_per_launch": round(wb / nw),
+                                 "bytes_per_launch": round(fb / nf + wb / nw), "launches_profiled": nf}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

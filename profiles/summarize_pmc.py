@@ -23,7 +23,7 @@ def main(paths):
         for (name, disp), d in meta.items():
             dur[name].append(d)
     for name in sorted(agg, key=lambda n: -sum(dur[n])):
-        short = name.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         print("%s   dispatches=%d  avg_us(profiled)=%.1f" % (short, len(dur[name]), sum(dur[name]) / len(dur[name]) / 1e3))
         for cn in sorted(agg[name]):
             v = agg[name][cn]
