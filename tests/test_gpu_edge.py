@@ -146,3 +146,81 @@ def test_argument_errors(ctx):
     crf.close()
     with pytest.raises(_lib.WscError):
         _lib.cam_postprocess(ctx, ctx.alloc(4 * 21 * 21 * 4), 1, 4, 21, 21, [(10, 10)], [[7]])  # key out of range
+
+
+def _adp_like_image(rng, H, W):
+    """near-white background with pink/purple blobs: the expit(4 (mean - 240)) term is exercised."""
+    img = np.full((H, W, 3), 244.0) + rng.normal(0, 3, (H, W, 3))
+    yy, xx = np.mgrid[:H, :W]
+    for _ in range(4):
+        cy, cx, r = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(5, 14)
+        m = ((yy - cy) ** 2 + (xx - cx) ** 2) < r * r
+        img[m] = rng.uniform([150, 60, 130], [220, 130, 200])
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("dataset", ["adp_func", "adp_morph", "deepglobe"])
+def test_make_cam_run_adp_and_deepglobe(tmp_path, dataset):
+    """make_cam.run on the VGG16 networks of the other datasets: ADP joins host-synthesised background /
+    other channels with the use_cls CAM channels before the tail and always keeps them (make_cam.py:44-61,
+    vgg16_cam.py:51-58); DeepGlobe writes no high_res (make_cam.py:83-85)."""
+    import scipy.ndimage
+    import scipy.special
+
+    from wsscam.adp import dataloader as adp_dl
+
+    adp = dataset.startswith("adp")
+    C = 31 if adp else 6
+    sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, not adp, seed=3)  # ADP models have no BN
+    rng = np.random.default_rng(6)
+    S = 65
+    sizes = [(72, 72), (65, 65), (90, 70)]
+    norm = adp_dl.TorchvisionNormalize("int") if adp else None
+    data = []
+    for i, sz in enumerate(sizes):
+        img = _adp_like_image(rng, *sz) if adp else cnn_ref.synth_image(rng, *sz)
+        if adp:
+            x, orig = adp_dl.msf_item(img, (S, S), norm)
+            lab = np.zeros(28 if dataset == "adp_morph" else 3, np.float32)
+            lab[[i % len(lab), (3 * i + 1) % len(lab)]] = 1
+            data.append({"name": "%03d.png_crop_%d" % (i, i), "img": x, "orig_img": orig, "size": sz, "label": lab})
+        else:
+            lab = np.zeros(6, np.float32)
+            lab[[i, 5 - i]] = 1
+            data.append({"name": "%06d" % (1000 + i), "img": cnn_ref.msf_pack(img, (S, S)), "size": sz, "label": lab})
+    if dataset == "adp_morph":
+        use_cls, bg_names = list(range(28)), ["background"]
+    elif dataset == "adp_func":
+        use_cls, bg_names = [28, 29, 30], ["background", "other"]
+    else:
+        use_cls, bg_names = list(range(6)), []
+    args = types.SimpleNamespace(cam_network="net.vgg16_cam", model_dir=None, dataset=dataset, tag="", num_classes=C,
+                                 use_cls=use_cls, model_id="vgg16", cam_weights_name=None, state_dict=sd,
+                                 dataset_obj=data, split="train", cam_out_dir=str(tmp_path), n_gpus=1,
+                                 cam_batch_images=2, cam_precision=_lib.PREC_BF16X3,
+                                 class_names={"bg": bg_names, "fg": ["c%d" % i for i in range(len(use_cls))]})
+    make_cam.run(args)
+    for d in data:
+        rec = np.load(os.path.join(tmp_path, d["name"] + ".npy"), allow_pickle=True).item()
+        with torch.no_grad():
+            cam, _ = cnn_ref.vgg16_cam_forward(torch.from_numpy(d["img"]), sd, C)
+        cam = cam.numpy()
+        if adp:  # common_cam.py:31-92 restated on the oracle CAM
+            mean_img = d["orig_img"][0].astype(np.float32).mean(2)
+            bgm = scipy.ndimage.gaussian_filter(0.75 * scipy.special.expit(4 * (mean_img - 240)), sigma=2)
+            bgm = cnn_ref.resize_bilinear_f64(bgm[..., None], cam.shape[1:])[..., 0].astype(np.float32)
+            if dataset == "adp_morph":
+                cam = np.concatenate((np.maximum(bgm - cam[[18, 19, 20]].max(0), 0)[None], cam[use_cls]), 0)
+            else:
+                mod = np.concatenate(((bgm - cam[[28, 29, 30]].max(0))[None], cam[use_cls]), 0)
+                other = np.maximum(0.05 * (1 - mod.max(0)), cam[[18, 19, 20]].max(0))
+                cam = np.concatenate((mod[:1], other[None], mod[1:]), 0)
+        n_bg = len(bg_names)
+        keys = np.concatenate((np.arange(n_bg), np.nonzero(d["label"])[0] + n_bg)).astype(np.int64)
+        s, h = cnn_ref.make_cam_tail(torch.from_numpy(cam), d["size"], torch.from_numpy(keys))
+        assert list(rec) == (["keys", "cam"] if dataset == "deepglobe" else ["keys", "cam", "high_res"])
+        assert np.array_equal(rec["keys"], keys)
+        assert rec["cam"].shape == tuple(s.shape)
+        assert np.abs(rec["cam"] - s.numpy()).max() <= 5e-4, np.abs(rec["cam"] - s.numpy()).max()
+        if dataset != "deepglobe":
+            assert np.abs(rec["high_res"] - h.numpy()).max() <= 5e-4

@@ -1,0 +1,98 @@
+"""ADP (Atlas of Digital Pathology) MSF classification dataset -- input contract of make_cam for the
+`adp_morph` / `adp_func` datasets (03b_irn/adp/dataloader.py: CAT_LIST :14-18, get_img_path :39-44,
+load_img_name_list :46-50, TorchvisionNormalize :64-88, ADPClassificationDatasetMSF :201-240).
+
+Items are dicts {"name", "img": float32 (2,3,S,S) [orig, h-flip] normalised with the ADP constants,
+"orig_img": uint8 (2,H0,W0,3) [orig, h-flip] (what common_cam.modify_by_htt needs), "size", "label"}.
+PNG decode uses PIL (imageio is not in this image); the resize is voc12.dataloader.resize_bilinear_f64."""
+import os
+
+import numpy as np
+
+from ..voc12.dataloader import resize_bilinear_f64
+
+CAT_LIST = {
+    "morph": ["E.M.S", "E.M.U", "E.M.O", "E.T.S", "E.T.U", "E.T.O", "E.P", "C.D.I", "C.D.R", "C.L", "H.E", "H.K",
+              "H.Y", "S.M.C", "S.M.S", "S.E", "S.C.H", "S.R", "A.W", "A.B", "A.M", "M.M", "M.K", "N.P", "N.R.B",
+              "N.R.A", "N.G.M", "N.G.W"],
+    "func": ["G.O", "G.N", "T"],
+}
+
+
+def get_img_path(img_name, root, is_eval):
+    return os.path.join(root, "PNGImagesSubset" if is_eval else "PNGImages", img_name + ".png")
+
+
+def load_img_name_list(dataset_path):
+    """np.loadtxt(dtype=str, comments='%') of the reference: one name per line, '%' starts a comment."""
+    names = []
+    for line in open(dataset_path):
+        line = line.split("%", 1)[0].strip()
+        if line:
+            names.append(line)
+    return np.array(names)
+
+
+def load_image_label_list_from_npy(img_name_list, htt_type, cls_labels_path=None):
+    """adp/dataloader.py:33-37 reads 'adp/cls_labels_<htt>.npy' relative to the working directory."""
+    path = cls_labels_path or os.path.join("adp", "cls_labels_" + htt_type + ".npy")
+    cls = np.load(path, allow_pickle=True).item()
+    return np.array([cls[n] for n in img_name_list])
+
+
+class TorchvisionNormalize:
+    def __init__(self, norm_mode="int"):
+        self.norm_mode = norm_mode
+        if norm_mode == "int":
+            self.mean, self.std = (193.09203,) * 3, (56.450138,) * 3
+        elif norm_mode == "float":
+            self.mean, self.std = (0.757,) * 3, (0.221,) * 3
+        elif norm_mode is not None:
+            raise ValueError("norm_mode value is not 'int' or 'float'")
+
+    def __call__(self, img):
+        img = np.float32(img)
+        if self.norm_mode is None:
+            return img
+        proc = np.empty(img.shape, np.float32)
+        for c in range(3):
+            if self.norm_mode == "int":
+                proc[..., c] = (img[..., c] - self.mean[c]) / self.std[c]
+            else:
+                proc[..., c] = (img[..., c] / 255.0 - self.mean[c]) / self.std[c]
+        return proc
+
+
+def msf_item(img_u8, outsize, norm):
+    """(img (2,3,S,S) float32, orig_img (2,H0,W0,3) uint8) of one scale-1.0 image."""
+    x = resize_bilinear_f64(img_u8, outsize) if outsize is not None else np.asarray(img_u8, np.float64)
+    x = np.transpose(norm(x), (2, 0, 1))
+    return (np.stack([x, np.flip(x, -1)], axis=0).astype(np.float32),
+            np.stack([img_u8, np.flip(img_u8, -1)], axis=0))
+
+
+class ADPClassificationDatasetMSF:
+    def __init__(self, img_name_list_path, dev_root, htt_type, is_eval, norm_mode="float", outsize=None,
+                 scales=(1.0,), cls_labels_path=None):
+        assert norm_mode in ["float", "int"]
+        assert outsize in [(321, 321), (224, 224), None]
+        assert tuple(scales) == (1.0,), "multi-scale inference (pil_rescale) is not implemented"
+        self.img_name_list = load_img_name_list(img_name_list_path)
+        self.dev_root = dev_root
+        self.htt_type = htt_type
+        self.is_eval = is_eval
+        self.outsize = outsize
+        self.norm = TorchvisionNormalize(norm_mode)
+        self.label_list = load_image_label_list_from_npy(self.img_name_list, htt_type, cls_labels_path)
+
+    def __len__(self):
+        return len(self.img_name_list)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+
+        name = str(self.img_name_list[idx])
+        img = np.asarray(Image.open(get_img_path(name, self.dev_root, self.is_eval)).convert("RGB"))
+        x, orig = msf_item(img, self.outsize, self.norm)
+        return {"name": name, "img": x, "orig_img": orig, "size": (img.shape[0], img.shape[1]),
+                "label": self.label_list[idx]}

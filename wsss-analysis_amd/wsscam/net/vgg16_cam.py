@@ -70,6 +70,16 @@ class CAM(DeviceCAMBase):
         other = np.maximum(0.05 * (1 - np.max(modified, axis=0)), np.max(cam[[18, 19, 20]], axis=0))
         return np.concatenate((modified[:1], other[None], modified[1:]), axis=0)
 
+    def adp_modify(self, cam, img_orig):
+        """cam (C,h,w) of one image -> the ADP map stack make_cam post-processes (vgg16_cam.py:51-58)."""
+        if "X1.7" in self.tag:
+            cam = cam[ADP_INDS_X17]
+        if self.dataset == "adp_morph":
+            return self._adp_modify_morph(cam, img_orig)
+        if self.dataset == "adp_func":
+            return self._adp_modify_func(cam, img_orig)
+        return cam
+
     def forward(self, x, x_orig=None):
         """-> (cam (C,h,w), y bool (C,)) as vgg16_cam.py:24-60 / m7_cam.py:22-57; for the ADP datasets
         `x_orig` is the (2,H0,W0,3) uint8 image pair of the ADP dataloader."""
@@ -78,12 +88,9 @@ class CAM(DeviceCAMBase):
         xn = x.detach().cpu().numpy() if is_torch else np.asarray(x)
         cam, score = self.forward_batch(xn[None], want_score=True)
         cam, y = cam[0], self.predict_labels(score[0])
-        if "X1.7" in self.tag:
-            cam = cam[ADP_INDS_X17]
-        if self.dataset == "adp_morph":
-            cam = self._adp_modify_morph(cam, x_orig.detach().cpu().numpy() if hasattr(x_orig, "detach") else x_orig)
-        elif self.dataset == "adp_func":
-            cam = self._adp_modify_func(cam, x_orig.detach().cpu().numpy() if hasattr(x_orig, "detach") else x_orig)
+        if x_orig is not None:
+            x_orig = x_orig.detach().cpu().numpy() if hasattr(x_orig, "detach") else np.asarray(x_orig)
+        cam = self.adp_modify(cam, x_orig)
         if is_torch:
             import torch
 

@@ -33,7 +33,11 @@ def _valid_cat(args, pack, score, model):
         label = model.predict_labels(score)
         if getattr(args, "use_cls", None) is not None:
             label = label[args.use_cls]
-    return np.nonzero(np.asarray(label))[0].astype(np.int64)
+    cat = np.nonzero(np.asarray(label))[0].astype(np.int64)
+    if args.dataset in ("adp_morph", "adp_func"):  # make_cam.py:56-61: the synthesised bg channels always count
+        n_bg = len(args.class_names["bg"])
+        cat = np.concatenate((np.arange(n_bg, dtype=np.int64), cat + n_bg))
+    return cat
 
 
 def _save(args, name, keys, strided, highres):
@@ -62,6 +66,14 @@ def process_batch(model, packs, args, save=True):
     score = ctx.to_host(score_dev, (B, C), np.float32) if has_cls else None
     keys = [_valid_cat(args, p, None if score is None else score[b], model) for b, p in enumerate(packs)]
     sizes = [tuple(int(v) for v in p["size"]) for p in packs]
+    if args.dataset in ("adp_morph", "adp_func"):
+        # vgg16_cam.py:51-58 / common_cam.py:31-92: background (and 'other') channels are synthesised from the
+        # ORIGINAL image on the host (scipy Gaussian filter) and joined with the use_cls CAM channels before
+        # the tail; the modified maps go back to the device for the two resizes + normalisation.
+        cam = ctx.to_host(cam_dev, (B, C, h, h), np.float32)
+        mod = np.stack([model.adp_modify(cam[b], np.asarray(p["orig_img"])) for b, p in enumerate(packs)])
+        C = mod.shape[1]
+        cam_dev = ctx.to_device(np.ascontiguousarray(mod, dtype=np.float32))
     s_dev, h_dev, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, B, C, h, h, sizes, keys)
     s_tot = sum(k * a * b for (k, a, b, _, _) in shapes)
     h_tot = sum(k * a * b for (k, _, _, a, b) in shapes)
@@ -106,6 +118,21 @@ def build_dataset(args):
         return dataloader.VOC12ClassificationDatasetMSF(args.val_list, norm_mode=args.norm_mode,
                                                         outsize=args.outsize, dev_root=args.dev_root,
                                                         scales=args.cam_scales)
+    if args.dataset in ("adp_morph", "adp_func"):
+        from ..adp import dataloader
+
+        return dataloader.ADPClassificationDatasetMSF(args.val_list, norm_mode=args.norm_mode, outsize=args.outsize,
+                                                      dev_root=args.dev_root, htt_type=args.dataset.split("_")[-1],
+                                                      is_eval=args.split == "evaluation", scales=args.cam_scales,
+                                                      cls_labels_path=getattr(args, "cls_labels_path", None))
+    if args.dataset in ("deepglobe", "deepglobe_balanced"):
+        from ..deepglobe import dataloader
+
+        return dataloader.DeepGlobeClassificationDatasetMSF(args.val_list, norm_mode=args.norm_mode,
+                                                            outsize=args.outsize, dev_root=args.dev_root,
+                                                            is_balanced=args.dataset == "deepglobe_balanced",
+                                                            scales=args.cam_scales,
+                                                            cls_labels_path=getattr(args, "cls_labels_path", None))
     raise KeyError("Dataset %s not yet implemented" % args.dataset)
 
 
