@@ -122,6 +122,21 @@ def test_crf_native_voc_size_label_unaries(ctx):
     assert np.abs(q - qr).max() <= 1e-3 and (a == ar).mean() >= 0.995
 
 
+@pytest.mark.parametrize("case", [(321, 321, 29, (1.5, 3, 40, 13, 10, 10)),     # HSN ADP-morph regime: M = 29
+                                  (1088, 1088, 5, (1.5, 3, 40, 13, 10, 10)),    # BASELINE config 5 stress: N = 1 183 744
+                                  (41, 41, 21, (3 / 12, 3, 80 / 12, 13, 10, 5))])  # SEC/DSRG training-time CRF
+def test_crf_config5_sizes(ctx, case):
+    H, W, M, cfg = case
+    rng = np.random.default_rng(50 + M)
+    rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
+    q, a, v = _gpu_crf(ctx, rgb, U, cfg)
+    qr, ar, ls = helpers.crf_oracle(rgb, U, cfg)
+    assert v == (ls[0], ls[1])
+    assert np.abs(q - qr).max() <= 1e-3, np.abs(q - qr).max()
+    assert (a == ar).mean() >= 0.995
+    assert np.abs(q.sum(0) - 1).max() <= 1e-5
+
+
 def test_dcrf_process_image_without_mass(ctx):
     """An image whose probabilities are all zero has no pass classes: its CRF output stays zero -> label 0."""
     rng = np.random.default_rng(6)
