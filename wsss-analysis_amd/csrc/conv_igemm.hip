@@ -44,6 +44,9 @@ struct ConvKArgs {
     int H, W, Cin, Ho, Wo, Cout;
     int kh, kw, stride, pad, relu;
     int M, HoWo;
+    // exact unsigned division by HoWo / Wo as multiply-high + shifts (Granlund-Montgomery): the prologue
+    // decodes 4 output rows per thread and a hardware-less 32-bit division costs ~25 VALU instructions
+    unsigned div_howo_mul, div_howo_s1, div_howo_s2, div_wo_mul, div_wo_s1, div_wo_s2;
     int cchunks;     // Cin / 64 (generic mode)
     int ksteps_base; // K-steps of one precision segment
     int nk;          // total K-steps (x3 in split mode)
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
 
     const int t = threadIdx.x;
     const int lane = t & 63;
-    const int wv = t >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform: LDS DMA destinations stay in SGPRs
     const int wm = wv >> 1, wn = wv & 1;
 
     // XCD-aware, bijective block -> tile map: consecutive tiles (which share the A rows)
@@ -113,9 +116,11 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + lrow + RSTEP * i;
         if (m < p.M) {
-            const int n = m / p.HoWo;
+            const unsigned t1 = __umulhi(p.div_howo_mul, (unsigned)m);
+            const int n = (int)((t1 + (((unsigned)m - t1) >> p.div_howo_s1)) >> p.div_howo_s2);
             const int rem = m - n * p.HoWo;
-            const int ho = rem / p.Wo;
+            const unsigned t2 = __umulhi(p.div_wo_mul, (unsigned)rem);
+            const int ho = (int)((t2 + (((unsigned)rem - t2) >> p.div_wo_s1)) >> p.div_wo_s2);
             const int wo = rem - ho * p.Wo;
             hb[i] = ho * p.stride - p.pad;
             wb[i] = wo * p.stride - p.pad;
@@ -134,6 +139,14 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
         const int r = brow0 + RSTEP * i;
         const int ks = GLDS ? (slot ^ ((r >> 1) & 7)) : slot;
         wrow[i] = p.w + (long long)(n0 + r) * p.Kw + ks * 8;
+    }
+
+    // LDS-DMA path: per-row element offset of the lane's 16-byte source slot (row base + swizzled k-slot)
+    long long aoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = lrow + RSTEP * i;
+        aoff[i] = base[i] + (slot ^ ((r >> 1) & 7)) * 8;
     }
 
     uint4 ra[4], rb[NB];
@@ -326,14 +339,95 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             cur = cur == 2 ? 0 : cur + 1;
         }
     } else if (GLDS && MODE == 0) {
-        // the DMA for K-step kt+1 is issued before the MFMAs of K-step kt and has landed when the
-        // barrier (which carries the vmcnt(0) for the in-flight DMA) releases
-        issue_dma(0, 0);
+        // Two LDS buffers.  The 4 + NB LDS-DMA pieces of K-step kt+1 are issued BETWEEN the MFMA groups of
+        // K-step kt (one A and one B piece after each k-slice): a DMA piece costs ~100 issue cycles (address
+        // math, M0, the VMEM slot) and a front-loaded batch of 8 left the matrix pipe idle for longer than
+        // the 16 MFMAs of the step take.  The (segment, tap, channel-chunk) decode of the next K-step is
+        // carried incrementally in SGPRs (no per-step integer divisions).  The barrier at the end of a step
+        // carries the vmcnt(0) for the pieces in flight.
+        int n_seg = 0, n_khi = 0, n_kwi = 0, n_cc = 0, n_ktl = 0; // decode of the next K-step to issue
+        const bf16_t *n_src = p.x;
+        long long n_tap = 0;
+        int n_wk = 0;
+        auto prep = [&]() {
+            n_src = (SPLIT && n_seg == 1) ? p.x_lo : p.x;
+            n_tap = ((long long)n_khi * p.W + n_kwi) * p.Cin + n_cc * 64;
+            n_wk = ((SPLIT && n_seg == 2) ? p.Kbase : 0) + n_ktl * 64;
+        };
+        auto advance = [&]() {
+            ++n_ktl;
+            if (++n_cc == p.cchunks) {
+                n_cc = 0;
+                if (++n_kwi == p.kw) {
+                    n_kwi = 0;
+                    if (++n_khi == p.kh) {
+                        n_khi = 0;
+                        n_ktl = 0;
+                        ++n_seg;
+                    }
+                }
+            }
+        };
+        auto issue_a = [&](int i, int buf) {
+            const int hi = hb[i] + n_khi, wi = wb[i] + n_kwi;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const bf16_t *g = ok ? n_src + (aoff[i] + n_tap) : p.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(smem + buf * A_BYTES + wv * 4096 + i * 1024),
+                                             16, 0, 0);
+        };
+        auto issue_b = [&](int i, int buf) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wrow[i] + n_wk),
+                                             (__attribute__((address_space(3))) void *)(smem + STAGES * A_BYTES + buf * B_BYTES + wv * (NB * 1024) + i * 1024),
+                                             16, 0, 0);
+        };
+        prep();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_a(i, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) issue_b(i, 0);
+        advance();
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk && !(p.debug & 1)) issue_dma(kt + 1, cur ^ 1);
-            if (!(p.debug & 2)) compute(cur);
+            const bool more = kt + 1 < nk && !(p.debug & 1);
+            if (more) {
+                prep();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) issue_a(i, cur ^ 1);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) issue_b(i, cur ^ 1);
+            }
+            if (!(p.debug & 2)) {
+                const unsigned sa = lds0 + cur * A_BYTES, sb = lds0 + STAGES * A_BYTES + cur * B_BYTES;
+                u32x4_t fa[2][2], fb[2][NI];
+                auto rd = [&](int set, int ks) {
+                    const int sl = ks * 2 + kgrp;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][mi]) : "v"(sa + lds_off(wm * 64 + mi * 32 + l31, sl)) : "memory");
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][ni]) : "v"(sb + lds_off(wn * WN + ni * 32 + l31, sl)) : "memory");
+                };
+                rd(0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int set = ks & 1;
+                    if (ks < 3) {
+                        rd(set ^ 1, ks + 1);
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 + NI) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) mfma(fa[set][mi], fb[set][ni], acc[mi][ni]);
+                }
+            }
+            if (more) advance();
             __syncthreads();
         }
     } else {
@@ -555,6 +649,15 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.relu = p.relu;
     a.M = p.N * p.Ho * p.Wo;
     a.HoWo = p.Ho * p.Wo;
+    auto fastdiv = [](unsigned d, unsigned &mul, unsigned &s1, unsigned &s2) {
+        unsigned l = 0;
+        while ((1ull << l) < d) ++l; // ceil(log2 d)
+        mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+        s1 = l < 1 ? l : 1;
+        s2 = l > 0 ? l - 1 : 0;
+    };
+    fastdiv((unsigned)(a.HoWo > 0 ? a.HoWo : 1), a.div_howo_mul, a.div_howo_s1, a.div_howo_s2);
+    fastdiv((unsigned)(p.Wo > 0 ? p.Wo : 1), a.div_wo_mul, a.div_wo_s1, a.div_wo_s2);
     if (p.small_cin == 0) {
         WSC_CHECK(p.Cin % 64 == 0, WSC_ERR_INVALID, "conv: Cin=%d not a multiple of 64", p.Cin);
         a.cchunks = p.Cin / 64;
