@@ -107,6 +107,27 @@ def test_crf_degenerate_sizes(ctx, shape):
     assert np.abs(q - qr).max() <= 1e-3 and np.array_equal(a, ar)
 
 
+def test_crf_noise_image_hash_table_fallback(ctx):
+    """Uniform-noise RGB: almost every pixel owns its six bilateral vertices, far more than the right-sized
+    hash table (N (d+1) / 8 slots) holds -> the build flags the overflow and repeats with the worst-case
+    table; a batch mixing a noise image with a smooth one takes the same path."""
+    rng = np.random.default_rng(41)
+    H, W, M = 64, 72, 3
+    noise = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+    smooth, U, _ = helpers.synth_crf_case(rng, H, W, M)
+    cfg = (3, 3, 50, 5, 10, 3)
+    q, a, v = _gpu_crf(ctx, noise, U, cfg)
+    qr, ar, ls = helpers.crf_oracle(noise, U, cfg)
+    assert v == (ls[0], ls[1]) and ls[1] > H * W  # more vertices than pixels
+    assert np.abs(q - qr).max() <= 1e-3 and (a == ar).mean() >= 0.995
+    from tests.test_gpu_crf import _gpu_crf as gpu_crf_batch
+
+    qb, ab, vg, vb = gpu_crf_batch(ctx, [smooth, noise], [U, U], cfg)
+    qs, as_, ls_s = helpers.crf_oracle(smooth, U, cfg)
+    assert (vb[0], vb[1]) == (ls_s[1], ls[1])
+    assert np.abs(qb[0] - qs).max() <= 1e-3 and np.abs(qb[1] - qr).max() <= 1e-3
+
+
 def test_crf_native_voc_size_label_unaries(ctx):
     """cam_to_ir_label's regime: native 375x500, M = K+1 = 3, label unaries, irn CRF parameters."""
     from wsscam.misc import imutils

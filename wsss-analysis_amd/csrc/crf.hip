@@ -115,13 +115,17 @@ __device__ __forceinline__ void unpack_key(unsigned long long k, int *key) {
     }
 }
 
+// Linear probing, at most HASH_MAX_PROBE slots: returns -1 when the run is longer (the table is too
+// full -- the caller flags it and the lattice is rebuilt with a worst-case-sized table).
+constexpr int HASH_MAX_PROBE = 256;
 __device__ __forceinline__ int hash_insert(unsigned long long *table, unsigned mask, unsigned long long key) {
     unsigned slot = (unsigned)mix64(key) & mask;
-    for (;;) {
+    for (int probe = 0; probe < HASH_MAX_PROBE; ++probe) {
         const unsigned long long prev = atomicCAS(&table[slot], EMPTY_KEY, key);
         if (prev == EMPTY_KEY || prev == key) return (int)slot;
         slot = (slot + 1) & mask;
     }
+    return -1;
 }
 __device__ __forceinline__ int hash_lookup(const unsigned long long *table, unsigned mask, unsigned long long key) {
     unsigned slot = (unsigned)mix64(key) & mask;
@@ -153,6 +157,9 @@ __device__ __forceinline__ unsigned long long wave_match(unsigned long long key,
     }
     return mine;
 }
+// (Matching only RUNS of adjacent lanes -- three shuffles and two ballots instead of one loop trip per
+// distinct key -- was measured: the lattice build went from 2.6 to 4.5 ms per 32-image batch; equal keys
+// are interleaved across the wave, not adjacent, and the extra atomics cost far more than the loop.)
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // XCD-contiguous work split for the gather kernels.  Blocks are dispatched round-robin over the 8
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(256) void lattice_embed_kernel(EmbedArgs a) {
             key[i] = (int)(short)(rem0[i] + (float)can);
         }
         unsigned long long pk;
-        if (!pack_key<D>(key, pk)) *a.err = 1;
+        if (!pack_key<D>(key, pk)) atomicOr(a.err, 1);
         int slot;
         if (true) {
             // lanes = consecutive pixels: the group leader (lowest lane = lowest pixel) inserts for all
@@ -304,13 +311,16 @@ __global__ __launch_bounds__(256) void lattice_embed_kernel(EmbedArgs a) {
             slot = 0;
             if (lane_id() == leader) {
                 slot = hash_insert(table, a.cap_mask, pk);
-                atomicMin(&first[slot], n * (D + 1) + r);
+                if (slot >= 0) atomicMin(&first[slot], n * (D + 1) + r);
+                else atomicOr(a.err, 2); // table too small
             }
             slot = __shfl(slot, leader, 64);
         } else {
             slot = hash_insert(table, a.cap_mask, pk);
-            atomicMin(&first[slot], n * (D + 1) + r);
+            if (slot >= 0) atomicMin(&first[slot], n * (D + 1) + r);
+            else atomicOr(a.err, 2);
         }
+        if (slot < 0) slot = 0; // keeps the bookkeeping kernels in range; the build is discarded
         a.eslot[e0 + r] = slot;
         a.bary[e0 + r] = bary[r];
     }
@@ -1030,8 +1040,11 @@ float *blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, float *a, float *b) 
     return a;
 }
 
+constexpr int WSC_RETRY_FULL_TABLE = 1; // internal status of build_lattice: the right-sized hash table overflowed
+
 template <int D>
-int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy, float srgb, bool shared) {
+int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy, float srgb, bool shared,
+                  bool full_table) {
     wsc_ctx *ctx = crf->ctx;
     // shared: build the lattice of ONE image and let all crf->B images use it (position-only features)
     const int B = shared ? 1 : crf->B, N = crf->N, dp1 = D + 1;
@@ -1042,8 +1055,14 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     L.d = D;
     L.n_pix = npix;
     L.alpha = 1.0f / (1.0f + powf(2.0f, -(float)D));
+    // Hash table slots per image.  Worst case (every pixel owns its d+1 vertices) needs 2 N (d+1); natural
+    // images have 1-2 orders of magnitude fewer vertices (10.8 k for 103 k pixels on the bench set), so the
+    // first attempt uses N (d+1) / 8 slots rounded up to a power of two (1 MB instead of 16 MB per image at
+    // 321^2: the probes stay in L2 and the table fill drops from 0.8 GB to 50 MB per batch).  An insert that
+    // probes more than HASH_MAX_PROBE slots flags the build, which is then repeated with the worst-case size.
     long long cap = 1;
-    while (cap < 2ll * N * dp1) cap <<= 1;
+    const long long want = full_table ? 2ll * N * dp1 : (long long)N * dp1 / 8;
+    while (cap < want || cap < 1024) cap <<= 1;
     WSC_CHECK(B * cap < (1ll << 31), WSC_ERR_CAPACITY, "CRF batch too large for the hash tables");
 
     TempBuf tmp(ctx);
@@ -1097,9 +1116,13 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
         WSC_HIP(hipMemcpyAsync(&bound[b], prefix + (long long)b * N * dp1, sizeof(unsigned), hipMemcpyDeviceToHost,
                                ctx->stream));
     WSC_HIP(hipStreamSynchronize(ctx->stream));
-    WSC_CHECK(herr == 0, WSC_ERR_KEY_RANGE,
+    WSC_CHECK((herr & 1) == 0, WSC_ERR_KEY_RANGE,
               "CRF lattice coordinate outside the packed-key range (sxy=%g srgb=%g too small for this image size)",
               (double)sxy, (double)srgb);
+    if (herr & 2) {
+        WSC_CHECK(!full_table, WSC_ERR_CAPACITY, "CRF lattice hash table overflow at worst-case size");
+        return WSC_RETRY_FULL_TABLE; // crf_alloc'ed arrays of this attempt are released with the crf / reused
+    }
     L.rows = (int)vtot + 1;
     L.v_per_image.resize(crf->B);
     if (shared)
@@ -1222,7 +1245,7 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
         crf->lat[0] = hit->L;
     } else {
         crf->persist = n_cached < GAUSS_CACHE_MAX;
-        st = build_lattice<2>(crf, crf->lat[0], rgb_dev, g_sxy, 1.f, true);
+        st = build_lattice<2>(crf, crf->lat[0], rgb_dev, g_sxy, 1.f, true, true); // built once: worst-case table
         if (st == WSC_OK && crf->persist) {
             GaussCache *g = new GaussCache{H, W, g_sxy, crf->lat[0]};
             ctx->attachments.emplace_back(g, &gauss_cache_delete);
@@ -1232,7 +1255,16 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
     }
     crf->lat[0].rep = B;
     crf->lat[0].v_per_image.assign(B, crf->lat[0].rows - 1);
-    if (st == WSC_OK) st = build_lattice<5>(crf, crf->lat[1], rgb_dev, bi_sxy, bi_srgb, false);
+    if (st == WSC_OK) {
+        const size_t mark = crf->allocs.size();
+        st = build_lattice<5>(crf, crf->lat[1], rgb_dev, bi_sxy, bi_srgb, false, false);
+        if (st == WSC_RETRY_FULL_TABLE) { // noise-like image: more vertices than the right-sized table holds
+            for (size_t i = mark; i < crf->allocs.size(); ++i) wsc_ctx_cached_free(ctx, crf->allocs[i]);
+            crf->allocs.resize(mark);
+            crf->lat[1] = LatticeDev();
+            st = build_lattice<5>(crf, crf->lat[1], rgb_dev, bi_sxy, bi_srgb, false, true);
+        }
+    }
     if (st == WSC_OK) st = crf_alloc(crf, sizeof(uint4) * 5 * (size_t)B * crf->N, (void **)&crf->pix_rec);
     if (st == WSC_OK) {
         const long long npix = (long long)B * crf->N;
