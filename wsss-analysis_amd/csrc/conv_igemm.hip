@@ -149,7 +149,8 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
         aoff[i] = base[i] + (slot ^ ((r >> 1) & 7)) * 8;
     }
 
-    uint4 ra[4], rb[NB];
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t ra[4], rb[NB]; // native vectors: with HIP's uint4 struct the B registers were kept in scratch
 
     // LDS-DMA issue of one K-step's A and B tiles into buffer `buf` (MODE 0 only)
     auto issue_dma = [&](int kt, int buf) {
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
                                              (__attribute__((address_space(3))) void *)(sb + i * 1024), 16, 0, 0);
     };
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
         int seg = 0, ktl = kt;
         if (SPLIT) {
             seg = kt / p.ksteps_base;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             for (int i = 0; i < 4; ++i) {
                 const int hi = hb[i] + khi, wi = wb[i] + kwi;
                 const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                ra[i] = ok ? *reinterpret_cast<const uint4 *>(src + base[i] + tap_off) : make_uint4(0, 0, 0, 0);
+                ra[i] = ok ? *reinterpret_cast<const u32x4_t *>(src + base[i] + tap_off) : u32x4_t{0u, 0u, 0u, 0u};
             }
         } else {
             // small-Cin mode: activation is [N][H][W][4]; one kernel row = 2^MODE slots of
@@ -216,21 +217,21 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
                 uint2 v0 = make_uint2(0, 0), v1 = make_uint2(0, 0);
                 if (okh && (unsigned)wi < (unsigned)p.W) v0 = q[0];
                 if (okh && (unsigned)(wi + 1) < (unsigned)p.W) v1 = q[1];
-                ra[i] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                ra[i] = u32x4_t{v0.x, v0.y, v1.x, v1.y};
             }
         }
         const int wk = ((SPLIT && seg == 2) ? p.Kbase : 0) + ktl * 64;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const uint4 *>(wrow[i] + wk);
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const u32x4_t *>(wrow[i] + wk);
     };
 
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf) __attribute__((always_inline)) {
         char *sa = smem + buf * A_BYTES;
         char *sb = smem + STAGES * A_BYTES + buf * B_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(sa + lds_off(lrow + 32 * i, slot)) = ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t *>(sa + lds_off(lrow + 32 * i, slot)) = ra[i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4 *>(sb + lds_off(lrow + 32 * i, slot)) = rb[i];
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4_t *>(sb + lds_off(lrow + 32 * i, slot)) = rb[i];
     };
 
     f32x16_t acc[2][NI];
@@ -244,7 +245,6 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     const int l31 = lane & 31;
     const int kgrp = lane >> 5;
 
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     auto mfma = [&](const u32x4_t &a, const u32x4_t &b, f32x16_t &c) {
         if (ET == 0)
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
