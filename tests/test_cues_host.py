@@ -87,3 +87,24 @@ def test_adp_cam_modifications_host_logic():
     other = np.maximum(0.05 * (1 - modified.max(0)), cam[[18, 19, 20]].max(0))
     assert np.allclose(outf[0], background, atol=1e-6) and np.allclose(outf[1], other, atol=1e-6)
     assert np.array_equal(outf[2:], cam[[28, 29, 30]])
+
+
+def test_adp_update_cues_per_image_threshold():
+    """02_cues/adp_cues.py:304-339: per-image, per-class max (Q7) -- scaling one image leaves the others' cues
+    unchanged, unlike the VOC/DeepGlobe variant."""
+    rng = np.random.default_rng(5)
+    g = rng.random((3, 5, 8, 8))
+    inds = [np.array([0, 2]), np.array([1]), np.array([3, 4])]
+    d = cues.update_cues_adp({}, g, inds, [7, 8, 9], 0.7)
+    loc = (g > 0.7 * g.max(axis=(2, 3), keepdims=True)).astype(np.int64)
+    ref = _brute(loc)
+    for i, x in enumerate([7, 8, 9]):
+        c = d["%d_cues" % x]
+        lab = np.zeros((8, 8), np.int64)
+        lab[c[1], c[2]] = c[0] + 1
+        assert np.array_equal(lab, ref[i])
+        assert np.array_equal(d["%d_labels" % x], inds[i])
+    g2 = g.copy()
+    g2[0] *= 10
+    d2 = cues.update_cues_adp({}, g2, inds, [7, 8, 9], 0.7)
+    assert all(np.array_equal(d2["%d_cues" % x], d["%d_cues" % x]) for x in (7, 8, 9))

@@ -142,3 +142,12 @@ def get_fg_cues(cues, H_fg, class_inds, indices, thresh):
     for c in range(C):
         loc[:, c] = H_fg[:, c] > thresh * np.max(H_fg[:, c])
     return _resolve_and_store(cues, loc, class_inds, indices)
+
+
+def update_cues_adp(cues, gradcam, class_inds, indices, thresh):
+    """02_cues/adp_cues.py:304-339 (ADP seed generation): like get_fg_cues, but a class's threshold is
+    thresh x its max over THAT image's map (np.max(gradcam, axis=(2, 3))), not over the batch (SURVEY.md Q7);
+    `gradcam` already holds the background / other channels modify_by_htt inserted."""
+    gradcam = np.asarray(gradcam)
+    loc = (gradcam > thresh * np.max(gradcam, axis=(2, 3))[:, :, None, None]).astype("int64")
+    return _resolve_and_store(cues, loc, class_inds, indices)
