@@ -19,5 +19,12 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$R
 { echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-include-regex '$RX' -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline"
   echo "# KiB per dispatch summed over the XCD instances; FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md, HBM section)"
   python profiles/summarize_pmc.py $out/pmc_f/*/*_results.db $out/pmc_w/*/*_results.db; } > $out/${tag}_pmc_hbm_traffic.txt 2>&1
+for i in 1 2; do
+  [ $i = 1 ] && C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES"
+  [ $i = 2 ] && C="SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_ANY"
+  rm -rf $out/pmcc_$i
+  timeout 200 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'conv_igemm' -d $out/pmcc_$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --workload cam > $out/${tag}_pmcc_$i.log 2>&1
+done
+{ echo "# rocprofv3 --kernel-trace --pmc <SQ set 1 | SQ set 2> --kernel-include-regex conv_igemm -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --workload cam"; python profiles/conv_pmc_table.py $out/pmcc_1/*/*_results.db $out/pmcc_2/*/*_results.db; } > $out/${tag}_pmc_conv.txt 2>&1
 python profiles/make_traffic_json.py $out/pmc_f/*/*_results.db $out/pmc_w/*/*_results.db > $out/${tag}_hbm_traffic.json 2>> $out/${tag}_bench.err
 ls -la $out | grep ${tag}_
