@@ -157,6 +157,19 @@ __device__ __forceinline__ unsigned long long wave_match(unsigned long long key,
     }
     return mine;
 }
+// 32-bit keys (row ids): one shuffle per distinct key instead of three
+__device__ __forceinline__ unsigned long long wave_match32(unsigned key) {
+    unsigned long long remaining = __ballot(1);
+    unsigned long long mine = 0;
+    while (remaining) {
+        const int leader = __ffsll((long long)remaining) - 1;
+        const bool same = key == (unsigned)__shfl((int)key, leader, 64);
+        const unsigned long long m = __ballot(same);
+        if (same) mine = m;
+        remaining &= ~m;
+    }
+    return mine;
+}
 // (Matching only RUNS of adjacent lanes -- three shuffles and two ballots instead of one loop trip per
 // distinct key -- was measured: the lattice build went from 2.6 to 4.5 ms per 32-image batch; equal keys
 // are interleaved across the wave, not adjacent, and the extra atomics cost far more than the loop.)
@@ -450,7 +463,7 @@ __global__ __launch_bounds__(256) void remap_count_kernel(const int32_t *__restr
         const long long e = gp * dp1 + r;
         const int row = slot2row[(long long)b * cap + eslot[e]];
         offset[e] = row;
-        const unsigned long long grp = wave_match((unsigned long long)(unsigned)row, 0);
+        const unsigned long long grp = wave_match32((unsigned)row);
         if (lane_id() == __ffsll((long long)grp) - 1) atomicAdd(&count[row], (unsigned)__popcll(grp));
     }
 }
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t *__restrict
     for (int r = 0; r < dp1; ++r) {
         const long long e = gp * dp1 + r;
         const int row = offset[e];
-        const unsigned long long grp = wave_match((unsigned long long)(unsigned)row, 0);
+        const unsigned long long grp = wave_match32((unsigned)row);
         const int leader = __ffsll((long long)grp) - 1;
         unsigned base = 0;
         if (lane == leader) base = atomicAdd(&cursor[row], (unsigned)__popcll(grp));
