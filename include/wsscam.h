@@ -50,7 +50,9 @@ typedef enum wsc_status {
 typedef enum wsc_arch {
     WSC_ARCH_RESNET50_CAM = 0, /* net/resnet50.py:57-108 + resnet50_cam.py:12-20,55-70 */
     WSC_ARCH_VGG16_CAM = 1,    /* net/vgg16.py:44 + common_cnn.py:128-141 + vgg16_cam.py:24-60 */
-    WSC_ARCH_M7_CAM = 2        /* net/m7.py:41 + m7_cam.py:22-57 */
+    WSC_ARCH_M7_CAM = 2,       /* net/m7.py:41 + m7_cam.py:22-57 */
+    WSC_ARCH_RESNET50_IRN = 3, /* net/resnet50_irn.py:8-132,210-232 (EdgeDisplacement) */
+    WSC_ARCH_VGG16_IRN = 4     /* net/vgg16_irn.py:8-212,301-321 (EdgeDisplacement, ds_fac = 0.25) */
 } wsc_arch;
 
 /* arithmetic of the conv stack */
@@ -146,6 +148,18 @@ int wsc_net_forward_cam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, in
  * K.function([input],[conv_output])): feat_dev float32 [N][h][w][F] (NHWC as Keras). */
 int wsc_net_forward_features(wsc_ctx *ctx, const wsc_net *net, const float *x_dev /*[N][3][S][S]*/,
                              int N, int S, float *feat_dev);
+
+/* IRNet EdgeDisplacement.forward (03b_irn/net/resnet50_irn.py:210-232, vgg16_irn.py:301-321) for B images,
+ * net created with WSC_ARCH_*_IRN from the EdgeDisplacement state dict (backbone keys as for the CAM nets,
+ * `fc_edge<k>.0.weight`, `fc_edge<k>.1.{weight,bias}` (GroupNorm), `fc_edge6.{weight,bias}`, `fc_dp<k>...`,
+ * `fc_dp7.3.weight`, `mean_shift.running_mean`):
+ *   x_dev    float32 [B][2][3][S][S] -- [orig, h-flip] pairs already zero-padded on the right / bottom to the
+ *            crop size S (F.pad(x, [0, S - w, 0, S - h]), step/make_sem_seg_labels.py:46 feeds pack['img'][0])
+ *   edge_dev float32 [B][feat_h][feat_w] = sigmoid(edge[0]/2 + edge[1].flip(-1)/2), cropped to the feature size
+ *            ((h-1)/stride+1, (w-1)/stride+1) of the un-padded image
+ *   dp_dev   float32 [B][2][feat_h][feat_w] = displacement field of sample 0 (minus MeanShift.running_mean) */
+int wsc_net_forward_edge(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int S, int feat_h, int feat_w,
+                         float *edge_dev, float *dp_dev);
 
 /* Grad-CAM for a plain batch of N samples (02_cues/utilities.py:128-133, 03c_hsn/utilities.py:258-263):
  *   cams[n][y][x][c] = [relu]( sum_f feat[n][y][x][f] * alpha[f][c] )      ('ijkl,lm->ijkm')

@@ -200,3 +200,14 @@ int launch_gap_linear_sigmoid(wsc_ctx *ctx, const bf16_t *feat, const bf16_t *fe
 int launch_bf16_to_f32(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, size_t n, float *y, int fmt);
 int launch_nchw_to_nhwc(wsc_ctx *ctx, const float *x, int N, int C, int HW, bf16_t *y, bf16_t *y_lo, int fmt);
 int launch_nhwc_to_nchw(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int C, int HW, float *y, int fmt);
+
+// ---- irn_kernels.hip ---------------------------------------------------------------------
+int launch_group_norm_stats(wsc_ctx *ctx, const float *x, int N, int H, int W, int C, int G, float eps, void *partial,
+                            void *stats);
+size_t group_norm_partial_bytes(int N, int H, int W, int G);
+int launch_group_norm_apply(wsc_ctx *ctx, const float *x, const void *stats, const float *gamma, const float *beta,
+                            int N, int H, int W, int C, int G, int up, int relu, bf16_t *y, bf16_t *y_lo, int Hd, int Wd,
+                            int Ctot, int coff, int fmt);
+int launch_edge_finish(wsc_ctx *ctx, const float *e, const float *d, int B, int He, int We, int fh, int fw, float ms0,
+                       float ms1, float *edge, float *dp);
+

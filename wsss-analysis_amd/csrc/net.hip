@@ -10,6 +10,7 @@
 //   construction/load: 03b_irn/step/make_cam.py:96-100
 #include "common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <unordered_map>
@@ -34,6 +35,15 @@ struct ConvW {
     int Cin = 0, Cout = 0, CoutPad = 0, kh = 1, kw = 1, stride = 1, pad = 0, relu = 0, small_cin = 0;
 };
 
+// one Conv2d(1x1, bias=False) -> GroupNorm -> [Upsample] -> ReLU head of the IRNet branches
+struct IrnHead {
+    ConvW conv;
+    int groups = 1, up = 1;
+    float *gamma = nullptr, *beta = nullptr; // device, [Cout]
+    int src = 0;                             // stage 1..5, or -6 / -7: the dp6 / dp7 concat buffers
+    int dst = 0, coff = 0;                   // destination concat: 0 edge, 1 dp6-input, 2 dp7-input, 3 dp7 hidden
+};
+
 enum OpType { OP_CONV = 0, OP_POOL = 1 };
 struct Op {
     int type;
@@ -54,6 +64,11 @@ struct wsc_net {
     float *cls_w = nullptr, *cls_b = nullptr; // classifier branch (vgg16 / m7), fp32 [Ccls][F]
     int Ccls = 0;
     int cls_max = 0; // 1: global max pooling (m7), 0: global average (vgg16)
+    // IRNet EdgeDisplacement (arch >= WSC_ARCH_RESNET50_IRN): backbone stage taps + the two head branches
+    std::vector<int> taps;       // op index whose output is stage k+1 (x1..x5)
+    std::vector<IrnHead> heads;  // fc_edge1..5, fc_dp1..5, fc_dp6, fc_dp7[0..2]
+    ConvW edge6, dp7b;           // fc_edge6 (bias), fc_dp7[3]
+    float mean_shift[2] = {0.f, 0.f};
     std::vector<void *> allocs;
 };
 
@@ -186,10 +201,11 @@ int resnet_conv(wsc_net *net, const Dict &d, const std::string &conv, const std:
     return add_conv_op(net, c, in, out, res);
 }
 
-int build_resnet50(wsc_net *net, const Dict &d) {
+int build_resnet50_backbone(wsc_net *net, const Dict &d) {
     // stem: conv1 7x7 s2 p3 + bn1 + relu, maxpool 3x3 s2 p1          (resnet50.py:62-64, 96-99)
     WSC_TRY(resnet_conv(net, d, "resnet50.conv1", "resnet50.bn1", 2, 3, 1, /*small_cin*/ 2, -1, 0, -1));
     add_pool_op(net, 3, 2, 1, 0, 1);
+    net->taps.push_back((int)net->ops.size() - 1); // stage1 = conv1, bn1, relu, maxpool (resnet50_irn.py:15)
     int cur = 1;
     const int planes[4] = {64, 128, 256, 512};
     const int blocks[4] = {3, 4, 6, 3};
@@ -213,8 +229,14 @@ int build_resnet50(wsc_net *net, const Dict &d) {
             WSC_TRY(resnet_conv(net, d, pre + ".conv3", pre + ".bn3", 1, 0, 1, 0, f[1], f[0], res));
             cur = f[0];
         }
+        net->taps.push_back((int)net->ops.size() - 1); // stage L+2 = layer L+1
     }
     net->final_buf = cur;
+    return WSC_OK;
+}
+
+int build_resnet50(wsc_net *net, const Dict &d) {
+    WSC_TRY(build_resnet50_backbone(net, d));
     // CAM head: F.conv2d(x, classifier.weight), resnet50_cam.py:65 (ReLU + flip-add are a separate kernel)
     const HostTensor *cw;
     WSC_TRY(get(d, "classifier.weight", 4, &cw));
@@ -229,7 +251,7 @@ int build_resnet50(wsc_net *net, const Dict &d) {
 // VGG-style stacks of common_cnn.make_layers: cfg entries >0 = conv out channels, -1 = 'M', -2 = 'D'.
 int build_plain_stack(wsc_net *net, const Dict &d, const std::string &root,
                       const std::vector<std::pair<std::string, std::vector<int>>> &cfg, int *cur_io,
-                      int *feat_channels) {
+                      int *feat_channels, std::vector<int> *layer_taps = nullptr) {
     int cur = *cur_io;
     int in_ch = 3;
     bool first = true;
@@ -270,6 +292,7 @@ int build_plain_stack(wsc_net *net, const Dict &d, const std::string &root,
                 first = false;
             }
         }
+        if (layer_taps) layer_taps->push_back((int)net->ops.size() - 1); // output of this layer
     }
     *cur_io = cur;
     *feat_channels = in_ch;
@@ -353,6 +376,92 @@ int build_m7(wsc_net *net, const Dict &d) {
     return WSC_OK;
 }
 
+// ---- IRNet EdgeDisplacement heads (resnet50_irn.py:22-92, vgg16_irn.py:28-98) -----------------------------
+struct HeadSpec {
+    const char *name;
+    int src, stride, cout, groups, up, dst, coff;
+};
+
+// Conv2d(Cin, Cout, 1, bias=False) weights `<name>.0.weight`, GroupNorm affine `<name>.1.{weight,bias}`
+int add_irn_head(wsc_net *net, const Dict &d, const HeadSpec &hs, int cin_pad) {
+    const HostTensor *w, *g, *b;
+    const std::string nm = hs.name;
+    WSC_TRY(get(d, nm + ".0.weight", 4, &w));
+    WSC_TRY(get(d, nm + ".1.weight", 1, &g));
+    WSC_TRY(get(d, nm + ".1.bias", 1, &b));
+    WSC_CHECK(w->shape[0] == hs.cout && w->shape[2] == 1 && w->shape[3] == 1 && g->shape[0] == hs.cout &&
+                  b->shape[0] == hs.cout,
+              WSC_ERR_SHAPE, "'%s': expected a 1x1 conv with %d outputs + GroupNorm", hs.name, hs.cout);
+    (void)cin_pad;
+    IrnHead h;
+    std::vector<float> one(hs.cout, 1.f), zero(hs.cout, 0.f);
+    WSC_TRY(make_conv(net, w, hs.stride, 0, 0, 0, one, zero, nullptr, nullptr, &h.conv));
+    h.groups = hs.groups; h.up = hs.up; h.src = hs.src; h.dst = hs.dst; h.coff = hs.coff;
+    WSC_TRY(upload(net, g->data, sizeof(float) * hs.cout, (void **)&h.gamma));
+    WSC_TRY(upload(net, b->data, sizeof(float) * hs.cout, (void **)&h.beta));
+    net->heads.push_back(h);
+    return WSC_OK;
+}
+
+int build_irn_heads(wsc_net *net, const Dict &d, const std::vector<HeadSpec> &specs) {
+    for (const HeadSpec &hs : specs) WSC_TRY(add_irn_head(net, d, hs, 0));
+    // fc_edge6 = Conv2d(160, 1, 1, bias=True) on the 5 x 32-channel concat, zero-padded to 192 input channels
+    const HostTensor *w6, *b6, *w7;
+    WSC_TRY(get(d, "fc_edge6.weight", 4, &w6));
+    WSC_TRY(get(d, "fc_edge6.bias", 1, &b6));
+    WSC_CHECK(w6->shape[0] == 1 && w6->shape[1] == 160, WSC_ERR_SHAPE, "fc_edge6.weight must be [1][160][1][1]");
+    std::vector<float> w6p(192, 0.f);
+    for (int i = 0; i < 160; ++i) w6p[i] = w6->data[i];
+    HostTensor t6;
+    t6.data = w6p.data(); t6.ndim = 4; t6.shape[0] = 1; t6.shape[1] = 192; t6.shape[2] = 1; t6.shape[3] = 1;
+    std::vector<float> one1(1, 1.f), bias1(1, b6->data[0]);
+    WSC_TRY(make_conv(net, &t6, 1, 0, 0, 0, one1, bias1, nullptr, nullptr, &net->edge6));
+    // fc_dp7[3] = Conv2d(256, 2, 1, bias=False); MeanShift subtracts running_mean in eval (resnet50_irn.py:96-108)
+    WSC_TRY(get(d, "fc_dp7.3.weight", 4, &w7));
+    WSC_CHECK(w7->shape[0] == 2 && w7->shape[1] == 256, WSC_ERR_SHAPE, "fc_dp7.3.weight must be [2][256][1][1]");
+    std::vector<float> one2(2, 1.f), zero2(2, 0.f);
+    WSC_TRY(make_conv(net, w7, 1, 0, 0, 0, one2, zero2, nullptr, nullptr, &net->dp7b));
+    if (has(d, "mean_shift.running_mean")) {
+        const HostTensor *ms;
+        WSC_TRY(get(d, "mean_shift.running_mean", 1, &ms));
+        WSC_CHECK(ms->shape[0] == 2, WSC_ERR_SHAPE, "mean_shift.running_mean must have 2 entries");
+        net->mean_shift[0] = ms->data[0];
+        net->mean_shift[1] = ms->data[1];
+    }
+    return WSC_OK;
+}
+
+// src: stage 1..5, -6 = concat of dp3|dp4|dp5 (768 ch), -7 = concat of dp1|dp2|dp_up3 (448 ch)
+// dst: 0 = edge concat (160 -> 192 ch), 1 = dp6 input, 2 = dp7 input, 3 = dp7 hidden (256 ch)
+int build_resnet50_irn(wsc_net *net, const Dict &d) {
+    WSC_TRY(build_resnet50_backbone(net, d));
+    const std::vector<HeadSpec> specs = {
+        {"fc_edge1", 1, 1, 32, 4, 1, 0, 0},   {"fc_edge2", 2, 1, 32, 4, 1, 0, 32},  {"fc_edge3", 3, 1, 32, 4, 2, 0, 64},
+        {"fc_edge4", 4, 1, 32, 4, 4, 0, 96},  {"fc_edge5", 5, 1, 32, 4, 4, 0, 128}, {"fc_dp1", 1, 1, 64, 8, 1, 2, 0},
+        {"fc_dp2", 2, 1, 128, 16, 1, 2, 64},  {"fc_dp3", 3, 1, 256, 16, 1, 1, 0},   {"fc_dp4", 4, 1, 256, 16, 2, 1, 256},
+        {"fc_dp5", 5, 1, 256, 16, 2, 1, 512}, {"fc_dp6", -6, 1, 256, 16, 2, 2, 192}, {"fc_dp7", -7, 1, 256, 16, 1, 3, 0}};
+    return build_irn_heads(net, d, specs);
+}
+
+int build_vgg16_irn(wsc_net *net, const Dict &d) {
+    const std::vector<std::pair<std::string, std::vector<int>>> cfg = {
+        {"layer1", {64, 64, -1}},
+        {"layer2", {128, 128, -1}},
+        {"layer3", {256, 256, 256, -1}},
+        {"layer4", {512, 512, 512, 512, 512, 512}},
+        {"layer5", {1024, -2, 1024, -2}}}; // vgg16.py:44; stage k = layer k (vgg16_irn.py:21-25)
+    int cur = 0;
+    WSC_TRY(build_plain_stack(net, d, "vgg16", cfg, &cur, &net->F, &net->taps));
+    net->final_buf = cur;
+    // ds_fac = 0.25 (vgg16_irn.py:30-98): stage1 is at 1/2 resolution and its heads use a stride-2 1x1 conv
+    const std::vector<HeadSpec> specs = {
+        {"fc_edge1", 1, 2, 32, 4, 1, 0, 0},   {"fc_edge2", 2, 1, 32, 4, 1, 0, 32},  {"fc_edge3", 3, 1, 32, 4, 2, 0, 64},
+        {"fc_edge4", 4, 1, 32, 4, 2, 0, 96},  {"fc_edge5", 5, 1, 32, 4, 2, 0, 128}, {"fc_dp1", 1, 2, 64, 8, 1, 2, 0},
+        {"fc_dp2", 2, 1, 128, 16, 1, 2, 64},  {"fc_dp3", 3, 1, 256, 16, 1, 1, 0},   {"fc_dp4", 4, 1, 256, 16, 1, 1, 256},
+        {"fc_dp5", 5, 1, 256, 16, 1, 1, 512}, {"fc_dp6", -6, 1, 256, 16, 2, 2, 192}, {"fc_dp7", -7, 1, 256, 16, 1, 3, 0}};
+    return build_irn_heads(net, d, specs);
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Plan {
@@ -389,9 +498,17 @@ int plan_dims(const wsc_net *net, int N, int S, Plan *pl) {
     return WSC_OK;
 }
 
-// Runs the conv stack on N samples; returns pointers to the final feature map planes.
+// bytes of one plane of stage tap k (x_{k+1}), 256-byte aligned
+size_t tap_plane_bytes(const wsc_net *net, const Plan &pl, int N, int k) {
+    const int op = net->taps[k];
+    return align_up((size_t)N * pl.H[op] * pl.W[op] * pl.C[op] * sizeof(bf16_t), 256);
+}
+
+// Runs the conv stack on N samples; returns pointers to the final feature map planes.  With copy_taps
+// the stage outputs x1..x5 (net->taps) are copied, plane by plane (hi [, lo]), to the start of the extra
+// region in stage order -- the rotating activation buffers are overwritten as the stack proceeds.
 int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, int S, size_t extra_bytes,
-                 const bf16_t **feat, const bf16_t **feat_lo, int *hf, int *wf, void **extra) {
+                 const bf16_t **feat, const bf16_t **feat_lo, int *hf, int *wf, void **extra, bool copy_taps = false) {
     Plan pl;
     WSC_TRY(plan_dims(net, N, S, &pl));
     const int planes = net->split ? 2 : 1;
@@ -437,6 +554,17 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
                                    buf_lo[op.out], net->fmt));
         }
         bh[op.out] = pl.H[i]; bw[op.out] = pl.W[i]; bc[op.out] = pl.C[i];
+        if (copy_taps)
+            for (size_t k = 0; k < net->taps.size(); ++k)
+                if (net->taps[k] == (int)i) {
+                    char *dst = (char *)*extra;
+                    for (size_t j = 0; j < k; ++j) dst += tap_plane_bytes(net, pl, N, (int)j) * planes;
+                    const size_t nb = (size_t)N * pl.H[i] * pl.W[i] * pl.C[i] * sizeof(bf16_t);
+                    WSC_HIP(hipMemcpyAsync(dst, buf[op.out], nb, hipMemcpyDeviceToDevice, ctx->stream));
+                    if (net->split)
+                        WSC_HIP(hipMemcpyAsync(dst + tap_plane_bytes(net, pl, N, (int)k), buf_lo[op.out], nb,
+                                               hipMemcpyDeviceToDevice, ctx->stream));
+                }
     }
     *feat = buf[net->final_buf];
     *feat_lo = buf_lo[net->final_buf];
@@ -481,6 +609,8 @@ int wsc_net_create(wsc_ctx *ctx, int arch, const wsc_tensor_desc *weights, int n
     case WSC_ARCH_RESNET50_CAM: st = build_resnet50(net, d); break;
     case WSC_ARCH_VGG16_CAM: st = build_vgg16(net, d); break;
     case WSC_ARCH_M7_CAM: st = build_m7(net, d); break;
+    case WSC_ARCH_RESNET50_IRN: st = build_resnet50_irn(net, d); break;
+    case WSC_ARCH_VGG16_IRN: st = build_vgg16_irn(net, d); break;
     default:
         wsc_set_error("unknown arch %d", arch);
         st = WSC_ERR_INVALID;
@@ -579,6 +709,112 @@ int wsc_net_forward_features(wsc_ctx *ctx, const wsc_net *net, const float *x_de
     void *extra;
     WSC_TRY(run_backbone(ctx, net, x_dev, N, S, 0, &feat, &feat_lo, &hf, &wf, &extra));
     return launch_bf16_to_f32(ctx, feat, feat_lo, (size_t)N * hf * wf * net->F, feat_dev, net->fmt);
+}
+
+// EdgeDisplacement.forward (resnet50_irn.py:212-232 / vgg16_irn.py:306-321) for B images: x is the
+// [orig, h-flip] pair of each image already zero-padded to the crop size S (F.pad(x, [0, S-w, 0, S-h])).
+// Backbone with stage taps -> 12 Conv-GroupNorm-[Upsample]-ReLU heads into three concat buffers -> fc_edge6 /
+// fc_dp7[3] -> crop to (feat_h, feat_w), sigmoid(edge[0]/2 + edge[1].flip(-1)/2), dp[0] - mean_shift.
+int wsc_net_forward_edge(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int S, int feat_h, int feat_w,
+                         float *edge_dev, float *dp_dev) {
+    WSC_CHECK(ctx && net && x_dev && edge_dev && dp_dev, WSC_ERR_INVALID, "wsc_net_forward_edge: null argument");
+    WSC_CHECK(net->arch == WSC_ARCH_RESNET50_IRN || net->arch == WSC_ARCH_VGG16_IRN, WSC_ERR_INVALID,
+              "wsc_net_forward_edge: the network is not an IRNet EdgeDisplacement net");
+    WSC_CHECK(B > 0 && S > 0 && feat_h > 0 && feat_w > 0, WSC_ERR_INVALID, "wsc_net_forward_edge: B=%d S=%d", B, S);
+    WSC_HIP(hipSetDevice(ctx->device));
+    const int N = 2 * B;
+    const int planes = net->split ? 2 : 1;
+    Plan pl;
+    WSC_TRY(plan_dims(net, N, S, &pl));
+    WSC_CHECK(net->taps.size() == 5, WSC_ERR_INVALID, "internal: %zu stage taps", net->taps.size());
+    int Hs[5], Ws[5], Cs[5];
+    size_t tap_off[5], off = 0;
+    for (int k = 0; k < 5; ++k) {
+        const int op = net->taps[k];
+        Hs[k] = pl.H[op]; Ws[k] = pl.W[op]; Cs[k] = pl.C[op];
+        tap_off[k] = off;
+        off += tap_plane_bytes(net, pl, N, k) * planes;
+    }
+    // concat geometry: everything ends at the resolution of the stage-2 heads; the dp6 input at stage 3's
+    auto outdim = [](int v, int stride) { return (v - 1) / stride + 1; };
+    const int H2 = outdim(Hs[1], 1), W2 = outdim(Ws[1], 1), H3 = outdim(Hs[2], 1), W3 = outdim(Ws[2], 1);
+    WSC_CHECK(feat_h <= H2 && feat_w <= W2, WSC_ERR_INVALID, "feature size %dx%d exceeds the head resolution %dx%d",
+              feat_h, feat_w, H2, W2);
+    const int cat_c[4] = {192, 768, 448, 256};
+    const int cat_h[4] = {H2, H3, H2, H2}, cat_w[4] = {W2, W3, W2, W2};
+    size_t cat_off[4], cat_bytes[4];
+    for (int i = 0; i < 4; ++i) {
+        cat_bytes[i] = align_up((size_t)N * cat_h[i] * cat_w[i] * cat_c[i] * sizeof(bf16_t), 256);
+        cat_off[i] = off;
+        off += cat_bytes[i] * planes;
+    }
+    size_t ftmp_elems = 0, part_bytes = 0;
+    for (const IrnHead &h : net->heads) {
+        const int sh = h.src > 0 ? Hs[h.src - 1] : cat_h[h.src == -6 ? 1 : 2];
+        const int sw = h.src > 0 ? Ws[h.src - 1] : cat_w[h.src == -6 ? 1 : 2];
+        const int ho = outdim(sh, h.conv.stride), wo = outdim(sw, h.conv.stride);
+        ftmp_elems = std::max(ftmp_elems, (size_t)N * ho * wo * h.conv.Cout);
+        part_bytes = std::max(part_bytes, group_norm_partial_bytes(N, ho, wo, h.groups));
+    }
+    const size_t ftmp_off = off; off += align_up(ftmp_elems * sizeof(float), 256);
+    const size_t part_off = off; off += align_up(part_bytes, 256);
+    const size_t stat_off = off; off += align_up(sizeof(float) * 2 * N * 16, 256);
+    const size_t e_off = off; off += align_up(sizeof(float) * (size_t)N * H2 * W2, 256);
+    const size_t d_off = off; off += align_up(sizeof(float) * (size_t)N * H2 * W2 * 2, 256);
+
+    const bf16_t *feat, *feat_lo;
+    int hf, wf;
+    void *extra;
+    WSC_TRY(run_backbone(ctx, net, x_dev, N, S, off, &feat, &feat_lo, &hf, &wf, &extra, true));
+    char *base = (char *)extra;
+    // channels 160..191 of the edge concat feed zero weights but must not hold NaN bit patterns
+    WSC_HIP(hipMemsetAsync(base + cat_off[0], 0, cat_bytes[0] * planes, ctx->stream));
+
+    auto plane = [&](size_t o, size_t bytes, int which) -> bf16_t * {
+        return which == 0 ? (bf16_t *)(base + o) : (net->split ? (bf16_t *)(base + o + bytes) : nullptr);
+    };
+    auto run_conv = [&](const ConvW &c, const bf16_t *x, const bf16_t *x_lo, int H, int W, float *y_f32) -> int {
+        ConvLaunch L;
+        memset(&L, 0, sizeof(L));
+        L.x = x; L.x_lo = x_lo; L.w = c.w;
+        L.s1 = c.s1; L.b1 = c.b1; L.s2 = nullptr; L.b2 = nullptr;
+        L.y = nullptr; L.y_lo = nullptr; L.y_f32 = y_f32;
+        L.N = N; L.H = H; L.W = W; L.Cin = c.Cin; L.Ho = outdim(H, c.stride); L.Wo = outdim(W, c.stride);
+        L.Cout = c.Cout; L.CoutPad = c.CoutPad;
+        L.kh = 1; L.kw = 1; L.stride = c.stride; L.pad = 0; L.relu = 0;
+        L.small_cin = 0; L.split = net->split; L.fmt = net->fmt;
+        return conv_igemm_launch(ctx, L);
+    };
+    float *ftmp = (float *)(base + ftmp_off);
+    for (const IrnHead &h : net->heads) {
+        const bf16_t *x, *x_lo;
+        int sh, sw, sc;
+        if (h.src > 0) {
+            const int k = h.src - 1;
+            const size_t pb = tap_plane_bytes(net, pl, N, k);
+            x = plane(tap_off[k], pb, 0); x_lo = plane(tap_off[k], pb, 1);
+            sh = Hs[k]; sw = Ws[k]; sc = Cs[k];
+        } else {
+            const int ci = h.src == -6 ? 1 : 2;
+            x = plane(cat_off[ci], cat_bytes[ci], 0); x_lo = plane(cat_off[ci], cat_bytes[ci], 1);
+            sh = cat_h[ci]; sw = cat_w[ci]; sc = cat_c[ci];
+        }
+        WSC_CHECK(sc == h.conv.Cin, WSC_ERR_SHAPE, "IRNet head: %d input channels, the weights expect %d", sc, h.conv.Cin);
+        WSC_TRY(run_conv(h.conv, x, x_lo, sh, sw, ftmp));
+        const int ho = outdim(sh, h.conv.stride), wo = outdim(sw, h.conv.stride);
+        WSC_TRY(launch_group_norm_stats(ctx, ftmp, N, ho, wo, h.conv.Cout, h.groups, 1e-5f, base + part_off,
+                                        base + stat_off));
+        const int di = h.dst;
+        WSC_TRY(launch_group_norm_apply(ctx, ftmp, base + stat_off, h.gamma, h.beta, N, ho, wo, h.conv.Cout, h.groups,
+                                        h.up, 1, plane(cat_off[di], cat_bytes[di], 0), plane(cat_off[di], cat_bytes[di], 1),
+                                        cat_h[di], cat_w[di], cat_c[di], h.coff, net->fmt));
+    }
+    float *e_out = (float *)(base + e_off), *d_out = (float *)(base + d_off);
+    WSC_TRY(run_conv(net->edge6, plane(cat_off[0], cat_bytes[0], 0), plane(cat_off[0], cat_bytes[0], 1), H2, W2, e_out));
+    WSC_TRY(run_conv(net->dp7b, plane(cat_off[3], cat_bytes[3], 0), plane(cat_off[3], cat_bytes[3], 1), H2, W2, d_out));
+    WSC_TRY(launch_edge_finish(ctx, e_out, d_out, B, H2, W2, feat_h, feat_w, net->mean_shift[0], net->mean_shift[1],
+                               edge_dev, dp_dev));
+    return WSC_OK;
 }
 
 // One convolution layer through the production kernel, NCHW fp32 in / out (layout changes and

@@ -26,6 +26,8 @@ WSC_ERR_CAPACITY = -8
 ARCH_RESNET50_CAM = 0
 ARCH_VGG16_CAM = 1
 ARCH_M7_CAM = 2
+ARCH_RESNET50_IRN = 3
+ARCH_VGG16_IRN = 4
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
@@ -80,6 +82,7 @@ _SIGNATURES = {
     "wsc_net_forward_cam": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "wsc_net_forward_gradcam": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "wsc_net_forward_features": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "wsc_net_forward_edge": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "wsc_conv2d_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "wsc_cam_postprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wsc_cam_eval_confusion": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _vp]),
@@ -311,6 +314,10 @@ class Net:
 
     def forward_features(self, x_dev, N, S, feat_dev):
         check(self.ctx._lib.wsc_net_forward_features(self.ctx.h, self.h, _ptr(x_dev), N, S, _ptr(feat_dev)))
+
+    def forward_edge(self, x_dev, B, S, feat_h, feat_w, edge_dev, dp_dev):
+        check(self.ctx._lib.wsc_net_forward_edge(self.ctx.h, self.h, _ptr(x_dev), B, S, feat_h, feat_w,
+                                                 _ptr(edge_dev), _ptr(dp_dev)))
 
 
 def cam_postprocess(ctx, cam_dev, B, C, h, w, sizes, keys_per_image, strided_dev=None, highres_dev=None):
