@@ -161,6 +161,19 @@ int wsc_net_forward_features(wsc_ctx *ctx, const wsc_net *net, const float *x_de
 int wsc_net_forward_edge(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int S, int feat_h, int feat_w,
                          float *edge_dev, float *dp_dev);
 
+/* misc.indexing.propagate_to_edge(x, edge, radius, beta, exp_times) -- the IRNet random walk called by
+ * 03b_irn/step/make_sem_seg_labels.py:59,76,93 (the `misc` package is missing from the reference tree; the
+ * algorithm is upstream IRNet's misc/indexing.py, its affinity step is in-tree as to_affinity,
+ * net/vgg16_irn.py:247-261):  rw = (x * (1 - edge)) @ T^(n_steps), T = column-normalised affinity^beta.
+ *   x_dev float32 [K][h][w], edge_dev float32 [h][w] (device); rw_dev float32 [K][h][w]
+ *   dirs_host int32 [D][2] search directions (dy, dx) of PathIndex (dy > 0, or dy == 0 and dx > 0),
+ *   path_start_host int32 [D+1], path_yx_host int32 [path_start[D]][2]: the pixels (relative to the source)
+ *   of the straight path of every direction, end points included
+ *   n_steps = 2^exp_times applications of T (the reference squares the dense matrix exp_times times) */
+int wsc_rw_propagate(wsc_ctx *ctx, const float *x_dev, const float *edge_dev, int K, int h, int w,
+                     const int32_t *dirs_host, const int32_t *path_start_host, const int32_t *path_yx_host, int D,
+                     float beta, int n_steps, float *rw_dev);
+
 /* Grad-CAM for a plain batch of N samples (02_cues/utilities.py:128-133, 03c_hsn/utilities.py:258-263):
  *   cams[n][y][x][c] = [relu]( sum_f feat[n][y][x][f] * alpha[f][c] )      ('ijkl,lm->ijkm')
  * with alpha the `gradcam_weights` tensor given to wsc_net_create (vgg16 / m7).  One CNN pass

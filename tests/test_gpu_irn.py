@@ -60,3 +60,44 @@ def test_forward_edge_argument_errors(ctx):
     net.close()
     with pytest.raises(_lib.WscError):  # missing head weights
         _lib.Net(ctx, _lib.ARCH_RESNET50_IRN, {k: v.numpy() for k, v in sd.items()}, 20, _lib.PREC_F16)
+
+
+@pytest.mark.parametrize("case", [(9, 11, 3, 5, 10, 3), (23, 31, 5, 5, 10, 8), (16, 16, 1, 5, 10, 0), (6, 40, 2, 3, 4, 5)])
+def test_propagate_to_edge_vs_dense_oracle(ctx, case):
+    """The 2^exp_times stencil applications equal the reference's dense matrix power (upstream irn
+    misc/indexing.py restated in oracle/rw_ref.py): same rw maps to fp32 round-off."""
+    from oracle import rw_ref
+    from wsscam.misc import indexing
+
+    h, w, K, radius, beta, exp_times = case
+    g = torch.Generator().manual_seed(h * 100 + w)
+    x = torch.rand(K, h, w, generator=g)
+    edge = torch.rand(1, h, w, generator=g) ** 2
+    ref = rw_ref.propagate_to_edge(x, edge, radius=radius, beta=beta, exp_times=exp_times).numpy()
+    exact = rw_ref.propagate_to_edge(x, edge, radius=radius, beta=beta, exp_times=exp_times, dtype=torch.float64).numpy()
+    out = indexing.propagate_to_edge(x.numpy(), edge.numpy(), radius=radius, beta=beta, exp_times=exp_times, ctx=ctx)
+    assert out.shape == ref.shape == (K, 1, h, w)
+    scale = max(1.0, float(np.abs(exact).max()))
+    # against the exact value of the reference's expression: 1e-5; against its fp32 evaluation (whose 8 dense
+    # squarings carry more round-off than the 256 stencil steps): 1e-4
+    assert np.abs(out - exact).max() <= 1e-5 * scale, np.abs(out - exact).max()
+    assert np.abs(out - ref).max() <= 1e-4 * scale, np.abs(out - ref).max()
+    out_t = indexing.propagate_to_edge(x, edge, radius=radius, beta=beta, exp_times=exp_times, ctx=ctx)
+    assert torch.is_tensor(out_t) and np.array_equal(out_t.numpy(), out)  # bit-reproducible, torch in -> torch out
+
+
+def test_path_index_tables():
+    """PathIndex(radius=5): 34 directions in the upper half plane, paths include both end points, destinations
+    first; radius 10 (cam_to_ir_label / train_irn) also builds."""
+    from wsscam.misc.indexing import PathIndex
+
+    pi = PathIndex(5, default_size=(12, 20))
+    dirs, start, yx = pi.device_tables()
+    assert dirs.shape == (34, 2) and start[0] == 0 and start[-1] == len(yx)
+    assert all(d[0] > 0 or (d[0] == 0 and d[1] > 0) for d in dirs.tolist())
+    for d in range(34):
+        path = yx[start[d]:start[d + 1]].tolist()
+        assert path[0] == dirs[d].tolist() and [0, 0] in path
+    assert pi.search_dst.shape == (34, 2) and pi.radius_floor == 4
+    assert sum(p.shape[0] for p in pi.path_indices) == 34 and pi.src_indices.shape[0] == (12 - 4) * (20 - 8)
+    assert PathIndex(10).device_tables()[0].shape[0] > 100

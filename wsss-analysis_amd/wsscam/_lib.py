@@ -83,6 +83,7 @@ _SIGNATURES = {
     "wsc_net_forward_gradcam": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "wsc_net_forward_features": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "wsc_net_forward_edge": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "wsc_rw_propagate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i, _vp]),
     "wsc_conv2d_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "wsc_cam_postprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wsc_cam_eval_confusion": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _vp]),
@@ -432,3 +433,19 @@ class Crf:
         run = ctx or self.ctx
         check(self.ctx._lib.wsc_crf_inference(run.h, self.h, _ptr(unary_dev), M, float(g_compat),
                                               float(bi_compat), int(n_iters), _ptr(q_dev), _ptr(argmax_dev)))
+
+
+def rw_propagate(ctx, x_dev, edge_dev, K, h, w, dirs, path_start, path_yx, beta, n_steps, rw_dev=None):
+    """wsc_rw_propagate: x_dev [K][h][w], edge_dev [h][w] device buffers -> rw_dev [K][h][w] (allocated if None)."""
+    import numpy as np
+
+    dirs = np.ascontiguousarray(dirs, dtype=np.int32)
+    path_start = np.ascontiguousarray(path_start, dtype=np.int32)
+    path_yx = np.ascontiguousarray(path_yx, dtype=np.int32)
+    if rw_dev is None:
+        rw_dev = ctx.alloc(K * h * w * 4)
+    check(ctx._lib.wsc_rw_propagate(ctx.h, _ptr(x_dev), _ptr(edge_dev), K, h, w, dirs.ctypes.data_as(_vp),
+                                    path_start.ctypes.data_as(_vp), path_yx.ctypes.data_as(_vp), int(dirs.shape[0]),
+                                    float(beta), int(n_steps), _ptr(rw_dev)))
+    return rw_dev
+
