@@ -101,3 +101,60 @@ def test_path_index_tables():
     assert pi.search_dst.shape == (34, 2) and pi.radius_floor == 4
     assert sum(p.shape[0] for p in pi.path_indices) == 34 and pi.src_indices.shape[0] == (12 - 4) * (20 - 8)
     assert PathIndex(10).device_tables()[0].shape[0] > 100
+
+
+def test_make_sem_seg_labels_end_to_end(tmp_path):
+    """make_cam.run -> make_sem_seg_labels.run on the files it wrote (VOC flavour): label PNGs against the oracle
+    chain irn_ref (network) -> rw_ref (dense random walk, as the reference computes it) -> torch interpolate."""
+    import types
+
+    from PIL import Image
+
+    from oracle import rw_ref
+    from wsscam.step import make_cam, make_sem_seg_labels
+
+    rng = np.random.default_rng(9)
+    S = 65
+    sizes = [(60, 80), (72, 64), (50, 50)]
+    labels = [np.zeros(20, np.float32) for _ in sizes]
+    labels[0][[2, 5]] = 1
+    labels[1][[11]] = 1
+    # labels[2] empty: make_cam writes empty arrays and the label map is all background
+    data = [{"name": "2008_%06d" % i, "img": cnn_ref.msf_pack(cnn_ref.synth_image(rng, *sz), (S, S)), "size": sz,
+             "label": lb} for i, (sz, lb) in enumerate(zip(sizes, labels))]
+    cam_dir, seg_dir, clr_dir = tmp_path / "cam", tmp_path / "seg", tmp_path / "clr"
+    cam_sd = cnn_ref.make_resnet50_cam_state_dict(20, seed=0)
+    a1 = types.SimpleNamespace(cam_network="net.resnet50_cam", model_dir=None, dataset="voc12", tag="", num_classes=20,
+                               use_cls=None, model_id="resnet50", cam_weights_name=None, state_dict=cam_sd,
+                               dataset_obj=data, split="train_aug", cam_out_dir=str(cam_dir), n_gpus=1,
+                               cam_batch_images=4, cam_precision=_lib.PREC_BF16X3)
+    make_cam.run(a1)
+    irn_sd = irn_ref.make_vgg16_irn_state_dict(seed=5)
+    colours = {"bg": np.array([(0, 0, 0)]), "fg": np.array([(8 * i + 8, 255 - 8 * i, 17 * (i % 15)) for i in range(20)])}
+    a2 = types.SimpleNamespace(irn_network="net.vgg16_irn", model_dir=None, dataset="voc12", tag="", num_classes=20,
+                               use_cls=None, irn_weights_name=None, state_dict=irn_sd, dataset_obj=data, split="train_aug",
+                               cam_out_dir=str(cam_dir), sem_seg_out_dir=str(seg_dir), sem_seg_clr_out_dir=str(clr_dir),
+                               beta=10, exp_times=8, sem_seg_bg_thres=0.25, class_colours=colours, overlay_r=0.75,
+                               n_gpus=1, irn_crop_size=96, irn_precision=_lib.PREC_BF16X3)
+    make_sem_seg_labels.run(a2)
+    for d in data:
+        png = np.asarray(Image.open(seg_dir / (d["name"] + ".png")))
+        assert png.shape == d["size"] and png.dtype == np.uint8
+        assert (clr_dir / (d["name"] + ".png")).exists()
+        cam = np.load(cam_dir / (d["name"] + ".npy"), allow_pickle=True).item()
+        if len(cam["keys"]) == 0:
+            assert not png.any()
+            continue
+        with torch.no_grad():
+            edge, _ = irn_ref.edge_displacement_forward(torch.from_numpy(d["img"]), irn_sd, "vgg16", crop_size=96, stride=4)
+            cams = torch.from_numpy(cam["cam"])
+            if edge.shape[1:] != cams.shape[1:]:
+                edge = torch.nn.functional.interpolate(edge.unsqueeze(0), size=cams.shape[1:], mode="bilinear",
+                                                       align_corners=False)[0]
+            rw = rw_ref.propagate_to_edge(cams, edge, beta=10, exp_times=8, radius=5)
+            up = torch.nn.functional.interpolate(rw, size=d["size"], mode="bilinear", align_corners=False)[..., 0, :d["size"][0], :d["size"][1]]
+            up = up / torch.max(up)
+            up_bg = torch.nn.functional.pad(up, (0, 0, 0, 0, 1, 0), value=0.25)
+            ref = np.pad(cam["keys"] + 1, (1, 0), mode="constant")[torch.argmax(up_bg, dim=0).numpy()]
+        assert set(np.unique(png)) <= set(np.pad(cam["keys"] + 1, (1, 0)).tolist())
+        assert (png == ref).mean() >= 0.99, (png == ref).mean()
