@@ -1,0 +1,77 @@
+"""BASELINE config 4 (IRNet inference) stage timings on one MI355X -- not the contract bench (bench.py).
+
+    python profiles/bench_irn.py [--batch 8] [--arch vgg16|resnet50] [--precision f16]
+Per image: EdgeDisplacement on the [orig, flip] pair zero-padded to 512x512 (make_sem_seg_labels.py:46), then the
+random walk of K = 2 strided CAMs at 94 x 125 (375x500 VOC image), beta 10, 2^8 steps, then the x4 upsample.
+Prints one JSON line: ms per image of each stage, images/s, and the work the reference's dense formulation
+(8 squarings of the 11750 x 11750 transition matrix) would have needed."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "wsss-analysis_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--arch", default="vgg16", choices=["vgg16", "resnet50"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "bf16x3"])
+    ap.add_argument("--steps", type=int, default=5)
+    args = ap.parse_args()
+    import numpy as np
+
+    from oracle import irn_ref  # synthetic weights only
+    from wsscam import _lib
+    from wsscam.misc.indexing import PathIndex
+
+    ctx = _lib.Context(0)
+    prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3}[args.precision]
+    if args.arch == "vgg16":
+        sd, arch = irn_ref.make_vgg16_irn_state_dict(0), _lib.ARCH_VGG16_IRN
+    else:
+        sd, arch = irn_ref.make_resnet50_irn_state_dict(0), _lib.ARCH_RESNET50_IRN
+    net = _lib.Net(ctx, arch, {k: v.numpy() for k, v in sd.items()}, 20, prec)
+    B, S, fh, fw = args.batch, 512, 81, 81  # 321x321 network input -> (321-1)//4+1 = 81
+    rng = np.random.default_rng(0)
+    x = np.zeros((B, 2, 3, S, S), np.float32)
+    x[..., :321, :321] = rng.normal(0, 1, (B, 2, 3, 321, 321)).astype(np.float32)
+    x_dev = ctx.to_device(x)
+    edge_dev, dp_dev = ctx.alloc(B * fh * fw * 4), ctx.alloc(B * 2 * fh * fw * 4)
+    h, w, K = 94, 125, 2
+    dirs, start, yx = PathIndex(5).device_tables()
+    cams_dev = ctx.to_device(rng.random((K, h, w)).astype(np.float32))
+    e2_dev = ctx.to_device((rng.random((h, w)) ** 2).astype(np.float32))
+    rw_dev = ctx.alloc(K * h * w * 4)
+    up_dev = ctx.alloc(K * 375 * 500 * 4)
+
+    def timed(fn, reps):
+        fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    t_net = timed(lambda: net.forward_edge(x_dev, B, S, fh, fw, edge_dev, dp_dev), args.steps)
+    t_rw = timed(lambda: _lib.rw_propagate(ctx, cams_dev, e2_dev, K, h, w, dirs, start, yx, 10.0, 256, rw_dev), args.steps)
+    t_up = timed(lambda: _lib.bilinear_resize(ctx, rw_dev, K, h, w, up_dev, 375, 500), args.steps)
+    per_img = t_net / B + t_rw + t_up
+    hw = h * w
+    print(json.dumps({
+        "workload": "IRNet inference (BASELINE config 4): %s EdgeDisplacement @512 pad + random walk K=%d %dx%d 2^8 steps"
+                    % (args.arch, K, h, w),
+        "dtype": args.precision, "batch_images": B,
+        "edge_net_ms_per_image": round(t_net / B, 3), "random_walk_ms_per_image": round(t_rw, 3),
+        "upsample_ms_per_image": round(t_up, 3), "images_per_s": round(1e3 / per_img, 1),
+        "stencil_GFLOP_per_image": round(256 * K * hw * 69 * 2 / 1e9, 2),
+        "reference_dense_TFLOP_per_image": round(8 * 2 * hw ** 3 / 1e12, 1)}))
+
+
+if __name__ == "__main__":
+    main()
