@@ -173,6 +173,13 @@ int wsc_net_forward_edge(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, i
 int wsc_rw_propagate(wsc_ctx *ctx, const float *x_dev, const float *edge_dev, int K, int h, int w,
                      const int32_t *dirs_host, const int32_t *path_start_host, const int32_t *path_yx_host, int D,
                      float beta, int n_steps, float *rw_dev);
+/* The same for n_img images of different sizes in one pass (every stencil step is one launch over all of them --
+ * a single 94 x 125 image is launch-bound at ~15 us per step): image b has K_host[b] maps on an h_host[b] x
+ * w_host[b] grid; x_dev / rw_dev hold the images' [K][h][w] blocks back to back, edge_dev their [h][w] maps. */
+int wsc_rw_propagate_batch(wsc_ctx *ctx, int n_img, const int32_t *K_host, const int32_t *h_host,
+                           const int32_t *w_host, const float *x_dev, const float *edge_dev,
+                           const int32_t *dirs_host, const int32_t *path_start_host, const int32_t *path_yx_host,
+                           int D, float beta, int n_steps, float *rw_dev);
 
 /* Grad-CAM for a plain batch of N samples (02_cues/utilities.py:128-133, 03c_hsn/utilities.py:258-263):
  *   cams[n][y][x][c] = [relu]( sum_f feat[n][y][x][f] * alpha[f][c] )      ('ijkl,lm->ijkm')

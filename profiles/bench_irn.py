@@ -59,7 +59,13 @@ def main():
         return (time.perf_counter() - t0) / reps * 1e3
 
     t_net = timed(lambda: net.forward_edge(x_dev, B, S, fh, fw, edge_dev, dp_dev), args.steps)
-    t_rw = timed(lambda: _lib.rw_propagate(ctx, cams_dev, e2_dev, K, h, w, dirs, start, yx, 10.0, 256, rw_dev), args.steps)
+    t_rw1 = timed(lambda: _lib.rw_propagate(ctx, cams_dev, e2_dev, K, h, w, dirs, start, yx, 10.0, 256, rw_dev), args.steps)
+    RB = 32  # images per random-walk pass (make_sem_seg_labels mirror: args.irn_batch_images)
+    cams_b = ctx.to_device(rng.random((RB, K, h, w)).astype(np.float32))
+    e2_b = ctx.to_device((rng.random((RB, h, w)) ** 2).astype(np.float32))
+    rw_b = ctx.alloc(RB * K * h * w * 4)
+    t_rw = timed(lambda: _lib.rw_propagate_batch(ctx, cams_b, e2_b, [K] * RB, [h] * RB, [w] * RB, dirs, start, yx, 10.0,
+                                                 256, rw_b), args.steps) / RB
     t_up = timed(lambda: _lib.bilinear_resize(ctx, rw_dev, K, h, w, up_dev, 375, 500), args.steps)
     per_img = t_net / B + t_rw + t_up
     hw = h * w
@@ -68,6 +74,7 @@ def main():
                     % (args.arch, K, h, w),
         "dtype": args.precision, "batch_images": B,
         "edge_net_ms_per_image": round(t_net / B, 3), "random_walk_ms_per_image": round(t_rw, 3),
+        "random_walk_batch_images": RB, "random_walk_ms_single_image_call": round(t_rw1, 3),
         "upsample_ms_per_image": round(t_up, 3), "images_per_s": round(1e3 / per_img, 1),
         "stencil_GFLOP_per_image": round(256 * K * hw * 69 * 2 / 1e9, 2),
         "reference_dense_TFLOP_per_image": round(8 * 2 * hw ** 3 / 1e12, 1)}))

@@ -86,6 +86,20 @@ def test_propagate_to_edge_vs_dense_oracle(ctx, case):
     assert torch.is_tensor(out_t) and np.array_equal(out_t.numpy(), out)  # bit-reproducible, torch in -> torch out
 
 
+def test_propagate_batch_equals_single(ctx):
+    """Images of different sizes / map counts in one pass give bit-identical maps to one call each."""
+    from wsscam.misc import indexing
+
+    rng = np.random.default_rng(2)
+    shapes = [(2, 15, 20), (1, 18, 16), (3, 7, 33), (1, 1, 1)]
+    xs = [rng.random(s).astype(np.float32) for s in shapes]
+    es = [(rng.random((1,) + s[1:]) ** 2).astype(np.float32) for s in shapes]
+    outs = indexing.propagate_to_edge_batch(xs, es, beta=10, exp_times=6, ctx=ctx)
+    for x, e, o in zip(xs, es, outs):
+        single = indexing.propagate_to_edge(x, e, beta=10, exp_times=6, ctx=ctx)
+        assert o.shape == single.shape and np.array_equal(o, single)
+
+
 def test_path_index_tables():
     """PathIndex(radius=5): 34 directions in the upper half plane, paths include both end points, destinations
     first; radius 10 (cam_to_ir_label / train_irn) also builds."""

@@ -20,16 +20,28 @@
 // stay resident in L2.
 #include "common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
 namespace {
 
-// S[d][p] = aff(p, p + dir_d)^beta, 0 when p + dir_d is off the grid
-__global__ void rw_affinity_kernel(const float *__restrict__ edge, int h, int w, const int32_t *__restrict__ dirs,
-                                   const int32_t *__restrict__ path_start, const int32_t *__restrict__ path_yx, int D,
-                                   float beta, double *__restrict__ S) {
-    const int hw = h * w;
+// one image of a batch: K score maps on an h x w grid; offsets into the packed buffers
+struct RwImg {
+    int K, h, w, hw;
+    long long x_off;   // floats into x / rw / the fp64 state buffers (K*hw each)
+    long long e_off;   // floats into edge / the fp64 column-sum buffer (hw each)
+    long long s_off;   // doubles into S (D*hw each)
+};
+
+// S[d][p] = aff(p, p + dir_d)^beta, 0 when p + dir_d is off the grid        (grid: x over D*hw, y = image)
+__global__ void rw_affinity_kernel(const RwImg *__restrict__ imgs, const float *__restrict__ edge_all,
+                                   const int32_t *__restrict__ dirs, const int32_t *__restrict__ path_start,
+                                   const int32_t *__restrict__ path_yx, int D, float beta, double *__restrict__ S_all) {
+    const RwImg im = imgs[blockIdx.y];
+    const int h = im.h, w = im.w, hw = im.hw;
+    const float *edge = edge_all + im.e_off;
+    double *S = S_all + im.s_off;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)D * hw;
          i += (long long)gridDim.x * blockDim.x) {
         const int d = (int)(i / hw);
@@ -48,9 +60,12 @@ __global__ void rw_affinity_kernel(const float *__restrict__ edge, int h, int w,
 }
 
 // inv_col[j] = 1 / (1 + sum over neighbours i of j of A[i][j]^beta)
-__global__ void rw_colsum_kernel(const double *__restrict__ S, int h, int w, const int32_t *__restrict__ dirs, int D,
-                                 double *__restrict__ inv_col) {
-    const int hw = h * w;
+__global__ void rw_colsum_kernel(const RwImg *__restrict__ imgs, const double *__restrict__ S_all,
+                                 const int32_t *__restrict__ dirs, int D, double *__restrict__ inv_col_all) {
+    const RwImg im = imgs[blockIdx.y];
+    const int h = im.h, w = im.w, hw = im.hw;
+    const double *S = S_all + im.s_off;
+    double *inv_col = inv_col_all + im.e_off;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < hw; j += gridDim.x * blockDim.x) {
         const int y = j / w, x = j - y * w;
         double c = 1.0;
@@ -64,18 +79,23 @@ __global__ void rw_colsum_kernel(const double *__restrict__ S, int h, int w, con
     }
 }
 
-// one application of T to K maps: out[k][j] = (in[k][j] + sum_d S_d[j] in[k][j+d] + S_d[j-d] in[k][j-d]) * inv_col[j]
-__global__ __launch_bounds__(256) void rw_step_kernel(const double *__restrict__ in, const double *__restrict__ S,
-                                                      const double *__restrict__ inv_col, int K, int h, int w,
-                                                      const int32_t *__restrict__ dirs, int D, double *__restrict__ out,
-                                                      float *__restrict__ out_f32) {
-    const int hw = h * w;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)K * hw;
+// one application of T to the K maps of every image:
+//   out[k][j] = (in[k][j] + sum_d S_d[j] in[k][j+d] + S_d[j-d] in[k][j-d]) * inv_col[j]
+__global__ __launch_bounds__(256) void rw_step_kernel(const RwImg *__restrict__ imgs, const double *__restrict__ in_all,
+                                                      const double *__restrict__ S_all,
+                                                      const double *__restrict__ inv_col_all,
+                                                      const int32_t *__restrict__ dirs, int D,
+                                                      double *__restrict__ out_all, float *__restrict__ out_f32_all) {
+    const RwImg im = imgs[blockIdx.y];
+    const int h = im.h, w = im.w, hw = im.hw;
+    const double *S = S_all + im.s_off;
+    const double *inv_col = inv_col_all + im.e_off;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)im.K * hw;
          i += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(i / hw);
         const int j = (int)(i - (long long)k * hw);
         const int y = j / w, x = j - y * w;
-        const double *v = in + (long long)k * hw;
+        const double *v = in_all + im.x_off + (long long)k * hw;
         double acc = v[j];
         for (int d = 0; d < D; ++d) {
             const int dy = dirs[2 * d], dx = dirs[2 * d + 1];
@@ -88,19 +108,20 @@ __global__ __launch_bounds__(256) void rw_step_kernel(const double *__restrict__
             }
         }
         acc *= inv_col[j];
-        if (out_f32) out_f32[i] = (float)acc; // the last step writes the result
-        else out[i] = acc;
+        if (out_f32_all) out_f32_all[im.x_off + i] = (float)acc; // the last step writes the result
+        else out_all[im.x_off + i] = acc;
     }
 }
 
-__global__ void rw_mask_kernel(const float *__restrict__ x, const float *__restrict__ edge, int K, int hw,
-                               double *__restrict__ v, float *__restrict__ v_f32) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)K * hw;
-         i += (long long)gridDim.x * blockDim.x)
-    {
-        const float m = x[i] * (1.f - edge[i % hw]); // fp32 product, as the reference forms it
-        v[i] = (double)m;
-        if (v_f32) v_f32[i] = m;
+__global__ void rw_mask_kernel(const RwImg *__restrict__ imgs, const float *__restrict__ x_all,
+                               const float *__restrict__ edge_all, double *__restrict__ v_all,
+                               float *__restrict__ v_f32_all) {
+    const RwImg im = imgs[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)im.K * im.hw;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float m = x_all[im.x_off + i] * (1.f - edge_all[im.e_off + i % im.hw]); // fp32, as the reference forms it
+        v_all[im.x_off + i] = (double)m;
+        if (v_f32_all) v_f32_all[im.x_off + i] = m;
     }
 }
 
@@ -113,15 +134,16 @@ inline int grid_for(long long total) {
 
 } // namespace
 
-extern "C" int wsc_rw_propagate(wsc_ctx *ctx, const float *x_dev, const float *edge_dev, int K, int h, int w,
-                                const int32_t *dirs_host, const int32_t *path_start_host, const int32_t *path_yx_host,
-                                int D, float beta, int n_steps, float *rw_dev) {
-    WSC_CHECK(ctx && x_dev && edge_dev && rw_dev && dirs_host && path_start_host && path_yx_host, WSC_ERR_INVALID,
-              "wsc_rw_propagate: null argument");
-    WSC_CHECK(K > 0 && h > 0 && w > 0 && D > 0 && D <= 1024 && n_steps >= 0, WSC_ERR_INVALID,
-              "wsc_rw_propagate: K=%d h=%d w=%d D=%d n_steps=%d", K, h, w, D, n_steps);
+extern "C" int wsc_rw_propagate_batch(wsc_ctx *ctx, int n_img, const int32_t *K_host, const int32_t *h_host,
+                                      const int32_t *w_host, const float *x_dev, const float *edge_dev,
+                                      const int32_t *dirs_host, const int32_t *path_start_host,
+                                      const int32_t *path_yx_host, int D, float beta, int n_steps, float *rw_dev) {
+    WSC_CHECK(ctx && K_host && h_host && w_host && x_dev && edge_dev && rw_dev && dirs_host && path_start_host &&
+                  path_yx_host,
+              WSC_ERR_INVALID, "wsc_rw_propagate: null argument");
+    WSC_CHECK(n_img > 0 && n_img <= 65535 && D > 0 && D <= 1024 && n_steps >= 0, WSC_ERR_INVALID,
+              "wsc_rw_propagate: n_img=%d D=%d n_steps=%d", n_img, D, n_steps);
     WSC_HIP(hipSetDevice(ctx->device));
-    const int hw = h * w;
     const int n_path = path_start_host[D];
     for (int d = 0; d < D; ++d) {
         WSC_CHECK(path_start_host[d] <= path_start_host[d + 1], WSC_ERR_INVALID, "wsc_rw_propagate: path table");
@@ -130,37 +152,63 @@ extern "C" int wsc_rw_propagate(wsc_ctx *ctx, const float *x_dev, const float *e
                   "wsc_rw_propagate: direction %d = (%d, %d) is not in the upper half plane", d, dirs_host[2 * d],
                   dirs_host[2 * d + 1]);
     }
+    std::vector<RwImg> imgs(n_img);
+    long long xo = 0, eo = 0, so = 0, max_khw = 0, max_hw = 0;
+    for (int b = 0; b < n_img; ++b) {
+        WSC_CHECK(K_host[b] > 0 && h_host[b] > 0 && w_host[b] > 0, WSC_ERR_INVALID,
+                  "wsc_rw_propagate: image %d has K=%d h=%d w=%d", b, K_host[b], h_host[b], w_host[b]);
+        RwImg &im = imgs[b];
+        im.K = K_host[b]; im.h = h_host[b]; im.w = w_host[b]; im.hw = im.h * im.w;
+        im.x_off = xo; im.e_off = eo; im.s_off = so;
+        xo += (long long)im.K * im.hw;
+        eo += im.hw;
+        so += (long long)D * im.hw;
+        max_khw = std::max(max_khw, (long long)im.K * im.hw);
+        max_hw = std::max(max_hw, (long long)im.hw);
+    }
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t tbl = al(sizeof(int32_t) * (2 * (size_t)D + (D + 1) + 2 * (size_t)n_path));
-    const size_t sb = al(sizeof(double) * (size_t)D * hw), cb = al(sizeof(double) * hw), vb = al(sizeof(double) * (size_t)K * hw);
+    const size_t tbl_ints = 2 * (size_t)D + (D + 1) + 2 * (size_t)n_path;
+    const size_t tbl = al(sizeof(int32_t) * tbl_ints + 8) + al(sizeof(RwImg) * (size_t)n_img);
+    const size_t sb = al(sizeof(double) * (size_t)so), cb = al(sizeof(double) * (size_t)eo), vb = al(sizeof(double) * (size_t)xo);
     void *ws;
     WSC_TRY(wsc_ctx_workspace(ctx, tbl + sb + cb + 2 * vb, &ws));
     char *p = (char *)ws;
     int32_t *dirs = (int32_t *)p;
     int32_t *pstart = dirs + 2 * D;
     int32_t *pyx = pstart + (D + 1);
+    RwImg *imgs_dev = (RwImg *)(p + al(sizeof(int32_t) * tbl_ints + 8));
     p += tbl;
     double *S = (double *)p; p += sb;
     double *inv_col = (double *)p; p += cb;
     double *va = (double *)p; p += vb;
     double *vbuf = (double *)p; p += vb;
-    std::vector<int32_t> packed(2 * (size_t)D + (D + 1) + 2 * (size_t)n_path);
+    std::vector<int32_t> packed(tbl_ints);
     memcpy(packed.data(), dirs_host, sizeof(int32_t) * 2 * D);
     memcpy(packed.data() + 2 * D, path_start_host, sizeof(int32_t) * (D + 1));
     memcpy(packed.data() + 2 * D + D + 1, path_yx_host, sizeof(int32_t) * 2 * n_path);
     WSC_TRY(wsc_ctx_upload_small(ctx, dirs, packed.data(), packed.size() * sizeof(int32_t)));
+    WSC_TRY(wsc_ctx_upload_small(ctx, imgs_dev, imgs.data(), imgs.size() * sizeof(RwImg)));
 
-    hipLaunchKernelGGL(rw_affinity_kernel, dim3(grid_for((long long)D * hw)), dim3(256), 0, ctx->stream, edge_dev, h, w,
-                       dirs, pstart, pyx, D, beta, S);
-    hipLaunchKernelGGL(rw_colsum_kernel, dim3(grid_for(hw)), dim3(256), 0, ctx->stream, S, h, w, dirs, D, inv_col);
-    hipLaunchKernelGGL(rw_mask_kernel, dim3(grid_for((long long)K * hw)), dim3(256), 0, ctx->stream, x_dev, edge_dev, K,
-                       hw, va, n_steps == 0 ? rw_dev : (float *)nullptr);
+    const dim3 g_khw(grid_for(max_khw), n_img), g_hw(grid_for(max_hw), n_img), g_dhw(grid_for(max_hw * D), n_img);
+    hipLaunchKernelGGL(rw_affinity_kernel, g_dhw, dim3(256), 0, ctx->stream, imgs_dev, edge_dev, dirs, pstart, pyx, D,
+                       beta, S);
+    hipLaunchKernelGGL(rw_colsum_kernel, g_hw, dim3(256), 0, ctx->stream, imgs_dev, S, dirs, D, inv_col);
+    hipLaunchKernelGGL(rw_mask_kernel, g_khw, dim3(256), 0, ctx->stream, imgs_dev, x_dev, edge_dev, va,
+                       n_steps == 0 ? rw_dev : (float *)nullptr);
     double *cur = va, *nxt = vbuf;
     for (int s = 0; s < n_steps; ++s) {
-        hipLaunchKernelGGL(rw_step_kernel, dim3(grid_for((long long)K * hw)), dim3(256), 0, ctx->stream, cur, S, inv_col,
-                           K, h, w, dirs, D, nxt, s == n_steps - 1 ? rw_dev : (float *)nullptr);
+        hipLaunchKernelGGL(rw_step_kernel, g_khw, dim3(256), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt,
+                           s == n_steps - 1 ? rw_dev : (float *)nullptr);
         double *t = cur; cur = nxt; nxt = t;
     }
     WSC_HIP(hipGetLastError());
     return WSC_OK;
+}
+
+extern "C" int wsc_rw_propagate(wsc_ctx *ctx, const float *x_dev, const float *edge_dev, int K, int h, int w,
+                                const int32_t *dirs_host, const int32_t *path_start_host, const int32_t *path_yx_host,
+                                int D, float beta, int n_steps, float *rw_dev) {
+    const int32_t k = K, hh = h, ww = w;
+    return wsc_rw_propagate_batch(ctx, 1, &k, &hh, &ww, x_dev, edge_dev, dirs_host, path_start_host, path_yx_host, D,
+                                  beta, n_steps, rw_dev);
 }

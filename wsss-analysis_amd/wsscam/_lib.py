@@ -84,6 +84,7 @@ _SIGNATURES = {
     "wsc_net_forward_features": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "wsc_net_forward_edge": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "wsc_rw_propagate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i, _vp]),
+    "wsc_rw_propagate_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp]),
     "wsc_conv2d_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "wsc_cam_postprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wsc_cam_eval_confusion": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _vp]),
@@ -447,5 +448,22 @@ def rw_propagate(ctx, x_dev, edge_dev, K, h, w, dirs, path_start, path_yx, beta,
     check(ctx._lib.wsc_rw_propagate(ctx.h, _ptr(x_dev), _ptr(edge_dev), K, h, w, dirs.ctypes.data_as(_vp),
                                     path_start.ctypes.data_as(_vp), path_yx.ctypes.data_as(_vp), int(dirs.shape[0]),
                                     float(beta), int(n_steps), _ptr(rw_dev)))
+    return rw_dev
+
+
+def rw_propagate_batch(ctx, x_dev, edge_dev, Ks, hs, ws, dirs, path_start, path_yx, beta, n_steps, rw_dev=None):
+    """wsc_rw_propagate_batch: packed [K_b][h_b][w_b] blocks / [h_b][w_b] edge maps of several images."""
+    import numpy as np
+
+    Ks, hs, ws = (np.ascontiguousarray(v, dtype=np.int32) for v in (Ks, hs, ws))
+    dirs = np.ascontiguousarray(dirs, dtype=np.int32)
+    path_start = np.ascontiguousarray(path_start, dtype=np.int32)
+    path_yx = np.ascontiguousarray(path_yx, dtype=np.int32)
+    if rw_dev is None:
+        rw_dev = ctx.alloc(int((Ks.astype(np.int64) * hs * ws).sum()) * 4)
+    check(ctx._lib.wsc_rw_propagate_batch(ctx.h, int(len(Ks)), Ks.ctypes.data_as(_vp), hs.ctypes.data_as(_vp),
+                                          ws.ctypes.data_as(_vp), _ptr(x_dev), _ptr(edge_dev), dirs.ctypes.data_as(_vp),
+                                          path_start.ctypes.data_as(_vp), path_yx.ctypes.data_as(_vp),
+                                          int(dirs.shape[0]), float(beta), int(n_steps), _ptr(rw_dev)))
     return rw_dev
 

@@ -107,3 +107,27 @@ def propagate_to_edge(x, edge, radius=5, beta=10, exp_times=8, ctx=None):
 
         return torch.from_numpy(rw)
     return rw
+
+
+def propagate_to_edge_batch(xs, edges, radius=5, beta=10, exp_times=8, ctx=None):
+    """propagate_to_edge for a list of images of different sizes in one device pass (every stencil step is one
+    launch over all of them): xs[b] (K_b,h_b,w_b), edges[b] (1,h_b,w_b) or (h_b,w_b) -> list of (K_b,1,h_b,w_b)."""
+    xs = [np.ascontiguousarray(x, dtype=np.float32) for x in xs]
+    es = [np.ascontiguousarray(e, dtype=np.float32).reshape(x.shape[-2], x.shape[-1]) for x, e in zip(xs, edges)]
+    if radius not in _PATH_CACHE:
+        _PATH_CACHE[radius] = PathIndex(radius=radius).device_tables()
+    dirs, start, yx = _PATH_CACHE[radius]
+    ctx = ctx or imutils.default_context()
+    Ks, hs, ws = [x.shape[0] for x in xs], [x.shape[1] for x in xs], [x.shape[2] for x in xs]
+    x_dev = ctx.to_device(np.concatenate([x.ravel() for x in xs]))
+    e_dev = ctx.to_device(np.concatenate([e.ravel() for e in es]))
+    rw_dev = _lib.rw_propagate_batch(ctx, x_dev, e_dev, Ks, hs, ws, dirs, start, yx, float(beta), 2 ** int(exp_times))
+    flat = ctx.to_host(rw_dev, (sum(k * h * w for k, h, w in zip(Ks, hs, ws)),), np.float32)
+    for b in (x_dev, e_dev, rw_dev):
+        b.free()
+    out, off = [], 0
+    for k, h, w in zip(Ks, hs, ws):
+        out.append(flat[off:off + k * h * w].reshape(k, 1, h, w).copy())
+        off += k * h * w
+    return out
+

@@ -47,55 +47,66 @@ def _upsample_norm(ctx, rw, size, crop):
         return up / np.max(up)
 
 
-def sem_seg_one(model, pack, cam_dict, args):
-    """One image: (2,3,h,w) input pair + its make_cam dict -> label map (make_sem_seg_labels.py:34-104)."""
-    ctx = model.ctx
+def _resize(ctx, maps, hw):
+    """F.interpolate(maps[None], size=hw, mode='bilinear', align_corners=False)[0] on the device."""
+    maps = np.ascontiguousarray(maps, dtype=np.float32)
+    if maps.shape[1:] == tuple(hw):
+        return maps
+    src = ctx.to_device(maps)
+    dst = ctx.alloc(maps.shape[0] * int(hw[0]) * int(hw[1]) * 4)
+    _lib.bilinear_resize(ctx, src, maps.shape[0], maps.shape[1], maps.shape[2], dst, int(hw[0]), int(hw[1]))
+    out = ctx.to_host(dst, (maps.shape[0], int(hw[0]), int(hw[1])), np.float32)
+    src.free()
+    dst.free()
+    return out
+
+
+def _prepare(ctx, edge, pack, cam_dict, args):
+    """Per-image inputs of the random walk (make_sem_seg_labels.py:50-93): (cams, edge at the cam size, keys,
+    output size) or a finished label map when there is nothing to propagate."""
     size = np.asarray(pack["size"]).reshape(-1)
-    edge, _dp = model.forward(np.asarray(pack["img"], dtype=np.float32))  # edge (1,fh,fw)
     cams = np.asarray(cam_dict["cam"], dtype=np.float32)
     keys_in = np.asarray(cam_dict["keys"])
-
-    def fit_edge(target_hw):
-        if edge.shape[1:] == tuple(target_hw):
-            return edge
-        src = ctx.to_device(np.ascontiguousarray(edge))
-        dst = ctx.alloc(int(target_hw[0]) * int(target_hw[1]) * 4)
-        _lib.bilinear_resize(ctx, src, 1, edge.shape[1], edge.shape[2], dst, int(target_hw[0]), int(target_hw[1]))
-        out = ctx.to_host(dst, (1, int(target_hw[0]), int(target_hw[1])), np.float32)
-        src.free()
-        dst.free()
-        return out
-
     if args.dataset == "voc12":
         if len(keys_in) == 0:
             return np.zeros(tuple(size), dtype="uint8")
-        keys = np.pad(keys_in + 1, (1, 0), mode="constant")
-        e = fit_edge(cams.shape[1:])
-        rw = indexing.propagate_to_edge(cams, e, beta=args.beta, exp_times=args.exp_times, radius=5, ctx=ctx)
-        rw_up = _upsample_norm(ctx, rw, size, size)
-        rw_up_bg = np.concatenate((np.full((1,) + rw_up.shape[1:], float(args.sem_seg_bg_thres), np.float32), rw_up))
-        return keys[np.argmax(rw_up_bg, axis=0)]
+        return cams, _resize(ctx, edge, cams.shape[1:]), np.pad(keys_in + 1, (1, 0), mode="constant"), size
     if args.dataset in ("adp_morph", "adp_func"):
-        e = fit_edge(cams.shape[1:])
-        rw = indexing.propagate_to_edge(cams, e, beta=args.beta, exp_times=args.exp_times, radius=5, ctx=ctx)
-        rw_up = _upsample_norm(ctx, rw, size, size)
-        return keys_in[np.argmax(rw_up, axis=0)]
+        return cams, _resize(ctx, edge, cams.shape[1:]), keys_in, size
     if args.dataset in ("deepglobe", "deepglobe_balanced"):
         if len(keys_in) == 0:
             return 5 * np.ones(tuple(size // 4))
-        down_fac = 6
-        small = [v // down_fac for v in cams.shape[1:]]
-        src = ctx.to_device(np.ascontiguousarray(cams))
-        dst = ctx.alloc(cams.shape[0] * small[0] * small[1] * 4)
-        _lib.bilinear_resize(ctx, src, cams.shape[0], cams.shape[1], cams.shape[2], dst, small[0], small[1])
-        cams_s = ctx.to_host(dst, (cams.shape[0], small[0], small[1]), np.float32)
-        src.free()
-        dst.free()
-        e = fit_edge(small)
-        rw = indexing.propagate_to_edge(cams_s, e, beta=args.beta, exp_times=args.exp_times, radius=5, ctx=ctx)
-        rw_up = _upsample_norm(ctx, rw, size // 4, size // 4)
-        return keys_in[np.argmax(rw_up, axis=0)]
+        small = [v // 6 for v in cams.shape[1:]]  # down_fac = 6
+        return _resize(ctx, cams, small), _resize(ctx, edge, small), keys_in, size // 4
     raise KeyError("Dataset %s not yet implemented" % args.dataset)
+
+
+def _finish(ctx, rw, keys, size, args):
+    rw_up = _upsample_norm(ctx, rw, size, size)
+    if args.dataset == "voc12":
+        rw_up = np.concatenate((np.full((1,) + rw_up.shape[1:], float(args.sem_seg_bg_thres), np.float32), rw_up))
+    return keys[np.argmax(rw_up, axis=0)]
+
+
+def sem_seg_batch(model, packs, cam_dicts, args):
+    """A list of images -> list of label maps: one EdgeDisplacement pass and ONE random-walk pass for all of them
+    (every stencil step is a single launch over the whole list), then the per-image upsample / argmax."""
+    ctx = model.ctx
+    edges, _dp = model.forward_batch(np.stack([np.asarray(p["img"], dtype=np.float32) for p in packs]))
+    prepared = [_prepare(ctx, edges[i], p, c, args) for i, (p, c) in enumerate(zip(packs, cam_dicts))]
+    todo = [i for i, v in enumerate(prepared) if isinstance(v, tuple)]
+    out = [None if isinstance(v, tuple) else v for v in prepared]
+    if todo:
+        rws = indexing.propagate_to_edge_batch([prepared[i][0] for i in todo], [prepared[i][1] for i in todo], radius=5,
+                                               beta=args.beta, exp_times=args.exp_times, ctx=ctx)
+        for i, rw in zip(todo, rws):
+            out[i] = _finish(ctx, rw, prepared[i][2], prepared[i][3], args)
+    return out
+
+
+def sem_seg_one(model, pack, cam_dict, args):
+    """One image: (2,3,h,w) input pair + its make_cam dict -> label map (make_sem_seg_labels.py:34-104)."""
+    return sem_seg_batch(model, [pack], [cam_dict], args)[0]
 
 
 def _save(args, name, rw_pred, orig_rgb=None):
@@ -126,13 +137,13 @@ def _save(args, name, rw_pred, orig_rgb=None):
 def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     model.cuda(process_id)
-    for i in range(len(databin)):
-        pack = databin[i]
-        name = pack["name"]
-        cam_dict = np.load(os.path.join(args.cam_out_dir, name + ".npy"), allow_pickle=True).item()
-        pred = sem_seg_one(model, pack, cam_dict, args)
-        orig = pack.get("orig_img")
-        _save(args, name, pred, None if orig is None else np.asarray(orig)[0])
+    bs = int(getattr(args, "irn_batch_images", 16))  # images per device pass (the reference does one at a time)
+    for i0 in range(0, len(databin), bs):
+        packs = [databin[i] for i in range(i0, min(i0 + bs, len(databin)))]
+        cams = [np.load(os.path.join(args.cam_out_dir, p["name"] + ".npy"), allow_pickle=True).item() for p in packs]
+        for p, pred in zip(packs, sem_seg_batch(model, packs, cams, args)):
+            orig = p.get("orig_img")
+            _save(args, p["name"], pred, None if orig is None else np.asarray(orig)[0])
     model.ctx.sync()
 
 
