@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/${tag}_pytest_gpu.txt
 timeout 300 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 python bench.py --no-cpu-baseline --no-pipeline > $out/${tag}_bench_nopipeline.json 2>> $out/${tag}_bench.err
+timeout 300 python profiles/bench_irn.py > $out/${tag}_bench_irn.json 2>> $out/${tag}_bench.err
 rm -rf $out/prof_stats $out/pmc_f $out/pmc_w
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline > $out/${tag}_prof_stats.log 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline"; python profiles/summarize_rocpd.py $out/prof_stats/*/*_results.db; } > $out/${tag}_kernel_stats_bench.txt 2>&1
