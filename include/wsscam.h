@@ -52,7 +52,8 @@ typedef enum wsc_arch {
     WSC_ARCH_VGG16_CAM = 1,    /* net/vgg16.py:44 + common_cnn.py:128-141 + vgg16_cam.py:24-60 */
     WSC_ARCH_M7_CAM = 2,       /* net/m7.py:41 + m7_cam.py:22-57 */
     WSC_ARCH_RESNET50_IRN = 3, /* net/resnet50_irn.py:8-132,210-232 (EdgeDisplacement) */
-    WSC_ARCH_VGG16_IRN = 4     /* net/vgg16_irn.py:8-212,301-321 (EdgeDisplacement, ds_fac = 0.25) */
+    WSC_ARCH_VGG16_IRN = 4,    /* net/vgg16_irn.py:8-212,301-321 (EdgeDisplacement, ds_fac = 0.25) */
+    WSC_ARCH_M7_IRN = 5        /* net/m7_irn.py:8-118,195-213 (EdgeDisplacement; edge map at 1/2 resolution) */
 } wsc_arch;
 
 /* arithmetic of the conv stack */

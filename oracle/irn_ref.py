@@ -29,6 +29,52 @@ VGG16_HEADS = {  # ds_fac == 0.25 branch, vgg16_irn.py:30-98
 }
 
 
+M7_HEADS = {  # m7_irn.py:24-69: (name, source, conv stride, out channels, groups, upsample); fc_dp4 reads fc_dp3's output
+    "edge": [("fc_edge1", 1, 1, 32, 4, 1), ("fc_edge2", 2, 1, 32, 4, 2), ("fc_edge3", 3, 1, 32, 4, 4)],
+    "dp": [("fc_dp1", 1, 2, 64, 8, 1), ("fc_dp2", 2, 1, 128, 16, 1), ("fc_dp3", 3, 1, 256, 16, 1)],
+    "stage_channels": (64, 128, 256),
+}
+M7_STAGES = [[("layer1", [64, 64, "M"])], [("layer2", [128, 128, "M"])],
+             [("layer3_p1", [256, 256, 256]), ("layer3_p2", ["M", "D"])]]  # m7_irn.py:19-21
+
+
+def make_m7_irn_state_dict(seed=0):
+    sd = cnn_ref.make_plain_state_dict("m7", cnn_ref.M7_CFG, 20, True, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1000)
+
+    def head(name, cin, cout):
+        sd[name + ".0.weight"] = cnn_ref._conv_w(g, cout, cin, 1)
+        sd[name + ".1.weight"] = torch.empty(cout).uniform_(0.5, 1.5, generator=g)
+        sd[name + ".1.bias"] = torch.randn(cout, generator=g) * 0.1
+
+    for name, src, _, cout, _, _ in M7_HEADS["edge"] + M7_HEADS["dp"]:
+        head(name, M7_HEADS["stage_channels"][src - 1], cout)
+    head("fc_dp4", 256, 256)
+    head("fc_dp5", 448, 256)
+    sd["fc_edge4.weight"] = torch.randn(1, 96, 1, 1, generator=g) * 0.1
+    sd["fc_edge4.bias"] = torch.randn(1, generator=g) * 0.1
+    sd["fc_dp5.3.weight"] = cnn_ref._conv_w(g, 2, 256, 1)
+    sd["mean_shift.running_mean"] = torch.randn(2, generator=g) * 0.1
+    return sd
+
+
+def m7_net_forward(x, sd):
+    """m7_irn.Net.forward (:96-112)."""
+    xs = []
+    for stage in M7_STAGES:
+        x = cnn_ref.plain_features(x, sd, "m7", stage)
+        xs.append(x)
+    e = [_head(xs[src - 1], sd, n, st, g, up) for n, src, st, _, g, up in M7_HEADS["edge"]]
+    h1, w1 = e[0].shape[2], e[0].shape[3]
+    edge_out = F.conv2d(torch.cat([e[0], e[1][..., :h1, :w1], e[2][..., :h1, :w1]], dim=1), sd["fc_edge4.weight"],
+                        sd["fc_edge4.bias"])
+    d = [_head(xs[src - 1], sd, n, st, g, up) for n, src, st, _, g, up in M7_HEADS["dp"]]
+    dp4 = _head(d[2], sd, "fc_dp4", 1, 16, 2)
+    hid = _head(torch.cat([d[0], d[1], dp4], dim=1), sd, "fc_dp5", 1, 16, 1)
+    dp_out = F.conv2d(hid, sd["fc_dp5.3.weight"]) - sd["mean_shift.running_mean"].view(1, 2, 1, 1)
+    return edge_out, dp_out
+
+
 def add_head_weights(sd, heads, seed):
     """Random weights for the two branches (there are no trained IRNet weights offline)."""
     g = torch.Generator().manual_seed(seed)
@@ -94,6 +140,8 @@ def _head(x, sd, name, stride, groups, up, relu=True):
 
 def irn_net_forward(x, sd, arch):
     """Net.forward (resnet50_irn.py:110-132 / vgg16_irn.py:192-212): x (N,3,S,S) -> (edge_out (N,1,h,w), dp_out (N,2,h,w))."""
+    if arch == "m7":
+        return m7_net_forward(x, sd)
     heads = RESNET50_HEADS if arch == "resnet50" else VGG16_HEADS
     xs = resnet50_stages(x, sd) if arch == "resnet50" else vgg16_stages(x, sd)
     e = [_head(xs[src - 1], sd, n, st, g, up) for n, src, st, _, g, up in heads["edge"]]

@@ -11,7 +11,7 @@ import torch
 
 from oracle import cnn_ref, irn_ref
 from wsscam import _lib
-from wsscam.net import resnet50_irn, vgg16_irn
+from wsscam.net import m7_irn, resnet50_irn, vgg16_irn
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resnet50_irn.npz")
@@ -48,6 +48,23 @@ def test_vgg16_irn_vs_oracle(batchnorm):
         assert edge[b].shape == tuple(e.shape) == (1, 20, 23) and dp[b].shape == tuple(d.shape)
         assert np.abs(edge[b] - e.numpy()).max() <= 2e-4, np.abs(edge[b] - e.numpy()).max()
         assert np.abs(dp[b] - d.numpy()).max() <= 2e-3 * max(1.0, float(d.abs().max()))
+
+
+def test_m7_irn_vs_oracle():
+    """m7_irn: edge map at 1/2 resolution cropped with the stride-4 feature size (as the reference does), the
+    displacement branch at 1/4; fc_dp4 chained on fc_dp3."""
+    sd = irn_ref.make_m7_irn_state_dict(seed=4)
+    m = m7_irn.EdgeDisplacement(None, "voc12", "", 20, None, crop_size=64, stride=4, precision=_lib.PREC_BF16X3)
+    m.load_state_dict(sd)
+    m.eval().cuda(0)
+    rng = np.random.default_rng(6)
+    x = cnn_ref.msf_pack(cnn_ref.synth_image(rng, 52, 61), (52, 61))
+    edge, dp = m.forward(x)
+    with torch.no_grad():
+        e, d = irn_ref.edge_displacement_forward(torch.from_numpy(x), sd, "m7", crop_size=64, stride=4)
+    assert edge.shape == tuple(e.shape) == (1, 13, 16) and dp.shape == tuple(d.shape) == (2, 13, 16)
+    assert np.abs(edge - e.numpy()).max() <= 2e-4, np.abs(edge - e.numpy()).max()
+    assert np.abs(dp - d.numpy()).max() <= 2e-3 * max(1.0, float(d.abs().max()))
 
 
 def test_forward_edge_argument_errors(ctx):

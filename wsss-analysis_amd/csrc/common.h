@@ -208,6 +208,6 @@ size_t group_norm_partial_bytes(int N, int H, int W, int G);
 int launch_group_norm_apply(wsc_ctx *ctx, const float *x, const void *stats, const float *gamma, const float *beta,
                             int N, int H, int W, int C, int G, int up, int relu, bf16_t *y, bf16_t *y_lo, int Hd, int Wd,
                             int Ctot, int coff, int fmt);
-int launch_edge_finish(wsc_ctx *ctx, const float *e, const float *d, int B, int He, int We, int fh, int fw, float ms0,
-                       float ms1, float *edge, float *dp);
+int launch_edge_finish(wsc_ctx *ctx, const float *e, int He, int We, const float *d, int Hd, int Wd, int B, int fh, int fw,
+                       float ms0, float ms1, float *edge, float *dp);
 

@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
     }
 }
 
-// e: fp32 [2B][He][We] (Cout = 1), d: fp32 [2B][He][We][2]
-__global__ void edge_finish_kernel(const float *__restrict__ e, const float *__restrict__ d, int B, int He, int We,
-                                   int fh, int fw, float ms0, float ms1, float *__restrict__ edge,
+// e: fp32 [2B][He][We] (Cout = 1), d: fp32 [2B][Hd][Wd][2] (the M7 net has its edge map at twice the resolution)
+__global__ void edge_finish_kernel(const float *__restrict__ e, int He, int We, const float *__restrict__ d, int Hd,
+                                   int Wd, int B, int fh, int fw, float ms0, float ms1, float *__restrict__ edge,
                                    float *__restrict__ dp) {
     const long long total = (long long)B * fh * fw;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -130,7 +130,7 @@ __global__ void edge_finish_kernel(const float *__restrict__ e, const float *__r
         const float e1 = e[((long long)(2 * b + 1) * He + y) * We + (fw - 1 - x)]; // crop to fw, then flip(-1)
         const float z = e0 / 2.f + e1 / 2.f;
         edge[i] = 1.f / (1.f + expf(-z));
-        const float *dd = d + (((long long)(2 * b) * He + y) * We + x) * 2;
+        const float *dd = d + (((long long)(2 * b) * Hd + y) * Wd + x) * 2;
         dp[((long long)b * 2 + 0) * fh * fw + (long long)y * fw + x] = dd[0] - ms0;
         dp[((long long)b * 2 + 1) * fh * fw + (long long)y * fw + x] = dd[1] - ms1;
     }
@@ -176,11 +176,12 @@ int launch_group_norm_apply(wsc_ctx *ctx, const float *x, const void *stats, con
     return WSC_OK;
 }
 
-int launch_edge_finish(wsc_ctx *ctx, const float *e, const float *d, int B, int He, int We, int fh, int fw, float ms0,
-                       float ms1, float *edge, float *dp) {
-    WSC_CHECK(fh <= He && fw <= We, WSC_ERR_INVALID, "edge: feature size %dx%d exceeds the map %dx%d", fh, fw, He, We);
-    hipLaunchKernelGGL(edge_finish_kernel, dim3(grid_for((long long)B * fh * fw)), dim3(256), 0, ctx->stream, e, d, B,
-                       He, We, fh, fw, ms0, ms1, edge, dp);
+int launch_edge_finish(wsc_ctx *ctx, const float *e, int He, int We, const float *d, int Hd, int Wd, int B, int fh, int fw,
+                       float ms0, float ms1, float *edge, float *dp) {
+    WSC_CHECK(fh <= He && fw <= We && fh <= Hd && fw <= Wd, WSC_ERR_INVALID,
+              "edge: feature size %dx%d exceeds the maps %dx%d / %dx%d", fh, fw, He, We, Hd, Wd);
+    hipLaunchKernelGGL(edge_finish_kernel, dim3(grid_for((long long)B * fh * fw)), dim3(256), 0, ctx->stream, e, He, We,
+                       d, Hd, Wd, B, fh, fw, ms0, ms1, edge, dp);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }

@@ -40,8 +40,12 @@ struct IrnHead {
     ConvW conv;
     int groups = 1, up = 1;
     float *gamma = nullptr, *beta = nullptr; // device, [Cout]
-    int src = 0;                             // stage 1..5, or -6 / -7: the dp6 / dp7 concat buffers
-    int dst = 0, coff = 0;                   // destination concat: 0 edge, 1 dp6-input, 2 dp7-input, 3 dp7 hidden
+    int src = 0;                             // stage k (1-based) when > 0, concat buffer -src - 1 when < 0
+    int dst = 0, coff = 0;                   // destination concat buffer and channel offset inside it
+};
+// a concat buffer: NHWC with `channels` channels at the resolution of stage `stage` divided by `stride`
+struct IrnCat {
+    int channels, stage, stride;
 };
 
 enum OpType { OP_CONV = 0, OP_POOL = 1 };
@@ -66,8 +70,9 @@ struct wsc_net {
     int cls_max = 0; // 1: global max pooling (m7), 0: global average (vgg16)
     // IRNet EdgeDisplacement (arch >= WSC_ARCH_RESNET50_IRN): backbone stage taps + the two head branches
     std::vector<int> taps;       // op index whose output is stage k+1 (x1..x5)
-    std::vector<IrnHead> heads;  // fc_edge1..5, fc_dp1..5, fc_dp6, fc_dp7[0..2]
-    ConvW edge6, dp7b;           // fc_edge6 (bias), fc_dp7[3]
+    std::vector<IrnHead> heads;  // every Conv-GroupNorm-[Upsample]-ReLU head in execution order
+    std::vector<IrnCat> cats;    // concat buffers; cats[0] feeds the final edge conv, cats.back() the final dp conv
+    ConvW edge6, dp7b;           // final edge conv (bias) / final displacement conv
     float mean_shift[2] = {0.f, 0.f};
     std::vector<void *> allocs;
 };
@@ -403,22 +408,28 @@ int add_irn_head(wsc_net *net, const Dict &d, const HeadSpec &hs, int cin_pad) {
     return WSC_OK;
 }
 
-int build_irn_heads(wsc_net *net, const Dict &d, const std::vector<HeadSpec> &specs) {
+int build_irn_heads(wsc_net *net, const Dict &d, const std::vector<HeadSpec> &specs, const std::vector<IrnCat> &cats,
+                    const std::string &edge_final, int edge_in, const std::string &dp_final) {
+    net->cats = cats;
     for (const HeadSpec &hs : specs) WSC_TRY(add_irn_head(net, d, hs, 0));
-    // fc_edge6 = Conv2d(160, 1, 1, bias=True) on the 5 x 32-channel concat, zero-padded to 192 input channels
+    // final edge conv = Conv2d(edge_in, 1, 1, bias=True) on the edge concat, zero-padded to cats[0].channels inputs
     const HostTensor *w6, *b6, *w7;
-    WSC_TRY(get(d, "fc_edge6.weight", 4, &w6));
-    WSC_TRY(get(d, "fc_edge6.bias", 1, &b6));
-    WSC_CHECK(w6->shape[0] == 1 && w6->shape[1] == 160, WSC_ERR_SHAPE, "fc_edge6.weight must be [1][160][1][1]");
-    std::vector<float> w6p(192, 0.f);
-    for (int i = 0; i < 160; ++i) w6p[i] = w6->data[i];
+    WSC_TRY(get(d, edge_final + ".weight", 4, &w6));
+    WSC_TRY(get(d, edge_final + ".bias", 1, &b6));
+    WSC_CHECK(w6->shape[0] == 1 && w6->shape[1] == edge_in, WSC_ERR_SHAPE, "%s.weight must be [1][%d][1][1]",
+              edge_final.c_str(), edge_in);
+    const int cin_pad = cats[0].channels;
+    std::vector<float> w6p(cin_pad, 0.f);
+    for (int i = 0; i < edge_in; ++i) w6p[i] = w6->data[i];
     HostTensor t6;
-    t6.data = w6p.data(); t6.ndim = 4; t6.shape[0] = 1; t6.shape[1] = 192; t6.shape[2] = 1; t6.shape[3] = 1;
+    t6.data = w6p.data(); t6.ndim = 4; t6.shape[0] = 1; t6.shape[1] = cin_pad; t6.shape[2] = 1; t6.shape[3] = 1;
     std::vector<float> one1(1, 1.f), bias1(1, b6->data[0]);
     WSC_TRY(make_conv(net, &t6, 1, 0, 0, 0, one1, bias1, nullptr, nullptr, &net->edge6));
-    // fc_dp7[3] = Conv2d(256, 2, 1, bias=False); MeanShift subtracts running_mean in eval (resnet50_irn.py:96-108)
-    WSC_TRY(get(d, "fc_dp7.3.weight", 4, &w7));
-    WSC_CHECK(w7->shape[0] == 2 && w7->shape[1] == 256, WSC_ERR_SHAPE, "fc_dp7.3.weight must be [2][256][1][1]");
+    // final displacement conv = Conv2d(256, 2, 1, bias=False); MeanShift subtracts running_mean in eval
+    // (resnet50_irn.py:96-108)
+    WSC_TRY(get(d, dp_final + ".weight", 4, &w7));
+    WSC_CHECK(w7->shape[0] == 2 && w7->shape[1] == cats.back().channels, WSC_ERR_SHAPE, "%s.weight must be [2][%d][1][1]",
+              dp_final.c_str(), cats.back().channels);
     std::vector<float> one2(2, 1.f), zero2(2, 0.f);
     WSC_TRY(make_conv(net, w7, 1, 0, 0, 0, one2, zero2, nullptr, nullptr, &net->dp7b));
     if (has(d, "mean_shift.running_mean")) {
@@ -431,16 +442,20 @@ int build_irn_heads(wsc_net *net, const Dict &d, const std::vector<HeadSpec> &sp
     return WSC_OK;
 }
 
-// src: stage 1..5, -6 = concat of dp3|dp4|dp5 (768 ch), -7 = concat of dp1|dp2|dp_up3 (448 ch)
-// dst: 0 = edge concat (160 -> 192 ch), 1 = dp6 input, 2 = dp7 input, 3 = dp7 hidden (256 ch)
+// HeadSpec: {name, src, conv stride, out channels, GroupNorm groups, upsample, dst concat, channel offset};
+// src > 0 is a backbone stage, src < 0 the concat buffer -src - 1.
+// ResNet50 / VGG16 concat buffers: 0 = edge concat (5 x 32 -> 192 ch), 1 = dp3|dp4|dp5 (768, stage-3 resolution),
+// 2 = dp1|dp2|dp_up3 (448), 3 = fc_dp7 hidden (256); all but 1 at the stage-2 resolution.
+const std::vector<IrnCat> IRN_CATS5 = {{192, 2, 1}, {768, 3, 1}, {448, 2, 1}, {256, 2, 1}};
+
 int build_resnet50_irn(wsc_net *net, const Dict &d) {
     WSC_TRY(build_resnet50_backbone(net, d));
     const std::vector<HeadSpec> specs = {
         {"fc_edge1", 1, 1, 32, 4, 1, 0, 0},   {"fc_edge2", 2, 1, 32, 4, 1, 0, 32},  {"fc_edge3", 3, 1, 32, 4, 2, 0, 64},
         {"fc_edge4", 4, 1, 32, 4, 4, 0, 96},  {"fc_edge5", 5, 1, 32, 4, 4, 0, 128}, {"fc_dp1", 1, 1, 64, 8, 1, 2, 0},
         {"fc_dp2", 2, 1, 128, 16, 1, 2, 64},  {"fc_dp3", 3, 1, 256, 16, 1, 1, 0},   {"fc_dp4", 4, 1, 256, 16, 2, 1, 256},
-        {"fc_dp5", 5, 1, 256, 16, 2, 1, 512}, {"fc_dp6", -6, 1, 256, 16, 2, 2, 192}, {"fc_dp7", -7, 1, 256, 16, 1, 3, 0}};
-    return build_irn_heads(net, d, specs);
+        {"fc_dp5", 5, 1, 256, 16, 2, 1, 512}, {"fc_dp6", -2, 1, 256, 16, 2, 2, 192}, {"fc_dp7", -3, 1, 256, 16, 1, 3, 0}};
+    return build_irn_heads(net, d, specs, IRN_CATS5, "fc_edge6", 160, "fc_dp7.3");
 }
 
 int build_vgg16_irn(wsc_net *net, const Dict &d) {
@@ -458,8 +473,26 @@ int build_vgg16_irn(wsc_net *net, const Dict &d) {
         {"fc_edge1", 1, 2, 32, 4, 1, 0, 0},   {"fc_edge2", 2, 1, 32, 4, 1, 0, 32},  {"fc_edge3", 3, 1, 32, 4, 2, 0, 64},
         {"fc_edge4", 4, 1, 32, 4, 2, 0, 96},  {"fc_edge5", 5, 1, 32, 4, 2, 0, 128}, {"fc_dp1", 1, 2, 64, 8, 1, 2, 0},
         {"fc_dp2", 2, 1, 128, 16, 1, 2, 64},  {"fc_dp3", 3, 1, 256, 16, 1, 1, 0},   {"fc_dp4", 4, 1, 256, 16, 1, 1, 256},
-        {"fc_dp5", 5, 1, 256, 16, 1, 1, 512}, {"fc_dp6", -6, 1, 256, 16, 2, 2, 192}, {"fc_dp7", -7, 1, 256, 16, 1, 3, 0}};
-    return build_irn_heads(net, d, specs);
+        {"fc_dp5", 5, 1, 256, 16, 1, 1, 512}, {"fc_dp6", -2, 1, 256, 16, 2, 2, 192}, {"fc_dp7", -3, 1, 256, 16, 1, 3, 0}};
+    return build_irn_heads(net, d, specs, IRN_CATS5, "fc_edge6", 160, "fc_dp7.3");
+}
+
+// m7_irn.py:19-21,24-69,96-112: three stages (layer1 @1/2, layer2 @1/4, layer3_p1 + layer3_p2 @1/8); the edge
+// branch ends at the stage-1 resolution (1/2), the displacement branch at 1/4; fc_dp4 is a head on fc_dp3's output.
+int build_m7_irn(wsc_net *net, const Dict &d) {
+    const std::vector<std::pair<std::string, std::vector<int>>> cfg = {
+        {"layer1", {64, 64, -1}}, {"layer2", {128, 128, -1}}, {"layer3_p1", {256, 256, 256}}, {"layer3_p2", {-1, -2}}};
+    int cur = 0;
+    std::vector<int> layer_taps;
+    WSC_TRY(build_plain_stack(net, d, "m7", cfg, &cur, &net->F, &layer_taps));
+    net->final_buf = cur;
+    net->taps = {layer_taps[0], layer_taps[1], layer_taps[3]};
+    const std::vector<IrnCat> cats = {{128, 1, 1}, {256, 3, 1}, {448, 2, 1}, {256, 2, 1}}; // edge | dp3 | dp1|dp2|dp4 | hidden
+    const std::vector<HeadSpec> specs = {
+        {"fc_edge1", 1, 1, 32, 4, 1, 0, 0},  {"fc_edge2", 2, 1, 32, 4, 2, 0, 32},  {"fc_edge3", 3, 1, 32, 4, 4, 0, 64},
+        {"fc_dp1", 1, 2, 64, 8, 1, 2, 0},    {"fc_dp2", 2, 1, 128, 16, 1, 2, 64},  {"fc_dp3", 3, 1, 256, 16, 1, 1, 0},
+        {"fc_dp4", -2, 1, 256, 16, 2, 2, 192}, {"fc_dp5", -3, 1, 256, 16, 1, 3, 0}};
+    return build_irn_heads(net, d, specs, cats, "fc_edge4", 96, "fc_dp5.3");
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -611,6 +644,7 @@ int wsc_net_create(wsc_ctx *ctx, int arch, const wsc_tensor_desc *weights, int n
     case WSC_ARCH_M7_CAM: st = build_m7(net, d); break;
     case WSC_ARCH_RESNET50_IRN: st = build_resnet50_irn(net, d); break;
     case WSC_ARCH_VGG16_IRN: st = build_vgg16_irn(net, d); break;
+    case WSC_ARCH_M7_IRN: st = build_m7_irn(net, d); break;
     default:
         wsc_set_error("unknown arch %d", arch);
         st = WSC_ERR_INVALID;
@@ -718,7 +752,7 @@ int wsc_net_forward_features(wsc_ctx *ctx, const wsc_net *net, const float *x_de
 int wsc_net_forward_edge(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int S, int feat_h, int feat_w,
                          float *edge_dev, float *dp_dev) {
     WSC_CHECK(ctx && net && x_dev && edge_dev && dp_dev, WSC_ERR_INVALID, "wsc_net_forward_edge: null argument");
-    WSC_CHECK(net->arch == WSC_ARCH_RESNET50_IRN || net->arch == WSC_ARCH_VGG16_IRN, WSC_ERR_INVALID,
+    WSC_CHECK(!net->heads.empty() && net->cats.size() >= 2, WSC_ERR_INVALID,
               "wsc_net_forward_edge: the network is not an IRNet EdgeDisplacement net");
     WSC_CHECK(B > 0 && S > 0 && feat_h > 0 && feat_w > 0, WSC_ERR_INVALID, "wsc_net_forward_edge: B=%d S=%d", B, S);
     WSC_HIP(hipSetDevice(ctx->device));
@@ -726,48 +760,53 @@ int wsc_net_forward_edge(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, i
     const int planes = net->split ? 2 : 1;
     Plan pl;
     WSC_TRY(plan_dims(net, N, S, &pl));
-    WSC_CHECK(net->taps.size() == 5, WSC_ERR_INVALID, "internal: %zu stage taps", net->taps.size());
-    int Hs[5], Ws[5], Cs[5];
-    size_t tap_off[5], off = 0;
-    for (int k = 0; k < 5; ++k) {
+    const int NS = (int)net->taps.size(), NC = (int)net->cats.size();
+    std::vector<int> Hs(NS), Ws(NS), Cs(NS);
+    std::vector<size_t> tap_off(NS);
+    size_t off = 0;
+    for (int k = 0; k < NS; ++k) {
         const int op = net->taps[k];
         Hs[k] = pl.H[op]; Ws[k] = pl.W[op]; Cs[k] = pl.C[op];
         tap_off[k] = off;
         off += tap_plane_bytes(net, pl, N, k) * planes;
     }
-    // concat geometry: everything ends at the resolution of the stage-2 heads; the dp6 input at stage 3's
     auto outdim = [](int v, int stride) { return (v - 1) / stride + 1; };
-    const int H2 = outdim(Hs[1], 1), W2 = outdim(Ws[1], 1), H3 = outdim(Hs[2], 1), W3 = outdim(Ws[2], 1);
-    WSC_CHECK(feat_h <= H2 && feat_w <= W2, WSC_ERR_INVALID, "feature size %dx%d exceeds the head resolution %dx%d",
-              feat_h, feat_w, H2, W2);
-    const int cat_c[4] = {192, 768, 448, 256};
-    const int cat_h[4] = {H2, H3, H2, H2}, cat_w[4] = {W2, W3, W2, W2};
-    size_t cat_off[4], cat_bytes[4];
-    for (int i = 0; i < 4; ++i) {
+    std::vector<int> cat_c(NC), cat_h(NC), cat_w(NC);
+    std::vector<size_t> cat_off(NC), cat_bytes(NC);
+    for (int i = 0; i < NC; ++i) {
+        const IrnCat &c = net->cats[i];
+        cat_c[i] = c.channels;
+        cat_h[i] = outdim(Hs[c.stage - 1], c.stride);
+        cat_w[i] = outdim(Ws[c.stage - 1], c.stride);
         cat_bytes[i] = align_up((size_t)N * cat_h[i] * cat_w[i] * cat_c[i] * sizeof(bf16_t), 256);
         cat_off[i] = off;
         off += cat_bytes[i] * planes;
     }
+    const int He = cat_h[0], We = cat_w[0], Hd = cat_h[NC - 1], Wd = cat_w[NC - 1]; // edge / displacement maps
+    WSC_CHECK(feat_h <= He && feat_w <= We && feat_h <= Hd && feat_w <= Wd, WSC_ERR_INVALID,
+              "feature size %dx%d exceeds the head resolution %dx%d / %dx%d", feat_h, feat_w, He, We, Hd, Wd);
     size_t ftmp_elems = 0, part_bytes = 0;
+    int max_groups = 1;
     for (const IrnHead &h : net->heads) {
-        const int sh = h.src > 0 ? Hs[h.src - 1] : cat_h[h.src == -6 ? 1 : 2];
-        const int sw = h.src > 0 ? Ws[h.src - 1] : cat_w[h.src == -6 ? 1 : 2];
+        const int sh = h.src > 0 ? Hs[h.src - 1] : cat_h[-h.src - 1];
+        const int sw = h.src > 0 ? Ws[h.src - 1] : cat_w[-h.src - 1];
         const int ho = outdim(sh, h.conv.stride), wo = outdim(sw, h.conv.stride);
         ftmp_elems = std::max(ftmp_elems, (size_t)N * ho * wo * h.conv.Cout);
         part_bytes = std::max(part_bytes, group_norm_partial_bytes(N, ho, wo, h.groups));
+        max_groups = std::max(max_groups, h.groups);
     }
     const size_t ftmp_off = off; off += align_up(ftmp_elems * sizeof(float), 256);
     const size_t part_off = off; off += align_up(part_bytes, 256);
-    const size_t stat_off = off; off += align_up(sizeof(float) * 2 * N * 16, 256);
-    const size_t e_off = off; off += align_up(sizeof(float) * (size_t)N * H2 * W2, 256);
-    const size_t d_off = off; off += align_up(sizeof(float) * (size_t)N * H2 * W2 * 2, 256);
+    const size_t stat_off = off; off += align_up(sizeof(float) * 2 * N * max_groups, 256);
+    const size_t e_off = off; off += align_up(sizeof(float) * (size_t)N * He * We, 256);
+    const size_t d_off = off; off += align_up(sizeof(float) * (size_t)N * Hd * Wd * 2, 256);
 
     const bf16_t *feat, *feat_lo;
     int hf, wf;
     void *extra;
     WSC_TRY(run_backbone(ctx, net, x_dev, N, S, off, &feat, &feat_lo, &hf, &wf, &extra, true));
     char *base = (char *)extra;
-    // channels 160..191 of the edge concat feed zero weights but must not hold NaN bit patterns
+    // the padding channels of the edge concat feed zero weights but must not hold NaN bit patterns
     WSC_HIP(hipMemsetAsync(base + cat_off[0], 0, cat_bytes[0] * planes, ctx->stream));
 
     auto plane = [&](size_t o, size_t bytes, int which) -> bf16_t * {
@@ -795,7 +834,7 @@ int wsc_net_forward_edge(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, i
             x = plane(tap_off[k], pb, 0); x_lo = plane(tap_off[k], pb, 1);
             sh = Hs[k]; sw = Ws[k]; sc = Cs[k];
         } else {
-            const int ci = h.src == -6 ? 1 : 2;
+            const int ci = -h.src - 1;
             x = plane(cat_off[ci], cat_bytes[ci], 0); x_lo = plane(cat_off[ci], cat_bytes[ci], 1);
             sh = cat_h[ci]; sw = cat_w[ci]; sc = cat_c[ci];
         }
@@ -810,10 +849,11 @@ int wsc_net_forward_edge(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, i
                                         cat_h[di], cat_w[di], cat_c[di], h.coff, net->fmt));
     }
     float *e_out = (float *)(base + e_off), *d_out = (float *)(base + d_off);
-    WSC_TRY(run_conv(net->edge6, plane(cat_off[0], cat_bytes[0], 0), plane(cat_off[0], cat_bytes[0], 1), H2, W2, e_out));
-    WSC_TRY(run_conv(net->dp7b, plane(cat_off[3], cat_bytes[3], 0), plane(cat_off[3], cat_bytes[3], 1), H2, W2, d_out));
-    WSC_TRY(launch_edge_finish(ctx, e_out, d_out, B, H2, W2, feat_h, feat_w, net->mean_shift[0], net->mean_shift[1],
-                               edge_dev, dp_dev));
+    WSC_TRY(run_conv(net->edge6, plane(cat_off[0], cat_bytes[0], 0), plane(cat_off[0], cat_bytes[0], 1), He, We, e_out));
+    WSC_TRY(run_conv(net->dp7b, plane(cat_off[NC - 1], cat_bytes[NC - 1], 0), plane(cat_off[NC - 1], cat_bytes[NC - 1], 1),
+                     Hd, Wd, d_out));
+    WSC_TRY(launch_edge_finish(ctx, e_out, He, We, d_out, Hd, Wd, B, feat_h, feat_w, net->mean_shift[0],
+                               net->mean_shift[1], edge_dev, dp_dev));
     return WSC_OK;
 }
 

@@ -28,6 +28,7 @@ ARCH_VGG16_CAM = 1
 ARCH_M7_CAM = 2
 ARCH_RESNET50_IRN = 3
 ARCH_VGG16_IRN = 4
+ARCH_M7_IRN = 5
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
