@@ -108,3 +108,39 @@ def test_adp_update_cues_per_image_threshold():
     g2[0] *= 10
     d2 = cues.update_cues_adp({}, g2, inds, [7, 8, 9], 0.7)
     assert all(np.array_equal(d2["%d_cues" % x], d["%d_cues" % x]) for x in (7, 8, 9))
+
+
+def test_eval_sem_seg_report(tmp_path):
+    """step.eval_sem_seg.run: confusion / IoU / CSV / log lines from label PNGs (eval_sem_seg.py:12-64)."""
+    import types
+
+    from PIL import Image
+
+    from wsscam.step import eval_sem_seg
+
+    rng = np.random.default_rng(8)
+    names = ["2007_000033", "2007_000042"]
+    seg_dir = tmp_path / "seg"
+    seg_dir.mkdir()
+    gts, preds = {}, {}
+    for n in names:
+        gt = rng.integers(0, 4, (20, 30))
+        gt[rng.random((20, 30)) < 0.1] = 255
+        pr = np.where(rng.random((20, 30)) < 0.7, np.where(gt == 255, 0, gt), rng.integers(0, 4, (20, 30))).astype(np.uint8)
+        gts[n], preds[n] = gt, pr
+        Image.fromarray(pr).save(seg_dir / (n + ".png"))
+    args = types.SimpleNamespace(dataset="voc12", ids=names, gt_labels=gts, sem_seg_out_dir=str(seg_dir),
+                                 class_names={"bg": ["background"], "fg": ["a", "b", "c"]}, eval_dir=str(tmp_path / "eval"),
+                                 run_name="run", split="val", logfile=str(tmp_path / "log.txt"))
+    out = eval_sem_seg.run(args)
+    conf = np.zeros((4, 4), np.int64)
+    for n in names:
+        m = gts[n] != 255
+        np.add.at(conf, (gts[n][m], preds[n][m]), 1)
+    assert np.array_equal(out["confusion"], conf)
+    iou = np.diag(conf) / (conf.sum(0) + conf.sum(1) - np.diag(conf))
+    assert np.allclose(out["iou"], iou) and abs(out["miou"] - iou.mean()) < 1e-12
+    rows = open(tmp_path / "eval" / "run_val_iou.csv").read().strip().split("\n")
+    assert rows[0] == ",iou" and [r.split(",")[0] for r in rows[1:]] == ["background", "a", "b", "c", "miou"]
+    log = open(tmp_path / "log.txt").read()
+    assert "[eval_sem_seg, val] miou: " + str(np.nanmean(iou)) in log
