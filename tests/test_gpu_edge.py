@@ -260,3 +260,55 @@ def test_make_cam_run_adp_and_deepglobe(tmp_path, dataset):
         assert np.abs(rec["cam"] - s.numpy()).max() <= 5e-4, np.abs(rec["cam"] - s.numpy()).max()
         if dataset != "deepglobe":
             assert np.abs(rec["high_res"] - h.numpy()).max() <= 5e-4
+
+
+def test_full_config_batch_properties(ctx):
+    """BASELINE config 2/3 at full size (32 images = 64 samples at 321x321, M = 21, 10 iterations), checked through
+    size-independent properties: an image's result does not depend on what else is in the batch (bit-exact, CNN
+    and CRF), Q rows are distributions, labels are the arg-max of Q, and the run is bit-reproducible."""
+    from wsscam.net import resnet50_cam
+
+    B, S, C = 32, 321, 20
+    sd = cnn_ref.make_resnet50_cam_state_dict(C, seed=0)
+    m = resnet50_cam.CAM(None, "voc12", "", C, None, precision=_lib.PREC_F16)
+    m.load_state_dict(sd)
+    m.eval().cuda(0)
+    rng = np.random.default_rng(77)
+    imgs = [cnn_ref.synth_image(rng, S, S) for _ in range(B)]
+    x = np.stack([cnn_ref.msf_pack(im, (S, S)) for im in imgs])
+    cam = m.forward_batch(x)
+    assert cam.shape == (B, C, 21, 21) and np.isfinite(cam).all() and (cam >= 0).all()
+    for b in (0, 17, 31):
+        assert np.array_equal(m.forward_batch(x[b:b + 1])[0], cam[b])
+    assert np.array_equal(m.forward_batch(x), cam)
+
+    M = C + 1
+    hi = np.stack([np.stack([np.full((S, S), 0.15, np.float32)] + [cnn_ref.resize_bilinear_f64(
+        (cam[b, c] / (cam[b, c].max() + 1e-5))[..., None], (S, S))[..., 0].astype(np.float32) for c in range(C)])
+        for b in range(B)])
+    p = hi / hi.sum(1, keepdims=True)
+    U = np.ascontiguousarray(-np.log(np.clip(p, 1e-5, 1.0)).reshape(B, M, S * S).astype(np.float32))
+    rgb = np.stack(imgs)
+    cfg = (1.5, 3, 40, 13, 10, 10)
+
+    def run(rgbs, Us):
+        n = len(rgbs)
+        crf = _lib.Crf(ctx, ctx.to_device(np.ascontiguousarray(rgbs)), n, S, S, cfg[0], cfg[2], cfg[3])
+        q_dev, a_dev = ctx.alloc(n * M * S * S * 4), ctx.alloc(n * S * S * 4)
+        crf.inference(ctx.to_device(np.ascontiguousarray(Us)), M, cfg[1], cfg[4], cfg[5], q_dev, a_dev)
+        q, a = ctx.to_host(q_dev, (n, M, S * S), np.float32), ctx.to_host(a_dev, (n, S * S), np.int32)
+        vg, vb = crf.lattice_sizes()
+        crf.close()
+        q_dev.free()
+        a_dev.free()
+        return q, a, vg, vb
+
+    q, a, vg, vb = run(rgb, U)
+    assert np.abs(q.sum(1) - 1).max() <= 1e-5 and (q >= 0).all()
+    assert np.array_equal(a, q.argmax(1))
+    assert len(set(vg)) == 1 and min(vb) > 1000
+    for b in (0, 31):
+        q1, a1, _, vb1 = run(rgb[b:b + 1], U[b:b + 1])
+        assert np.array_equal(q1[0], q[b]) and np.array_equal(a1[0], a[b]) and vb1[0] == vb[b]
+    q2, a2, _, _ = run(rgb, U)
+    assert np.array_equal(q2, q) and np.array_equal(a2, a)
