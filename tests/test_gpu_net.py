@@ -327,3 +327,52 @@ def test_eval_cam_confusion_exact(ctx, tmp_path):
     eval_cam.write_report(Args, conf, ["c%d" % i for i in range(21)])
     assert "[eval_cam, val] miou: " in open(Args.logfile).read()
     assert open(tmp_path / "r_val_cam_iou.csv").readline().strip() == ",iou,precision,recall"
+
+
+def test_gen_cues_driver(tmp_path):
+    """02_cues/demo.py:26-222 for VOC2012: fg + bg models, class gating by score threshold x image label, Grad-CAM ->
+    41 x 41 seeds -> localization_cues.pickle; every stage against its torch / numpy restatement."""
+    import pickle
+
+    from wsscam.cues import demo as cues_demo
+    from wsscam.cues import utilities as cues
+
+    C = 20
+    fg, sd_fg = _vgg_model(C, seed=8)
+    bg, sd_bg = _vgg_model(C, seed=9)
+    rng = np.random.default_rng(10)
+    images = [cnn_ref.synth_image(rng, 321, 321) for _ in range(3)]  # already at the network size
+    labels = (rng.random((3, C)) < 0.2).astype(np.float64)
+    labels[:, 3] = 1
+    alphas = {"fg": cnn_ref.grad_cam_weights(sd_fg, "vgg16", cnn_ref.VGG16_CFG, 33, C),
+              "bg": cnn_ref.grad_cam_weights(sd_bg, "vgg16", cnn_ref.VGG16_CFG, 33, C)}
+    thr = {"fg": np.full((1, C), 0.45), "bg": np.full((1, C), 0.45)}
+    out = cues_demo.gen_cues("VOC2012", "VGG16", 0.2, 2, models={"fg": fg, "bg": bg}, alphas=alphas, thresholds=thr,
+                             images=images, labels=labels, out_dir=str(tmp_path), is_verbose=False)
+    saved = pickle.load(open(tmp_path / "localization_cues.pickle", "rb"))
+    assert sorted(saved) == sorted(out) == sorted(["%d_%s" % (i, k) for i in range(3) for k in ("cues", "labels")])
+    # restatement with the oracle network (batch maxima are per batch of 2: Q7)
+    x = np.stack([cnn_ref.normalize_int(im.astype(np.float64)) for im in images])
+    ref = {}
+    for lo, hi in ((0, 2), (2, 3)):
+        Hm, ip = {}, {}
+        for m, sd, a in (("fg", sd_fg, alphas["fg"]), ("bg", sd_bg, alphas["bg"])):
+            xt = torch.from_numpy(np.transpose(x[lo:hi], (0, 3, 1, 2)).astype(np.float32).copy())
+            with torch.no_grad():
+                feat = cnn_ref.plain_features(xt, sd, "vgg16", cnn_ref.VGG16_CFG)
+                sc = torch.sigmoid(torch.nn.functional.linear(feat.mean((2, 3)), sd["vgg16.classifier.0.weight"],
+                                                              sd["vgg16.classifier.0.bias"])).numpy()
+            ip[m] = (sc >= 0.45) * labels[lo:hi]
+            cam = np.maximum(np.einsum("ijkl,lm->ijkm", np.transpose(feat.numpy(), (0, 2, 3, 1)).astype(np.float64), a), 0)
+            cam = cam * ip[m][:, None, None, :]
+            Hm[m] = torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cam, (0, 3, 1, 2))), (41, 41),
+                                                    mode="bilinear", align_corners=False).numpy()
+        ci = [np.where(ip["fg"][i])[0] + 1 for i in range(hi - lo)]
+        cues.get_fgbg_cues(ref, Hm["fg"], Hm["bg"], ci, list(range(lo, hi)), 0.2)
+    for i in range(3):
+        assert np.array_equal(out["%d_labels" % i], ref["%d_labels" % i])
+        a, b = out["%d_cues" % i], ref["%d_cues" % i]
+        la, lb = np.zeros((41, 41), np.int64), np.zeros((41, 41), np.int64)
+        la[a[1], a[2]] = a[0] + 1
+        lb[b[1], b[2]] = b[0] + 1
+        assert (la == lb).mean() >= 0.995  # thresholded maps: a pixel on the 0.2 x max contour may flip

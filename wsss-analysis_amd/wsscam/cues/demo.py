@@ -1,0 +1,81 @@
+"""gen_cues -- mirror of 02_cues/demo.py:26-222 (VOC2012 / DeepGlobe seed generation; the ADP redirect uses
+cues.utilities.update_cues_adp on hsn.utilities.modify_by_htt's output).
+
+Same positional signature.  What the reference loads from `MODEL_ROOT` (Keras `.json/.h5/.mat` files) and from
+its Keras `Dataset` generators cannot be read here, so the loaded objects are passed in keyword-only:
+  models     {'fg': CAM wrapper, 'bg': CAM wrapper}  (wsscam.net.vgg16_cam.CAM / m7_cam.CAM with weights loaded)
+  alphas     {'fg': (F,C), 'bg': (F,C)} Grad-CAM weights (cues.utilities.get_grad_cam_weights or precomputed)
+  thresholds {'fg': (1,C), 'bg': (1,C)}  optimalScoreThresh of the .mat files
+  images     uint8 RGB images (list of (H,W,3)), `labels` (n, C) image-level labels (gen_curr.data)
+  out_dir    where `localization_cues.pickle` / `localization_cues_val.pickle` is written
+Per batch: scores + Grad-CAMs of the fg (and, for VOC2012, bg) model in ONE device pass each (the reference runs
+model.predict and K.function separately), resize to the 41 x 41 seed size on the device, threshold / overlap
+resolution on the host, pickle in the layout 03a_sec-dsrg/model.py:238-246 reads."""
+import math
+import os
+import pickle
+
+import numpy as np
+
+from ..voc12.dataloader import resize_bilinear_f64
+from . import utilities as cu
+
+SEED_SIZE = 41
+
+
+def read_batch(images, size, img_mean, img_std):
+    """02_cues/utilities.py:146-181 on in-memory images: (normalised float (B,S,S,3), original (B,S,S,3))."""
+    B = len(images)
+    norm = np.empty((B, size[0], size[1], 3))
+    raw = np.empty((B, size[0], size[1], 3))
+    for i, im in enumerate(images):
+        r = resize_bilinear_f64(np.asarray(im), size)  # the reference leaves same-size images uninitialised (Q4)
+        raw[i] = r
+        norm[i] = (r - np.asarray(img_mean, np.float64)) / np.asarray(img_std, np.float64)
+    return norm, raw
+
+
+def gen_cues(dataset, model_type, thresh, batch_size, set_name=None, run_train=True, is_verbose=True, *, models,
+             alphas, thresholds, images, labels, out_dir, class_names=None):
+    assert dataset in ["VOC2012", "DeepGlobe", "DeepGlobe_balanced"], "ADP: use gen_cues_adp"
+    assert model_type in ["X1.7", "M7", "VGG16"]
+    assert batch_size > 0 and set_name in [None, "tuning", "segtest"]
+    img_size = 321 if model_type in ["VGG16", "VGG16bg"] else 224
+    fgbg_modes = ["fg", "bg"] if dataset == "VOC2012" else ["fg"]
+    labels = np.asarray(labels)
+    n_cls = labels.shape[1]
+    if dataset == "VOC2012":
+        mean, std, ignore_ind = [104, 117, 123], [255, 255, 255], None
+    else:
+        mean, std, ignore_ind = [0, 0, 0], [255, 255, 255], 6
+    keep_inds = np.arange(n_cls)
+    thr = {m: np.asarray(thresholds[m]).reshape(1, -1) for m in fgbg_modes}
+    if ignore_ind is not None:
+        keep_inds = np.delete(keep_inds, ignore_ind)
+        thr = {m: t[:, keep_inds] for m, t in thr.items()}
+    cues = {}
+    n_batches = math.ceil(len(images) / batch_size)
+    for ib in range(n_batches):
+        lo, hi = ib * batch_size, min((ib + 1) * batch_size, len(images))
+        if is_verbose:
+            print("\tBatch #%d of %d" % (ib + 1, n_batches))
+        norm, _ = read_batch(images[lo:hi], (img_size, img_size), mean, std)
+        H, is_pass = {}, {}
+        for m in fgbg_modes:
+            cams, scores = cu.conv_and_cams(models[m], np.asarray(alphas[m]), norm, relu=True, want_scores=True)
+            scores = scores[:, keep_inds]
+            is_pass[m] = np.greater_equal(scores, thr[m]) * labels[lo:hi][:, keep_inds]
+            cams = cams[:, :, :, keep_inds].astype(np.float64) * is_pass[m][:, None, None, :]  # grad_cam :135-144
+            H[m] = cu.resize_stack(np.transpose(cams, (0, 3, 1, 2)), (SEED_SIZE, SEED_SIZE), ctx=models[m].ctx)
+        idx = list(range(lo, hi))
+        if dataset == "VOC2012":
+            class_inds = [np.where(is_pass["fg"][i])[0] + 1 for i in range(hi - lo)]
+            cues = cu.get_fgbg_cues(cues, H["fg"], H["bg"], class_inds, idx, thresh)
+        else:
+            class_inds = [np.where(is_pass["fg"][i])[0] for i in range(hi - lo)]
+            cues = cu.get_fg_cues(cues, H["fg"], class_inds, idx, thresh)
+    os.makedirs(out_dir, exist_ok=True)
+    name = "localization_cues.pickle" if run_train else "localization_cues_val.pickle"
+    with open(os.path.join(out_dir, name), "wb") as f:
+        pickle.dump(cues, f)
+    return cues
