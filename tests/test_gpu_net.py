@@ -376,3 +376,56 @@ def test_gen_cues_driver(tmp_path):
         la[a[1], a[2]] = a[0] + 1
         lb[b[1], b[2]] = b[0] + 1
         assert (la == lb).mean() >= 0.995  # thresholded maps: a pixel on the 0.2 x max contour may flip
+
+
+def test_hsn_segment_driver():
+    """03c_hsn/demo.py:18-268 (VOC2012 branch) end to end at the real 321 x 321 size: scores -> 1/3 threshold ->
+    HSN Grad-CAM -> batch-max background channel -> dense CRF; labels vs the oracle chain (torch net, numpy
+    post-processing, C CRF)."""
+    import scipy.special
+
+    from wsscam.hsn import demo as hsn_demo
+
+    C = 5
+    sd_fg = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, True, seed=11)
+    sd_bg = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, True, seed=12)
+    fg = _model(vgg16_cam.CAM, sd_fg, C, _lib.PREC_BF16X3)
+    bg = _model(vgg16_cam.CAM, sd_bg, C, _lib.PREC_BF16X3)
+    rng = np.random.default_rng(13)
+    images = [cnn_ref.synth_image(rng, 321, 321) for _ in range(2)]
+    alphas = {"fg": cnn_ref.grad_cam_weights(sd_fg, "vgg16", cnn_ref.VGG16_CFG, 33, C),
+              "bg": cnn_ref.grad_cam_weights(sd_bg, "vgg16", cnn_ref.VGG16_CFG, 33, C)}
+    out = hsn_demo.segment("VOC2012", "VGG16", 2, models={"fg": fg, "bg": bg}, alphas=alphas, images=images,
+                           is_verbose=False)
+    assert len(out) == 2 and out[0].shape == (321, 321)
+    x = np.stack([cnn_ref.normalize_int(im.astype(np.float64)) for im in images])
+    xt = torch.from_numpy(np.transpose(x, (0, 3, 1, 2)).astype(np.float32).copy())
+    H = {}
+    for m, sd in (("fg", sd_fg), ("bg", sd_bg)):
+        with torch.no_grad():
+            feat = cnn_ref.plain_features(xt, sd, "vgg16", cnn_ref.VGG16_CFG)
+            sc = torch.sigmoid(torch.nn.functional.linear(feat.mean((2, 3)), sd["vgg16.classifier.0.weight"],
+                                                          sd["vgg16.classifier.0.bias"])).numpy().astype(np.float64)
+        cams = np.einsum("ijkl,lm->ijkm", np.transpose(feat.numpy(), (0, 2, 3, 1)).astype(np.float64), alphas[m])
+        up = torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cams, (0, 3, 1, 2))), (321, 321),
+                                             mode="bilinear", align_corners=False).numpy()
+        up = np.maximum(up, 0)
+        H[m] = up / np.maximum(up.max(axis=(1, 2, 3), keepdims=True), 1e-7) * (sc * (sc >= 1 / 3))[:, :, None, None]
+    Y = np.zeros((2, C + 1, 321, 321))
+    X_bg = H["bg"].sum(1)
+    Y[:, 0] = 0.15 * scipy.special.expit(X_bg.max() - X_bg)
+    Y[:, 1:] = H["fg"]
+    cfg = (1.5, 3, 40, 13, 10, 10)
+    for b in range(2):
+        keep = np.where(Y[b].sum(axis=(1, 2)) > 0)[0]  # dcrf_process: classes with positive mass (utilities.py:425)
+        p = Y[b][keep]
+        U = np.ascontiguousarray(-np.log(np.clip(p, 1e-5, 1.0)).reshape(len(keep), -1).astype(np.float32))
+        _, ar, _ = helpers_crf(images[b], U, cfg)
+        ref = keep[ar.reshape(321, 321)]
+        assert (out[b] == ref).mean() >= 0.99, (out[b] == ref).mean()
+
+
+def helpers_crf(rgb, U, cfg):
+    from tests import helpers
+
+    return helpers.crf_oracle(rgb, U, cfg)
