@@ -189,3 +189,39 @@ def test_make_sem_seg_labels_end_to_end(tmp_path):
             ref = np.pad(cam["keys"] + 1, (1, 0), mode="constant")[torch.argmax(up_bg, dim=0).numpy()]
         assert set(np.unique(png)) <= set(np.pad(cam["keys"] + 1, (1, 0)).tolist())
         assert (png == ref).mean() >= 0.99, (png == ref).mean()
+
+
+@pytest.mark.parametrize("dataset", ["adp_func", "deepglobe"])
+def test_sem_seg_other_datasets(dataset):
+    """The ADP and DeepGlobe branches of make_sem_seg_labels._work (:71-99): no background padding, keys used as
+    they are; DeepGlobe walks on CAMs downsampled by 6 and writes a quarter-size label map."""
+    import types
+
+    from oracle import rw_ref
+    from wsscam.step import make_sem_seg_labels as mssl
+
+    sd = irn_ref.make_vgg16_irn_state_dict(seed=7, batchnorm=dataset != "adp_func")
+    m = vgg16_irn.EdgeDisplacement(None, dataset, "", 5, None, crop_size=96, stride=4, precision=_lib.PREC_BF16X3)
+    m.load_state_dict(sd)
+    m.eval().cuda(0)
+    rng = np.random.default_rng(12)
+    size = (68, 72) if dataset == "adp_func" else (288, 336)
+    x = cnn_ref.msf_pack(cnn_ref.synth_image(rng, 65, 65), (65, 65))
+    cam_hw = ((size[0] - 1) // 4 + 1, (size[1] - 1) // 4 + 1)
+    cam = {"keys": np.array([0, 1, 3]), "cam": rng.random((3,) + cam_hw).astype(np.float32)}
+    args = types.SimpleNamespace(dataset=dataset, beta=10, exp_times=6, sem_seg_bg_thres=0.25)
+    pred = mssl.sem_seg_one(m, {"img": x, "size": size, "name": "t"}, cam, args)
+    with torch.no_grad():
+        edge, _ = irn_ref.edge_displacement_forward(torch.from_numpy(x), sd, "vgg16", crop_size=96, stride=4)
+        cams = torch.from_numpy(cam["cam"])
+        out_size = size
+        if dataset == "deepglobe":
+            cams = torch.nn.functional.interpolate(cams.unsqueeze(0), size=[v // 6 for v in cams.shape[1:]], mode="bilinear",
+                                                   align_corners=False)[0]
+            out_size = (size[0] // 4, size[1] // 4)
+        edge = torch.nn.functional.interpolate(edge.unsqueeze(0), size=cams.shape[1:], mode="bilinear", align_corners=False)[0]
+        rw = rw_ref.propagate_to_edge(cams, edge, beta=10, exp_times=6, radius=5)
+        up = torch.nn.functional.interpolate(rw, size=out_size, mode="bilinear", align_corners=False)[..., 0, :out_size[0], :out_size[1]]
+        ref = cam["keys"][torch.argmax(up / torch.max(up), dim=0).numpy()]
+    assert pred.shape == ref.shape == out_size
+    assert (pred == ref).mean() >= 0.99, (pred == ref).mean()
