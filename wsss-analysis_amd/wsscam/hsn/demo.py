@@ -54,3 +54,61 @@ def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True,
         if is_verbose:
             print("\tBatch #%d of %d" % (ib + 1, n_batches))
     return out
+
+
+# ---- ADP (03c_hsn/demo.py:271-407 with the class bookkeeping of 03c_hsn/adp_cues.py:20-58) --------------------------
+ADP_MORPH = ["E.M.S", "E.M.U", "E.M.O", "E.T.S", "E.T.U", "E.T.O", "E.P", "C.D.I", "C.D.R", "C.L", "H.E", "H.K", "H.Y",
+             "S.M.C", "S.M.S", "S.E", "S.C.H", "S.R", "A.W", "A.B", "A.M", "M.M", "M.K", "N.P", "N.R.B", "N.R.A", "N.G.M",
+             "N.G.W"]
+ADP_FUNC = ["G.O", "G.N", "T"]
+
+
+class ADPClasses:
+    """classes / classinds of ADPCues.__init__ for the 31-class (non-X1.7) models."""
+
+    def __init__(self, all_classes=None):
+        self.classes = {"all": list(all_classes) if all_classes is not None else ADP_MORPH + ADP_FUNC, "morph": ADP_MORPH,
+                        "func": ADP_FUNC, "valid_morph": ["Background"] + ADP_MORPH,
+                        "valid_func": ["Background", "Other"] + ADP_FUNC}
+        c = self.classes
+        self.classinds = {
+            "morph2valid": [i for i, x in enumerate(c["valid_morph"]) if x in c["morph"]],
+            "func2valid": [i for i, x in enumerate(c["valid_func"]) if x in c["func"]],
+            "all2morph": [i for i, x in enumerate(c["all"]) if x in c["valid_morph"]],
+            "all2func": [i for i, x in enumerate(c["all"]) if x in c["valid_func"]],
+        }
+
+
+def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size, is_verbose=False, all_classes=None):
+    """demo.py:271-380 for one ADP model: per batch scores >= thresholds -> HSN Grad-CAM at (size, size) -> per
+    HTT type {morph, func}: scatter into the valid-class stack, modify_by_htt (background / other channels),
+    get_cs_gradcam, dense CRF with that type's configuration.  `images` are uint8 RGB (any size; resized like
+    ADPCues.read_batch), `dcrf_configs` {'morph': 6-vector, 'func': 6-vector} (the reference reads
+    `<htt>_optimal_pcc.npy`).  Returns {'morph': [label maps], 'func': [label maps]} at (size, size)."""
+    ac = ADPClasses(all_classes)
+    out = {"morph": [], "func": []}
+    thr = np.asarray(thresholds).reshape(1, -1)
+    for lo in range(0, len(images), batch_size):
+        hi = min(lo + batch_size, len(images))
+        _, raw = read_batch(images[lo:hi], (size, size), [0, 0, 0], [1, 1, 1])
+        raw = np.clip(np.rint(raw), 0, 255).astype(np.uint8)  # ADPCues.read_batch keeps the resized batch as uint8
+        norm = (raw - 193.09203) / 56.450138                  # adp_cues.py:130
+        _, scores = cu.conv_and_cams(model, np.asarray(alpha), norm, relu=False, want_scores=True)
+        is_pass = np.greater_equal(scores, thr)
+        H = np.transpose(hu.grad_cam(model, alpha, norm, is_pass, "final", scores, orig_sz=[size, size],
+                                     should_upsample=True), (0, 3, 1, 2))
+        Y = {}
+        for htt in ("morph", "func"):
+            valid = ac.classes["valid_" + htt]
+            Y[htt] = np.zeros((hi - lo, len(valid), size, size))
+            Y[htt][:, ac.classinds[htt + "2valid"]] = H[:, ac.classinds["all2" + htt]]
+            if htt == "morph":
+                Y[htt] = hu.modify_by_htt(Y[htt], raw, valid)
+            else:
+                adipose = [i for i, x in enumerate(ac.classes["morph"]) if x in ["A.W", "A.B", "A.M"]]
+                Y[htt] = hu.modify_by_htt(Y[htt], raw, valid, gradcam_adipose=Y["morph"][:, adipose])
+            cs = hu.get_cs_gradcam(Y[htt], valid, htt)
+            out[htt].extend(list(hu.dcrf_process(cs, raw, dcrf_configs[htt], ctx=model.ctx)))
+        if is_verbose:
+            print("\tBatch %d-%d" % (lo, hi))
+    return out
