@@ -490,3 +490,59 @@ def test_hsn_segment_adp_driver():
             _, ar, _ = helpers_crf(images[b], U, tuple(cfg))
             ref = keep[ar.reshape(S, S)]
             assert (out[htt][b] == ref).mean() >= 0.99, (htt, b, (out[htt][b] == ref).mean())
+
+
+def test_gen_cues_adp_driver(tmp_path):
+    """02_cues/demo.py:224-310: ADP seeds for both HTT types from one 31-class model; checks the cue layout, that
+    every cue class is a passing class (plus the synthesised Background / Other), and the restated chain for morph."""
+    import pickle
+
+    import scipy.ndimage
+    import scipy.special
+
+    from tests.test_gpu_edge import _adp_like_image
+    from wsscam.cues import demo as cues_demo
+    from wsscam.cues import utilities as cues
+    from wsscam.hsn.demo import ADPClasses
+
+    C, S = 31, 224
+    sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, False, seed=31)
+    model = _model(vgg16_cam.CAM, sd, C, _lib.PREC_BF16X3)
+    rng = np.random.default_rng(32)
+    images = [_adp_like_image(rng, S, S) for _ in range(3)]
+    alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 33, C)
+    dirs = {"morph": str(tmp_path / "m"), "func": str(tmp_path / "f")}
+    out = cues_demo.gen_cues_adp("VGG16", 0.2, 2, S, dirs, "tuning", False, model=model, alpha=alpha,
+                                 thresholds=np.full((1, C), 0.5), images=images)
+    assert pickle.load(open(tmp_path / "m" / "localization_cues.pickle", "rb")).keys() == out["morph"].keys()
+    raw = np.stack(images)
+    xt = torch.from_numpy(np.transpose((raw - 193.09203) / 56.450138, (0, 3, 1, 2)).astype(np.float32).copy())
+    with torch.no_grad():
+        feat = cnn_ref.plain_features(xt, sd, "vgg16", cnn_ref.VGG16_CFG)
+        sc = torch.sigmoid(torch.nn.functional.linear(feat.mean((2, 3)), sd["vgg16.classifier.0.weight"],
+                                                      sd["vgg16.classifier.0.bias"])).numpy()
+    ip = sc >= 0.5
+    cam = np.maximum(np.einsum("ijkl,lm->ijkm", np.transpose(feat.numpy(), (0, 2, 3, 1)).astype(np.float64), alpha), 0)
+    H = torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cam * ip[:, None, None, :], (0, 3, 1, 2))), (41, 41),
+                                        mode="bilinear", align_corners=False).numpy()
+    ac = ADPClasses()
+    valid = ac.classes["valid_morph"]
+    ref = {}
+    for lo, hi in ((0, 2), (2, 3)):
+        seeds = np.zeros((hi - lo, len(valid), 41, 41))
+        seeds[:, ac.classinds["morph2valid"]] = H[lo:hi][:, ac.classinds["all2morph"]]
+        bgm = np.stack([scipy.ndimage.gaussian_filter(0.75 * scipy.special.expit(4 * (raw[i].mean(-1) - 240)), sigma=2)
+                        for i in range(lo, hi)])
+        bgm = torch.nn.functional.interpolate(torch.from_numpy(bgm)[:, None], (41, 41), mode="bilinear",
+                                              align_corners=False).numpy()[:, 0]
+        seeds[:, 0] = bgm - seeds[:, [valid.index(c) for c in ("A.W", "A.B", "A.M")]].max(1)
+        ci = [np.array(ac.classinds["morph2valid"])[ip[i][:28]] for i in range(lo, hi)]
+        cues.update_cues_adp(ref, seeds, ci, list(range(lo, hi)), 0.2)
+    for i in range(3):
+        assert np.array_equal(out["morph"]["%d_labels" % i], ref["%d_labels" % i])
+        a, b = out["morph"]["%d_cues" % i], ref["%d_cues" % i]
+        la, lb = np.zeros((41, 41), np.int64), np.zeros((41, 41), np.int64)
+        la[a[1], a[2]] = a[0] + 1
+        lb[b[1], b[2]] = b[0] + 1
+        assert (la == lb).mean() >= 0.99
+        assert out["func"]["%d_labels" % i][0] == 1 and out["func"]["%d_cues" % i].shape[0] == 3

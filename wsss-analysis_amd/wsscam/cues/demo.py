@@ -79,3 +79,51 @@ def gen_cues(dataset, model_type, thresh, batch_size, set_name=None, run_train=T
     with open(os.path.join(out_dir, name), "wb") as f:
         pickle.dump(cues, f)
     return cues
+
+
+def gen_cues_adp(model_type, thresh, batch_size, size, cues_dir, set_name, is_verbose, *, model, alpha, thresholds,
+                 images, all_classes=None):
+    """02_cues/demo.py:224-310 (ADP seed generation): one model, scores >= thresholds, ReLU Grad-CAM, 41 x 41
+    seeds, per HTT type {morph, func} the valid-class stack with the background / other channels of
+    modify_by_htt and update_cues's per-image thresholds; writes `<cues_dir>/ADP-<htt>_.../localization_cues.pickle`
+    like the reference when `cues_dir` is a dict {'morph': dir, 'func': dir}, else returns the two cue dicts."""
+    from ..hsn import utilities as hu
+    from ..hsn.demo import ADPClasses
+
+    ac = ADPClasses(all_classes)
+    arr = {k: np.array(ac.classinds[k]) for k in ("morph2valid", "func2valid")}
+    morph_all = [i for i, x in enumerate(ac.classes["all"]) if x in ac.classes["morph"]]
+    func_all = [i for i, x in enumerate(ac.classes["all"]) if x in ac.classes["func"]]
+    cues = {"morph": {}, "func": {}}
+    thr = np.asarray(thresholds).reshape(1, -1)
+    for lo in range(0, len(images), batch_size):
+        hi = min(lo + batch_size, len(images))
+        _, raw = read_batch(images[lo:hi], (size, size), [0, 0, 0], [1, 1, 1])
+        raw = np.clip(np.rint(raw), 0, 255).astype(np.uint8)  # ADPCues.read_batch keeps the batch as uint8
+        norm = (raw - 193.09203) / 56.450138
+        cams, scores = cu.conv_and_cams(model, np.asarray(alpha), norm, relu=True, want_scores=True)
+        is_pass = np.greater_equal(scores, thr)
+        H = cams.astype(np.float64) * is_pass[:, None, None, :]          # ADPCues.grad_cam, adp_cues.py:191-223
+        H = cu.resize_stack(np.transpose(H, (0, 3, 1, 2)), (SEED_SIZE, SEED_SIZE), ctx=model.ctx)
+        ip = {"morph": is_pass[:, morph_all], "func": is_pass[:, func_all]}
+        seeds = {}
+        for htt in ("morph", "func"):
+            valid = ac.classes["valid_" + htt]
+            seeds[htt] = np.zeros((hi - lo, len(valid), SEED_SIZE, SEED_SIZE))
+            seeds[htt][:, ac.classinds[htt + "2valid"]] = H[:, ac.classinds["all2" + htt]]
+            class_inds = [arr[htt + "2valid"][ip[htt][i]] for i in range(hi - lo)]
+            if htt == "morph":
+                seeds[htt] = hu.modify_by_htt(seeds[htt], raw, valid)
+            else:
+                class_inds = [np.append(1, x) for x in class_inds]
+                adipose = [i for i, x in enumerate(ac.classes["morph"]) if x in ["A.W", "A.B", "A.M"]]
+                seeds[htt] = hu.modify_by_htt(seeds[htt], raw, valid, gradcam_adipose=seeds["morph"][:, adipose])
+            cu.update_cues_adp(cues[htt], seeds[htt], class_inds, list(range(lo, hi)), thresh)
+        if is_verbose:
+            print("\tBatch %d-%d" % (lo, hi))
+    if isinstance(cues_dir, dict):
+        for htt in ("morph", "func"):
+            os.makedirs(cues_dir[htt], exist_ok=True)
+            with open(os.path.join(cues_dir[htt], "localization_cues.pickle"), "wb") as f:
+                pickle.dump(cues[htt], f)
+    return cues
