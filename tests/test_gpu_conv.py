@@ -95,3 +95,31 @@ def test_conv_identity_weights_detect_transposes(ctx):
     w[np.arange(64), perm, 0, 0] = 1.0
     y = _run(ctx, x, w, 1, 0, None, None, None, False, _lib.PREC_BF16)
     assert np.array_equal(y, bf16_round(x)[:, perm])
+
+
+def test_conv_random_shapes_sweep(ctx):
+    """Seeded random sweep over shapes the fixed list does not hit: odd sizes, 5x5 / 1x3 kernels, pads that differ
+    from k//2, stride-2 1x1 heads (IRNet), Cout = 8 ... 264, batch sizes whose M straddles tile boundaries."""
+    rng = np.random.default_rng(2024)
+    for it in range(24):
+        Cin = int(rng.choice([64, 128, 192]))
+        k = int(rng.choice([1, 1, 3, 5]))
+        stride = int(rng.choice([1, 2]))
+        pad = int(rng.integers(0, k // 2 + 2)) if k > 1 else 0
+        H, W = int(rng.integers(max(k, 2), 30)), int(rng.integers(max(k, 2), 30))
+        N = int(rng.integers(1, 5))
+        Cout = int(rng.choice([8, 32, 40, 64, 72, 128, 200, 264]))
+        if (H + 2 * pad - k) // stride + 1 < 1 or (W + 2 * pad - k) // stride + 1 < 1:
+            continue
+        x = rng.normal(0, 1, (N, Cin, H, W)).astype(np.float32)
+        w = (rng.normal(0, 1, (Cout, Cin, k, k)) * np.sqrt(2.0 / (Cin * k * k))).astype(np.float32)
+        scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+        shift = rng.normal(0, 0.2, Cout).astype(np.float32)
+        y = _run(ctx, x, w, stride, pad, scale, shift, None, bool(it & 1), _lib.PREC_BF16X3)
+        ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), stride=stride, padding=pad)
+        ref = ref * torch.from_numpy(scale).double()[None, :, None, None] + torch.from_numpy(shift).double()[None, :, None, None]
+        if it & 1:
+            ref = torch.relu(ref)
+        ref = ref.numpy()
+        assert y.shape == ref.shape, (it, y.shape, ref.shape)
+        assert np.abs(y - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-3), (it, N, Cin, H, W, Cout, k, stride, pad)
