@@ -191,3 +191,22 @@ def test_cam_to_ir_label_mirror(ctx):
     assert out.shape == (H, W) and out.dtype == np.uint8
     assert (out == ref).mean() >= 0.995
     assert set(np.unique(out)) <= {0, 5, 12, 255}
+
+
+def test_crf_random_sweep(ctx):
+    """Seeded random sweep: image sizes 5..90 (non-square), M 1..32, batches of 1..4, all three configurations and
+    iteration counts 1..10 -- identical lattices, max|dQ| <= 1e-3, label agreement >= 99.5 % on every image."""
+    rng = np.random.default_rng(77)
+    for it in range(10):
+        H, W = int(rng.integers(5, 90)), int(rng.integers(5, 90))
+        M = int(rng.integers(1, 33))
+        B = int(rng.integers(1, 5))
+        base = CFGS[it % len(CFGS)]
+        cfg = base[:5] + (int(rng.integers(1, 11)),)
+        cases = [helpers.synth_crf_case(rng, H, W, M) for _ in range(B)]
+        q, a, vg, vb = _gpu_crf(ctx, [c[0] for c in cases], [c[1] for c in cases], cfg)
+        for b, (rgb, U, _) in enumerate(cases):
+            qr, ar, ls = helpers.crf_oracle(rgb, U, cfg)
+            assert (vg[b], vb[b]) == (ls[0], ls[1]), (it, H, W, M, B)
+            assert np.abs(q[b] - qr).max() <= 1e-3, (it, H, W, M, B, cfg, np.abs(q[b] - qr).max())
+            assert (a[b] == ar).mean() >= 0.995, (it, H, W, M, B, (a[b] == ar).mean())
