@@ -123,3 +123,30 @@ def test_conv_random_shapes_sweep(ctx):
         ref = ref.numpy()
         assert y.shape == ref.shape, (it, y.shape, ref.shape)
         assert np.abs(y - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-3), (it, N, Cin, H, W, Cout, k, stride, pad)
+
+
+@pytest.mark.parametrize("precision", [_lib.PREC_F16, _lib.PREC_BF16X3])
+def test_conv_square_tile_large_layer(ctx, precision):
+    """A layer big enough for the 256 x 256 tile (CoutPad % 256 == 0, >= 8 K-steps, >= 768 tiles: conv_igemm.hip tile
+    choice), with a ragged last tile row, residual and ReLU; fp32 oracle (float64 is too slow at 58 GFLOP)."""
+    N, Cin, H, W, Cout, k = 50, 64, 63, 63, 256, 3
+    rng = np.random.default_rng(77)
+    x = rng.normal(0, 1, (N, Cin, H, W)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, Cin, k, k)) * np.sqrt(2.0 / (Cin * k * k))).astype(np.float32)
+    w *= (1.0 + 0.5 * np.arange(Cout, dtype=np.float32) / Cout)[:, None, None, None]
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.normal(0, 0.2, Cout).astype(np.float32)
+    res = rng.normal(0, 1, (N, Cout, H, W)).astype(np.float32)
+    assert ((N * H * W + 255) // 256) * (Cout // 256) >= 768
+    y = _run(ctx, x, w, 1, 1, scale, shift, res, True, precision)
+    if precision == _lib.PREC_F16:
+        xr, wr, rr = f16_round(x), f16_round(w), f16_round(res)
+    else:
+        xr, wr, rr = x, w, res
+    ref = F.conv2d(torch.from_numpy(xr), torch.from_numpy(wr), stride=1, padding=1)
+    ref = torch.relu(ref * torch.from_numpy(scale)[None, :, None, None] + torch.from_numpy(shift)[None, :, None, None] +
+                     torch.from_numpy(rr)).numpy()
+    mx = np.abs(ref).max()
+    err = np.abs(y - ref)
+    bound = 2.0 ** -11 * np.abs(ref) + 3e-4 * mx if precision == _lib.PREC_F16 else np.full_like(ref, 1e-4 * mx)
+    assert not (err > bound).any(), "max err %.4g (max|ref| %.3g)" % (err.max(), mx)

@@ -172,7 +172,7 @@ int wsc_ctx_upload_small(wsc_ctx *ctx, void *dst_dev, const void *src_host, size
 // precision every activation has a second ("lo") plane.
 struct ConvLaunch {
     const bf16_t *x, *x_lo;     // input  [N][H][W][Cin]   (Cin = 4 in small-Cin mode)
-    const bf16_t *w;            // packed [CoutPad][Kw] bf16, K order (kh, kw, cin); split: [hi K | lo K]
+    const bf16_t *w;            // packed [CoutPad][Kw] bf16, K order (cin/64, kh, kw, cin%64); split: [hi K | lo K]
     const float *s1, *b1;       // y = acc*s1 + b1 (folded BN, or conv bias with s1 = 1)
     const float *s2, *b2;       // optional post-ReLU affine (VGG's conv->ReLU->BN order), or null
     const bf16_t *res, *res_lo; // optional residual [M][Cout]

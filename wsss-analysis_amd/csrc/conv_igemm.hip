@@ -48,6 +48,7 @@ struct ConvKArgs {
     // decodes 4 output rows per thread and a hardware-less 32-bit division costs ~25 VALU instructions
     unsigned div_howo_mul, div_howo_s1, div_howo_s2, div_wo_mul, div_wo_s1, div_wo_s2;
     int cchunks;     // Cin / 64 (generic mode)
+    int ntaps;       // kh * kw
     int ksteps_base; // K-steps of one precision segment
     int nk;          // total K-steps (x3 in split mode)
     int Kw;          // packed weight row length in elements
@@ -67,12 +68,19 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 //   256-row tile: 8 waves, 3 stages (144 KB), 1 block per CU: 0.73x the L2->LDS bytes per FLOP and a
 //   prefetch distance of two K-steps, with counted s_waitcnt vmcnt + raw s_barrier so a stage stays in
 //   flight across the barrier (a __syncthreads() would drain the LDS DMA every K-step).
-template <int BM, int BN, int MODE, bool SPLIT, int ET, bool GLDS, int STAGES>
+template <int BM, int BN, int MODE, bool SPLIT, int ET, bool GLDS, int STAGES, int WMT = 64>
 __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     constexpr int NT = BM * 2;   // threads
     constexpr int NW = BM / 32;  // waves
-    constexpr int WN = BN / 2;
+    // waves are laid out WR (along M) x WC (along N); a wave owns a WMT x WN tile = MI x NI MFMA tiles.
+    // WMT = 64 (default): WC = 2, 64 x BN/2 per wave.  WMT = 128 with a 256 x 256 block: 2 x 4 waves of 128 x 64 --
+    // half the LDS-DMA bytes per FLOP of the 128 x 128 block and 0.75x the fragment reads per MFMA.
+    constexpr int WR = BM / WMT;
+    constexpr int WC = NW / WR;
+    constexpr int WN = BN / WC;
+    constexpr int MI = WMT / 32;
     constexpr int NI = WN / 32;
+    static_assert(WR * WC == NW && WN % 32 == 0 && (WMT == 64 || WMT == 128), "wave layout");
     constexpr int NB = BN * 8 / NT; // B 16-byte slots per thread per K-step
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int B_BYTES = BN * BK * 2;
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform: LDS DMA destinations stay in SGPRs
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wm = wv / WC, wn = wv - wm * WC;
 
     // XCD-aware, bijective block -> tile map: consecutive tiles (which share the A rows)
     // stay on one XCD's L2.
@@ -160,8 +168,8 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             ktl = kt - seg * p.ksteps_base;
         }
         const bf16_t *src = (SPLIT && seg == 1) ? p.x_lo : p.x;
-        const int tap = ktl / p.cchunks;
-        const int cc = ktl - tap * p.cchunks;
+        const int cc = ktl / p.ntaps;
+        const int tap = ktl - cc * p.ntaps;
         const int khi = tap / p.kw;
         const int kwi = tap - khi * p.kw;
         const long long tap_off = ((long long)khi * p.W + kwi) * p.Cin + cc * 64;
@@ -192,8 +200,8 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
         }
         const bf16_t *src = (SPLIT && seg == 1) ? p.x_lo : p.x;
         if (MODE == 0) {
-            const int tap = ktl / p.cchunks;
-            const int cc = ktl - tap * p.cchunks;
+            const int cc = ktl / p.ntaps;
+            const int tap = ktl - cc * p.ntaps;
             const int khi = tap / p.kw;
             const int kwi = tap - khi * p.kw;
             const long long tap_off = ((long long)khi * p.W + kwi) * p.Cin + cc * 64 + slot * 8;
@@ -234,9 +242,9 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
         for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4_t *>(sb + lds_off(lrow + 32 * i, slot)) = rb[i];
     };
 
-    f32x16_t acc[2][NI];
+    f32x16_t acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -265,12 +273,12 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             // k-slice ks+1 are issued before the MFMAs of ks; LDS returns in order, so lgkmcnt(4)
             // means "all but the 4 newest reads have landed".
             const unsigned sa = lds0 + buf * A_BYTES, sb = lds0 + STAGES * A_BYTES + buf * B_BYTES;
-            u32x4_t fa[2][2], fb[2][NI];
+            u32x4_t fa[2][MI], fb[2][NI];
             auto rd = [&](int set, int ks) {
                 const int sl = ks * 2 + kgrp;
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][mi]) : "v"(sa + lds_off(wm * 64 + mi * 32 + l31, sl)) : "memory");
+                for (int mi = 0; mi < MI; ++mi)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][mi]) : "v"(sa + lds_off(wm * WMT + mi * 32 + l31, sl)) : "memory");
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][ni]) : "v"(sb + lds_off(wn * WN + ni * 32 + l31, sl)) : "memory");
@@ -281,13 +289,13 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
                 const int set = ks & 1;
                 if (ks < 3) {
                     rd(set ^ 1, ks + 1);
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 + NI) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI + NI) : "memory");
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) mfma(fa[set][mi], fb[set][ni], acc[mi][ni]);
             }
@@ -298,15 +306,15 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int sl = ks * 2 + kgrp;
-            u32x4_t af[2], bfr[NI];
+            u32x4_t af[MI], bfr[NI];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                af[mi] = *reinterpret_cast<const u32x4_t *>(sa + lds_off(wm * 64 + mi * 32 + l31, sl));
+            for (int mi = 0; mi < MI; ++mi)
+                af[mi] = *reinterpret_cast<const u32x4_t *>(sa + lds_off(wm * WMT + mi * 32 + l31, sl));
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 bfr[ni] = *reinterpret_cast<const u32x4_t *>(sb + lds_off(wn * WN + ni * 32 + l31, sl));
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) mfma(af[mi], bfr[ni], acc[mi][ni]);
         }
@@ -355,13 +363,14 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             n_wk = ((SPLIT && n_seg == 2) ? p.Kbase : 0) + n_ktl * 64;
         };
         auto advance = [&]() {
+            // K order (channel chunk, kh, kw): the taps of one 64-channel chunk are consecutive K-steps
             ++n_ktl;
-            if (++n_cc == p.cchunks) {
-                n_cc = 0;
-                if (++n_kwi == p.kw) {
-                    n_kwi = 0;
-                    if (++n_khi == p.kh) {
-                        n_khi = 0;
+            if (++n_kwi == p.kw) {
+                n_kwi = 0;
+                if (++n_khi == p.kh) {
+                    n_khi = 0;
+                    if (++n_cc == p.cchunks) {
+                        n_cc = 0;
                         n_ktl = 0;
                         ++n_seg;
                     }
@@ -400,12 +409,12 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             }
             if (!(p.debug & 2)) {
                 const unsigned sa = lds0 + cur * A_BYTES, sb = lds0 + STAGES * A_BYTES + cur * B_BYTES;
-                u32x4_t fa[2][2], fb[2][NI];
+                u32x4_t fa[2][MI], fb[2][NI];
                 auto rd = [&](int set, int ks) {
                     const int sl = ks * 2 + kgrp;
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][mi]) : "v"(sa + lds_off(wm * 64 + mi * 32 + l31, sl)) : "memory");
+                    for (int mi = 0; mi < MI; ++mi)
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][mi]) : "v"(sa + lds_off(wm * WMT + mi * 32 + l31, sl)) : "memory");
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][ni]) : "v"(sb + lds_off(wn * WN + ni * 32 + l31, sl)) : "memory");
@@ -416,13 +425,13 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
                     const int set = ks & 1;
                     if (ks < 3) {
                         rd(set ^ 1, ks + 1);
-                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 + NI) : "memory");
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI + NI) : "memory");
                     } else {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni) mfma(fa[set][mi], fb[set][ni], acc[mi][ni]);
                 }
@@ -458,18 +467,26 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     const bool cok = c < p.Cout;
     const bool full = c + 8 <= p.Cout;
     const bool has_res = p.res != nullptr && full;
-    uint4 rres[NPASS], rres_lo[NPASS];
+    // (the 256 x 256 tile requests them per 128-row group: 16 passes of residual rows next to 128 accumulator
+    // registers would not fit the 256-VGPR budget of 2 waves per SIMD)
+    constexpr bool PRE_ALL = WMT == 64;
+    constexpr int NHALF_R = STAGES == 1 ? BM / 64 : (WMT == 128 ? BM / 128 : 1);
+    constexpr int NRES = PRE_ALL ? NPASS : NPASS / NHALF_R;
+    uint4 rres[NRES], rres_lo[NRES];
+    auto fetch_res = [&](int first_pass) {
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int m = m0 + pass * RPP + r0;
-        rres[pass] = make_uint4(0, 0, 0, 0);
-        rres_lo[pass] = make_uint4(0, 0, 0, 0);
-        if (has_res && m < p.M) {
-            const long long o = (long long)m * p.Cout + c;
-            rres[pass] = *reinterpret_cast<const uint4 *>(p.res + o);
-            if (SPLIT) rres_lo[pass] = *reinterpret_cast<const uint4 *>(p.res_lo + o);
+        for (int i = 0; i < NRES; ++i) {
+            const int m = m0 + (first_pass + i) * RPP + r0;
+            rres[i] = make_uint4(0, 0, 0, 0);
+            rres_lo[i] = make_uint4(0, 0, 0, 0);
+            if (has_res && m < p.M) {
+                const long long o = (long long)m * p.Cout + c;
+                rres[i] = *reinterpret_cast<const uint4 *>(p.res + o);
+                if (SPLIT) rres_lo[i] = *reinterpret_cast<const uint4 *>(p.res_lo + o);
+            }
         }
-    }
+    };
+    if (PRE_ALL) fetch_res(0);
     float s1[8], b1[8], s2[8], b2[8];
     const bool post = p.s2 != nullptr;
 #pragma unroll
@@ -486,17 +503,19 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     // and a third block fits the CU: layer1.conv3 of the ResNet50 stack went from 190-205 us to 128 us.
     // (Splitting everywhere costs more than it gains: stem 179 -> 219 us, layer2.0.conv1 88 -> 105 us.)
     float *ct = reinterpret_cast<float *>(smem);
-    constexpr int NHALF = STAGES == 1 ? BM / 64 : 1;
+    // The 256 x 256 tile goes in two 128-row groups (130 KB of fp32; the whole tile would need 260 KB).
+    constexpr int NHALF = STAGES == 1 ? BM / 64 : (WMT == 128 ? BM / 128 : 1);
     constexpr int GR = BM / NHALF;     // tile rows per group
     constexpr int PPH = NPASS / NHALF; // passes per group
-    static_assert(NPASS % NHALF == 0 && PPH * RPP == GR, "epilogue pass layout");
-    const int grp = (wm * 64) / GR, roff = wm * 64 - grp * GR;
+    static_assert(NPASS % NHALF == 0 && PPH * RPP == GR && GR % WMT == 0, "epilogue pass layout");
+    const int grp = (wm * WMT) / GR, roff = wm * WMT - grp * GR;
 #pragma unroll
     for (int half = 0; half < NHALF; ++half) {
         if (half > 0) __syncthreads(); // the previous group's reads are done
+        if (!PRE_ALL) fetch_res(half * PPH);
         if (grp == half) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -526,14 +545,15 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
                 for (int j = 0; j < 8; ++j) v[j] = v[j] * s1[j] + b1[j];
                 const long long o = (long long)m * p.Cout + c;
                 if (has_res) {
-                    const uint32_t rw[4] = {rres[pass].x, rres[pass].y, rres[pass].z, rres[pass].w};
+                    const int ri = PRE_ALL ? pass : pp;
+                    const uint32_t rw[4] = {rres[ri].x, rres[ri].y, rres[ri].z, rres[ri].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         v[2 * j] += h16_to_f32((bf16_t)(rw[j] & 0xffffu), ET);
                         v[2 * j + 1] += h16_to_f32((bf16_t)(rw[j] >> 16), ET);
                     }
                     if (SPLIT) {
-                        const uint32_t lw[4] = {rres_lo[pass].x, rres_lo[pass].y, rres_lo[pass].z, rres_lo[pass].w};
+                        const uint32_t lw[4] = {rres_lo[ri].x, rres_lo[ri].y, rres_lo[ri].z, rres_lo[ri].w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             v[2 * j] += bf16_to_f32((bf16_t)(lw[j] & 0xffffu));
@@ -578,15 +598,17 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     }
 }
 
-template <int BM, int BN, int MODE, bool SPLIT, int ET, int STAGES>
+template <int BM, int BN, int MODE, bool SPLIT, int ET, int STAGES, int WMT = 64>
 int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     constexpr bool GLDS = MODE == 0; // LDS-DMA staging for every generic layer; small-Cin layers stage via registers
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int PIPE = STAGES * (A_BYTES + B_BYTES);
-    constexpr int EPI = (STAGES == 1 ? 64 : BM) * (BN + 4) * 4; // fp32 transpose (64-row groups in the single-buffer variant)
+    // fp32 transpose: 64-row groups in the single-buffer variant, 128-row groups in the 256 x 256 tile
+    constexpr int EPI = (STAGES == 1 ? 64 : (WMT == 128 ? 128 : BM)) * (BN + 4) * 4;
     constexpr int LDS = PIPE > EPI ? PIPE : EPI;
+    static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<BM, BN, MODE, SPLIT, ET, GLDS, STAGES>;
+    auto kern = conv_igemm_kernel<BM, BN, MODE, SPLIT, ET, GLDS, STAGES, WMT>;
     if (!attr_set) {
         WSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -602,7 +624,9 @@ int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
 
 template <int BM, int BN, int MODE, bool SPLIT, int ET>
 int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
-    if constexpr (BM == 256) {
+    if constexpr (BM == 256 && BN == 256) {
+        return launch_stages<BM, BN, MODE, SPLIT, ET, 2, 128>(ctx, a);
+    } else if constexpr (BM == 256) {
         return launch_stages<BM, BN, MODE, SPLIT, ET, 3>(ctx, a);
     } else if constexpr (MODE == 0) {
         // a one-K-step layer (1x1 conv, 64 input channels) needs one LDS buffer: 34 KB per block, 4 blocks per CU
@@ -636,6 +660,12 @@ int launch_big(wsc_ctx *ctx, const ConvKArgs &a, int split, int fmt) {
     if (fmt) return launch_variant<256, 128, 0, false, 1>(ctx, a);
     return launch_variant<256, 128, 0, false, 0>(ctx, a);
 }
+// 256 x 256 tile, 128 x 64 per wave (generic layers with CoutPad % 256 == 0 only)
+int launch_square(wsc_ctx *ctx, const ConvKArgs &a, int split, int fmt) {
+    if (split) return launch_variant<256, 256, 0, true, 0>(ctx, a);
+    if (fmt) return launch_variant<256, 256, 0, false, 1>(ctx, a);
+    return launch_variant<256, 256, 0, false, 0>(ctx, a);
+}
 
 } // namespace
 
@@ -661,10 +691,12 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     if (p.small_cin == 0) {
         WSC_CHECK(p.Cin % 64 == 0, WSC_ERR_INVALID, "conv: Cin=%d not a multiple of 64", p.Cin);
         a.cchunks = p.Cin / 64;
+        a.ntaps = p.kh * p.kw;
         a.ksteps_base = p.kh * p.kw * a.cchunks;
     } else {
         WSC_CHECK(p.Cin == 4, WSC_ERR_INVALID, "conv: small-Cin mode needs a 4-channel activation");
         a.cchunks = 1;
+        a.ntaps = p.kh * p.kw;
         // kh kernel rows, 2^small_cin slots each, 8 slots per K-step
         a.ksteps_base = ((p.kh << p.small_cin) + 7) / 8;
     }
@@ -694,6 +726,18 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     bool big = false;
     if (force == -1) big = p.small_cin == 0 && BN == 128 && a.Kbase >= 512 && blocks256 >= 200;
     if (force == 256) big = p.small_cin == 0 && BN == 128;
+    // 256 x 256 tile: half the L2->LDS bytes per FLOP of the 128 x 128 tile; needs enough K-steps to amortise
+    // its 130 KB prologue/epilogue and enough tiles to fill 256 CUs at one block per CU.
+    const long long blocks_sq = ((a.M + 255) / 256) * (long long)(p.CoutPad / 256);
+    bool square = p.small_cin == 0 && p.CoutPad % 256 == 0 && a.nk >= 8 && blocks_sq >= 3 * 256;
+    if (force == 512) square = p.small_cin == 0 && p.CoutPad % 256 == 0;
+    if (force != 0 && force != 512) square = false;
+    if (square) {
+        WSC_CHECK(!(p.split && p.fmt), WSC_ERR_INVALID, "conv: split precision requires bf16 planes");
+        a.ntiles_n = p.CoutPad / 256;
+        a.nblocks = (int)blocks_sq;
+        return launch_square(ctx, a, p.split, p.fmt);
+    }
     const int BMsel = big ? 256 : 128;
     a.nblocks = ((a.M + BMsel - 1) / BMsel) * a.ntiles_n;
     if (big) {

@@ -122,7 +122,9 @@ int fold_bn(const Dict &d, const std::string &bn, int C, double eps_default, std
     return WSC_OK;
 }
 
-// Pack OIHW fp32 weights to [CoutPad][Kw] bf16 in the kernel's K order.
+// Pack OIHW fp32 weights to [CoutPad][Kw] bf16 in the kernel's K order: generic layers
+// (cin / 64, kh, kw, cin % 64) -- the kh*kw taps of one 64-channel chunk are consecutive K-steps, so the
+// activation lines a block gathers are re-touched within a few K-steps (L2 hits) instead of Cin/64 steps later.
 int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, int small_cin,
               const std::vector<float> &s1, const std::vector<float> &b1, const std::vector<float> *s2,
               const std::vector<float> *b2, ConvW *out) {
@@ -157,7 +159,7 @@ int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, 
                 for (int s = 0; s < kw; ++s) {
                     const float v = w->data[(((size_t)co * Cin + ci) * kh + r) * kw + s];
                     if (small_cin == 0) {
-                        put((r * kw + s) * Cin + ci, v);
+                        put((((ci >> 6) * kh + r) * kw + s) * 64 + (ci & 63), v);
                     } else {
                         // kernel row r owns 2^small_cin slots of 8 = (2 pixels x 4 channels)
                         put((r << small_cin) * 8 + s * 4 + ci, v);
