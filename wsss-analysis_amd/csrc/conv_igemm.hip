@@ -720,14 +720,16 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     // takes 2.2 ms), not by L2->LDS bytes per FLOP, so the 128-row tile stays the default.  128x64 tiles
     // (3 blocks per CU) on the K <= 128 / 256 / 512 layers were also measured: no layer gained, layer1.conv3
     // lost 10 %.
-    // WSC_CONV_TILE=256 selects the 256-row tile wherever it applies, =-1 where K >= 512 (A/B runs).
+    // WSC_CONV_TILE (A/B runs): 256 selects the 256x128 tile wherever it applies, -1 where K >= 512, 512 the
+    // 256x256 tile wherever CoutPad % 256 == 0, 1 (any other value) the 128-row tiles everywhere.
     static const int force = [] { const char *e = getenv("WSC_CONV_TILE"); return e ? atoi(e) : 0; }();
     const long long blocks256 = ((a.M + 255) / 256) * (long long)a.ntiles_n;
     bool big = false;
     if (force == -1) big = p.small_cin == 0 && BN == 128 && a.Kbase >= 512 && blocks256 >= 200;
     if (force == 256) big = p.small_cin == 0 && BN == 128;
     // 256 x 256 tile: half the L2->LDS bytes per FLOP of the 128 x 128 tile; needs enough K-steps to amortise
-    // its 130 KB prologue/epilogue and enough tiles to fill 256 CUs at one block per CU.
+    // its 130 KB prologue/epilogue and enough tiles to fill 256 CUs at one block per CU.  VGG16 @321, 64
+    // samples: 806 -> 920 TFLOP/s on the 11 layers it takes (stack 11.5 -> 10.8 ms); ResNet50: 4 launches, +-0.
     const long long blocks_sq = ((a.M + 255) / 256) * (long long)(p.CoutPad / 256);
     bool square = p.small_cin == 0 && p.CoutPad % 256 == 0 && a.nk >= 8 && blocks_sq >= 3 * 256;
     if (force == 512) square = p.small_cin == 0 && p.CoutPad % 256 == 0;
