@@ -56,7 +56,11 @@ def test_deepglobe_dataset_item(tmp_path):
         _write(str(tmp_path / "JPEGImages" / (n + ".jpg")), im)
     lst = tmp_path / "test.txt"
     lst.write_text("\n".join(names) + "\n")
-    ds = dg_dl.DeepGlobeClassificationDatasetMSF(str(lst), str(tmp_path), True, norm_mode="int", outsize=(224, 224))
+    # label table in the reference's format: {name: 7-vector incl. 'unknown'} (deepglobe/dataloader.py:29-35)
+    lp = tmp_path / "cls_labels_balanced.npy"
+    np.save(str(lp), {names[0]: np.array([1, 0, 0, 1, 0, 0, 0.]), names[1]: np.array([0, 1, 0, 0, 0, 0, 1.])})
+    ds = dg_dl.DeepGlobeClassificationDatasetMSF(str(lst), str(tmp_path), True, norm_mode="int", outsize=(224, 224),
+                                                 cls_labels_path=str(lp))
     it = ds[0]
     assert it["img"].shape == (2, 3, 224, 224) and it["orig_img"].shape == (2, 300, 260, 3)
     assert it["label"].shape == (6,)  # 'unknown' dropped (deepglobe/dataloader.py:35)
@@ -66,17 +70,23 @@ def test_deepglobe_dataset_item(tmp_path):
     assert np.allclose(it["img"][0], ref.transpose(2, 0, 1), atol=1e-6)
 
 
-def test_voc_dataset_item(tmp_path):
+def test_voc_dataset_item(tmp_path, monkeypatch):
     rng = np.random.default_rng(2)
     im = rng.integers(0, 256, (50, 70, 3)).astype(np.uint8)
     _write(str(tmp_path / "JPEGImages" / "2007_000032.jpg"), im)
     lst = tmp_path / "val.txt"
     lst.write_text("2007_000032\n")
+    # label table in the reference's format: {int-coded name: 20-vector} (voc12/dataloader.py:60-66)
+    (tmp_path / "voc12").mkdir()
+    row = np.zeros(20, np.float32)
+    row[[0, 14]] = 1
+    np.save(str(tmp_path / "voc12" / "cls_labels.npy"), {int(voc_dl.load_img_name_list(str(lst))[0]): row})
+    monkeypatch.setenv("WSSCAM_CLS_LABELS_ROOT", str(tmp_path))  # the lookup order of adp.dataloader.find_cls_labels
     ds = voc_dl.VOC12ClassificationDatasetMSF(str(lst), str(tmp_path), norm_mode="int", outsize=(224, 224))
     it = ds[0]
     assert it["name"] == "2007_000032" and it["size"] == (50, 70)
     assert it["img"].shape == (2, 3, 224, 224)
-    assert it["label"].shape == (20,) and it["label"].sum() >= 1  # the reference's own cls_labels.npy row
+    assert np.array_equal(it["label"], row)
     # Caffe BGR means applied to R,G,B in that order
     x = np.float64(np.asarray(PIL_Image.open(voc_dl.get_img_path("2007_000032", str(tmp_path))).convert("RGB")))
     r = voc_dl.resize_bilinear_f64(x, (224, 224))

@@ -33,9 +33,28 @@ def load_img_name_list(dataset_path):
     return np.array(names)
 
 
+def find_cls_labels(rel_path, explicit=None):
+    """Where the image-level label tables are looked for.  They are dataset annotation files the reference keeps
+    next to its loaders ('voc12/cls_labels.npy', 'adp/cls_labels_<htt>.npy', 'deepglobe/cls_labels_*.npy', read
+    relative to the working directory: e.g. adp/dataloader.py:33-37); this package does not ship copies.
+    Order: the explicit path, $WSSCAM_CLS_LABELS_ROOT/<rel_path>, <cwd>/<rel_path>, this package's directory."""
+    if explicit:
+        return explicit
+    cands = []
+    if os.environ.get("WSSCAM_CLS_LABELS_ROOT"):
+        cands.append(os.path.join(os.environ["WSSCAM_CLS_LABELS_ROOT"], rel_path))
+    cands.append(rel_path)
+    cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), rel_path))
+    for c in cands:
+        if os.path.exists(c):
+            return c
+    raise FileNotFoundError("label table %r not found (looked in %s); pass cls_labels_path=... or set "
+                            "WSSCAM_CLS_LABELS_ROOT to the reference's 03b_irn directory" % (rel_path, cands))
+
+
 def load_image_label_list_from_npy(img_name_list, htt_type, cls_labels_path=None):
     """adp/dataloader.py:33-37 reads 'adp/cls_labels_<htt>.npy' relative to the working directory."""
-    path = cls_labels_path or os.path.join("adp", "cls_labels_" + htt_type + ".npy")
+    path = find_cls_labels(os.path.join("adp", "cls_labels_" + htt_type + ".npy"), cls_labels_path)
     cls = np.load(path, allow_pickle=True).item()
     return np.array([cls[n] for n in img_name_list])
 

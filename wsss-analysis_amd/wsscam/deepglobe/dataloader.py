@@ -6,10 +6,9 @@ import os
 
 import numpy as np
 
-from ..adp.dataloader import load_img_name_list, msf_item
+from ..adp.dataloader import find_cls_labels, load_img_name_list, msf_item
 
 CAT_LIST = ["urban", "agriculture", "rangeland", "forest", "water", "barren", "unknown"]
-_HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def get_img_path(img_name, root):
@@ -17,8 +16,8 @@ def get_img_path(img_name, root):
 
 
 def load_image_label_list_from_npy(img_name_list, is_balanced, cls_labels_path=None):
-    path = cls_labels_path or os.path.join(_HERE, "cls_labels_balanced.npy" if is_balanced
-                                           else "cls_labels_unbalanced.npy")
+    path = find_cls_labels(os.path.join("deepglobe", "cls_labels_balanced.npy" if is_balanced
+                                        else "cls_labels_unbalanced.npy"), cls_labels_path)
     cls = np.load(path, allow_pickle=True).item()
     return np.array([cls[n][:-1] for n in img_name_list])
 

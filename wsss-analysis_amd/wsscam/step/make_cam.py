@@ -117,7 +117,8 @@ def build_dataset(args):
 
         return dataloader.VOC12ClassificationDatasetMSF(args.val_list, norm_mode=args.norm_mode,
                                                         outsize=args.outsize, dev_root=args.dev_root,
-                                                        scales=args.cam_scales)
+                                                        scales=args.cam_scales,
+                                                        cls_labels_path=getattr(args, "cls_labels_path", None))
     if args.dataset in ("adp_morph", "adp_func"):
         from ..adp import dataloader
 

@@ -11,7 +11,6 @@ import os
 import numpy as np
 
 IMG_FOLDER_NAME = "JPEGImages"
-_HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def decode_int_filename(int_filename):
@@ -88,8 +87,10 @@ class VOC12ClassificationDatasetMSF:
         self.dev_root = dev_root
         self.outsize = outsize
         self.norm = TorchvisionNormalize(norm_mode)
-        cls_labels_path = cls_labels_path or os.path.join(_HERE, "cls_labels.npy")
-        cls = np.load(cls_labels_path, allow_pickle=True).item()
+        from ..adp.dataloader import find_cls_labels
+
+        cls = np.load(find_cls_labels(os.path.join("voc12", "cls_labels.npy"), cls_labels_path),
+                      allow_pickle=True).item()
         self.label_list = np.array([cls[n] for n in self.img_name_list])
 
     def __len__(self):
