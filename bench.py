@@ -7,8 +7,8 @@ in HBM (BASELINE config 2/3: ResNet50 CAM + dense-CRF, 321x321, batch 32 images 
   wsc_net_forward_cam      ResNet50 (strides 2,2,2,1) on orig+flip, 1x1 CAM head, ReLU, flip-add
   wsc_cam_postprocess      make_cam tail for the image's GT classes at its native size
                            (strided /4 map + high-res map, per-class max-normalised)
-  wsc_cam_postprocess      all 20 class maps at 321x321 (the CRF's probability stack)
-  wsc_unary_from_maps      [bg=0.15 | maps] -> -log(clip(p)) unaries, M = 21
+  wsc_cam_unary            all 20 class maps at 321x321, max-normalised, [bg=0.15 | maps] -> -log(clip(p))
+                           unaries, M = 21 (wsc_cam_postprocess + wsc_unary_from_maps fused: same bits)
   wsc_crf_create           Gaussian + bilateral permutohedral lattices of the 32 images (second
                            context/stream: overlaps the conv stack, joined by wsc_ctx_wait)
   wsc_crf_inference        10 mean-field iterations -> arg-max label map
@@ -140,9 +140,6 @@ class Workload:
         self.highres_dev = ctx.alloc(max(h_tot, 1) * 4)
         # CRF stack
         N = S * S
-        self.all_keys = [np.arange(NUM_CLASSES, dtype=np.int32)] * batch
-        self.maps_dev = ctx.alloc(batch * NUM_CLASSES * N * 4)
-        self.maps_s_dev = ctx.alloc(batch * NUM_CLASSES * ((S - 1) // 4 + 1) ** 2 * 4)
         # unaries / labels are double-buffered: step i+1 writes its unaries while step i's loop reads its own
         self.unary_bufs = [ctx.alloc(batch * (NUM_CLASSES + 1) * N * 4) for _ in range(2)]
         self.label_bufs = [ctx.alloc(batch * N * 4) for _ in range(2)]
@@ -159,9 +156,9 @@ class Workload:
                                   self.strided_dev, self.highres_dev)
 
     def run_unary(self):
-        self._lib.cam_postprocess(self.ctx, self.cam_dev, self.B, NUM_CLASSES, self.h, self.h, [(S, S)] * self.B,
-                                  self.all_keys, self.maps_s_dev, self.maps_dev)
-        self._lib.unary_from_maps(self.ctx, self.maps_dev, self.B, NUM_CLASSES, S * S, 0.15, self.unary_dev)
+        # upsample all 20 class maps to S x S, x /= max + 1e-5, [bg = 0.15 | maps] -> unaries: one fused call
+        # (wsc_cam_postprocess + wsc_unary_from_maps give the same bits through 0.5 GB of intermediate maps)
+        self._lib.cam_unary(self.ctx, self.cam_dev, self.B, NUM_CLASSES, self.h, self.h, S, S, 0.15, self.unary_dev)
 
     def crf_create(self):
         return self._lib.Crf(self.ctx_build, self.rgb_dev, self.B, S, S, CRF_CFG[0], CRF_CFG[2], CRF_CFG[3])

@@ -238,6 +238,15 @@ int wsc_cam_eval_confusion(wsc_ctx *ctx, const float *highres_dev, int B, const 
 int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N, float bg_value,
                         float *unary_dev);
 
+/* wsc_cam_postprocess (all C classes, every image at H0 x W0) followed by wsc_unary_from_maps, fused: the
+ * max-normalised high-resolution maps are never written to HBM, only the unaries are (bit-identical to the
+ * two-step path).  Replaces, for a whole batch, make_cam.py:64-76 (upsample to the strided-up size, crop,
+ * x /= max + 1e-5) + eval_cam.py:49-51 (background channel) + pydensecrf.utils.unary_from_softmax
+ * (03c_hsn/utilities.py:431).
+ *   cam_dev float32 [B][C][h][w] (wsc_net_forward_cam)  ->  unary_dev float32 [B][C+1][H0*W0] */
+int wsc_cam_unary(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
+                  float *unary_dev);
+
 /* F.interpolate(mode='bilinear', align_corners=False) on float32 [C][h][w] -> [C][H][W]
  * (make_cam.py:64-69; also resize_stack 02_cues/utilities.py:20-40 up to the
  * cv2/torch border convention). */

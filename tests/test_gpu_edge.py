@@ -80,6 +80,33 @@ def test_cam_tail_large_native_size(ctx):
     assert np.abs(hi - rh.numpy()).max() <= 2e-6
 
 
+@pytest.mark.parametrize("size", [(321, 321), (97, 130), (16, 33)])
+def test_cam_unary_fused_equals_two_step_and_oracle(ctx, size):
+    """wsc_cam_unary = wsc_cam_postprocess (all classes) + wsc_unary_from_maps without the maps in HBM: bit-identical
+    to the two-step path, and both within 2e-5 of the torch/numpy restatement (make_cam.py:64-76, eval_cam.py:49-51,
+    unary_from_softmax); one all-zero class map (0 / 1e-5 = 0 -> the 1e-5 clip) included."""
+    B, C, h, w = 3, 20, 21, 21
+    H0, W0 = size
+    rng = np.random.default_rng(H0 * 1000 + W0)
+    cam = np.maximum(rng.normal(0.3, 1.0, (B, C, h, w)), 0).astype(np.float32)
+    cam[1, 7] = 0.0
+    cam_dev = ctx.to_device(cam)
+    n = H0 * W0
+    _, h_dev, _, _, _ = _lib.cam_postprocess(ctx, cam_dev, B, C, h, w, [size] * B, [list(range(C))] * B)
+    u2_dev = ctx.alloc(B * (C + 1) * n * 4)
+    _lib.unary_from_maps(ctx, h_dev, B, C, n, 0.15, u2_dev)
+    u1_dev = ctx.alloc(B * (C + 1) * n * 4)
+    _lib.cam_unary(ctx, cam_dev, B, C, h, w, H0, W0, 0.15, u1_dev)
+    u1 = ctx.to_host(u1_dev, (B, C + 1, n), np.float32)
+    u2 = ctx.to_host(u2_dev, (B, C + 1, n), np.float32)
+    assert np.array_equal(u1, u2)
+    for b in range(B):
+        _, rh = cnn_ref.make_cam_tail(torch.from_numpy(cam[b]), size, torch.arange(C))
+        v = np.concatenate([np.full((1, n), 0.15, np.float32), rh.numpy().reshape(C, n)], axis=0)
+        ref = -np.log(np.clip(v / v.sum(0, keepdims=True), 1e-5, 1.0))
+        assert np.abs(u1[b] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
 def _gpu_crf(ctx, rgb, U, cfg):
     H, W, _ = rgb.shape
     M = U.shape[0]

@@ -29,7 +29,7 @@ struct TailJob {
 constexpr int PIX_PER_BLOCK = 4096;
 
 __device__ __forceinline__ void src_index(int dst, float scale, int in, int &i0, int &i1, float &l0, float &l1) {
-    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    float s = __builtin_fmaf(scale, (float)dst + 0.5f, -0.5f);
     s = s < 0.f ? 0.f : s;
     i0 = (int)s;
     if (i0 > in - 1) i0 = in - 1;
@@ -41,9 +41,11 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in, int &i0,
 
 __device__ __forceinline__ float bilerp(const float *src, int w, int y0, int y1, float ly0, float ly1, int x0, int x1,
                                         float lx0, float lx1) {
-    const float top = lx0 * src[y0 * w + x0] + lx1 * src[y0 * w + x1];
-    const float bot = lx0 * src[y1 * w + x0] + lx1 * src[y1 * w + x1];
-    return ly0 * top + ly1 * bot;
+    // the fused multiply-adds are spelled out (not left to -ffp-contract): every kernel that samples a map --
+    // cam_tail_kernel, cam_max_kernel, cam_unary_kernel, bilinear_kernel -- then computes the same bits
+    const float top = __builtin_fmaf(lx0, src[y0 * w + x0], lx1 * src[y0 * w + x1]);
+    const float bot = __builtin_fmaf(lx0, src[y1 * w + x0], lx1 * src[y1 * w + x1]);
+    return __builtin_fmaf(ly0, top, ly1 * bot);
 }
 
 // WRITE = false: atomicMax the per-job maxima; WRITE = true: write v / (max + 1e-5).
@@ -137,6 +139,70 @@ __global__ void unary_from_maps_kernel(const float *__restrict__ maps, float bg,
         const float inv = 1.f / sum;
         dst[0] = -logf(fminf(fmaxf(bg * inv, 1e-5f), 1.f));
         for (int c = 0; c < C; ++c) dst[(long long)(c + 1) * N] = -logf(fminf(fmaxf(src[(long long)c * N] * inv, 1e-5f), 1.f));
+    }
+}
+
+// Fused form of cam_tail (high_res of ALL C classes at one size) + unary_from_maps: nothing but the unaries is
+// written.  Pass 1: per (image, class) maximum of the upsampled, cropped map; pass 2: a thread owns one pixel,
+// recomputes the C bilinear samples from the image's C source maps in LDS (C*h*w floats), divides by
+// (max + 1e-5), and applies the unary formula.  Same float operations in the same order as the two-step
+// path (cam_tail_kernel<true> then unary_from_maps_kernel), so the results are bit-identical.
+__global__ __launch_bounds__(256) void cam_max_kernel(const float *__restrict__ cam, int C, int h, int w, int H0, int W0,
+                                                      int Hu, int Wu, unsigned int *__restrict__ mx) {
+    extern __shared__ float src[]; // h*w
+    const int bc = blockIdx.y;     // b*C + c
+    for (int i = threadIdx.x; i < h * w; i += blockDim.x) src[i] = cam[(long long)bc * h * w + i];
+    __syncthreads();
+    const float sh = (float)h / (float)Hu, sw = (float)w / (float)Wu;
+    const int n = H0 * W0;
+    float m = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int yy = i / W0, xx = i - yy * W0;
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index(yy, sh, h, y0, y1, ly0, ly1);
+        src_index(xx, sw, w, x0, x1, lx0, lx1);
+        m = fmaxf(m, bilerp(src, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&mx[bc], __float_as_uint(m)); // values >= 0: uint order = float order
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void cam_unary_kernel(const float *__restrict__ cam, int C, int h, int w, int H0, int W0,
+                                                        int Hu, int Wu, const unsigned int *__restrict__ mx, float bg,
+                                                        float *__restrict__ unary) {
+    extern __shared__ float src[]; // C*h*w maps of this image, then C divisors
+    const int b = blockIdx.y;
+    const int hw = h * w;
+    float *div = src + C * hw;
+    for (int i = threadIdx.x; i < C * hw; i += blockDim.x) src[i] = cam[(long long)b * C * hw + i];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) div[c] = __uint_as_float(mx[b * C + c]) + 1e-5f;
+    __syncthreads();
+    const float sh = (float)h / (float)Hu, sw = (float)w / (float)Wu;
+    const int n = H0 * W0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int yy = i / W0, xx = i - yy * W0;
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index(yy, sh, h, y0, y1, ly0, ly1);
+        src_index(xx, sw, w, x0, x1, lx0, lx1);
+        float v[CMAX]; // the pixel's C normalised class values stay in registers (fully unrolled)
+        float sum = bg;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            v[c] = 0.f;
+            if (c < C) {
+                v[c] = bilerp(src + c * hw, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1) / div[c];
+                sum += v[c];
+            }
+        }
+        const float inv = 1.f / sum;
+        float *dst = unary + (long long)b * (C + 1) * n + i;
+        dst[0] = -logf(fminf(fmaxf(bg * inv, 1e-5f), 1.f));
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) dst[(long long)(c + 1) * n] = -logf(fminf(fmaxf(v[c] * inv, 1e-5f), 1.f));
     }
 }
 
@@ -236,6 +302,39 @@ int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N
     hipLaunchKernelGGL(unary_from_maps_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, maps_dev, bg_value, C, N,
                        total, unary_dev);
     WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+int wsc_cam_unary(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
+                  float *unary_dev) {
+    WSC_CHECK(ctx && cam_dev && unary_dev, WSC_ERR_INVALID, "wsc_cam_unary: null argument");
+    WSC_CHECK(B > 0 && C > 0 && h > 0 && w > 0 && H0 > 0 && W0 > 0 && bg_value > 0.f, WSC_ERR_INVALID,
+              "wsc_cam_unary: bad argument");
+    WSC_CHECK((long long)H0 * W0 < (1ll << 31) && B <= 65535 && (long long)B * C <= 65535, WSC_ERR_INVALID,
+              "wsc_cam_unary: batch too large for one call");
+    WSC_CHECK(C <= 32, WSC_ERR_INVALID, "wsc_cam_unary: C=%d > 32 classes (use wsc_cam_postprocess + wsc_unary_from_maps)", C);
+    const size_t lds = ((size_t)C * h * w + C) * sizeof(float);
+    WSC_CHECK(lds <= 64 * 1024, WSC_ERR_INVALID, "wsc_cam_unary: %d maps of %dx%d do not fit the 64 KB LDS tile", C, h, w);
+    WSC_HIP(hipSetDevice(ctx->device));
+    // misc.imutils.get_strided_up_size(size, 16)
+    const int Hu = ((H0 - 1) / 16 + 1) * 16, Wu = ((W0 - 1) / 16 + 1) * 16;
+    unsigned int *mx = nullptr;
+    WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(unsigned int) * (size_t)B * C, (void **)&mx));
+    WSC_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned int) * (size_t)B * C, ctx->stream));
+    const int n = H0 * W0;
+    WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, (double)B * (C + 1) * n * 4);
+    hipLaunchKernelGGL(cam_max_kernel, dim3((unsigned)std::min((n + 255) / 256, 64), (unsigned)(B * C)), dim3(256),
+                       (size_t)h * w * sizeof(float), ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu, mx);
+    // each block re-reads its image's C source maps (35 KB for 20 x 21 x 21): a few pixels per thread amortise that
+    const dim3 ugrid((unsigned)std::min((n + 1023) / 1024, 512), (unsigned)B);
+    if (C <= 20)
+        hipLaunchKernelGGL(cam_unary_kernel<20>, ugrid, dim3(256), lds, ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu,
+                           (const unsigned int *)mx, bg_value, unary_dev);
+    else
+        hipLaunchKernelGGL(cam_unary_kernel<32>, ugrid, dim3(256), lds, ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu,
+                           (const unsigned int *)mx, bg_value, unary_dev);
+    WSC_HIP(hipGetLastError());
+    wsc_ctx_cached_free(ctx, mx); // stream-ordered reuse
     return WSC_OK;
 }
 

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "wsc_cam_postprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wsc_cam_eval_confusion": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _vp]),
     "wsc_unary_from_maps": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
+    "wsc_cam_unary": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     "wsc_crf_create": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _f, ctypes.POINTER(_vp)]),
     "wsc_crf_destroy": (None, [_vp]),
@@ -395,6 +396,11 @@ def cam_eval_confusion(ctx, highres_dev, sizes, keys_per_image, highres_off, bg_
 
 def unary_from_maps(ctx, maps_dev, B, C, N, bg_value, unary_dev):
     check(ctx._lib.wsc_unary_from_maps(ctx.h, _ptr(maps_dev), B, C, N, float(bg_value), _ptr(unary_dev)))
+
+
+def cam_unary(ctx, cam_dev, B, C, h, w, H0, W0, bg_value, unary_dev):
+    """cam_postprocess (all classes at H0 x W0) + unary_from_maps without the intermediate maps in HBM."""
+    check(ctx._lib.wsc_cam_unary(ctx.h, _ptr(cam_dev), B, C, h, w, H0, W0, float(bg_value), _ptr(unary_dev)))
 
 
 def bilinear_resize(ctx, src_dev, C, h, w, dst_dev, H, W):
