@@ -44,6 +44,7 @@ struct ConvKArgs {
     int H, W, Cin, Ho, Wo, Cout;
     int kh, kw, stride, pad, relu;
     int M, HoWo;
+    int m_base, m_end; // rows [m_base, m_end) of the M = N*Ho*Wo output rows are this launch's (a layer may be cut in two)
     // exact unsigned division by HoWo / Wo as multiply-high + shifts (Granlund-Montgomery): the prologue
     // decodes 4 output rows per thread and a hardware-less 32-bit division costs ~25 VALU instructions
     unsigned div_howo_mul, div_howo_s1, div_howo_s2, div_wo_mul, div_wo_s1, div_wo_s2;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     }
     const int mt = tile / p.ntiles_n;
     const int nt = tile - mt * p.ntiles_n;
-    const int m0 = mt * BM;
+    const int m0 = p.m_base + mt * BM;
     const int n0 = nt * BN;
 
     // ---- per-thread A gather state: 4 rows, one 16-byte slot each -------------
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + lrow + RSTEP * i;
-        if (m < p.M) {
+        if (m < p.m_end) {
             const unsigned t1 = __umulhi(p.div_howo_mul, (unsigned)m);
             const int n = (int)((t1 + (((unsigned)m - t1) >> p.div_howo_s1)) >> p.div_howo_s2);
             const int rem = m - n * p.HoWo;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             const int m = m0 + (first_pass + i) * RPP + r0;
             rres[i] = make_uint4(0, 0, 0, 0);
             rres_lo[i] = make_uint4(0, 0, 0, 0);
-            if (has_res && m < p.M) {
+            if (has_res && m < p.m_end) {
                 const long long o = (long long)m * p.Cout + c;
                 rres[i] = *reinterpret_cast<const uint4 *>(p.res + o);
                 if (SPLIT) rres_lo[i] = *reinterpret_cast<const uint4 *>(p.res_lo + o);
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             const int pass = half * PPH + pp;
             const int lrow_e = pp * RPP + r0; // row inside the group
             const int m = m0 + half * GR + lrow_e;
-            if (m < p.M) {
+            if (m < p.m_end) {
                 float v[8];
                 const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(ct + lrow_e * CT_STRIDE + c8 * 8);
                 const f32x4_t q1 = *reinterpret_cast<const f32x4_t *>(ct + lrow_e * CT_STRIDE + c8 * 8 + 4);
@@ -615,7 +616,7 @@ int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
         attr_set = true;
     }
     // algorithmic FLOPs: 2 * M * Cout * (kh*kw*Cin_real), x1 regardless of the precision mode
-    const double flops = 2.0 * a.M * a.Cout * (MODE == 0 ? (double)a.kh * a.kw * a.Cin : (double)a.kh * a.kw * 3);
+    const double flops = 2.0 * (a.m_end - a.m_base) * a.Cout * (MODE == 0 ? (double)a.kh * a.kw * a.Cin : (double)a.kh * a.kw * 3);
     WscKernelTimer timer(ctx, MODE != 0 ? WSC_K_CONV_SMALLCIN : (BM == 256 ? WSC_K_CONV256 : (BN == 128 ? WSC_K_CONV128 : WSC_K_CONV64)), flops);
     hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(BM * 2), LDS, ctx->stream, a);
     WSC_HIP(hipGetLastError());
@@ -678,6 +679,8 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     a.H = p.H; a.W = p.W; a.Cin = p.Cin; a.Ho = p.Ho; a.Wo = p.Wo; a.Cout = p.Cout;
     a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.relu = p.relu;
     a.M = p.N * p.Ho * p.Wo;
+    a.m_base = 0;
+    a.m_end = a.M;
     a.HoWo = p.Ho * p.Wo;
     auto fastdiv = [](unsigned d, unsigned &mul, unsigned &s1, unsigned &s2) {
         unsigned l = 0;
@@ -736,7 +739,25 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     if (force != 0 && force != 512) square = false;
     if (square) {
         WSC_CHECK(!(p.split && p.fmt), WSC_ERR_INVALID, "conv: split precision requires bf16 planes");
-        a.ntiles_n = p.CoutPad / 256;
+        const int ntn = p.CoutPad / 256;
+        // One block per CU: a grid of r * 256 + rem tiles takes r + 1 rounds.  When the last round would be less
+        // than half full, the square tiles take whole rounds only and the remaining rows go to the 128 x 128 kernel
+        // (<= 512 tiles = one round at 2 blocks per CU, ~0.56 of a square round): VGG16 conv4 (840 tiles) 4 -> 3.6
+        // rounds.  The two launches write disjoint output rows.
+        const long long rounds = blocks_sq / ctx->num_cus, rem = blocks_sq - rounds * ctx->num_cus;
+        static const int nosplit = [] { const char *e = getenv("WSC_CONV_NOSPLIT"); return e ? atoi(e) : 0; }();
+        if (!nosplit && rounds >= 1 && rem > 0 && rem * 2 <= ctx->num_cus && ctx->num_cus > 0) {
+            const int big_rows = (int)((rounds * ctx->num_cus) / ntn); // 256-row tile rows given to the square kernel
+            ConvKArgs b = a;
+            b.ntiles_n = ntn;
+            b.m_end = big_rows * 256;
+            b.nblocks = big_rows * ntn;
+            WSC_TRY(launch_square(ctx, b, p.split, p.fmt));
+            a.m_base = big_rows * 256;
+            a.nblocks = ((a.M - a.m_base + 127) / 128) * a.ntiles_n; // BN = 128 here (CoutPad % 256 == 0)
+            return launch_bn<128>(ctx, a, p.small_cin, p.split, p.fmt);
+        }
+        a.ntiles_n = ntn;
         a.nblocks = (int)blocks_sq;
         return launch_square(ctx, a, p.split, p.fmt);
     }
