@@ -127,8 +127,8 @@ def test_conv_random_shapes_sweep(ctx):
 
 @pytest.mark.parametrize("precision", [_lib.PREC_F16, _lib.PREC_BF16X3])
 def test_conv_square_tile_large_layer(ctx, precision):
-    """A layer big enough for the 256 x 256 tile (CoutPad % 256 == 0, >= 8 K-steps, >= 768 tiles: conv_igemm.hip tile
-    choice), with a ragged last tile row, residual and ReLU; fp32 oracle (float64 is too slow at 58 GFLOP)."""
+    """A layer big enough for the 256 x 256 tile (CoutPad % 256 == 0, >= 4 K-steps, >= 256 tiles: conv_igemm.hip tile
+    choice; 776 tiles = 3 whole rounds on the square kernel + a 128 x 128 remainder launch), with a ragged last tile row, residual and ReLU; fp32 oracle (float64 is too slow at 58 GFLOP)."""
     N, Cin, H, W, Cout, k = 50, 64, 63, 63, 256, 3
     rng = np.random.default_rng(77)
     x = rng.normal(0, 1, (N, Cin, H, W)).astype(np.float32)
