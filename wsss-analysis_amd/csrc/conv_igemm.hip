@@ -86,7 +86,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int B_BYTES = BN * BK * 2;
     constexpr int CT_STRIDE = BN + 4;
-    static_assert(GLDS || (BM == 128 && STAGES == 2), "register staging exists for the 128-row tile only");
+    static_assert(GLDS || (BM == 128 && STAGES <= 2), "register staging exists for the 128-row tile only");
     static_assert(STAGES >= 1 && STAGES <= 3, "1 (single K-step layers), 2 or 3 LDS buffers");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -634,6 +634,8 @@ int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
         if (a.nk == 1) return launch_stages<BM, BN, MODE, SPLIT, ET, 1>(ctx, a);
         return launch_stages<BM, BN, MODE, SPLIT, ET, 2>(ctx, a);
     } else {
+        // one-K-step small-Cin layer (3x3 on <= 4 channels: VGG16 / M7 first conv): single LDS buffer, 64-row epilogue
+        if (a.nk == 1) return launch_stages<BM, BN, MODE, SPLIT, ET, 1>(ctx, a);
         return launch_stages<BM, BN, MODE, SPLIT, ET, 2>(ctx, a);
     }
 }
