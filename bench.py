@@ -219,6 +219,7 @@ class Workload:
 
     def timed(self, fn, reps):
         """Average device time of fn() over reps, HIP events on the ctx stream."""
+        fn()  # untimed: the first call on this ctx may grow its workspace arena (a hipMalloc of a few GB)
         self.ctx.sync()
         self.ctx.timer_begin()
         for _ in range(reps):

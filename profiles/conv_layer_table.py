@@ -34,6 +34,20 @@ def resnet50_layers(S):
     return L
 
 
+def n_dispatches(M, cin, cout, k, num_cus=256):
+    """Launches conv_igemm_launch makes for one generic layer (csrc/conv_igemm.hip tile choice): a layer on the
+    256 x 256 tile whose grid is r * 256 + rem tiles with 0 < rem <= 128 is cut into the square kernel (r whole
+    rounds) and a 128 x 128 remainder launch."""
+    if cin % 64 or cout % 256:
+        return 1
+    nk = k * k * cin // 64
+    blocks_sq = ((M + 255) // 256) * (cout // 256)
+    if nk < 4 or blocks_sq < 256:
+        return 1
+    rounds, rem = divmod(blocks_sq, num_cus)
+    return 2 if rounds >= 1 and 0 < rem and rem * 2 <= num_cus else 1
+
+
 def main(db, N=64, S=321):
     c = sqlite3.connect(db)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -46,14 +60,19 @@ def main(db, N=64, S=321):
     layers = resnet50_layers(S)
     print("%-44s %8s %8s %9s %7s %6s" % ("layer", "us", "TFLOP/s", "act TB/s", "blocks", "LDS KB"))
     tot = 0.0
-    for (name, ho, cin, cout, k), r in zip(layers, convs):
-        us = (r[2] - r[1]) / 1000.0
-        tot += us
+    pos = 0
+    for (name, ho, cin, cout, k) in layers:
         M = N * ho * ho
+        nd = n_dispatches(M, cin, cout, k)
+        rs = convs[pos:pos + nd]
+        pos += nd
+        us = sum(r[2] - r[1] for r in rs) / 1000.0
+        tot += us
         fl = 2.0 * M * cout * k * k * cin
         # 16-bit activations in + out (+ residual); weights ignored
         by = 2.0 * M * cout * (2 if "+res" in name else 1) + 2.0 * N * (ho * (2 if "s2" in name else 1)) ** 2 * cin
-        print("%-44s %8.1f %8.0f %9.2f %7d %6.1f" % (name, us, fl / us / 1e6, by / us / 1e6, r[3], r[4] / 1024.0))
+        print("%-44s %8.1f %8.0f %9.2f %7s %6s" % (name, us, fl / us / 1e6, by / us / 1e6, "+".join(str(r[3]) for r in rs),
+                                                    "/".join("%.0f" % (r[4] / 1024.0) for r in rs)))
     print("conv kernels total %.1f us" % tot)
 
 

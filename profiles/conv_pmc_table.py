@@ -9,7 +9,7 @@ SIMD's matrix pipe for 32 cycles (MI355X_MICROARCH.md), so this is the fraction 
 import sqlite3
 import sys
 
-from conv_layer_table import resnet50_layers
+from conv_layer_table import n_dispatches, resnet50_layers
 
 
 def load(db):
@@ -24,15 +24,28 @@ def load(db):
 def main(db1, db2, N=64, S=321):
     a, b = load(db1), load(db2)
     L = resnet50_layers(S)
-    a, b = a[-len(L):], b[-len(L):]
+    nds = [n_dispatches(N * ho * ho, cin, cout, k) for (_, ho, cin, cout, k) in L]
+    a, b = a[-sum(nds):], b[-sum(nds):]
+
+    def merge(rows):  # a layer cut into two launches: add durations and counters
+        out = {"dur": sum(r["dur"] for r in rows)}
+        for r in rows:
+            for kk, v in r.items():
+                if kk not in ("name", "dur"):
+                    out[kk] = out.get(kk, 0) + v
+        return out
+
     print("%-36s %7s %9s %8s %9s %9s %8s %6s %6s" % ("layer", "us", "mfma_util", "mfma/wv", "valu/wave", "salu/wave",
                                                     "lds/wave", "wait%", "bank%"))
     busy = cyc_tot = 0.0
-    for (name, ho, cin, cout, k), x, y in zip(L, a, b):
+    pos = 0
+    for (name, ho, cin, cout, k), nd in zip(L, nds):
+        x, y = merge(a[pos:pos + nd]), merge(b[pos:pos + nd])
+        pos += nd
         M = N * ho * ho
         cpad = (cout + 63) // 64 * 64
         bn = 128 if cpad % 128 == 0 else 64
-        nw = ((M + 127) // 128) * (cpad // bn) * 4
+        nw = ((M + 127) // 128) * (cpad // bn) * 4  # in units of 128-row-tile waves, whatever tile ran
         cyc = x["dur"] * 2.4 * 1024
         busy += x["SQ_VALU_MFMA_BUSY_CYCLES"]
         cyc_tot += cyc
