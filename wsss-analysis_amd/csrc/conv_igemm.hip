@@ -608,12 +608,14 @@ int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     constexpr int EPI = (STAGES == 1 ? 64 : (WMT == 128 ? 128 : BM)) * (BN + 4) * 4;
     constexpr int LDS = PIPE > EPI ? PIPE : EPI;
     static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
-    static bool attr_set = false;
+    // the attribute belongs to the (function, device) pair: a process may hold contexts on several GPUs
+    static bool attr_set[64] = {};
     auto kern = conv_igemm_kernel<BM, BN, MODE, SPLIT, ET, GLDS, STAGES, WMT>;
-    if (!attr_set) {
+    const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    if (!attr_set[dev] || ctx->device != dev) {
         WSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     // algorithmic FLOPs: 2 * M * Cout * (kh*kw*Cin_real), x1 regardless of the precision mode
     const double flops = 2.0 * (a.m_end - a.m_base) * a.Cout * (MODE == 0 ? (double)a.kh * a.kw * a.Cin : (double)a.kh * a.kw * 3);
