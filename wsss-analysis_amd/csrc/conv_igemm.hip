@@ -737,9 +737,10 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     // 256 x 256 tile: half the L2->LDS bytes per FLOP of the 128 x 128 tile; needs enough K-steps to amortise
     // its 130 KB prologue/epilogue and enough tiles to fill 256 CUs at one block per CU.  VGG16 @321, 64
     // samples: 806 -> 920 TFLOP/s on the 11 layers it takes (stack 11.5 -> 10.8 ms).  Thresholds (>= 4 K-steps, >= one
-    // round of tiles) from a sweep on ResNet50: (8, 768) 3.96 ms, (8, 256) 3.96, (4, 768) 3.94, (4, 256) 3.92; VGG16 +-0.
+    // round of tiles, later 3/4 of a round) from a sweep on ResNet50: (8, 768) 3.96 ms, (8, 256) 3.96, (4, 768) 3.94, (4, 256) 3.92; VGG16 +-0.
+    // A grid of 192+ tiles (3/4 of a round: layer4's 3x3 and 1x1 -> 512 convs, 222 tiles) also wins: 4.11 -> 3.97 ms.
     const long long blocks_sq = ((a.M + 255) / 256) * (long long)(p.CoutPad / 256);
-    bool square = p.small_cin == 0 && p.CoutPad % 256 == 0 && a.nk >= 4 && blocks_sq >= 256;
+    bool square = p.small_cin == 0 && p.CoutPad % 256 == 0 && a.nk >= 4 && blocks_sq >= 192;
     if (force == 512) square = p.small_cin == 0 && p.CoutPad % 256 == 0;
     if (force != 0 && force != 512) square = false;
     if (square) {
