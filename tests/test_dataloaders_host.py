@@ -92,3 +92,24 @@ def test_voc_dataset_item(tmp_path, monkeypatch):
     r = voc_dl.resize_bilinear_f64(x, (224, 224))
     assert np.allclose(it["img"][0, 0], (np.float32(r[..., 0]) - 104.0) / 255.0, atol=1e-6)
     assert np.allclose(it["img"][0, 2], (np.float32(r[..., 2]) - 123.0) / 255.0, atol=1e-6)
+
+
+def test_label_table_lookup_order(tmp_path, monkeypatch):
+    """adp.dataloader.find_cls_labels: explicit path > $WSSCAM_CLS_LABELS_ROOT > working directory; a clear error when
+    the table is nowhere (the package ships no copies of the reference's annotation files)."""
+    from wsscam.adp.dataloader import find_cls_labels
+
+    monkeypatch.delenv("WSSCAM_CLS_LABELS_ROOT", raising=False)
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError) as ei:
+        find_cls_labels(os.path.join("voc12", "no_such_table.npy"))
+    assert "WSSCAM_CLS_LABELS_ROOT" in str(ei.value)
+    (tmp_path / "voc12").mkdir()
+    (tmp_path / "voc12" / "t.npy").write_bytes(b"x")
+    assert find_cls_labels(os.path.join("voc12", "t.npy")) == os.path.join("voc12", "t.npy")  # cwd, as the reference
+    root = tmp_path / "root"
+    (root / "voc12").mkdir(parents=True)
+    (root / "voc12" / "t.npy").write_bytes(b"y")
+    monkeypatch.setenv("WSSCAM_CLS_LABELS_ROOT", str(root))
+    assert find_cls_labels(os.path.join("voc12", "t.npy")) == str(root / "voc12" / "t.npy")
+    assert find_cls_labels(os.path.join("voc12", "t.npy"), "/explicit/path.npy") == "/explicit/path.npy"

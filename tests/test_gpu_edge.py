@@ -209,6 +209,11 @@ def test_argument_errors(ctx):
     crf.close()
     with pytest.raises(_lib.WscError):
         _lib.cam_postprocess(ctx, ctx.alloc(4 * 21 * 21 * 4), 1, 4, 21, 21, [(10, 10)], [[7]])  # key out of range
+    with pytest.raises(_lib.WscError) as ei:  # more classes than the fused kernel keeps in registers
+        _lib.cam_unary(ctx, ctx.alloc(33 * 8 * 8 * 4), 1, 33, 8, 8, 16, 16, 0.15, ctx.alloc(34 * 256 * 4))
+    assert ei.value.status == _lib.WSC_ERR_INVALID
+    with pytest.raises(_lib.WscError):  # background value must be positive (it is a probability mass)
+        _lib.cam_unary(ctx, ctx.alloc(4 * 8 * 8 * 4), 1, 4, 8, 8, 16, 16, 0.0, ctx.alloc(5 * 256 * 4))
 
 
 def _adp_like_image(rng, H, W):
