@@ -210,3 +210,25 @@ def test_crf_random_sweep(ctx):
             assert (vg[b], vb[b]) == (ls[0], ls[1]), (it, H, W, M, B)
             assert np.abs(q[b] - qr).max() <= 1e-3, (it, H, W, M, B, cfg, np.abs(q[b] - qr).max())
             assert (a[b] == ar).mean() >= 0.995, (it, H, W, M, B, (a[b] == ar).mean())
+
+
+@pytest.mark.parametrize("case", [(47, 61, 5, 2, (1.5, 3, 40, 13, 10, 5)), (96, 130, 21, 3, (3, 3, 50, 5, 10, 4)),
+                                  (9, 7, 2, 1, (3 / 12, 3, 80 / 12, 13, 10, 3)), (33, 200, 29, 1, (5, 3, 40, 13, 10, 2))])
+def test_crf_fused_gaussian_blur_is_bit_identical(ctx, case, monkeypatch):
+    """The tiled three-pass blur of the Gaussian lattice (blur3_tile_kernel: one read + one write of the rows) against
+    the three separate blur4 passes (WSC_CRF_NO_FUSED_BLUR=1, read per call): identical bits, on sizes whose lattices
+    have ragged edge tiles, several replicas, wide (sxy = 5) and narrow (sxy = 0.25) kernels, M = 29 (LP = 8: the fused
+    kernel's tile is exactly the 64 KB dynamic-LDS default)."""
+    H, W, M, B, cfg = case
+    rng = np.random.default_rng(H * 7 + W)
+    rgbs, Us = [], []
+    for _ in range(B):
+        rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
+        rgbs.append(rgb)
+        Us.append(U)
+    monkeypatch.setenv("WSC_CRF_NO_FUSED_BLUR", "1")
+    q_ref, a_ref, vg, _ = _gpu_crf(ctx, rgbs, Us, cfg)
+    monkeypatch.setenv("WSC_CRF_NO_FUSED_BLUR", "0")
+    q, a, vg2, _ = _gpu_crf(ctx, rgbs, Us, cfg)
+    assert list(vg) == list(vg2)
+    assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)

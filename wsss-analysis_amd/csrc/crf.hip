@@ -59,6 +59,10 @@ struct LatticeDev {
     long long n_pix = 0; // pixels of one replica (B*N when rep == 1)
     int M_cur = 0;       // class count of the inference in flight (algorithmic byte accounting)
     float alpha = 0.f;
+    // Gaussian lattice only (d = 2): tiles of the dense (i, j) index space for the fused three-pass blur
+    int32_t *tile_rows = nullptr; // [n_tiles][GT_BOX * GT_BOX] row id of every point of the tile's halo box (0 = absent)
+    int32_t *tile_list = nullptr; // [n_tiles_occ] tiles with at least one interior vertex
+    int n_tiles_occ = 0;
     std::vector<int32_t> v_per_image;
 };
 
@@ -756,6 +760,111 @@ __global__ __launch_bounds__(256) void blur4_kernel(const f32x4_t *__restrict__ 
     }
 }
 
+// ---- fused three-pass blur of the Gaussian lattice -----------------------------------------------------
+// For d = 2 the lattice points (k0, k1, -k0-k1), k0 = k1 (mod 3), are the integer pairs
+//   i = (2 k0 + k1) / 3,  j = (k0 + 2 k1) / 3        (k0 = 2i - j, k1 = 2j - i)
+// and the blur neighbours along the three axes (neighbors_kernel) are (i +- 1, j), (i, j +- 1), (i -+ 1, j -+ 1).
+// The (i, j) plane is cut into GT x GT tiles; a block loads a tile with a halo of 2 (a GT_BOX x GT_BOX box of
+// points, absent ones as zeros -- exactly what a neighbour pointer to the zero row reads) into LDS, runs the
+// three passes there with fixed local offsets (no neighbour table), and writes the GT x GT interior: one read
+// and one write of the value array instead of three of each.  Per pass the arithmetic is blur4_kernel's
+// (c + 0.5f * (a + b), a + b commutes), so the result is bit-identical.
+constexpr int GT = 12, GT_BOX = GT + 4;
+
+__global__ void gauss_ij_kernel(const unsigned long long *__restrict__ rowkey, int rows, int2 *__restrict__ ij,
+                                int *__restrict__ bbox /* imin jmin imax jmax err */) {
+    for (int row = 1 + blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+        int key[2];
+        unpack_key<2>(rowkey[row], key);
+        const int a = 2 * key[0] + key[1], b = key[0] + 2 * key[1];
+        if (a % 3 != 0 || b % 3 != 0) atomicOr(&bbox[4], 1);
+        const int i = a / 3, j = b / 3;
+        ij[row] = make_int2(i, j);
+        atomicMin(&bbox[0], i);
+        atomicMin(&bbox[1], j);
+        atomicMax(&bbox[2], i);
+        atomicMax(&bbox[3], j);
+    }
+}
+
+__global__ void gauss_tile_fill_kernel(const int2 *__restrict__ ij, int rows, int imin, int jmin, int nti, int ntj,
+                                       int32_t *__restrict__ tile_rows, int32_t *__restrict__ occ) {
+    for (int row = 1 + blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+        const int i = ij[row].x - imin, j = ij[row].y - jmin;
+        occ[(i / GT) * ntj + j / GT] = 1; // interior owner
+        // every tile whose halo box [ti*GT - 2, ti*GT + GT + 2) contains the point
+        for (int ti = (i - GT - 1 >= 0 ? (i - GT - 1) / GT : 0); ti <= (i + 2) / GT && ti < nti; ++ti) {
+            const int li = i - ti * GT + 2;
+            if (li < 0 || li >= GT_BOX) continue;
+            for (int tj = (j - GT - 1 >= 0 ? (j - GT - 1) / GT : 0); tj <= (j + 2) / GT && tj < ntj; ++tj) {
+                const int lj = j - tj * GT + 2;
+                if (lj < 0 || lj >= GT_BOX) continue;
+                tile_rows[((long long)ti * ntj + tj) * (GT_BOX * GT_BOX) + li * GT_BOX + lj] = row;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void blur3_tile_kernel(const f32x4_t *__restrict__ in, const int32_t *__restrict__ tile_rows,
+                                                         const int32_t *__restrict__ tile_list, int n_occ, int LP,
+                                                         int rows_local, int rep, f32x4_t *__restrict__ out) {
+    // thread p owns point p of the 16 x 16 box and walks the row's LP float4s; LDS layout [l][p] (conflict-free
+    // 16-byte accesses, neighbours at fixed offsets in p)
+    extern __shared__ __attribute__((aligned(16))) char g_lds[];
+    constexpr int P = GT_BOX * GT_BOX;
+    static_assert(P == 256, "one thread per point of the halo box");
+    f32x4_t *b0 = reinterpret_cast<f32x4_t *>(g_lds);
+    f32x4_t *b1 = b0 + P * LP;
+    // XCD-contiguous logical block id: neighbouring tiles of one replica (which share halo rows) on one L2
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nb >> 3, rr = nb & 7;
+    const int lb = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int k = lb / n_occ, t = lb - k * n_occ;
+    in += (size_t)k * rows_local * LP;
+    out += (size_t)k * rows_local * LP;
+    const int p = threadIdx.x;
+    const int li = p / GT_BOX, lj = p - li * GT_BOX;
+    const int row = tile_rows[(long long)tile_list[t] * P + p];
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < LP; ++l) b0[l * P + p] = row ? in[(unsigned)row * (unsigned)LP + l] : zero;
+    if (t == 0 && p < LP) out[p] = zero; // the permanent zero row of this replica
+    __syncthreads();
+    // pass 0, axis 0: (i +- 1, j) = p +- GT_BOX; li in [1, GT_BOX - 1)
+    const bool r0 = row && li >= 1 && li < GT_BOX - 1;
+    for (int l = 0; l < LP; ++l) {
+        f32x4_t o = zero;
+        if (r0) {
+            const f32x4_t c = b0[l * P + p], a = b0[l * P + p + GT_BOX], b = b0[l * P + p - GT_BOX];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
+        }
+        b1[l * P + p] = o;
+    }
+    __syncthreads();
+    // pass 1, axis 1: (i, j +- 1) = p +- 1; li, lj in [1, GT_BOX - 1)
+    const bool r1 = r0 && lj >= 1 && lj < GT_BOX - 1;
+    for (int l = 0; l < LP; ++l) {
+        f32x4_t o = zero;
+        if (r1) {
+            const f32x4_t c = b1[l * P + p], a = b1[l * P + p - 1], b = b1[l * P + p + 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
+        }
+        b0[l * P + p] = o;
+    }
+    __syncthreads();
+    // pass 2, axis 2: (i -+ 1, j -+ 1) = p -+ (GT_BOX + 1); interior li, lj in [2, GT_BOX - 2)
+    if (row && li >= 2 && li < GT_BOX - 2 && lj >= 2 && lj < GT_BOX - 2) {
+        for (int l = 0; l < LP; ++l) {
+            const f32x4_t c = b0[l * P + p], a = b0[l * P + p - GT_BOX - 1], b = b0[l * P + p + GT_BOX + 1];
+            f32x4_t o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
+            out[(unsigned)row * (unsigned)LP + l] = o;
+        }
+    }
+}
+
 // Slice of the ones-filter and norm = 1/sqrt(x + 1e-20)   (DenseKernel::initLattice)
 __global__ void slice_norm_kernel(const int32_t *__restrict__ offset, const float *__restrict__ bary, int dp1,
                                   float alpha, const float *__restrict__ val, long long npix,
@@ -1043,6 +1152,17 @@ float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
     return a;
 }
 float *blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, float *a, float *b) {
+    // WSC_CRF_NO_FUSED_BLUR=1 (read per call, so a test can flip it) keeps the three separate passes
+    const char *fe = getenv("WSC_CRF_NO_FUSED_BLUR");
+    const bool fused_off = fe && atoi(fe) != 0;
+    const size_t lds = GT_BOX * GT_BOX * 2 * (size_t)LP * sizeof(f32x4_t);
+    if (L.d == 2 && L.tile_rows && L.n_tiles_occ > 0 && !fused_off && lds <= 64 * 1024) {
+        // one read + one write of the value rows (the halo re-reads come out of L2)
+        WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.rep * L.M_cur * 4);
+        hipLaunchKernelGGL(blur3_tile_kernel, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(256), lds, ctx->stream,
+                           (const f32x4_t *)a, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b);
+        return b;
+    }
     for (int j = 0; j <= L.d; ++j) {
         WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.rep * L.M_cur * 4); // read + write every row once
         hipLaunchKernelGGL(blur4_kernel, dim3(grid_rep((long long)L.rows * L.rep, (256 / LP) * 4, L.rep)), dim3(256),
@@ -1167,6 +1287,43 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     hipLaunchKernelGGL(neighbors_kernel<D>, dim3(grid1d((long long)L.rows * dp1)), dim3(256), 0, ctx->stream, rowkey,
                        rowimg, table, slot2row, cap, (unsigned)(cap - 1), L.rows, L.nbr);
     WSC_HIP(hipGetLastError());
+    if (D == 2) { // tile tables of the fused blur (one-off per cached Gaussian lattice: the host syncs are fine)
+        int2 *ij;
+        int *bbox;
+        WSC_TRY(tmp.alloc(sizeof(int2) * L.rows, (void **)&ij));
+        WSC_TRY(tmp.alloc(sizeof(int) * 5, (void **)&bbox));
+        const int init[5] = {0x7fffffff, 0x7fffffff, -0x7fffffff, -0x7fffffff, 0};
+        WSC_TRY(wsc_ctx_upload_small(ctx, bbox, init, sizeof(init)));
+        hipLaunchKernelGGL(gauss_ij_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream, rowkey, L.rows, ij, bbox);
+        int hb[5] = {0, 0, -1, -1, 1};
+        WSC_HIP(hipMemcpyAsync(hb, bbox, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+        WSC_HIP(hipStreamSynchronize(ctx->stream));
+        const long long nti = hb[2] >= hb[0] ? ((long long)hb[2] - hb[0]) / GT + 1 : 0;
+        const long long ntj = hb[3] >= hb[1] ? ((long long)hb[3] - hb[1]) / GT + 1 : 0;
+        // a lattice that is not the expected dense (i, j) plane, or a degenerate / huge box: keep the three passes
+        if (hb[4] == 0 && nti > 0 && ntj > 0 && nti * ntj <= 4ll * L.rows + 64) {
+            const long long nt = nti * ntj;
+            int32_t *occ;
+            WSC_TRY(tmp.alloc(sizeof(int32_t) * nt, (void **)&occ));
+            WSC_TRY(crf_alloc(crf, sizeof(int32_t) * nt * GT_BOX * GT_BOX, (void **)&L.tile_rows));
+            WSC_HIP(hipMemsetAsync(L.tile_rows, 0, sizeof(int32_t) * nt * GT_BOX * GT_BOX, ctx->stream));
+            WSC_HIP(hipMemsetAsync(occ, 0, sizeof(int32_t) * nt, ctx->stream));
+            hipLaunchKernelGGL(gauss_tile_fill_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream, ij, L.rows, hb[0],
+                               hb[1], (int)nti, (int)ntj, L.tile_rows, occ);
+            std::vector<int32_t> hocc(nt), list;
+            WSC_HIP(hipMemcpyAsync(hocc.data(), occ, sizeof(int32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
+            WSC_HIP(hipStreamSynchronize(ctx->stream));
+            for (long long t = 0; t < nt; ++t)
+                if (hocc[t]) list.push_back((int32_t)t);
+            L.n_tiles_occ = (int)list.size();
+            if (L.n_tiles_occ > 0) {
+                WSC_TRY(crf_alloc(crf, sizeof(int32_t) * list.size(), (void **)&L.tile_list));
+                WSC_HIP(hipMemcpyAsync(L.tile_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice,
+                                       ctx->stream));
+                WSC_HIP(hipStreamSynchronize(ctx->stream)); // `list` is pageable host memory
+            }
+        }
+    }
     {   // splat chunk tables
         unsigned *nch, *sums3, *n_long_dev;
         const int nb3 = (L.rows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
