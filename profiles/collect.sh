@@ -14,7 +14,7 @@ rm -rf $out/prof_stats $out/pmc_f $out/pmc_w
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline > $out/${tag}_prof_stats.log 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline"; python profiles/summarize_rocpd.py $out/prof_stats/*/*_results.db; } > $out/${tag}_kernel_stats_bench.txt 2>&1
 { echo "# one ResNet50-CAM forward (64 samples @321^2, f16) out of the same trace"; python profiles/conv_layer_table.py $out/prof_stats/*/*_results.db; } > $out/${tag}_conv_layers.txt 2>&1
-RX='splat4_kernel|splat_combine|slice_update|blur4_kernel|conv_igemm'
+RX='splat4_kernel|splat_combine|slice_update|blur4_kernel|blur3_tile_kernel|conv_igemm'
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$RX" -d $out/pmc_f -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > $out/${tag}_pmc_f.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$RX" -d $out/pmc_w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > $out/${tag}_pmc_w.log 2>&1
 { echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-include-regex '$RX' -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline"

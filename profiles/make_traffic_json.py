@@ -13,7 +13,8 @@ from collections import defaultdict
 
 CLASSES = {  # bench.py kernel-class label -> (kernel-name substrings, substring whose dispatches count as launches)
     "splat4+combine": (("splat4_kernel", "splat_combine_kernel"), "splat4_kernel"),
-    "blur4_kernel": (("blur4_kernel",), "blur4_kernel"),
+    "blur4+blur3_tile": (("blur4_kernel", "blur3_tile_kernel"), ("blur4_kernel", "blur3_tile_kernel")),
+    "blur3_tile_kernel": (("blur3_tile_kernel",), "blur3_tile_kernel"),
     "slice_update_kernel": (("slice_update_kernel",), "slice_update_kernel"),
 }
 
@@ -37,8 +38,9 @@ def main(fetch_db, write_db):
     for label, (subs, launch_sub) in CLASSES.items():
         fb = sum(v for k, v in f.items() if any(s in k for s in subs)) * 1024.0 * 2.0
         wb = sum(v for k, v in w.items() if any(s in k for s in subs)) * 1024.0
-        nf = sum(v for k, v in fd.items() if launch_sub in k)
-        nw = sum(v for k, v in wd.items() if launch_sub in k)
+        ls = (launch_sub,) if isinstance(launch_sub, str) else launch_sub
+        nf = sum(v for k, v in fd.items() if any(x in k for x in ls))
+        nw = sum(v for k, v in wd.items() if any(x in k for x in ls))
         if nf == 0 or nw == 0:
             continue
         out["classes"][label] = {"read_bytes_per_launch": round(fb / nf), "write_bytes_per_launch": round(wb / nw),

@@ -118,7 +118,7 @@ WscKernelTimer::~WscKernelTimer() {
 
 static const char *kClassNames[WSC_K_COUNT] = {
     "conv_igemm_kernel<256-row tiles,glds>", "conv_igemm_kernel<128x128,glds>", "conv_igemm_kernel<128x64,glds>", "conv_igemm_kernel<small-Cin>",
-    "pool/layout/flip-add", "cam_tail+unary", "crf_build(all)", "splat4+combine", "blur4_kernel",
+    "pool/layout/flip-add", "cam_tail+unary", "crf_build(all)", "splat4+combine", "blur4+blur3_tile",
     "slice_update_kernel", "crf init/finish"};
 
 extern "C" {

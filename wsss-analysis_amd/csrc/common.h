@@ -112,7 +112,7 @@ enum WscKernelClass {
     WSC_K_CAM_TAIL,      // cam_tail_kernel (both passes) + unary_from_maps
     WSC_K_CRF_BUILD,     // every kernel of wsc_crf_create
     WSC_K_SPLAT,         // splat4_kernel + splat_combine_kernel
-    WSC_K_BLUR,          // blur4_kernel
+    WSC_K_BLUR,          // blur4_kernel (bilateral passes) + blur3_tile_kernel (fused Gaussian passes)
     WSC_K_SLICE_UPDATE,  // slice_update_kernel
     WSC_K_CRF_MISC,      // init_q / finish
     WSC_K_COUNT
