@@ -217,8 +217,8 @@ def test_crf_random_sweep(ctx):
 def test_crf_fused_gaussian_blur_is_bit_identical(ctx, case, monkeypatch):
     """The tiled three-pass blur of the Gaussian lattice (blur3_tile_kernel: one read + one write of the rows) against
     the three separate blur4 passes (WSC_CRF_NO_FUSED_BLUR=1, read per call): identical bits, on sizes whose lattices
-    have ragged edge tiles, several replicas, wide (sxy = 5) and narrow (sxy = 0.25) kernels, M = 29 (LP = 8: the fused
-    kernel's tile is exactly the 64 KB dynamic-LDS default)."""
+    have ragged edge tiles, several replicas, wide (sxy = 5) and narrow (sxy = 0.25) kernels, M = 29 (LP = 8: two
+    groups of float4s per row in the fused kernel)."""
     H, W, M, B, cfg = case
     rng = np.random.default_rng(H * 7 + W)
     rgbs, Us = [], []

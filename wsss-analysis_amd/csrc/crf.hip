@@ -805,16 +805,15 @@ __global__ void gauss_tile_fill_kernel(const int2 *__restrict__ ij, int rows, in
     }
 }
 
+template <int LH>
 __global__ __launch_bounds__(256) void blur3_tile_kernel(const f32x4_t *__restrict__ in, const int32_t *__restrict__ tile_rows,
                                                          const int32_t *__restrict__ tile_list, int n_occ, int LP,
                                                          int rows_local, int rep, f32x4_t *__restrict__ out) {
-    // thread p owns point p of the 16 x 16 box and walks the row's LP float4s; LDS layout [l][p] (conflict-free
-    // 16-byte accesses, neighbours at fixed offsets in p)
-    extern __shared__ __attribute__((aligned(16))) char g_lds[];
+    // thread p owns point p of the 16 x 16 box and walks the row's float4s, LH at a time (rows wider than LH float4s
+    // take several groups); LDS layout [l][p] (conflict-free 16-byte accesses, neighbours at fixed offsets in p)
     constexpr int P = GT_BOX * GT_BOX;
     static_assert(P == 256, "one thread per point of the halo box");
-    f32x4_t *b0 = reinterpret_cast<f32x4_t *>(g_lds);
-    f32x4_t *b1 = b0 + P * LP;
+    __shared__ f32x4_t b0[LH * P], b1[LH * P];
     // XCD-contiguous logical block id: neighbouring tiles of one replica (which share halo rows) on one L2
     const int nb = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qq = nb >> 3, rr = nb & 7;
@@ -826,41 +825,50 @@ __global__ __launch_bounds__(256) void blur3_tile_kernel(const f32x4_t *__restri
     const int li = p / GT_BOX, lj = p - li * GT_BOX;
     const int row = tile_rows[(long long)tile_list[t] * P + p];
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
-    for (int l = 0; l < LP; ++l) b0[l * P + p] = row ? in[(unsigned)row * (unsigned)LP + l] : zero;
     if (t == 0 && p < LP) out[p] = zero; // the permanent zero row of this replica
-    __syncthreads();
-    // pass 0, axis 0: (i +- 1, j) = p +- GT_BOX; li in [1, GT_BOX - 1)
-    const bool r0 = row && li >= 1 && li < GT_BOX - 1;
-    for (int l = 0; l < LP; ++l) {
-        f32x4_t o = zero;
-        if (r0) {
-            const f32x4_t c = b0[l * P + p], a = b0[l * P + p + GT_BOX], b = b0[l * P + p - GT_BOX];
+    const bool r0 = row && li >= 1 && li < GT_BOX - 1;      // pass 0 region
+    const bool r1 = r0 && lj >= 1 && lj < GT_BOX - 1;       // pass 1 region
+    const bool r2 = row && li >= 2 && li < GT_BOX - 2 && lj >= 2 && lj < GT_BOX - 2; // interior
+    for (int lbase = 0; lbase < LP; lbase += LH) {
+        if (lbase > 0) __syncthreads(); // the previous group's pass-2 reads of b0 are done
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
+        for (int l = 0; l < LH; ++l) b0[l * P + p] = (row && lbase + l < LP) ? in[(unsigned)row * (unsigned)LP + lbase + l] : zero;
+        __syncthreads();
+        // pass 0, axis 0: (i +- 1, j) = p +- GT_BOX
+#pragma unroll
+        for (int l = 0; l < LH; ++l) {
+            f32x4_t o = zero;
+            if (r0) {
+                const f32x4_t c = b0[l * P + p], a = b0[l * P + p + GT_BOX], b = b0[l * P + p - GT_BOX];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
+            }
+            b1[l * P + p] = o;
         }
-        b1[l * P + p] = o;
-    }
-    __syncthreads();
-    // pass 1, axis 1: (i, j +- 1) = p +- 1; li, lj in [1, GT_BOX - 1)
-    const bool r1 = r0 && lj >= 1 && lj < GT_BOX - 1;
-    for (int l = 0; l < LP; ++l) {
-        f32x4_t o = zero;
-        if (r1) {
-            const f32x4_t c = b1[l * P + p], a = b1[l * P + p - 1], b = b1[l * P + p + 1];
+        __syncthreads();
+        // pass 1, axis 1: (i, j +- 1) = p +- 1
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
+        for (int l = 0; l < LH; ++l) {
+            f32x4_t o = zero;
+            if (r1) {
+                const f32x4_t c = b1[l * P + p], a = b1[l * P + p - 1], b = b1[l * P + p + 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
+            }
+            b0[l * P + p] = o;
         }
-        b0[l * P + p] = o;
-    }
-    __syncthreads();
-    // pass 2, axis 2: (i -+ 1, j -+ 1) = p -+ (GT_BOX + 1); interior li, lj in [2, GT_BOX - 2)
-    if (row && li >= 2 && li < GT_BOX - 2 && lj >= 2 && lj < GT_BOX - 2) {
-        for (int l = 0; l < LP; ++l) {
-            const f32x4_t c = b0[l * P + p], a = b0[l * P + p - GT_BOX - 1], b = b0[l * P + p + GT_BOX + 1];
-            f32x4_t o;
+        __syncthreads();
+        // pass 2, axis 2: (i -+ 1, j -+ 1) = p -+ (GT_BOX + 1); interior only
+        if (r2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
-            out[(unsigned)row * (unsigned)LP + l] = o;
+            for (int l = 0; l < LH; ++l) {
+                if (lbase + l >= LP) break;
+                const f32x4_t c = b0[l * P + p], a = b0[l * P + p - GT_BOX - 1], b = b0[l * P + p + GT_BOX + 1];
+                f32x4_t o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
+                out[(unsigned)row * (unsigned)LP + lbase + l] = o;
+            }
         }
     }
 }
@@ -1155,11 +1163,12 @@ float *blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, float *a, float *b) 
     // WSC_CRF_NO_FUSED_BLUR=1 (read per call, so a test can flip it) keeps the three separate passes
     const char *fe = getenv("WSC_CRF_NO_FUSED_BLUR");
     const bool fused_off = fe && atoi(fe) != 0;
-    const size_t lds = GT_BOX * GT_BOX * 2 * (size_t)LP * sizeof(f32x4_t);
-    if (L.d == 2 && L.tile_rows && L.n_tiles_occ > 0 && !fused_off && lds <= 64 * 1024) {
-        // one read + one write of the value rows (the halo re-reads come out of L2)
+    if (L.d == 2 && L.tile_rows && L.n_tiles_occ > 0 && !fused_off) {
+        // one read + one write of the value rows (the halo re-reads come out of L2).  Whole rows per group
+        // (6 float4 = 49 KB of LDS, 3 blocks per CU) beat 3 / 2 / 1 float4 per group at 6+ blocks per CU:
+        // blur 2.37 vs 2.42 / 2.72 / 3.15 ms per step.
         WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.rep * L.M_cur * 4);
-        hipLaunchKernelGGL(blur3_tile_kernel, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(256), lds, ctx->stream,
+        hipLaunchKernelGGL(blur3_tile_kernel<6>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(256), 0, ctx->stream,
                            (const f32x4_t *)a, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b);
         return b;
     }
