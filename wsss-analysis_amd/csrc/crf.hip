@@ -60,7 +60,7 @@ struct LatticeDev {
     int M_cur = 0;       // class count of the inference in flight (algorithmic byte accounting)
     float alpha = 0.f;
     // Gaussian lattice only (d = 2): tiles of the dense (i, j) index space for the fused three-pass blur
-    int32_t *tile_rows = nullptr; // [n_tiles][GT_BOX * GT_BOX] row id of every point of the tile's halo box (0 = absent)
+    int32_t *tile_rows = nullptr; // [n_tiles][GBI * GBJ] row id of every point of the tile's halo box (0 = absent)
     int32_t *tile_list = nullptr; // [n_tiles_occ] tiles with at least one interior vertex
     int n_tiles_occ = 0;
     std::vector<int32_t> v_per_image;
@@ -764,12 +764,21 @@ __global__ __launch_bounds__(256) void blur4_kernel(const f32x4_t *__restrict__ 
 // For d = 2 the lattice points (k0, k1, -k0-k1), k0 = k1 (mod 3), are the integer pairs
 //   i = (2 k0 + k1) / 3,  j = (k0 + 2 k1) / 3        (k0 = 2i - j, k1 = 2j - i)
 // and the blur neighbours along the three axes (neighbors_kernel) are (i +- 1, j), (i, j +- 1), (i -+ 1, j -+ 1).
-// The (i, j) plane is cut into GT x GT tiles; a block loads a tile with a halo of 2 (a GT_BOX x GT_BOX box of
+// The (i, j) plane is cut into GTI x GTJ tiles; a block loads a tile with a halo of 2 (a GBI x GBJ box of
 // points, absent ones as zeros -- exactly what a neighbour pointer to the zero row reads) into LDS, runs the
-// three passes there with fixed local offsets (no neighbour table), and writes the GT x GT interior: one read
+// three passes there with fixed local offsets (no neighbour table), and writes the GTI x GTJ interior: one read
 // and one write of the value array instead of three of each.  Per pass the arithmetic is blur4_kernel's
 // (c + 0.5f * (a + b), a + b commutes), so the result is bit-identical.
-constexpr int GT = 12, GT_BOX = GT + 4;
+#ifndef WSC_GTI
+#define WSC_GTI 12
+#endif
+#ifndef WSC_GTJ
+#define WSC_GTJ 12
+#endif
+#ifndef WSC_GLH
+#define WSC_GLH 6
+#endif
+constexpr int GTI = WSC_GTI, GTJ = WSC_GTJ, GBI = GTI + 4, GBJ = GTJ + 4; // tile interior / halo box in i and j
 
 __global__ void gauss_ij_kernel(const unsigned long long *__restrict__ rowkey, int rows, int2 *__restrict__ ij,
                                 int *__restrict__ bbox /* imin jmin imax jmax err */) {
@@ -791,28 +800,27 @@ __global__ void gauss_tile_fill_kernel(const int2 *__restrict__ ij, int rows, in
                                        int32_t *__restrict__ tile_rows, int32_t *__restrict__ occ) {
     for (int row = 1 + blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
         const int i = ij[row].x - imin, j = ij[row].y - jmin;
-        occ[(i / GT) * ntj + j / GT] = 1; // interior owner
-        // every tile whose halo box [ti*GT - 2, ti*GT + GT + 2) contains the point
-        for (int ti = (i - GT - 1 >= 0 ? (i - GT - 1) / GT : 0); ti <= (i + 2) / GT && ti < nti; ++ti) {
-            const int li = i - ti * GT + 2;
-            if (li < 0 || li >= GT_BOX) continue;
-            for (int tj = (j - GT - 1 >= 0 ? (j - GT - 1) / GT : 0); tj <= (j + 2) / GT && tj < ntj; ++tj) {
-                const int lj = j - tj * GT + 2;
-                if (lj < 0 || lj >= GT_BOX) continue;
-                tile_rows[((long long)ti * ntj + tj) * (GT_BOX * GT_BOX) + li * GT_BOX + lj] = row;
+        occ[(i / GTI) * ntj + j / GTJ] = 1; // interior owner
+        // every tile whose halo box [ti*GTI - 2, ti*GTI + GTI + 2) x [tj*GTJ - 2, ...) contains the point
+        for (int ti = (i - GTI - 1 >= 0 ? (i - GTI - 1) / GTI : 0); ti <= (i + 2) / GTI && ti < nti; ++ti) {
+            const int li = i - ti * GTI + 2;
+            if (li < 0 || li >= GBI) continue;
+            for (int tj = (j - GTJ - 1 >= 0 ? (j - GTJ - 1) / GTJ : 0); tj <= (j + 2) / GTJ && tj < ntj; ++tj) {
+                const int lj = j - tj * GTJ + 2;
+                if (lj < 0 || lj >= GBJ) continue;
+                tile_rows[((long long)ti * ntj + tj) * (GBI * GBJ) + li * GBJ + lj] = row;
             }
         }
     }
 }
 
 template <int LH>
-__global__ __launch_bounds__(256) void blur3_tile_kernel(const f32x4_t *__restrict__ in, const int32_t *__restrict__ tile_rows,
+__global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__restrict__ in, const int32_t *__restrict__ tile_rows,
                                                          const int32_t *__restrict__ tile_list, int n_occ, int LP,
                                                          int rows_local, int rep, f32x4_t *__restrict__ out) {
     // thread p owns point p of the 16 x 16 box and walks the row's float4s, LH at a time (rows wider than LH float4s
     // take several groups); LDS layout [l][p] (conflict-free 16-byte accesses, neighbours at fixed offsets in p)
-    constexpr int P = GT_BOX * GT_BOX;
-    static_assert(P == 256, "one thread per point of the halo box");
+    constexpr int P = GBI * GBJ; // one thread per point of the halo box
     __shared__ f32x4_t b0[LH * P], b1[LH * P];
     // XCD-contiguous logical block id: neighbouring tiles of one replica (which share halo rows) on one L2
     const int nb = gridDim.x, bid = blockIdx.x;
@@ -822,24 +830,24 @@ __global__ __launch_bounds__(256) void blur3_tile_kernel(const f32x4_t *__restri
     in += (size_t)k * rows_local * LP;
     out += (size_t)k * rows_local * LP;
     const int p = threadIdx.x;
-    const int li = p / GT_BOX, lj = p - li * GT_BOX;
+    const int li = p / GBJ, lj = p - li * GBJ;
     const int row = tile_rows[(long long)tile_list[t] * P + p];
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     if (t == 0 && p < LP) out[p] = zero; // the permanent zero row of this replica
-    const bool r0 = row && li >= 1 && li < GT_BOX - 1;      // pass 0 region
-    const bool r1 = r0 && lj >= 1 && lj < GT_BOX - 1;       // pass 1 region
-    const bool r2 = row && li >= 2 && li < GT_BOX - 2 && lj >= 2 && lj < GT_BOX - 2; // interior
+    const bool r0 = row && li >= 1 && li < GBI - 1;      // pass 0 region
+    const bool r1 = r0 && lj >= 1 && lj < GBJ - 1;       // pass 1 region
+    const bool r2 = row && li >= 2 && li < GBI - 2 && lj >= 2 && lj < GBJ - 2; // interior
     for (int lbase = 0; lbase < LP; lbase += LH) {
         if (lbase > 0) __syncthreads(); // the previous group's pass-2 reads of b0 are done
 #pragma unroll
         for (int l = 0; l < LH; ++l) b0[l * P + p] = (row && lbase + l < LP) ? in[(unsigned)row * (unsigned)LP + lbase + l] : zero;
         __syncthreads();
-        // pass 0, axis 0: (i +- 1, j) = p +- GT_BOX
+        // pass 0, axis 0: (i +- 1, j) = p +- GBJ
 #pragma unroll
         for (int l = 0; l < LH; ++l) {
             f32x4_t o = zero;
             if (r0) {
-                const f32x4_t c = b0[l * P + p], a = b0[l * P + p + GT_BOX], b = b0[l * P + p - GT_BOX];
+                const f32x4_t c = b0[l * P + p], a = b0[l * P + p + GBJ], b = b0[l * P + p - GBJ];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
             }
@@ -858,12 +866,12 @@ __global__ __launch_bounds__(256) void blur3_tile_kernel(const f32x4_t *__restri
             b0[l * P + p] = o;
         }
         __syncthreads();
-        // pass 2, axis 2: (i -+ 1, j -+ 1) = p -+ (GT_BOX + 1); interior only
+        // pass 2, axis 2: (i -+ 1, j -+ 1) = p -+ (GBJ + 1); interior only
         if (r2) {
 #pragma unroll
             for (int l = 0; l < LH; ++l) {
                 if (lbase + l >= LP) break;
-                const f32x4_t c = b0[l * P + p], a = b0[l * P + p - GT_BOX - 1], b = b0[l * P + p + GT_BOX + 1];
+                const f32x4_t c = b0[l * P + p], a = b0[l * P + p - GBJ - 1], b = b0[l * P + p + GBJ + 1];
                 f32x4_t o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
@@ -1168,7 +1176,7 @@ float *blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, float *a, float *b) 
         // (6 float4 = 49 KB of LDS, 3 blocks per CU) beat 3 / 2 / 1 float4 per group at 6+ blocks per CU:
         // blur 2.37 vs 2.42 / 2.72 / 3.15 ms per step.
         WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.rep * L.M_cur * 4);
-        hipLaunchKernelGGL(blur3_tile_kernel<6>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(blur3_tile_kernel<WSC_GLH>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, ctx->stream,
                            (const f32x4_t *)a, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b);
         return b;
     }
@@ -1307,15 +1315,15 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
         int hb[5] = {0, 0, -1, -1, 1};
         WSC_HIP(hipMemcpyAsync(hb, bbox, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
         WSC_HIP(hipStreamSynchronize(ctx->stream));
-        const long long nti = hb[2] >= hb[0] ? ((long long)hb[2] - hb[0]) / GT + 1 : 0;
-        const long long ntj = hb[3] >= hb[1] ? ((long long)hb[3] - hb[1]) / GT + 1 : 0;
+        const long long nti = hb[2] >= hb[0] ? ((long long)hb[2] - hb[0]) / GTI + 1 : 0;
+        const long long ntj = hb[3] >= hb[1] ? ((long long)hb[3] - hb[1]) / GTJ + 1 : 0;
         // a lattice that is not the expected dense (i, j) plane, or a degenerate / huge box: keep the three passes
         if (hb[4] == 0 && nti > 0 && ntj > 0 && nti * ntj <= 4ll * L.rows + 64) {
             const long long nt = nti * ntj;
             int32_t *occ;
             WSC_TRY(tmp.alloc(sizeof(int32_t) * nt, (void **)&occ));
-            WSC_TRY(crf_alloc(crf, sizeof(int32_t) * nt * GT_BOX * GT_BOX, (void **)&L.tile_rows));
-            WSC_HIP(hipMemsetAsync(L.tile_rows, 0, sizeof(int32_t) * nt * GT_BOX * GT_BOX, ctx->stream));
+            WSC_TRY(crf_alloc(crf, sizeof(int32_t) * nt * GBI * GBJ, (void **)&L.tile_rows));
+            WSC_HIP(hipMemsetAsync(L.tile_rows, 0, sizeof(int32_t) * nt * GBI * GBJ, ctx->stream));
             WSC_HIP(hipMemsetAsync(occ, 0, sizeof(int32_t) * nt, ctx->stream));
             hipLaunchKernelGGL(gauss_tile_fill_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream, ij, L.rows, hb[0],
                                hb[1], (int)nti, (int)ntj, L.tile_rows, occ);
