@@ -50,7 +50,7 @@ struct LatticeDev {
     float *csr_w = nullptr;       // [B*N*(d+1)]
     uint2 *csr_ent = nullptr;     // [B*N*(d+1)] {pixel, bits(w * norm[pixel])}: one 8-byte load per gathered pixel
     int2 *nbr = nullptr;          // [(d+1)][rows]
-    // splat work items: every row is cut into chunks of <= SPLAT_CHUNK gathered pixels (64: 32 -> 294.5 us, 64 -> 288.6, 128 -> 322.9 per splat)
+    // splat work items: every row is cut into chunks of <= SPLAT_CHUNK gathered pixels (64: 32 -> 294.5 us, 64 -> 288.6, 128 -> 322.9 per splat; with the final kernels 8 / 16 / 32 / 64 -> 473 / 358 / 299 / 269 us)
     int32_t *chunk_base = nullptr; // [rows + 1] first chunk of each row
     int32_t *chunk_row = nullptr;  // [n_chunks] owning row
     int4 *chunk_desc = nullptr;    // [n_chunks] {first entry, entry count, row, 1 if the row's only chunk}
