@@ -569,17 +569,26 @@ __global__ __launch_bounds__(256) void splat_ones_kernel(const unsigned *__restr
                                                          const int32_t *__restrict__ chunk_row,
                                                          const float *__restrict__ csr_w, int n_chunks,
                                                          float *__restrict__ val, long long *__restrict__ part) {
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks;
-         c += (long long)gridDim.x * blockDim.x) {
+    // 8 lanes per chunk (coalesced 32-byte runs of the weight list), integer partial sums folded by shuffles; the
+    // 8 lanes of a group share c, so they enter and leave the loop together
+    const int sub = threadIdx.x & 7;
+    const long long nthr8 = (long long)gridDim.x * blockDim.x / 8;
+    for (long long c = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / 8; c < n_chunks; c += nthr8) {
         const int row = chunk_row[c];
         const int cb = chunk_base[row];
         const bool single = chunk_base[row + 1] - cb == 1;
         const unsigned s = start[row] + (unsigned)(c - cb) * SPLAT_CHUNK;
         const unsigned e = min(s + SPLAT_CHUNK, start[row + 1]);
         long long acc = 0;
-        for (unsigned i = s; i < e; ++i) acc += (long long)__float2int_rn(csr_w[i] * FIX_SCALE);
-        if (single) val[row] = (float)acc * FIX_INV;
-        else part[c] = acc;
+        for (unsigned i = s + sub; i < e; i += 8) acc += (long long)__float2int_rn(csr_w[i] * FIX_SCALE);
+        for (int o = 4; o > 0; o >>= 1) {
+            const unsigned lo = __shfl_down((unsigned)acc, o, 8), hi = __shfl_down((unsigned)(acc >> 32), o, 8);
+            acc += (long long)(((unsigned long long)hi << 32) | lo);
+        }
+        if (sub == 0) {
+            if (single) val[row] = (float)acc * FIX_INV;
+            else part[c] = acc;
+        }
     }
 }
 
@@ -1136,7 +1145,7 @@ struct TempBuf { // build-time scratch handed back to the ctx cache at the end o
 
 // the normalisation pass: val = Lattice-splat of the all-ones vector (one value per row)
 void splat_ones(wsc_ctx *ctx, const LatticeDev &L, float *val, long long *part) {
-    hipLaunchKernelGGL(splat_ones_kernel, dim3(grid1d(L.n_chunks)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(splat_ones_kernel, dim3(grid1d((long long)L.n_chunks * 8)), dim3(256), 0, ctx->stream,
                        (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_w, L.n_chunks, val, part);
     if (L.n_long > 0)
         hipLaunchKernelGGL(splat_combine_kernel, dim3(grid1d(L.n_long, 256, 4096)), dim3(256), 0, ctx->stream,
