@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void splat4_kernel(const int4 *__restrict__ ch
     // per batch (288 us) and 32-bit accumulators at 2^-23 (272 us) change nothing: the kernel is bound by
     // the gather path (L1/L2 requests), neither by VALU nor by exposed latency.
     constexpr int CU_ = SPLAT_CU;
-    for (long long c0 = cbeg + (threadIdx.x >> 6) * gpw * CU_ + g; c0 < cend; c0 += 4 * gpw * CU_) {
+    for (long long c0 = cbeg + (threadIdx.x >> 6) * gpw * CU_ + g; c0 < cend; c0 += (int)(blockDim.x >> 6) * gpw * CU_) {
         int4 d[CU_];
 #pragma unroll
         for (int u = 0; u < CU_; ++u) {
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(256) void slice_update_kernel(UpdateArgs a) {
     long long pbeg, pend;
     xcd_range(a.npix, pbeg, pend);
     constexpr int U = 1; // pixels per lane group per trip (2 measured slower: 362 vs 332 us)
-    for (long long p0 = pbeg + (long long)(threadIdx.x >> 6) * gpw * U; p0 < pend; p0 += 4ll * gpw * U) {
+    for (long long p0 = pbeg + (long long)(threadIdx.x >> 6) * gpw * U; p0 < pend; p0 += (long long)(blockDim.x >> 6) * gpw * U) {
         long long pp[U];
         bool ok[U];
         uint32_t rc[U][20];
@@ -1158,6 +1158,7 @@ void splat4(wsc_ctx *ctx, const LatticeDev &L, const float *q, int LP, float *va
     // algorithmic bytes: read the batch's Q once + (pixel index, weight) per gathered pixel + write the rows
     const double npix = (double)L.n_pix * L.rep, rows = (double)L.rows * L.rep;
     WscKernelTimer timer(ctx, WSC_K_SPLAT, npix * L.M_cur * 4 + npix * (L.d + 1) * 8 + rows * L.M_cur * 4);
+    // 256 threads per block: 128 / 64 measured 289 / 320 us against 270 (the opposite of slice_update)
     hipLaunchKernelGGL(splat4_kernel, dim3(grid_rep((long long)L.n_chunks * L.rep, 4 * SPLAT_CU * gpw, L.rep)), dim3(256), 0,
                        ctx->stream, L.chunk_desc, L.csr_ent, q, LP, L.n_chunks, L.rep, (unsigned)L.n_pix,
                        (unsigned)L.rows, val, part);
@@ -1410,7 +1411,8 @@ void launch_update(wsc_ctx *ctx, const UpdateArgs &a) {
     WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, (double)a.npix * (9 * 8 + 4.0 * a.M * 4));
     // one trip (4 * gpw pixels) per block: with the grid capped at 16 384 / 65 536 blocks the kernel took 324 / 353 us,
     // uncapped (82 k blocks for 32 images at 321^2) 299 us -- whole trips per block, no ragged per-block ranges
-    hipLaunchKernelGGL(slice_update_kernel, dim3(grid1d(a.npix, 4 * gpw, 1 << 22)), dim3(256), 0, ctx->stream, a);
+    // ... and 128-thread blocks (20 pixels): 302 -> 289 us (64 threads: 291)
+    hipLaunchKernelGGL(slice_update_kernel, dim3(grid1d(a.npix, 2 * gpw, 1 << 22)), dim3(128), 0, ctx->stream, a);
 }
 
 } // namespace
