@@ -45,26 +45,69 @@ struct LatticeDev {
     int32_t *offset = nullptr;  // [B*N*(d+1)]
     float *bary = nullptr;      // [B*N*(d+1)]
     float *norm = nullptr;      // [B*N]
-    int32_t *csr_start = nullptr; // [rows + 1]
-    int32_t *csr_pix = nullptr;   // [B*N*(d+1)]  global pixel index
-    float *csr_w = nullptr;       // [B*N*(d+1)]
-    uint2 *csr_ent = nullptr;     // [B*N*(d+1)] {pixel, bits(w * norm[pixel])}: one 8-byte load per gathered pixel
     int2 *nbr = nullptr;          // [(d+1)][rows]
-    // splat work items: every row is cut into chunks of <= SPLAT_CHUNK gathered pixels (64: 32 -> 294.5 us, 64 -> 288.6, 128 -> 322.9 per splat; with the final kernels 8 / 16 / 32 / 64 -> 473 / 358 / 299 / 269 us)
-    int32_t *chunk_base = nullptr; // [rows + 1] first chunk of each row
-    int32_t *chunk_row = nullptr;  // [n_chunks] owning row
-    int4 *chunk_desc = nullptr;    // [n_chunks] {first entry, entry count, row, 1 if the row's only chunk}
-    int32_t *long_rows = nullptr;  // [n_long] rows with more than one chunk
-    int n_chunks = 0, n_long = 0;
+    // Splat tables, pixel-tile major (see "pixel tiles" below).  The splat of a tile's pixels is a gather per
+    // SLOT: a slot is a run of <= SLOT_ENT entries (pixel of the tile, weight) that go to one lattice row, in a
+    // fixed (sorted) order, so plain fp32 sums are reproducible; every slot produces one partial row, and a row's
+    // value is the (order-independent, fixed-point) sum of its slots' partials.
+    int32_t *tslot_start = nullptr;  // [n_tiles + 1] first slot of each tile
+    int2 *slot_desc = nullptr;       // [n_slots] {first entry (relative to the tile) | entry count << 16, index of its partial row}
+    uint2 *tent = nullptr;           // [B*N*(d+1)] {pixel index inside the tile, bits(w * norm[pixel])}, tile-major, grouped by row
+    // partial rows are laid out ROW-major: the slots of row r write partial rows [row_slot_start[r], row_slot_start[r+1])
+    int32_t *row_slot_start = nullptr; // [rows + 1]
+    int n_tiles = 0, n_slots = 0;
     long long n_pix = 0; // pixels of one replica (B*N when rep == 1)
     int M_cur = 0;       // class count of the inference in flight (algorithmic byte accounting)
     float alpha = 0.f;
     // Gaussian lattice only (d = 2): tiles of the dense (i, j) index space for the fused three-pass blur
     int32_t *tile_rows = nullptr; // [n_tiles][GBI * GBJ] row id of every point of the tile's halo box (0 = absent)
+    int2 *tile_pstart = nullptr;  // [n_tiles][GBI * GBJ] {first partial row, count} of that row
     int32_t *tile_list = nullptr; // [n_tiles_occ] tiles with at least one interior vertex
     int n_tiles_occ = 0;
     std::vector<int32_t> v_per_image;
 };
+
+// ---- pixel tiles ------------------------------------------------------------------------------------
+// The iteration kernels walk the image in 2-D pixel tiles of at most TILE_H x TILE_W pixels (balanced split: an
+// image of W columns is cut into ceil(W / TILE_W) tile columns whose widths differ by at most one).  Neighbouring
+// pixels share lattice vertices (a 16 x 16 tile of a 321 x 321 image touches ~120 of the image's ~10 000 bilateral
+// vertices and ~160 Gaussian ones), so a tile's contribution to a vertex is summed on chip and leaves the CU once.
+#ifndef WSC_TILE_W
+#define WSC_TILE_W 16
+#endif
+#ifndef WSC_TILE_H
+#define WSC_TILE_H 16
+#endif
+constexpr int TILE_W = WSC_TILE_W, TILE_H = WSC_TILE_H, TILE_PIX = TILE_W * TILE_H;
+constexpr int SLOT_ENT = 32;       // entries per slot (bounds the serial chain of one lane group)
+constexpr int SORT_MAX = 2048;     // >= TILE_PIX * 6 entries of a bilateral tile, power of two
+static_assert(TILE_PIX * 6 <= SORT_MAX && SORT_MAX <= 65535, "tile too large for the in-LDS grouping");
+
+struct TileGeom {
+    int H, W, ntx, nty, tpi; // tile columns / rows / tiles per image
+};
+__host__ __device__ inline TileGeom make_geom(int H, int W) {
+    TileGeom g;
+    g.H = H; g.W = W;
+    g.ntx = (W + TILE_W - 1) / TILE_W;
+    g.nty = (H + TILE_H - 1) / TILE_H;
+    g.tpi = g.ntx * g.nty;
+    return g;
+}
+struct TileBox {
+    int x0, y0, cw, ch; // origin and size of the tile
+    int ebase;          // pixels of the image in tiles before this one (tile-major pixel order)
+};
+__host__ __device__ inline TileBox tile_box(const TileGeom &g, int j) {
+    const int ty = j / g.ntx, tx = j - ty * g.ntx;
+    TileBox b;
+    b.x0 = (int)((long long)tx * g.W / g.ntx);
+    b.y0 = (int)((long long)ty * g.H / g.nty);
+    b.cw = (int)((long long)(tx + 1) * g.W / g.ntx) - b.x0;
+    b.ch = (int)((long long)(ty + 1) * g.H / g.nty) - b.y0;
+    b.ebase = b.y0 * g.W + b.x0 * b.ch;
+    return b;
+}
 
 } // namespace
 
@@ -76,6 +119,9 @@ struct wsc_crf {
     uint4 *pix_rec = nullptr;
     std::vector<void *> allocs;
     bool persist = false; // allocations made while set belong to the ctx (cached Gaussian lattice)
+    // set by wsc_crf_inference on a ctx other than the build ctx: the last loop's completion on that stream
+    hipEvent_t use_ev = nullptr;
+    bool used_elsewhere = false;
 };
 
 namespace {
@@ -454,43 +500,244 @@ __global__ void assign_ids_kernel(const int32_t *__restrict__ eslot, const unsig
     }
 }
 
-// offset[e] = row of entry e; count entries per row.  One thread per pixel, r in the loop, so the
-// lanes of a wave are neighbouring pixels and share rows: one atomicAdd per distinct row per wave.
-__global__ __launch_bounds__(256) void remap_count_kernel(const int32_t *__restrict__ eslot,
-                                                          const int32_t *__restrict__ slot2row, long long cap, int N,
-                                                          int dp1, long long npix, int32_t *__restrict__ offset,
-                                                          unsigned *__restrict__ count) {
-    const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gp >= npix) return;
-    const int b = (int)(gp / N);
-    for (int r = 0; r < dp1; ++r) {
-        const long long e = gp * dp1 + r;
-        const int row = slot2row[(long long)b * cap + eslot[e]];
-        offset[e] = row;
-        const unsigned long long grp = wave_match32((unsigned)row);
-        if (lane_id() == __ffsll((long long)grp) - 1) atomicAdd(&count[row], (unsigned)__popcll(grp));
+// offset[e] = row of entry e
+__global__ __launch_bounds__(256) void remap_kernel(const int32_t *__restrict__ eslot,
+                                                    const int32_t *__restrict__ slot2row, long long cap, int N,
+                                                    int dp1, long long total, int32_t *__restrict__ offset) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(e / ((long long)N * dp1));
+        offset[e] = slot2row[(long long)b * cap + eslot[e]];
     }
 }
 
-__global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t *__restrict__ offset,
-                                                       const float *__restrict__ bary, int dp1, long long npix,
-                                                       const unsigned *__restrict__ start,
-                                                       unsigned *__restrict__ cursor, int32_t *__restrict__ csr_pix,
-                                                       float *__restrict__ csr_w) {
-    const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gp >= npix) return;
-    const int lane = lane_id();
-    for (int r = 0; r < dp1; ++r) {
-        const long long e = gp * dp1 + r;
-        const int row = offset[e];
-        const unsigned long long grp = wave_match32((unsigned)row);
-        const int leader = __ffsll((long long)grp) - 1;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(&cursor[row], (unsigned)__popcll(grp));
-        base = __shfl(base, leader, 64);
-        const unsigned pos = start[row] + base + (unsigned)__popcll(grp & ((1ull << lane) - 1ull));
-        csr_pix[pos] = (int32_t)gp;
-        csr_w[pos] = bary[e];
+// ---- splat tables of a pixel tile (lattice build) -------------------------------------------------------
+// Block-wide inclusive scan of an int array in LDS (n <= SORT_MAX, 256 threads, 8 consecutive elements per
+// thread).  MAXOP: running maximum instead of running sum.
+template <bool MAXOP>
+__device__ __forceinline__ void block_scan_lds(int *v, int n, int *wtot /* [4] */) {
+    constexpr int PER = SORT_MAX / 256;
+    const int t0 = threadIdx.x * PER;
+    int loc[PER];
+    int run = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int x = t0 + i < n ? v[t0 + i] : 0;
+        run = MAXOP ? max(run, x) : run + x;
+        loc[i] = run;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int x = run;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x = MAXOP ? max(x, y) : x + y;
+    }
+    if (lane == 63) wtot[wv] = x;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wv; ++i) base = MAXOP ? max(base, wtot[i]) : base + wtot[i];
+    int prev = __shfl_up(x, 1, 64); // inclusive result of the previous thread of this wave
+    if (lane == 0) prev = 0;
+    const int carry = MAXOP ? max(base, prev) : base + prev;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+        if (t0 + i < n) v[t0 + i] = MAXOP ? max(carry, loc[i]) : carry + loc[i];
+    __syncthreads();
+}
+
+// Grouped rows of a tile in LDS -> flag[i] = 1 where a slot starts (a new row, or SLOT_ENT entries into a row's
+// run); on return aux[i] holds the inclusive count of slot starts (aux[ne-1] = slots of the tile).
+__device__ __forceinline__ void tile_slot_flags(const int *srow, int ne, int *aux, int *flag, int *wtot) {
+    for (int i = threadIdx.x; i < ne; i += 256) aux[i] = (i == 0 || srow[i] != srow[i - 1]) ? i : 0;
+    __syncthreads();
+    block_scan_lds<true>(aux, ne, wtot); // aux[i] = start of the run of equal rows containing i
+    for (int i = threadIdx.x; i < ne; i += 256) flag[i] = ((i - aux[i]) % SLOT_ENT == 0) ? 1 : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < ne; i += 256) aux[i] = flag[i];
+    __syncthreads();
+    block_scan_lds<false>(aux, ne, wtot);
+}
+
+// Pass 1, one block per tile: bring the tile's entries (pixel t of the tile, vertex rank r; index e = t*(d+1)+r) into
+// groups of equal lattice row, keeping the entries of a group in index order, and write them out tile-major.  That
+// makes the summation order of every slot a function of the image alone -- not of the batch it is in, nor of an
+// atomic's arrival order.  (The ORDER OF THE GROUPS within the tile is that of an LDS hash table and may differ from
+// run to run: it only decides where a slot's partial row lives, never a value.)
+//   A  rows -> slots of an LDS hash table (compare-and-swap insert);   B  stable rank of every entry inside its group:
+//   wave q walks the q-th quarter of the index range in order, 64 entries at a time -- equal slots are matched with
+//   ballots, the running per-(wave, slot) count gives the rank within the quarter;   C  group sizes, scan -> group
+//   starts; position = start + entries of the group in earlier quarters + rank.
+constexpr int GROUP_HT = SORT_MAX; // hash slots (load <= 0.75 even when every entry has its own row)
+__global__ __launch_bounds__(256) void tile_group_kernel(const int32_t *__restrict__ offset, const float *__restrict__ bary,
+                                                         int dp1, TileGeom tg, uint2 *__restrict__ tent,
+                                                         int32_t *__restrict__ srow_out, unsigned *__restrict__ tile_nslots) {
+    __shared__ unsigned table[GROUP_HT];
+    __shared__ int start[GROUP_HT];          // group size, then group start
+    __shared__ unsigned short wcnt[4][GROUP_HT];
+    __shared__ unsigned short eslot[SORT_MAX], erank[SORT_MAX];
+    __shared__ int wtot[4];
+    const int tile = blockIdx.x;
+    const int b = tile / tg.tpi, j = tile - b * tg.tpi;
+    const TileBox tb = tile_box(tg, j);
+    const int N = tg.H * tg.W;
+    const int np = tb.cw * tb.ch, ne = np * dp1;
+    for (int i = threadIdx.x; i < GROUP_HT; i += 256) {
+        table[i] = 0xFFFFFFFFu;
+        wcnt[0][i] = 0; wcnt[1][i] = 0; wcnt[2][i] = 0; wcnt[3][i] = 0;
+    }
+    __syncthreads();
+    const long long pbase = (long long)b * N;
+    for (int e = threadIdx.x; e < ne; e += 256) {
+        const int t = e / dp1, r = e - t * dp1;
+        const int ty = t / tb.cw, tx = t - ty * tb.cw;
+        const long long p = pbase + (long long)(tb.y0 + ty) * tg.W + tb.x0 + tx;
+        const unsigned row = (unsigned)offset[p * dp1 + r];
+        unsigned sl = (row * 2654435761u) >> 21 & (GROUP_HT - 1);
+        for (;;) {
+            const unsigned old = atomicCAS(&table[sl], 0xFFFFFFFFu, row);
+            if (old == 0xFFFFFFFFu || old == row) break;
+            sl = (sl + 1) & (GROUP_HT - 1);
+        }
+        eslot[e] = (unsigned short)sl;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int Q = ((ne + 3) / 4 + 63) / 64 * 64; // entries per quarter, whole wave trips
+    for (int c = q * Q; c < min(ne, (q + 1) * Q); c += 64) {
+        const int e = c + lane;
+        const bool valid = e < ne;
+        const unsigned sl = valid ? eslot[e] : 0u;
+        // match equal slots among the valid lanes
+        unsigned long long remaining = __ballot(valid);
+        unsigned long long mine = 0;
+        while (remaining) {
+            const int leader = __ffsll((long long)remaining) - 1;
+            const bool same = valid && sl == (unsigned)__shfl((int)sl, leader, 64);
+            const unsigned long long m = __ballot(same);
+            if (same) mine = m;
+            remaining &= ~m;
+        }
+        if (valid) {
+            const int leader = __ffsll((long long)mine) - 1;
+            int base = 0;
+            if (lane == leader) {
+                base = wcnt[q][sl];
+                wcnt[q][sl] = (unsigned short)(base + __popcll(mine));
+            }
+            base = __shfl(base, leader, 64);
+            erank[e] = (unsigned short)(base + __popcll(mine & ((1ull << lane) - 1ull)));
+        }
+    }
+    __syncthreads();
+    int my_slots = 0;
+    for (int i = threadIdx.x; i < GROUP_HT; i += 256) {
+        const int c0 = wcnt[0][i], c1 = wcnt[1][i], c2 = wcnt[2][i], c3 = wcnt[3][i];
+        const int tot = c0 + c1 + c2 + c3;
+        start[i] = tot;
+        wcnt[0][i] = 0;
+        wcnt[1][i] = (unsigned short)c0;
+        wcnt[2][i] = (unsigned short)(c0 + c1);
+        wcnt[3][i] = (unsigned short)(c0 + c1 + c2);
+        my_slots += (tot + SLOT_ENT - 1) / SLOT_ENT;
+    }
+    for (int o = 32; o > 0; o >>= 1) my_slots += __shfl_down(my_slots, o, 64);
+    __syncthreads();
+    if (lane == 0) wtot[q] = my_slots;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_nslots[tile] = (unsigned)(wtot[0] + wtot[1] + wtot[2] + wtot[3]);
+    __syncthreads();
+    block_scan_lds<false>(start, GROUP_HT, wtot); // inclusive
+    const long long ebase = (pbase + tb.ebase) * dp1;
+    for (int e = threadIdx.x; e < ne; e += 256) {
+        const int sl = eslot[e];
+        const int qq = e / Q;
+        const int cnt = (int)wcnt[qq][sl];
+        const int prev = sl > 0 ? start[sl - 1] : 0; // exclusive start of the group
+        const int pos = prev + cnt + (int)erank[e];
+        const int t = e / dp1, r = e - t * dp1;
+        const int ty = t / tb.cw, tx = t - ty * tb.cw;
+        const long long p = pbase + (long long)(tb.y0 + ty) * tg.W + tb.x0 + tx;
+        srow_out[ebase + pos] = (int32_t)table[sl];
+        tent[ebase + pos] = make_uint2((unsigned)t, __float_as_uint(bary[p * dp1 + r]));
+    }
+}
+
+// Pass 2, one block per tile: slot descriptors at their final (compact) index; slots per row counted.
+__global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restrict__ srow_in, int dp1, TileGeom tg,
+                                                         const int32_t *__restrict__ tslot_start, int2 *__restrict__ slot_desc,
+                                                         int32_t *__restrict__ slot_row, unsigned *__restrict__ row_nslots) {
+    __shared__ int rows_s[SORT_MAX];
+    __shared__ int aux[SORT_MAX];
+    __shared__ int flag[SORT_MAX];
+    __shared__ int pos[SORT_MAX + 1];
+    __shared__ int wtot[4];
+    const int tile = blockIdx.x;
+    const int b = tile / tg.tpi, j = tile - b * tg.tpi;
+    const TileBox tb = tile_box(tg, j);
+    const int N = tg.H * tg.W;
+    const int ne = tb.cw * tb.ch * dp1;
+    const long long ebase = ((long long)b * N + tb.ebase) * dp1;
+    for (int i = threadIdx.x; i < ne; i += 256) rows_s[i] = srow_in[ebase + i];
+    __syncthreads();
+    tile_slot_flags(rows_s, ne, aux, flag, wtot);
+    const int ns = aux[ne - 1];
+    for (int i = threadIdx.x; i < ne; i += 256)
+        if (flag[i]) pos[aux[i] - 1] = i;
+    if (threadIdx.x == 0) pos[ns] = ne;
+    __syncthreads();
+    // The tile's slots are stored longest first: the lane groups of a wave of the update kernel take consecutive
+    // slots and wait for the longest of them (the order of a tile's slots is free -- it only decides which
+    // descriptor index a slot gets).
+    __shared__ int hist[SLOT_ENT + 1], hcur[SLOT_ENT + 1];
+    if (threadIdx.x <= SLOT_ENT) { hist[threadIdx.x] = 0; hcur[threadIdx.x] = 0; }
+    __syncthreads();
+    for (int s = threadIdx.x; s < ns; s += 256) atomicAdd(&hist[pos[s + 1] - pos[s]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int n = SLOT_ENT; n >= 0; --n) {
+            const int c = hist[n];
+            hist[n] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const int s0 = tslot_start[tile];
+    for (int s = threadIdx.x; s < ns; s += 256) {
+        const int i = pos[s], n = pos[s + 1] - i;
+        const int row = rows_s[i];
+        const int dst = s0 + hist[n] + atomicAdd(&hcur[n], 1);
+        slot_desc[dst] = make_int2(i | (n << 16), 0);
+        slot_row[dst] = row;
+        atomicAdd(&row_nslots[row], 1u);
+    }
+}
+
+// every slot gets a partial row inside its row's range (any order: the combine adds fixed-point integers)
+__global__ void slot_dest_kernel(const int32_t *__restrict__ slot_row, int n_slots, const int32_t *__restrict__ row_slot_start,
+                                 unsigned *__restrict__ cursor, int2 *__restrict__ slot_desc) {
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += gridDim.x * blockDim.x) {
+        const int row = slot_row[s];
+        slot_desc[s].y = row_slot_start[row] + (int)atomicAdd(&cursor[row], 1u);
+    }
+}
+
+// entry weights: barycentric weight -> weight * norm[pixel]  (the splat input is norm * Q)
+__global__ __launch_bounds__(256) void tile_scale_entries_kernel(const float *__restrict__ norm, int dp1, TileGeom tg,
+                                                                 uint2 *__restrict__ tent) {
+    const int tile = blockIdx.x;
+    const int b = tile / tg.tpi, j = tile - b * tg.tpi;
+    const TileBox tb = tile_box(tg, j);
+    const int N = tg.H * tg.W;
+    const int ne = tb.cw * tb.ch * dp1;
+    const long long ebase = ((long long)b * N + tb.ebase) * dp1;
+    for (int i = threadIdx.x; i < ne; i += 256) {
+        uint2 en = tent[ebase + i];
+        const int t = (int)en.x;
+        const int ty = t / tb.cw, tx = t - ty * tb.cw;
+        const long long p = (long long)b * N + (long long)(tb.y0 + ty) * tg.W + tb.x0 + tx;
+        en.y = __float_as_uint(__uint_as_float(en.y) * norm[p]);
+        tent[ebase + i] = en;
     }
 }
 
@@ -543,176 +790,82 @@ __global__ void neighbors_kernel(const unsigned long long *__restrict__ rowkey, 
 
 // ---- iteration kernels ------------------------------------------------------------------
 
-// Splat in gather form: val[row][m] = sum over the row's pixels of w * (norm[p] * Q[p][m]).
-// Work item = one chunk (<= SPLAT_CHUNK consecutive entries of one row's pixel list) x M lanes;
-// a wave carries floor(64/M) chunks (M = 21 -> 63 of 64 lanes busy).  Rows of flat image regions
-// gather thousands of pixels; cutting them bounds the serial chain per work item.  Entries are
-// fetched 8 at a time so that 8 independent Q-row gathers are in flight per lane.
-//
-// The sum is accumulated in 64-bit FIXED POINT: every fp32 term w*norm*Q is rounded to a multiple
-// of 2^-28 (|term| <= 2.5 because norm <= 1/sqrt(alpha/(d+1)), so it fits an int32) and added as
-// an integer.  Integer addition is associative, so the result does not depend on the order in
-// which csr_fill's atomic cursors laid the row out -- the iteration loop is bit-reproducible from
-// run to run without sorting the lists and without float atomics.  Quantisation error per term is
-// <= 1.9e-9 absolute, far inside the 1e-3 parity budget on Q.
-// A single-chunk row writes val directly; chunks of long rows write int64 partials that
-// splat_combine_kernel adds up.
-// ONES: splat of the all-ones vector (M = 1) for the normalisation pass.
-constexpr int SPLAT_CHUNK = 64;
-constexpr int SPLAT_CU = 1; // chunks per lane group per trip of splat4_kernel
-constexpr float FIX_SCALE = 268435456.0f;        // 2^28
-constexpr float FIX_INV = 1.0f / 268435456.0f;   // 2^-28 (exact)
+// Splat, tile-gather form: val[row][m] = sum over the pixels p touching the row of w * (norm[p] * Q[p][m]).
+// The pixels of a tile are on chip (LDS) when their contributions are needed -- the update kernel below
+// has just computed them -- and every SLOT (<= SLOT_ENT entries of one row, fixed order) is summed by one lane
+// group in plain fp32 and written out as one partial row.  A row's value is the sum of its slots' partials;
+// that sum runs over a list filled through an atomic cursor (arbitrary order), so it is taken in FIXED POINT:
+// every partial is rounded to a multiple of 2^-24 (|partial| <= SLOT_ENT * 2.5 = 80 < 2^7 because
+// norm <= 1/sqrt(alpha/(d+1)), so it fits an int32) and added as a 64-bit integer.  Integer addition is
+// associative: the result does not depend on the order of the list, and the iteration loop is
+// bit-reproducible from run to run without sorting and without float atomics.
+constexpr float PFIX_SCALE = 16777216.0f;       // 2^24
+constexpr float PFIX_INV = 1.0f / 16777216.0f;  // 2^-24 (exact)
+static_assert(SLOT_ENT * 2.5f < 127.0f, "slot partials must fit the 2^24 fixed-point int32");
 
-// Scalar form, used for the normalisation pass only (splat of the all-ones vector, M = 1).
-__global__ __launch_bounds__(256) void splat_ones_kernel(const unsigned *__restrict__ start,
-                                                         const int32_t *__restrict__ chunk_base,
-                                                         const int32_t *__restrict__ chunk_row,
-                                                         const float *__restrict__ csr_w, int n_chunks,
-                                                         float *__restrict__ val, long long *__restrict__ part) {
-    // 8 lanes per chunk (coalesced 32-byte runs of the weight list), integer partial sums folded by shuffles; the
-    // 8 lanes of a group share c, so they enter and leave the loop together
-    const int sub = threadIdx.x & 7;
-    const long long nthr8 = (long long)gridDim.x * blockDim.x / 8;
-    for (long long c = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / 8; c < n_chunks; c += nthr8) {
-        const int row = chunk_row[c];
-        const int cb = chunk_base[row];
-        const bool single = chunk_base[row + 1] - cb == 1;
-        const unsigned s = start[row] + (unsigned)(c - cb) * SPLAT_CHUNK;
-        const unsigned e = min(s + SPLAT_CHUNK, start[row + 1]);
-        long long acc = 0;
-        for (unsigned i = s + sub; i < e; i += 8) acc += (long long)__float2int_rn(csr_w[i] * FIX_SCALE);
-        for (int o = 4; o > 0; o >>= 1) {
-            const unsigned lo = __shfl_down((unsigned)acc, o, 8), hi = __shfl_down((unsigned)(acc >> 32), o, 8);
-            acc += (long long)(((unsigned long long)hi << 32) | lo);
-        }
-        if (sub == 0) {
-            if (single) val[row] = (float)acc * FIX_INV;
-            else part[c] = acc;
-        }
-    }
-}
-
-// Iteration form.  Q / U / val rows are padded to Mp = 4*LP floats (16-byte aligned rows) and a
-// lane owns 4 consecutive classes: every gather is a 16-byte load.  (The L1 serves one access per
-// clock whatever its width; with 4-byte lanes the gathers of this kernel ran at 1.04 L1 accesses
-// per clock per CU -- L1-issue bound -- for 3.8 useful bytes each: profiles/r01_pmc_crf.txt.)
-// LP lanes per chunk, floor(64/LP) chunks per wave.
-__global__ __launch_bounds__(256) void splat4_kernel(const int4 *__restrict__ chunk_desc,
-                                                     const uint2 *__restrict__ csr_ent,
-                                                     const float *__restrict__ q, int LP, int n_local,
-                                                     int rep, unsigned pix_stride, unsigned row_stride,
-                                                     float *__restrict__ val, long long *__restrict__ part) {
-    // n_local chunks per replica; replica k reads pixels + k*pix_stride and writes rows + k*row_stride
-    const int gpw = 64 / LP;
-    const int lane = threadIdx.x & 63;
-    const int g = lane / LP;
-    const int l = lane - g * LP;
-    if (g >= gpw) return;
-    long long cbeg, cend;
-    int rk;
-    xcd_range_rep(n_local, rep, rk, cbeg, cend);
-    const f32x4_t *q4 = reinterpret_cast<const f32x4_t *>(q) + (size_t)rk * pix_stride * LP;
-    val += (size_t)rk * row_stride * LP * 4;
-    part += (size_t)rk * n_local * LP * 4;
-    // descriptor -> entries -> Q rows is a chain of three dependent memory latencies; it is hidden by
-    // occupancy, not by per-wave parallelism: one chunk per lane group per trip keeps the kernel at 63
-    // VGPRs = 8 waves per SIMD.  Measured splat + combine per iteration (G + B, 32 images, M = 21):
-    // 1 chunk 273 us, 2 chunks 278 us, 3 chunks 289 us, 4 chunks (161 VGPRs, 3 waves) 296 us.  16 entries
-    // per batch (288 us) and 32-bit accumulators at 2^-23 (272 us) change nothing: the kernel is bound by
-    // the gather path (L1/L2 requests), neither by VALU nor by exposed latency.
-    constexpr int CU_ = SPLAT_CU;
-    for (long long c0 = cbeg + (threadIdx.x >> 6) * gpw * CU_ + g; c0 < cend; c0 += (int)(blockDim.x >> 6) * gpw * CU_) {
-        int4 d[CU_];
+// sum of the partial rows [sb, se) (float4 l of each), 4 loads in flight
+__device__ __forceinline__ f32x4_t combine_slots4(const f32x4_t *__restrict__ part, int sb, int se, unsigned LP, unsigned l) {
+    if (se - sb == 1) return part[(unsigned)sb * LP + l];
+    long long acc[4] = {0, 0, 0, 0};
+    for (int i = sb; i < se; i += 4) {
+        f32x4_t v[4];
 #pragma unroll
-        for (int u = 0; u < CU_; ++u) {
-            const long long c = c0 + (long long)u * gpw;
-            d[u] = c < cend ? chunk_desc[c] : make_int4(0, 0, 0, 1);
-        }
-        long long acc[CU_][4];
+        for (int u = 0; u < 4; ++u) v[u] = part[(unsigned)min(i + u, se - 1) * LP + l];
 #pragma unroll
-        for (int u = 0; u < CU_; ++u)
+        for (int u = 0; u < 4; ++u)
+            if (i + u < se) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[u][k] = 0;
-        int maxlen = 0;
-#pragma unroll
-        for (int u = 0; u < CU_; ++u) maxlen = max(maxlen, d[u].y);
-        for (int i = 0; i < maxlen; i += 8) {
-            uint2 en[CU_][8];
-            f32x4_t in[CU_][8];
-#pragma unroll
-            for (int u = 0; u < CU_; ++u)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    en[u][j] = i + j < d[u].y ? csr_ent[(unsigned)d[u].x + i + j] : make_uint2(0, 0); // weight 0
-#pragma unroll
-            for (int u = 0; u < CU_; ++u)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) in[u][j] = q4[en[u][j].x * (unsigned)LP + l];
-#pragma unroll
-            for (int u = 0; u < CU_; ++u)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float w = __uint_as_float(en[u][j].y); // w * norm[pixel]
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[u][k] += (long long)__float2int_rn((w * in[u][j][k]) * FIX_SCALE);
-                }
-        }
-#pragma unroll
-        for (int u = 0; u < CU_; ++u) {
-            const long long c = c0 + (long long)u * gpw;
-            if (c >= cend) continue;
-            if (d[u].w) {
-                f32x4_t o = {(float)acc[u][0] * FIX_INV, (float)acc[u][1] * FIX_INV, (float)acc[u][2] * FIX_INV,
-                             (float)acc[u][3] * FIX_INV};
-                reinterpret_cast<f32x4_t *>(val)[(unsigned)d[u].z * (unsigned)LP + l] = o;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) part[(c * LP + l) * 4 + k] = acc[u][k];
+                for (int k = 0; k < 4; ++k) acc[k] += (long long)__float2int_rn(v[u][k] * PFIX_SCALE);
             }
-        }
     }
+    f32x4_t o = {(float)acc[0] * PFIX_INV, (float)acc[1] * PFIX_INV, (float)acc[2] * PFIX_INV, (float)acc[3] * PFIX_INV};
+    return o;
 }
 
-// sums the int64 partials of multi-chunk rows; Mp = values per row (1 for the ones pass)
-__global__ __launch_bounds__(256) void splat_combine_kernel(const int32_t *__restrict__ long_rows, int n_long,
-                                                            const int32_t *__restrict__ chunk_base,
-                                                            const long long *__restrict__ part, int Mp, int rep,
-                                                            int chunk_stride, int row_stride,
-                                                            float *__restrict__ val) {
-    const long long total = (long long)n_long * rep * Mp;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int gi = (int)(i / Mp);
-        const int m = (int)(i - (long long)gi * Mp);
-        const int k = gi / n_long; // replica
-        const int row = long_rows[gi - k * n_long];
-        const int cb = chunk_base[row], ce = chunk_base[row + 1];
-        const long long pbase = (long long)k * chunk_stride;
+// Normalisation pass (splat of the all-ones vector, one value per row): slot partials, then rows.
+__global__ __launch_bounds__(256) void slot_ones_kernel(const int32_t *__restrict__ tslot_start, const int2 *__restrict__ slot_desc,
+                                                        const uint2 *__restrict__ tent, int dp1, TileGeom tg,
+                                                        float *__restrict__ part) {
+    const int tile = blockIdx.x;
+    const int b = tile / tg.tpi, j = tile - b * tg.tpi;
+    const TileBox tb = tile_box(tg, j);
+    const long long ebase = ((long long)b * tg.H * tg.W + tb.ebase) * dp1;
+    for (int s = tslot_start[tile] + threadIdx.x; s < tslot_start[tile + 1]; s += 256) {
+        const int2 d = slot_desc[s];
+        const int i0 = d.x & 0xffff, n = d.x >> 16;
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += __uint_as_float(tent[ebase + i0 + i].y);
+        part[d.y] = acc;
+    }
+}
+__global__ void combine1_kernel(const float *__restrict__ part, const int32_t *__restrict__ row_slot_start, int rows,
+                                float *__restrict__ val) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
         long long acc = 0;
-        for (int c = cb; c < ce; ++c) acc += part[(pbase + c) * Mp + m];
-        val[((long long)k * row_stride + row) * Mp + m] = (float)acc * FIX_INV;
+        for (int i = row_slot_start[row]; i < row_slot_start[row + 1]; ++i)
+            acc += (long long)__float2int_rn(part[i] * PFIX_SCALE);
+        val[row] = (float)acc * PFIX_INV;
     }
 }
 
-// chunk bookkeeping (lattice build)
-__global__ void count_chunks_kernel(const unsigned *__restrict__ start, int rows, unsigned *__restrict__ nch) {
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
-        const unsigned len = start[row + 1] - start[row];
-        nch[row] = len <= SPLAT_CHUNK ? 1u : (len + SPLAT_CHUNK - 1) / SPLAT_CHUNK;
-    }
-}
-__global__ void fill_chunks_kernel(const unsigned *__restrict__ start, const int32_t *__restrict__ chunk_base,
-                                   int rows, int32_t *__restrict__ chunk_row, int4 *__restrict__ chunk_desc,
-                                   unsigned *__restrict__ n_long, int32_t *__restrict__ long_rows) {
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
-        const int cb = chunk_base[row], ce = chunk_base[row + 1];
-        const unsigned s = start[row], e = start[row + 1];
-        for (int c = cb; c < ce; ++c) {
-            chunk_row[c] = row;
-            const unsigned b = s + (unsigned)(c - cb) * SPLAT_CHUNK;
-            chunk_desc[c] = make_int4((int)b, (int)(min(b + SPLAT_CHUNK, e) - b), row, ce - cb == 1 ? 1 : 0);
-        }
-        if (ce - cb > 1) long_rows[atomicAdd(n_long, 1u)] = row;
+// Rows from slot partials, iteration form (bilateral lattice; the Gaussian lattice combines inside its fused
+// blur).  LP lanes per row, rows padded to Mp = 4*LP floats; a row's partials are consecutive.
+__global__ __launch_bounds__(256) void combine4_kernel(const f32x4_t *__restrict__ part, const int32_t *__restrict__ row_slot_start,
+                                                       int LP, int rows_local, int n_slots, int rep, f32x4_t *__restrict__ val) {
+    const int rpb = 256 / LP;
+    const int tr = threadIdx.x / LP;
+    const int l = threadIdx.x - tr * LP;
+    if (tr >= rpb) return;
+    long long rbeg, rend;
+    int rk;
+    xcd_range_rep(rows_local, rep, rk, rbeg, rend);
+    part += (size_t)rk * n_slots * LP;
+    val += (size_t)rk * rows_local * LP;
+    for (long long row = rbeg + tr; row < rend; row += rpb) {
+        const int sb = row_slot_start[row], se = row_slot_start[row + 1];
+        f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+        if (se > sb) o = combine_slots4(part, sb, se, (unsigned)LP, (unsigned)l);
+        val[(unsigned)row * (unsigned)LP + l] = o;
     }
 }
 
@@ -823,12 +976,22 @@ __global__ void gauss_tile_fill_kernel(const int2 *__restrict__ ij, int rows, in
     }
 }
 
+__global__ void gauss_tile_pstart_kernel(const int32_t *__restrict__ tile_rows, const int32_t *__restrict__ row_slot_start,
+                                         long long total, int2 *__restrict__ tile_pstart) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int row = tile_rows[i];
+        tile_pstart[i] = row ? make_int2(row_slot_start[row], row_slot_start[row + 1] - row_slot_start[row]) : make_int2(0, 0);
+    }
+}
+
 template <int LH>
 __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__restrict__ in, const int32_t *__restrict__ tile_rows,
                                                          const int32_t *__restrict__ tile_list, int n_occ, int LP,
-                                                         int rows_local, int rep, f32x4_t *__restrict__ out) {
-    // thread p owns point p of the 16 x 16 box and walks the row's float4s, LH at a time (rows wider than LH float4s
-    // take several groups); LDS layout [l][p] (conflict-free 16-byte accesses, neighbours at fixed offsets in p)
+                                                         int rows_local, int rep, f32x4_t *__restrict__ out,
+                                                         const f32x4_t *__restrict__ part, const int2 *__restrict__ tile_pstart,
+                                                         int n_slots) {
+    // part != null: the input rows are not in memory yet -- every box point sums its row from the slot partials
+    // of the splat (combine_slots4, consecutive partial rows) while loading; `in` is unused
     constexpr int P = GBI * GBJ; // one thread per point of the halo box
     __shared__ f32x4_t b0[LH * P], b1[LH * P];
     // XCD-contiguous logical block id: neighbouring tiles of one replica (which share halo rows) on one L2
@@ -836,11 +999,18 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
     const int xcd = bid & 7, qq = nb >> 3, rr = nb & 7;
     const int lb = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     const int k = lb / n_occ, t = lb - k * n_occ;
-    in += (size_t)k * rows_local * LP;
+    if (in) in += (size_t)k * rows_local * LP;
+    if (part) part += (size_t)k * n_slots * LP;
     out += (size_t)k * rows_local * LP;
     const int p = threadIdx.x;
     const int li = p / GBJ, lj = p - li * GBJ;
     const int row = tile_rows[(long long)tile_list[t] * P + p];
+    int sb = 0, se = 0;
+    if (part && row) {
+        const int2 ps = tile_pstart[(long long)tile_list[t] * P + p];
+        sb = ps.x;
+        se = ps.x + ps.y;
+    }
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     if (t == 0 && p < LP) out[p] = zero; // the permanent zero row of this replica
     const bool r0 = row && li >= 1 && li < GBI - 1;      // pass 0 region
@@ -848,8 +1018,23 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
     const bool r2 = row && li >= 2 && li < GBI - 2 && lj >= 2 && lj < GBJ - 2; // interior
     for (int lbase = 0; lbase < LP; lbase += LH) {
         if (lbase > 0) __syncthreads(); // the previous group's pass-2 reads of b0 are done
+        if (part) {
+            // first slot of the row for all LH float4s at once (independent loads), further slots (tile-border
+            // vertices, ~20 % of the rows) added in fixed point afterwards
+            f32x4_t v[LH];
 #pragma unroll
-        for (int l = 0; l < LH; ++l) b0[l * P + p] = (row && lbase + l < LP) ? in[(unsigned)row * (unsigned)LP + lbase + l] : zero;
+            for (int l = 0; l < LH; ++l) v[l] = (se > sb && lbase + l < LP) ? part[(unsigned)sb * (unsigned)LP + lbase + l] : zero;
+            if (se - sb > 1) {
+#pragma unroll
+                for (int l = 0; l < LH; ++l)
+                    if (lbase + l < LP) v[l] = combine_slots4(part, sb, se, (unsigned)LP, (unsigned)(lbase + l));
+            }
+#pragma unroll
+            for (int l = 0; l < LH; ++l) b0[l * P + p] = v[l];
+        } else {
+#pragma unroll
+            for (int l = 0; l < LH; ++l) b0[l * P + p] = (row && lbase + l < LP) ? in[(unsigned)row * (unsigned)LP + lbase + l] : zero;
+        }
         __syncthreads();
         // pass 0, axis 0: (i +- 1, j) = p +- GBJ
 #pragma unroll
@@ -902,16 +1087,6 @@ __global__ void slice_norm_kernel(const int32_t *__restrict__ offset, const floa
     }
 }
 
-// csr_ent[i] = {pixel, w * norm[pixel]}: the splat then needs one 8-byte load per gathered pixel
-__global__ void pack_entries_kernel(const int32_t *__restrict__ csr_pix, const float *__restrict__ csr_w,
-                                    const float *__restrict__ norm, long long total, uint2 *__restrict__ ent) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int p = csr_pix[i];
-        ent[i] = make_uint2((unsigned)p, __float_as_uint(csr_w[i] * norm[p]));
-    }
-}
-
 // everything slice_update needs to know about a pixel in 80 contiguous bytes
 __global__ void pack_pixels_kernel(const int32_t *__restrict__ off_g, const float *__restrict__ bary_g,
                                    const float *__restrict__ norm_g, const int32_t *__restrict__ off_b,
@@ -930,23 +1105,90 @@ __global__ void pack_pixels_kernel(const int32_t *__restrict__ off_g, const floa
     }
 }
 
+struct SplatTab { // splat tables of one lattice as the update kernel sees them
+    const int32_t *tslot_start;
+    const int2 *slot_desc;
+    const uint2 *tent;
+    float *part;        // [slots][Mp] partial rows out
+    int n_slots;        // per replica
+    int shared;         // 1: tables describe one image (tile index j), replica k writes part + k*n_slots*Mp
+    int dp1;
+};
+
 struct UpdateArgs {
     const uint4 *pix_rec; // [pixel][5]
     const float *val_g, *val_b;
     const float *u; // [pixel][Mp]
-    float *q;       // [pixel][Mp]
+    float *q;       // [pixel][Mp] or null (only the last iteration's Q leaves the chip)
     float alpha_g, alpha_b, compat_g, compat_b;
     int M, LP;
-    long long npix;
+    int B;
+    TileGeom tg;
     unsigned g_pix, g_rows; // shared Gaussian lattice: pixels / rows per replica (g_rows = 0: not shared)
+    SplatTab sg, sb;
 };
 
-// Slice both lattices, add the unary, softmax over classes (DenseCRF::inference loop body):
-//   E = -U - (-wG * normG * sliceG) - (-wB * normB * sliceB);  Q = expAndNormalize(E)
-// LP lanes per pixel (4 classes each, 16-byte gathers), floor(64/LP) pixels per wave; the max / sum
-// over a pixel's classes are reduced inside the lane, then across the pixel's LP lanes by
-// shuffle-down with a segment bound and a broadcast from the segment's first lane.
-__global__ __launch_bounds__(256) void slice_update_kernel(UpdateArgs a) {
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int GATHER_SB = 256; // slot descriptors staged per batch
+constexpr int GATHER_ENT = TILE_PIX * 6;
+
+// partial[slot] = sum over the slot's entries of w * stage[pixel] in the entries' order, one slot per lane group per
+// trip.  The tile's entries (contiguous in memory) and slot descriptors are copied into LDS first: the per-slot chains
+// (descriptor -> entries -> Q rows) then run on LDS latency, not on three dependent trips to L2 / HBM per slot.
+__device__ __forceinline__ void tile_gather(const SplatTab &T, int tile, long long ebase_pix, int np, int rep_k,
+                                            const f32x4_t *stage, uint2 *lent, int2 *ldesc, int LP, int l, int g, int gpw,
+                                            bool act) {
+    const int s_beg = T.tslot_start[tile], s_end = T.tslot_start[tile + 1];
+    f32x4_t *part = reinterpret_cast<f32x4_t *>(T.part) + (T.shared ? (size_t)rep_k * T.n_slots * LP : (size_t)0);
+    const int nw = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6);
+    const int ne = np * T.dp1;
+    const uint2 *src = T.tent + ebase_pix * T.dp1;
+    for (int i = threadIdx.x; i < ne; i += blockDim.x) lent[i] = src[i];
+    for (int sb0 = s_beg; sb0 < s_end; sb0 += GATHER_SB) {
+        const int nsb = min(GATHER_SB, s_end - sb0);
+        if ((int)threadIdx.x < nsb) ldesc[threadIdx.x] = T.slot_desc[sb0 + threadIdx.x];
+        __syncthreads();
+        for (int s0 = wv * gpw; s0 < nsb; s0 += nw * gpw) {
+            const int s = s0 + g;
+            const bool ok = act && s < nsb;
+            const int2 d = ok ? ldesc[s] : make_int2(0, 0);
+            const int i0 = d.x & 0xffff, n = d.x >> 16;
+            // explicit packed FMAs (this file is compiled with -ffp-contract=off for the simplex search): the gather
+            // is VALU/LDS-issue bound, 8 v_pk_fma_f32 per 4 entries instead of 16 mul + 16 add
+            f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+            for (int i = 0; i < n; i += 4) {
+                uint2 en[4];
+                f32x4_t in[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) en[jj] = lent[i0 + min(i + jj, n - 1)];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) in[jj] = stage[en[jj].x * (unsigned)LP + l];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float w = i + jj < n ? __uint_as_float(en[jj].y) : 0.f; // w * norm[pixel]
+                    const f32x2_t w2 = {w, w}, lo = {in[jj][0], in[jj][1]}, hi = {in[jj][2], in[jj][3]};
+                    a01 = __builtin_elementwise_fma(w2, lo, a01);
+                    a23 = __builtin_elementwise_fma(w2, hi, a23);
+                }
+            }
+            const f32x4_t acc = {a01[0], a01[1], a23[0], a23[1]};
+            if (ok) part[(unsigned)d.y * (unsigned)LP + l] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// One mean-field update of a pixel tile, and the splat of the result into both lattices:
+//   E = -U - (-wG * normG * sliceG) - (-wB * normB * sliceB);  Q = expAndNormalize(E)       (DenseCRF::inference loop body)
+//   partial rows of (norm * Q) for the tile's Gaussian and bilateral slots                    (Permutohedral::compute, splat)
+// SLICE = false: the messages are zero (Q = softmax(-U): the state before the first iteration).
+// SPLAT = false: last iteration, Q goes to memory instead.
+// LP lanes per pixel (4 classes each, 16-byte gathers), floor(64/LP) pixels per wave; the max / sum over a
+// pixel's classes are reduced inside the lane, then across the pixel's LP lanes by shuffle-down with a segment
+// bound and a broadcast from the segment's first lane.  Between iterations Q exists only as the tile's LDS copy.
+template <bool SLICE, bool SPLAT>
+__global__ __launch_bounds__(256) void update_splat_kernel(UpdateArgs a) {
+    extern __shared__ f32x4_t stage[]; // [TILE_PIX][LP]
     const int LP = a.LP;
     const int gpw = 64 / LP;
     const int lane = threadIdx.x & 63;
@@ -954,80 +1196,124 @@ __global__ __launch_bounds__(256) void slice_update_kernel(UpdateArgs a) {
     const int l = lane - g * LP;
     const bool act = g < gpw;
     const int seg0 = g * LP;
+    // XCD-contiguous logical block id: the tiles of one image (which share lattice rows) on one L2
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nb >> 3, rr = nb & 7;
+    const int lb = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int k = lb / a.tg.tpi, j = lb - k * a.tg.tpi; // image, tile of the image
+    const TileBox tb = tile_box(a.tg, j);
+    const int np = tb.cw * tb.ch;
+    const int N = a.tg.H * a.tg.W;
     const f32x4_t *vg4 = reinterpret_cast<const f32x4_t *>(a.val_g);
     const f32x4_t *vb4 = reinterpret_cast<const f32x4_t *>(a.val_b);
     const f32x4_t *u4 = reinterpret_cast<const f32x4_t *>(a.u);
     f32x4_t *q4 = reinterpret_cast<f32x4_t *>(a.q);
-    long long pbeg, pend;
-    xcd_range(a.npix, pbeg, pend);
-    constexpr int U = 1; // pixels per lane group per trip (2 measured slower: 362 vs 332 us)
-    for (long long p0 = pbeg + (long long)(threadIdx.x >> 6) * gpw * U; p0 < pend; p0 += (long long)(blockDim.x >> 6) * gpw * U) {
-        long long pp[U];
-        bool ok[U];
-        uint32_t rc[U][20];
+    const unsigned gofs = a.g_rows ? (unsigned)k * a.g_rows : 0u;
+    const int ppt = (int)(blockDim.x >> 6) * gpw; // pixels per trip
+    // pixel of the lane group in trip t0 (clamped to the tile: idle lanes re-read pixel 0)
+    auto pixel_of = [&](int t0) -> long long {
+        const int t = t0 + g;
+        const int tc = (act && t < np) ? t : 0;
+        const int ty = tc / tb.cw, tx = tc - ty * tb.cw;
+        return (long long)k * N + (long long)(tb.y0 + ty) * a.tg.W + tb.x0 + tx;
+    };
+    // the record and the unary of the NEXT trip are requested before this trip's lattice rows are gathered: two
+    // trips of loads in flight per wave (the kernel runs at 4 waves per SIMD; record -> rows is a dependent chain)
+    uint4 rq[5];
+    f32x4_t un;
+    {
+        const long long p = pixel_of((int)(threadIdx.x >> 6) * gpw);
+        if (SLICE) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            pp[u] = p0 + (long long)u * gpw + g;
-            ok[u] = act && pp[u] < pend;
-            const long long p = ok[u] ? pp[u] : pbeg;
+            for (int i = 0; i < 5; ++i) rq[i] = a.pix_rec[p * 5 + i];
+        }
+        un = u4[p * LP + l];
+    }
+    for (int t0 = (int)(threadIdx.x >> 6) * gpw; t0 < np; t0 += ppt) {
+        const int t = t0 + g;
+        const bool ok = act && t < np;
+        const long long p = pixel_of(t0);
+        uint4 rqn[5];
+        f32x4_t unn = un;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) rqn[i] = rq[i];
+        if (t0 + ppt < np) {
+            const long long pn = pixel_of(t0 + ppt);
+            if (SLICE) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) rqn[i] = a.pix_rec[pn * 5 + i];
+            }
+            unn = u4[pn * LP + l];
+        }
+        float e[4];
+        float mx = -3.0e38f;
+        if (SLICE) {
             // the pixel's record: 5 x 16 bytes, identical for the LP lanes of the pixel (broadcast loads)
+            uint32_t rc[20];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                const uint4 t = a.pix_rec[p * 5 + i];
-                rc[u][4 * i] = t.x; rc[u][4 * i + 1] = t.y; rc[u][4 * i + 2] = t.z; rc[u][4 * i + 3] = t.w;
+                rc[4 * i] = rq[i].x; rc[4 * i + 1] = rq[i].y; rc[4 * i + 2] = rq[i].z; rc[4 * i + 3] = rq[i].w;
             }
-        }
-        f32x4_t vg[U][3], vb[U][6], un[U];
+            f32x4_t vg[3], vb[6];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long long p = ok[u] ? pp[u] : pbeg;
-            const unsigned gofs = a.g_rows ? ((unsigned)p / a.g_pix) * a.g_rows : 0u;
+            for (int r = 0; r < 3; ++r) vg[r] = vg4[(rc[r] + gofs) * (unsigned)LP + l];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) vg[u][r] = vg4[(rc[u][r] + gofs) * (unsigned)LP + l];
+            for (int r = 0; r < 6; ++r) vb[r] = vb4[rc[3 + r] * (unsigned)LP + l];
+            const float ng = __uint_as_float(rc[18]), nbn = __uint_as_float(rc[19]);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) vb[u][r] = vb4[rc[u][3 + r] * (unsigned)LP + l];
-            un[u] = u4[p * LP + l];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float ng = __uint_as_float(rc[u][18]), nb = __uint_as_float(rc[u][19]);
-            float e[4];
-            float mx = -3.0e38f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int kk = 0; kk < 4; ++kk) {
                 float sg = 0.f, sb = 0.f;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) sg += __uint_as_float(rc[u][9 + r]) * vg[u][r][k] * a.alpha_g;
+                for (int r = 0; r < 3; ++r) sg += __uint_as_float(rc[9 + r]) * vg[r][kk] * a.alpha_g;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) sb += __uint_as_float(rc[u][12 + r]) * vb[u][r][k] * a.alpha_b;
-                float ek = -un[u][k];
+                for (int r = 0; r < 6; ++r) sb += __uint_as_float(rc[12 + r]) * vb[r][kk] * a.alpha_b;
+                float ek = -un[kk];
                 ek -= -a.compat_g * (sg * ng);
-                ek -= -a.compat_b * (sb * nb);
-                const bool valid = ok[u] && 4 * l + k < a.M;
-                e[k] = valid ? ek : -3.0e38f;
-                mx = fmaxf(mx, e[k]);
+                ek -= -a.compat_b * (sb * nbn);
+                e[kk] = (ok && 4 * l + kk < a.M) ? ek : -3.0e38f;
+                mx = fmaxf(mx, e[kk]);
             }
-            for (int o = 4; o > 0; o >>= 1) {
-                const float other = __shfl_down(mx, o, 64);
-                if (l + o < LP) mx = fmaxf(mx, other);
-            }
-            mx = __shfl(mx, seg0, 64);
-            float ex[4], sum = 0.f;
+        } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                ex[k] = (ok[u] && 4 * l + k < a.M) ? expf(e[k] - mx) : 0.f;
-                sum += ex[k];
-            }
-            for (int o = 4; o > 0; o >>= 1) {
-                const float other = __shfl_down(sum, o, 64);
-                if (l + o < LP) sum += other;
-            }
-            sum = __shfl(sum, seg0, 64);
-            if (ok[u]) {
-                f32x4_t o4 = {ex[0] / sum, ex[1] / sum, ex[2] / sum, ex[3] / sum};
-                q4[pp[u] * LP + l] = o4;
+            for (int kk = 0; kk < 4; ++kk) {
+                e[kk] = (ok && 4 * l + kk < a.M) ? -un[kk] : -3.0e38f;
+                mx = fmaxf(mx, e[kk]);
             }
         }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) rq[i] = rqn[i];
+        un = unn;
+        for (int o = 4; o > 0; o >>= 1) {
+            const float other = __shfl_down(mx, o, 64);
+            if (l + o < LP) mx = fmaxf(mx, other);
+        }
+        mx = __shfl(mx, seg0, 64);
+        float ex[4], sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            ex[kk] = (ok && 4 * l + kk < a.M) ? expf(e[kk] - mx) : 0.f;
+            sum += ex[kk];
+        }
+        for (int o = 4; o > 0; o >>= 1) {
+            const float other = __shfl_down(sum, o, 64);
+            if (l + o < LP) sum += other;
+        }
+        sum = __shfl(sum, seg0, 64);
+        if (ok) {
+            const f32x4_t o4 = {ex[0] / sum, ex[1] / sum, ex[2] / sum, ex[3] / sum};
+            if (SPLAT) stage[t * LP + l] = o4;
+            if (q4) q4[p * LP + l] = o4;
+        }
+    }
+    if (SPLAT) {
+        uint2 *lent = reinterpret_cast<uint2 *>(stage + TILE_PIX * LP);
+        int2 *ldesc = reinterpret_cast<int2 *>(lent + GATHER_ENT);
+        // (the entry copy of the first lattice needs no barrier of its own: the one inside tile_gather covers it and
+        // the stage writes above)
+        tile_gather(a.sg, a.sg.shared ? j : lb, (a.sg.shared ? 0ll : (long long)k * N) + tb.ebase, np, k, stage, lent, ldesc,
+                    LP, l, g, gpw, act);
+        tile_gather(a.sb, a.sb.shared ? j : lb, (a.sb.shared ? 0ll : (long long)k * N) + tb.ebase, np, k, stage, lent, ldesc,
+                    LP, l, g, gpw, act);
     }
 }
 
@@ -1061,7 +1347,7 @@ __global__ __launch_bounds__(TP) void init_q_kernel(const float *__restrict__ un
     for (int i = threadIdx.x; i < np * Mp; i += TP) {
         const int n = i / Mp, m = i - n * Mp;
         u[obase + i] = m < M ? tu[m * (TP + 1) + n] : 0.f; // padding classes: masked in slice_update
-        q[obase + i] = m < M ? tq[m * (TP + 1) + n] : 0.f;
+        if (q) q[obase + i] = m < M ? tq[m * (TP + 1) + n] : 0.f;
     }
 }
 
@@ -1144,31 +1430,20 @@ struct TempBuf { // build-time scratch handed back to the ctx cache at the end o
 };
 
 // the normalisation pass: val = Lattice-splat of the all-ones vector (one value per row)
-void splat_ones(wsc_ctx *ctx, const LatticeDev &L, float *val, long long *part) {
-    hipLaunchKernelGGL(splat_ones_kernel, dim3(grid1d((long long)L.n_chunks * 8)), dim3(256), 0, ctx->stream,
-                       (const unsigned *)L.csr_start, L.chunk_base, L.chunk_row, L.csr_w, L.n_chunks, val, part);
-    if (L.n_long > 0)
-        hipLaunchKernelGGL(splat_combine_kernel, dim3(grid1d(L.n_long, 256, 4096)), dim3(256), 0, ctx->stream,
-                           L.long_rows, L.n_long, L.chunk_base, part, 1, 1, 0, 0, val);
+void splat_ones(wsc_ctx *ctx, const LatticeDev &L, const TileGeom &tg, float *val, float *part) {
+    hipLaunchKernelGGL(slot_ones_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.tslot_start, L.slot_desc,
+                       L.tent, L.d + 1, tg, part);
+    hipLaunchKernelGGL(combine1_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream, part, L.row_slot_start, L.rows, val);
 }
 
-// part: scratch of n_chunks * Mp int64 (partials of multi-chunk rows)
-void splat4(wsc_ctx *ctx, const LatticeDev &L, const float *q, int LP, float *val, long long *part) {
-    const int gpw = 64 / LP;
-    // algorithmic bytes: read the batch's Q once + (pixel index, weight) per gathered pixel + write the rows
-    const double npix = (double)L.n_pix * L.rep, rows = (double)L.rows * L.rep;
-    WscKernelTimer timer(ctx, WSC_K_SPLAT, npix * L.M_cur * 4 + npix * (L.d + 1) * 8 + rows * L.M_cur * 4);
-    // 256 threads per block: 128 / 64 measured 289 / 320 us against 270 (the opposite of slice_update)
-    hipLaunchKernelGGL(splat4_kernel, dim3(grid_rep((long long)L.n_chunks * L.rep, 4 * SPLAT_CU * gpw, L.rep)), dim3(256), 0,
-                       ctx->stream, L.chunk_desc, L.csr_ent, q, LP, L.n_chunks, L.rep, (unsigned)L.n_pix,
-                       (unsigned)L.rows, val, part);
-    if (L.n_long > 0)
-        hipLaunchKernelGGL(splat_combine_kernel, dim3(grid1d((long long)L.n_long * L.rep * 4 * LP, 256, 4096)),
-                           dim3(256), 0, ctx->stream, L.long_rows, L.n_long, L.chunk_base, part, 4 * LP, L.rep,
-                           L.n_chunks, L.rows, val);
+// rows of a lattice from the slot partials of the splat
+void combine4(wsc_ctx *ctx, const LatticeDev &L, const float *part, int LP, float *val) {
+    WscKernelTimer timer(ctx, WSC_K_BLUR, ((double)L.n_slots + L.rows) * L.rep * L.M_cur * 4);
+    hipLaunchKernelGGL(combine4_kernel, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
+                       ctx->stream, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
 }
 
-// d+1 blur passes, ping-pong between a and b; returns the buffer holding the result
+// d+1 blur passes of the one-value-per-row normalisation lattice, ping-pong between a and b
 float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
     for (int j = 0; j <= L.d; ++j) {
         hipLaunchKernelGGL(blur1_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream, a,
@@ -1177,19 +1452,34 @@ float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
     }
     return a;
 }
-float *blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, float *a, float *b) {
+
+// Rows from the splat's slot partials (`part`), then the d+1 blur passes; a / b: two row buffers.  Returns the
+// buffer holding the result.
+float *combine_blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, const float *part, float *a, float *b) {
     // WSC_CRF_NO_FUSED_BLUR=1 (read per call, so a test can flip it) keeps the three separate passes
     const char *fe = getenv("WSC_CRF_NO_FUSED_BLUR");
     const bool fused_off = fe && atoi(fe) != 0;
-    if (L.d == 2 && L.tile_rows && L.n_tiles_occ > 0 && !fused_off) {
-        // one read + one write of the value rows (the halo re-reads come out of L2).  Whole rows per group
-        // (6 float4 = 49 KB of LDS, 3 blocks per CU) beat 3 / 2 / 1 float4 per group at 6+ blocks per CU:
-        // blur 2.37 vs 2.42 / 2.72 / 3.15 ms per step.
-        WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.rep * L.M_cur * 4);
+    if (L.d == 2 && L.tile_rows && L.tile_pstart && L.n_tiles_occ > 0 && !fused_off) {
+        // one read of the partials + one write of the value rows (the halo re-reads come out of L2).  Whole rows
+        // per group (6 float4 = 49 KB of LDS, 3 blocks per CU) beat 3 / 2 / 1 float4 per group at 6+ blocks per CU
+        WscKernelTimer timer(ctx, WSC_K_BLUR, ((double)L.n_slots + L.rows) * L.rep * L.M_cur * 4);
+        const char *ge = getenv("WSC_CRF_GLH");
+        const int glh = ge ? atoi(ge) : WSC_GLH;
+        if (glh == 3)
+            hipLaunchKernelGGL(blur3_tile_kernel<3>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, ctx->stream,
+                               (const f32x4_t *)nullptr, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b,
+                               (const f32x4_t *)part, L.tile_pstart, L.n_slots);
+        else if (glh == 2)
+            hipLaunchKernelGGL(blur3_tile_kernel<2>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, ctx->stream,
+                               (const f32x4_t *)nullptr, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b,
+                               (const f32x4_t *)part, L.tile_pstart, L.n_slots);
+        else
         hipLaunchKernelGGL(blur3_tile_kernel<WSC_GLH>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, ctx->stream,
-                           (const f32x4_t *)a, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b);
+                           (const f32x4_t *)nullptr, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b,
+                           (const f32x4_t *)part, L.tile_pstart, L.n_slots);
         return b;
     }
+    combine4(ctx, L, part, LP, a);
     for (int j = 0; j <= L.d; ++j) {
         WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.rep * L.M_cur * 4); // read + write every row once
         hipLaunchKernelGGL(blur4_kernel, dim3(grid_rep((long long)L.rows * L.rep, (256 / LP) * 4, L.rep)), dim3(256),
@@ -1228,7 +1518,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     TempBuf tmp(ctx);
     unsigned long long *table;
     int32_t *first, *eslot, *slot2row, *rowimg;
-    unsigned *flag, *prefix, *sums, *count, *cursor;
+    unsigned *flag, *prefix, *sums;
     unsigned long long *rowkey;
     int *err;
     WSC_TRY(tmp.alloc(sizeof(unsigned long long) * B * cap, (void **)&table));
@@ -1243,8 +1533,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(crf_alloc(crf, sizeof(int32_t) * total, (void **)&L.offset));
     WSC_TRY(crf_alloc(crf, sizeof(float) * total, (void **)&L.bary));
     WSC_TRY(crf_alloc(crf, sizeof(float) * npix, (void **)&L.norm));
-    WSC_TRY(crf_alloc(crf, sizeof(int32_t) * total, (void **)&L.csr_pix));
-    WSC_TRY(crf_alloc(crf, sizeof(float) * total, (void **)&L.csr_w));
+    WSC_TRY(crf_alloc(crf, sizeof(uint2) * total, (void **)&L.tent));
 
     hipLaunchKernelGGL(fill_u64_kernel, dim3(grid1d(B * cap)), dim3(256), 0, ctx->stream, table, EMPTY_KEY,
                        (long long)B * cap);
@@ -1292,25 +1581,44 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
 
     WSC_TRY(tmp.alloc(sizeof(unsigned long long) * L.rows, (void **)&rowkey));
     WSC_TRY(tmp.alloc(sizeof(int32_t) * L.rows, (void **)&rowimg));
-    WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&count));
-    WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&cursor));
-    WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (L.rows + 2), (void **)&L.csr_start));
     WSC_TRY(crf_alloc(crf, sizeof(int2) * (size_t)dp1 * L.rows, (void **)&L.nbr));
-    WSC_HIP(hipMemsetAsync(count, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
-    WSC_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
 
     hipLaunchKernelGGL(assign_ids_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, flag, prefix, table,
                        cap, N, dp1, total, slot2row, rowkey, rowimg);
-    hipLaunchKernelGGL(remap_count_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, eslot,
-                       slot2row, cap, N, dp1, npix, L.offset, count);
-    {
-        unsigned *sums2;
-        const int nb2 = (L.rows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(remap_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, slot2row, cap, N, dp1, total,
+                       L.offset);
+    {   // splat tables: entries sorted per pixel tile, slots, slots of each row
+        const TileGeom tg = make_geom(crf->H, crf->W);
+        L.n_tiles = B * tg.tpi;
+        int32_t *srow, *slot_row;
+        unsigned *tile_nslots, *sums2, *row_nslots, *cursor, *sums3;
+        const int nb2 = (L.n_tiles + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK, nb3 = (L.rows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        WSC_TRY(tmp.alloc(sizeof(int32_t) * total, (void **)&srow));
+        WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.n_tiles + 1), (void **)&tile_nslots));
         WSC_TRY(tmp.alloc(sizeof(unsigned) * (nb2 + 2), (void **)&sums2));
-        WSC_TRY(exclusive_scan(ctx, count, L.rows + 1, (unsigned *)L.csr_start, sums2));
+        WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&row_nslots));
+        WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&cursor));
+        WSC_TRY(tmp.alloc(sizeof(unsigned) * (nb3 + 2), (void **)&sums3));
+        WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (L.n_tiles + 2), (void **)&L.tslot_start));
+        WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (L.rows + 2), (void **)&L.row_slot_start));
+        WSC_HIP(hipMemsetAsync(tile_nslots, 0, sizeof(unsigned) * (L.n_tiles + 1), ctx->stream));
+        WSC_HIP(hipMemsetAsync(row_nslots, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
+        WSC_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
+        hipLaunchKernelGGL(tile_group_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1, tg,
+                           L.tent, srow, tile_nslots);
+        WSC_TRY(exclusive_scan(ctx, tile_nslots, L.n_tiles + 1, (unsigned *)L.tslot_start, sums2));
+        unsigned ns = 0;
+        WSC_HIP(hipMemcpyAsync(&ns, sums2 + nb2, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        WSC_HIP(hipStreamSynchronize(ctx->stream));
+        L.n_slots = (int)ns;
+        WSC_TRY(crf_alloc(crf, sizeof(int2) * (size_t)(L.n_slots + 1), (void **)&L.slot_desc));
+        WSC_TRY(tmp.alloc(sizeof(int32_t) * (size_t)(L.n_slots + 1), (void **)&slot_row));
+        hipLaunchKernelGGL(tile_slots_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, srow, dp1, tg,
+                           L.tslot_start, L.slot_desc, slot_row, row_nslots);
+        WSC_TRY(exclusive_scan(ctx, row_nslots, L.rows + 1, (unsigned *)L.row_slot_start, sums3));
+        hipLaunchKernelGGL(slot_dest_kernel, dim3(grid1d(L.n_slots)), dim3(256), 0, ctx->stream, slot_row, L.n_slots,
+                           L.row_slot_start, cursor, L.slot_desc);
     }
-    hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, L.offset,
-                       L.bary, dp1, npix, (const unsigned *)L.csr_start, cursor, L.csr_pix, L.csr_w);
     hipLaunchKernelGGL(neighbors_kernel<D>, dim3(grid1d((long long)L.rows * dp1)), dim3(256), 0, ctx->stream, rowkey,
                        rowimg, table, slot2row, cap, (unsigned)(cap - 1), L.rows, L.nbr);
     WSC_HIP(hipGetLastError());
@@ -1348,50 +1656,23 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
                 WSC_HIP(hipMemcpyAsync(L.tile_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice,
                                        ctx->stream));
                 WSC_HIP(hipStreamSynchronize(ctx->stream)); // `list` is pageable host memory
+                WSC_TRY(crf_alloc(crf, sizeof(int2) * nt * GBI * GBJ, (void **)&L.tile_pstart));
+                hipLaunchKernelGGL(gauss_tile_pstart_kernel, dim3(grid1d(nt * GBI * GBJ)), dim3(256), 0, ctx->stream,
+                                   L.tile_rows, L.row_slot_start, nt * GBI * GBJ, L.tile_pstart);
             }
         }
     }
-    {   // splat chunk tables
-        unsigned *nch, *sums3, *n_long_dev;
-        const int nb3 = (L.rows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&nch));
-        WSC_TRY(tmp.alloc(sizeof(unsigned) * (nb3 + 2), (void **)&sums3));
-        WSC_TRY(tmp.alloc(sizeof(unsigned), (void **)&n_long_dev));
-        WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (L.rows + 2), (void **)&L.chunk_base));
-        WSC_HIP(hipMemsetAsync(nch, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
-        WSC_HIP(hipMemsetAsync(n_long_dev, 0, sizeof(unsigned), ctx->stream));
-        hipLaunchKernelGGL(count_chunks_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream,
-                           (const unsigned *)L.csr_start, L.rows, nch);
-        WSC_TRY(exclusive_scan(ctx, nch, L.rows + 1, (unsigned *)L.chunk_base, sums3));
-        unsigned tc = 0;
-        WSC_HIP(hipMemcpyAsync(&tc, sums3 + nb3, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-        WSC_HIP(hipStreamSynchronize(ctx->stream));
-        L.n_chunks = (int)tc;
-        WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (size_t)L.n_chunks, (void **)&L.chunk_row));
-        WSC_TRY(crf_alloc(crf, sizeof(int4) * (size_t)L.n_chunks, (void **)&L.chunk_desc));
-        WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (size_t)L.rows, (void **)&L.long_rows));
-        hipLaunchKernelGGL(fill_chunks_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream,
-                           (const unsigned *)L.csr_start, L.chunk_base, L.rows, L.chunk_row, L.chunk_desc, n_long_dev,
-                           L.long_rows);
-        unsigned nl = 0;
-        WSC_HIP(hipMemcpyAsync(&nl, n_long_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-        WSC_HIP(hipStreamSynchronize(ctx->stream));
-        L.n_long = (int)nl;
-    }
-
     // norm = 1/sqrt(Lattice(1) + 1e-20)
-    float *va, *vb;
-    long long *vp;
+    float *va, *vb, *vp;
     WSC_TRY(tmp.alloc(sizeof(float) * L.rows, (void **)&va));
     WSC_TRY(tmp.alloc(sizeof(float) * L.rows, (void **)&vb));
-    WSC_TRY(tmp.alloc(sizeof(long long) * L.n_chunks, (void **)&vp));
-    splat_ones(ctx, L, va, vp);
+    WSC_TRY(tmp.alloc(sizeof(float) * (size_t)(L.n_slots + 1), (void **)&vp));
+    splat_ones(ctx, L, make_geom(crf->H, crf->W), va, vp);
     float *res = blur_all1(ctx, L, va, vb);
     hipLaunchKernelGGL(slice_norm_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1,
                        L.alpha, res, npix, L.norm);
-    WSC_TRY(crf_alloc(crf, sizeof(uint2) * total, (void **)&L.csr_ent));
-    hipLaunchKernelGGL(pack_entries_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, L.csr_pix, L.csr_w, L.norm,
-                       total, L.csr_ent);
+    hipLaunchKernelGGL(tile_scale_entries_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.norm, dp1,
+                       make_geom(crf->H, crf->W), L.tent);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
@@ -1404,15 +1685,22 @@ struct GaussCache {
 constexpr int GAUSS_CACHE_MAX = 16; // distinct image sizes kept per ctx; later sizes are rebuilt per call
 void gauss_cache_delete(void *p) { delete static_cast<GaussCache *>(p); }
 
-void launch_update(wsc_ctx *ctx, const UpdateArgs &a) {
-    const int gpw = 64 / a.LP;
-    // algorithmic bytes: slice index+weight of both lattices, read U, write Q (+ the two
-    // messages the reference materialises: N*M*4 each)
-    WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, (double)a.npix * (9 * 8 + 4.0 * a.M * 4));
-    // one trip (4 * gpw pixels) per block: with the grid capped at 16 384 / 65 536 blocks the kernel took 324 / 353 us,
-    // uncapped (82 k blocks for 32 images at 321^2) 299 us -- whole trips per block, no ragged per-block ranges
-    // ... and 128-thread blocks (20 pixels): 302 -> 289 us (64 threads: 291)
-    hipLaunchKernelGGL(slice_update_kernel, dim3(grid1d(a.npix, 2 * gpw, 1 << 22)), dim3(128), 0, ctx->stream, a);
+// slice: messages of both lattices are read (false before the first iteration); splat: the result is splatted
+// (false in the last iteration, whose Q is written to a.q instead)
+int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat) {
+    const double npix = (double)a.B * a.tg.H * a.tg.W;
+    // algorithmic bytes: read U, write Q; slice: index+weight of both lattices (9 entries of 8 bytes) and the
+    // two messages the reference materialises (N*M*4 each); splat: read Q for both lattices + index+weight
+    const double by = npix * (2.0 * a.M * 4 + (slice ? 9 * 8 + 2.0 * a.M * 4 : 0.0) + (splat ? 9 * 8 + 2.0 * a.M * 4 : 0.0));
+    WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, by);
+    const dim3 grid((unsigned)(a.B * a.tg.tpi)), block(256);
+    const size_t lds = splat ? sizeof(f32x4_t) * TILE_PIX * a.LP + sizeof(uint2) * GATHER_ENT + sizeof(int2) * GATHER_SB : 0;
+    if (slice && splat) hipLaunchKernelGGL((update_splat_kernel<true, true>), grid, block, lds, ctx->stream, a);
+    else if (slice) hipLaunchKernelGGL((update_splat_kernel<true, false>), grid, block, lds, ctx->stream, a);
+    else if (splat) hipLaunchKernelGGL((update_splat_kernel<false, true>), grid, block, lds, ctx->stream, a);
+    else hipLaunchKernelGGL((update_splat_kernel<false, false>), grid, block, lds, ctx->stream, a);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
 }
 
 } // namespace
@@ -1482,7 +1770,11 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
 
 void wsc_crf_destroy(wsc_crf *crf) {
     if (!crf) return;
+    // The blocks go back to the build ctx's stream-ordered cache.  A mean-field loop enqueued on ANOTHER ctx may still
+    // be reading them: make the build stream wait for it before anything it launches later can reuse the memory.
+    if (crf->used_elsewhere && crf->use_ev) (void)hipStreamWaitEvent(crf->ctx->stream, crf->use_ev, 0);
     for (void *p : crf->allocs) wsc_ctx_cached_free(crf->ctx, p); // reused in stream order
+    if (crf->use_ev) (void)hipEventDestroy(crf->use_ev);
     delete crf;
 }
 
@@ -1505,13 +1797,14 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     const long long npix = (long long)B * N;
     const LatticeDev &G = crf->lat[0], &Bl = crf->lat[1];
     const int LP = (M + 3) / 4, Mp = 4 * LP; // rows padded to 16-byte multiples
-    const long long g_rows = (long long)G.rows * G.rep, g_chunks = (long long)G.n_chunks * G.rep;
-    WSC_CHECK(npix * Mp < (1ll << 31) && g_rows * Mp < (1ll << 31) && (long long)Bl.rows * Mp < (1ll << 31),
+    const long long g_rows = (long long)G.rows * G.rep, g_slots = (long long)G.n_slots * G.rep;
+    WSC_CHECK(npix * Mp < (1ll << 31) && g_rows * Mp < (1ll << 31) && (long long)Bl.rows * Mp < (1ll << 31) &&
+                  g_slots * Mp < (1ll << 31) && (long long)Bl.n_slots * Mp < (1ll << 31),
               WSC_ERR_CAPACITY, "CRF batch too large for 32-bit element indices (B*N*Mp = %lld)", npix * Mp);
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t qb = al(sizeof(float) * npix * Mp);
     const size_t vg = al(sizeof(float) * (size_t)g_rows * Mp), vb = al(sizeof(float) * (size_t)Bl.rows * Mp);
-    const size_t pg = al(sizeof(long long) * (size_t)g_chunks * Mp), pb = al(sizeof(long long) * (size_t)Bl.n_chunks * Mp);
+    const size_t pg = al(sizeof(float) * (size_t)g_slots * Mp), pb = al(sizeof(float) * (size_t)Bl.n_slots * Mp);
     void *ws;
     WSC_TRY(wsc_ctx_workspace(ctx, 2 * qb + 2 * vg + 2 * vb + pg + pb, &ws));
     char *p = (char *)ws;
@@ -1521,8 +1814,8 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     float *vg1 = (float *)p; p += vg;
     float *vb0 = (float *)p; p += vb;
     float *vb1 = (float *)p; p += vb;
-    long long *partg = (long long *)p; p += pg;
-    long long *partb = (long long *)p; p += pb;
+    float *partg = (float *)p; p += pg;
+    float *partb = (float *)p; p += pb;
 
     crf->lat[0].M_cur = M;
     crf->lat[1].M_cur = M;
@@ -1530,26 +1823,41 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     {
         WscKernelTimer timer(ctx, WSC_K_CRF_MISC, (double)npix * M * 12);
         hipLaunchKernelGGL(init_q_kernel, tgrid, dim3(TP), 2 * (size_t)M * (TP + 1) * sizeof(float), ctx->stream,
-                           unary_dev, M, Mp, N, u, q);
+                           unary_dev, M, Mp, N, u, n_iters == 0 ? q : (float *)nullptr);
     }
-    for (int it = 0; it < n_iters; ++it) {
-        splat4(ctx, G, q, LP, vg0, partg);
-        float *rg = blur_all4(ctx, G, LP, vg0, vg1);
-        splat4(ctx, Bl, q, LP, vb0, partb);
-        float *rb = blur_all4(ctx, Bl, LP, vb0, vb1);
-        UpdateArgs a;
-        a.pix_rec = crf->pix_rec; a.val_g = rg; a.val_b = rb;
-        a.u = u; a.q = q;
-        a.alpha_g = G.alpha; a.alpha_b = Bl.alpha; a.compat_g = g_compat; a.compat_b = bi_compat;
-        a.M = M; a.LP = LP; a.npix = npix;
-        a.g_pix = (unsigned)G.n_pix; a.g_rows = G.rep > 1 ? (unsigned)G.rows : 0u;
-        launch_update(ctx, a);
+    UpdateArgs a;
+    a.pix_rec = crf->pix_rec; a.val_g = nullptr; a.val_b = nullptr;
+    a.u = u; a.q = nullptr;
+    a.alpha_g = G.alpha; a.alpha_b = Bl.alpha; a.compat_g = g_compat; a.compat_b = bi_compat;
+    a.M = M; a.LP = LP; a.B = B;
+    a.tg = make_geom(crf->H, crf->W);
+    a.g_pix = (unsigned)G.n_pix; a.g_rows = G.rep > 1 ? (unsigned)G.rows : 0u;
+    a.sg.tslot_start = G.tslot_start; a.sg.slot_desc = G.slot_desc; a.sg.tent = G.tent; a.sg.part = partg;
+    a.sg.n_slots = G.n_slots; a.sg.shared = G.rep > 1 ? 1 : 0; a.sg.dp1 = 3;
+    a.sb.tslot_start = Bl.tslot_start; a.sb.slot_desc = Bl.slot_desc; a.sb.tent = Bl.tent; a.sb.part = partb;
+    a.sb.n_slots = Bl.n_slots; a.sb.shared = 0; a.sb.dp1 = 6;
+    // Q(0) = softmax(-U) is splatted straight from the kernel that computes it; iteration t slices the blurred
+    // lattices, forms Q(t) and splats it for iteration t+1; the last iteration writes Q(T) instead.
+    for (int it = 0; it <= n_iters && n_iters > 0; ++it) {
+        const bool last = it == n_iters;
+        a.q = last ? q : nullptr;
+        WSC_TRY(launch_update(ctx, a, it > 0, !last));
+        if (last) break;
+        a.val_g = combine_blur_all4(ctx, G, LP, partg, vg0, vg1);
+        a.val_b = combine_blur_all4(ctx, Bl, LP, partb, vb0, vb1);
     }
-    WscKernelTimer ftimer(ctx, WSC_K_CRF_MISC, (double)npix * M * 8);
-    if (q_dev || argmax_dev)
-        hipLaunchKernelGGL(finish_kernel, tgrid, dim3(TP), (size_t)M * (TP + 1) * sizeof(float), ctx->stream, q, M, Mp,
-                           N, q_dev, argmax_dev);
+    {
+        WscKernelTimer ftimer(ctx, WSC_K_CRF_MISC, (double)npix * M * 8);
+        if (q_dev || argmax_dev)
+            hipLaunchKernelGGL(finish_kernel, tgrid, dim3(TP), (size_t)M * (TP + 1) * sizeof(float), ctx->stream, q, M, Mp,
+                               N, q_dev, argmax_dev);
+    }
     WSC_HIP(hipGetLastError());
+    if (ctx != crf->ctx) { // destroy must not hand the lattices back to the build ctx's cache before this loop is done
+        if (!crf->use_ev) WSC_HIP(hipEventCreateWithFlags(&crf->use_ev, hipEventDisableTiming));
+        WSC_HIP(hipEventRecord(crf->use_ev, ctx->stream));
+        crf->used_elsewhere = true;
+    }
     return WSC_OK;
 }
 
