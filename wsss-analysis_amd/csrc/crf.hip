@@ -33,6 +33,7 @@
 namespace {
 
 constexpr unsigned long long EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 struct LatticeDev {
     int d = 0;
@@ -56,6 +57,7 @@ struct LatticeDev {
     // partial rows are laid out ROW-major: the slots of row r write partial rows [row_slot_start[r], row_slot_start[r+1])
     int32_t *row_slot_start = nullptr; // [rows + 1]
     int n_tiles = 0, n_slots = 0;
+    bool sorted_dest = false; // partial rows of a row in deterministic order: plain fp32 combine (else fixed point)
     long long n_pix = 0; // pixels of one replica (B*N when rep == 1)
     int M_cur = 0;       // class count of the inference in flight (algorithmic byte accounting)
     float alpha = 0.f;
@@ -99,15 +101,19 @@ struct TileBox {
     int ebase;          // pixels of the image in tiles before this one (tile-major pixel order)
 };
 __host__ __device__ inline TileBox tile_box(const TileGeom &g, int j) {
-    const int ty = j / g.ntx, tx = j - ty * g.ntx;
+    // 32-bit arithmetic (tx * W < 2^32): this runs in every block of the iteration kernels
+    const unsigned ty = (unsigned)j / (unsigned)g.ntx, tx = (unsigned)j - ty * (unsigned)g.ntx;
     TileBox b;
-    b.x0 = (int)((long long)tx * g.W / g.ntx);
-    b.y0 = (int)((long long)ty * g.H / g.nty);
-    b.cw = (int)((long long)(tx + 1) * g.W / g.ntx) - b.x0;
-    b.ch = (int)((long long)(ty + 1) * g.H / g.nty) - b.y0;
+    b.x0 = (int)(tx * (unsigned)g.W / (unsigned)g.ntx);
+    b.y0 = (int)(ty * (unsigned)g.H / (unsigned)g.nty);
+    b.cw = (int)((tx + 1) * (unsigned)g.W / (unsigned)g.ntx) - b.x0;
+    b.ch = (int)((ty + 1) * (unsigned)g.H / (unsigned)g.nty) - b.y0;
     b.ebase = b.y0 * g.W + b.x0 * b.ch;
     return b;
 }
+// t / cw for t < TILE_PIX, cw <= TILE_W as a multiply and a shift (exact for cw <= 26, t < 4096)
+static_assert(TILE_W <= 26 && TILE_PIX <= 4096, "tile_div_magic range");
+__host__ __device__ inline unsigned tile_div_magic(int cw) { return (65536u + (unsigned)cw - 1u) / (unsigned)cw; }
 
 } // namespace
 
@@ -546,14 +552,16 @@ __device__ __forceinline__ void block_scan_lds(int *v, int n, int *wtot /* [4] *
 }
 
 // Grouped rows of a tile in LDS -> flag[i] = 1 where a slot starts (a new row, or SLOT_ENT entries into a row's
-// run); on return aux[i] holds the inclusive count of slot starts (aux[ne-1] = slots of the tile).
-__device__ __forceinline__ void tile_slot_flags(const int *srow, int ne, int *aux, int *flag, int *wtot) {
-    for (int i = threadIdx.x; i < ne; i += 256) aux[i] = (i == 0 || srow[i] != srow[i - 1]) ? i : 0;
+// run); on return aux[i] holds the inclusive count of slot starts (aux[ne-1] = slots of the tile) and seg[i] the
+// first entry of i's run of equal rows.
+__device__ __forceinline__ void tile_slot_flags(const int *srow, int ne, int *aux, int *flag, int *seg, int *wtot) {
+    for (int i = threadIdx.x; i < ne; i += 256) seg[i] = (i == 0 || srow[i] != srow[i - 1]) ? i : 0;
     __syncthreads();
-    block_scan_lds<true>(aux, ne, wtot); // aux[i] = start of the run of equal rows containing i
-    for (int i = threadIdx.x; i < ne; i += 256) flag[i] = ((i - aux[i]) % SLOT_ENT == 0) ? 1 : 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < ne; i += 256) aux[i] = flag[i];
+    block_scan_lds<true>(seg, ne, wtot); // seg[i] = start of the run of equal rows containing i
+    for (int i = threadIdx.x; i < ne; i += 256) {
+        flag[i] = ((i - seg[i]) % SLOT_ENT == 0) ? 1 : 0;
+        aux[i] = flag[i];
+    }
     __syncthreads();
     block_scan_lds<false>(aux, ne, wtot);
 }
@@ -665,10 +673,12 @@ __global__ __launch_bounds__(256) void tile_group_kernel(const int32_t *__restri
 // Pass 2, one block per tile: slot descriptors at their final (compact) index; slots per row counted.
 __global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restrict__ srow_in, int dp1, TileGeom tg,
                                                          const int32_t *__restrict__ tslot_start, int2 *__restrict__ slot_desc,
-                                                         int32_t *__restrict__ slot_row, unsigned *__restrict__ row_nslots) {
+                                                         int32_t *__restrict__ slot_row, unsigned *__restrict__ slot_key,
+                                                         unsigned *__restrict__ row_nslots) {
     __shared__ int rows_s[SORT_MAX];
     __shared__ int aux[SORT_MAX];
     __shared__ int flag[SORT_MAX];
+    __shared__ int seg[SORT_MAX];
     __shared__ int pos[SORT_MAX + 1];
     __shared__ int wtot[4];
     const int tile = blockIdx.x;
@@ -679,7 +689,7 @@ __global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restri
     const long long ebase = ((long long)b * N + tb.ebase) * dp1;
     for (int i = threadIdx.x; i < ne; i += 256) rows_s[i] = srow_in[ebase + i];
     __syncthreads();
-    tile_slot_flags(rows_s, ne, aux, flag, wtot);
+    tile_slot_flags(rows_s, ne, aux, flag, seg, wtot);
     const int ns = aux[ne - 1];
     for (int i = threadIdx.x; i < ne; i += 256)
         if (flag[i]) pos[aux[i] - 1] = i;
@@ -709,6 +719,8 @@ __global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restri
         const int dst = s0 + hist[n] + atomicAdd(&hcur[n], 1);
         slot_desc[dst] = make_int2(i | (n << 16), 0);
         slot_row[dst] = row;
+        // (tile, run of SLOT_ENT entries inside the tile's group of this row): the slot's identity, whatever index it got
+        if (slot_key) slot_key[dst] = (unsigned)tile * 64u + (unsigned)((i - seg[i]) / SLOT_ENT);
         atomicAdd(&row_nslots[row], 1u);
     }
 }
@@ -719,6 +731,29 @@ __global__ void slot_dest_kernel(const int32_t *__restrict__ slot_row, int n_slo
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += gridDim.x * blockDim.x) {
         const int row = slot_row[s];
         slot_desc[s].y = row_slot_start[row] + (int)atomicAdd(&cursor[row], 1u);
+    }
+}
+
+// Deterministic partial-row order inside every row (by slot identity): a lattice built this way can sum a row's
+// partials in plain fp32, in index order.  Used for the Gaussian lattice (few slots per row, built once per size).
+__global__ void dest_inverse_kernel(const int2 *__restrict__ slot_desc, int n_slots, int32_t *__restrict__ dest_slot) {
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += gridDim.x * blockDim.x) dest_slot[slot_desc[s].y] = s;
+}
+__global__ void row_sort_dest_kernel(const unsigned *__restrict__ slot_key, int32_t *__restrict__ dest_slot,
+                                     const int32_t *__restrict__ row_slot_start, int rows, int2 *__restrict__ slot_desc) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+        const int sb = row_slot_start[row], se = row_slot_start[row + 1];
+        for (int i = sb + 1; i < se; ++i) { // insertion sort of the row's slots by key
+            const int s = dest_slot[i];
+            const unsigned key = slot_key[s];
+            int j = i - 1;
+            while (j >= sb && slot_key[dest_slot[j]] > key) {
+                dest_slot[j + 1] = dest_slot[j];
+                --j;
+            }
+            dest_slot[j + 1] = s;
+        }
+        for (int i = sb; i < se; ++i) slot_desc[dest_slot[i]].y = i;
     }
 }
 
@@ -803,9 +838,20 @@ constexpr float PFIX_SCALE = 16777216.0f;       // 2^24
 constexpr float PFIX_INV = 1.0f / 16777216.0f;  // 2^-24 (exact)
 static_assert(SLOT_ENT * 2.5f < 127.0f, "slot partials must fit the 2^24 fixed-point int32");
 
-// sum of the partial rows [sb, se) (float4 l of each), 4 loads in flight
+// sum of the partial rows [sb, se) (float4 l of each), 4 loads in flight.  PLAIN: the lattice's partial rows are in
+// a deterministic order (row_sort_dest_kernel) and are added in plain fp32, in that order; otherwise in fixed point.
+template <bool PLAIN>
 __device__ __forceinline__ f32x4_t combine_slots4(const f32x4_t *__restrict__ part, int sb, int se, unsigned LP, unsigned l) {
-    if (se - sb == 1) return part[(unsigned)sb * LP + l];
+    f32x4_t first = part[(unsigned)sb * LP + l];
+    if (se - sb == 1) return first;
+    if (PLAIN) {
+        for (int i = sb + 1; i < se; ++i) {
+            const f32x4_t v = part[(unsigned)i * LP + l];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) first[k] += v[k];
+        }
+        return first;
+    }
     long long acc[4] = {0, 0, 0, 0};
     for (int i = sb; i < se; i += 4) {
         f32x4_t v[4];
@@ -850,6 +896,7 @@ __global__ void combine1_kernel(const float *__restrict__ part, const int32_t *_
 
 // Rows from slot partials, iteration form (bilateral lattice; the Gaussian lattice combines inside its fused
 // blur).  LP lanes per row, rows padded to Mp = 4*LP floats; a row's partials are consecutive.
+template <bool PLAIN>
 __global__ __launch_bounds__(256) void combine4_kernel(const f32x4_t *__restrict__ part, const int32_t *__restrict__ row_slot_start,
                                                        int LP, int rows_local, int n_slots, int rep, f32x4_t *__restrict__ val) {
     const int rpb = 256 / LP;
@@ -864,7 +911,7 @@ __global__ __launch_bounds__(256) void combine4_kernel(const f32x4_t *__restrict
     for (long long row = rbeg + tr; row < rend; row += rpb) {
         const int sb = row_slot_start[row], se = row_slot_start[row + 1];
         f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-        if (se > sb) o = combine_slots4(part, sb, se, (unsigned)LP, (unsigned)l);
+        if (se > sb) o = combine_slots4<PLAIN>(part, sb, se, (unsigned)LP, (unsigned)l);
         val[(unsigned)row * (unsigned)LP + l] = o;
     }
 }
@@ -1004,36 +1051,58 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
     out += (size_t)k * rows_local * LP;
     const int p = threadIdx.x;
     const int li = p / GBJ, lj = p - li * GBJ;
-    const int row = tile_rows[(long long)tile_list[t] * P + p];
-    int sb = 0, se = 0;
-    if (part && row) {
-        const int2 ps = tile_pstart[(long long)tile_list[t] * P + p];
-        sb = ps.x;
-        se = ps.x + ps.y;
-    }
+    const long long tbase = (long long)tile_list[t] * P;
+    const int row = tile_rows[tbase + p];
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     if (t == 0 && p < LP) out[p] = zero; // the permanent zero row of this replica
     const bool r0 = row && li >= 1 && li < GBI - 1;      // pass 0 region
     const bool r1 = r0 && lj >= 1 && lj < GBJ - 1;       // pass 1 region
     const bool r2 = row && li >= 2 && li < GBI - 2 && lj >= 2 && lj < GBJ - 2; // interior
+    // Memory side: LH consecutive lanes move the LH consecutive float4s of ONE row (a wave instruction touches
+    // 64/LH rows of LH*16 contiguous bytes; with a lane per point it touched 64 different rows, 16 bytes each, and
+    // the kernel was bound by the L1's line rate).  Item i of thread tid is float4 ll = idx % LH of point
+    // pp = idx / LH, idx = i*P + tid; the three passes below stay one thread per point.
+    int prow[LH], psb[LH], pse[LH];
+#pragma unroll
+    for (int i = 0; i < LH; ++i) {
+        const int pp = (i * P + p) / LH;
+        const int pli = pp / GBJ, plj = pp - pli * GBJ;
+        const int r = tile_rows[tbase + pp];
+        psb[i] = 0; pse[i] = 0;
+        if (part && r) {
+            const int2 ps = tile_pstart[tbase + pp];
+            psb[i] = ps.x;
+            pse[i] = ps.x + ps.y;
+        }
+        // negative: the point is not written back (halo, or absent)
+        prow[i] = (r && pli >= 2 && pli < GBI - 2 && plj >= 2 && plj < GBJ - 2) ? r : (r ? -r : 0);
+    }
     for (int lbase = 0; lbase < LP; lbase += LH) {
-        if (lbase > 0) __syncthreads(); // the previous group's pass-2 reads of b0 are done
-        if (part) {
-            // first slot of the row for all LH float4s at once (independent loads), further slots (tile-border
-            // vertices, ~20 % of the rows) added in fixed point afterwards
+        if (lbase > 0) __syncthreads(); // the previous group's reads of b0 / b1 are done
+        {
             f32x4_t v[LH];
 #pragma unroll
-            for (int l = 0; l < LH; ++l) v[l] = (se > sb && lbase + l < LP) ? part[(unsigned)sb * (unsigned)LP + lbase + l] : zero;
-            if (se - sb > 1) {
-#pragma unroll
-                for (int l = 0; l < LH; ++l)
-                    if (lbase + l < LP) v[l] = combine_slots4(part, sb, se, (unsigned)LP, (unsigned)(lbase + l));
+            for (int i = 0; i < LH; ++i) {
+                const int idx = i * P + p, pp = idx / LH, ll = idx - pp * LH;
+                const int r = prow[i] < 0 ? -prow[i] : prow[i];
+                v[i] = zero;
+                if (r && lbase + ll < LP) {
+                    if (part) {
+                        // first slot of the row (independent loads for all items); further slots -- tile-border
+                        // vertices, ~20 % of the rows -- are added below, in index order
+                        if (pse[i] > psb[i]) v[i] = part[(unsigned)psb[i] * (unsigned)LP + lbase + ll];
+                    } else {
+                        v[i] = in[(unsigned)r * (unsigned)LP + lbase + ll];
+                    }
+                }
             }
 #pragma unroll
-            for (int l = 0; l < LH; ++l) b0[l * P + p] = v[l];
-        } else {
-#pragma unroll
-            for (int l = 0; l < LH; ++l) b0[l * P + p] = (row && lbase + l < LP) ? in[(unsigned)row * (unsigned)LP + lbase + l] : zero;
+            for (int i = 0; i < LH; ++i) {
+                const int idx = i * P + p, pp = idx / LH, ll = idx - pp * LH;
+                if (part && pse[i] - psb[i] > 1 && lbase + ll < LP)
+                    v[i] = combine_slots4<true>(part, psb[i], pse[i], (unsigned)LP, (unsigned)(lbase + ll));
+                b0[ll * P + pp] = v[i];
+            }
         }
         __syncthreads();
         // pass 0, axis 0: (i +- 1, j) = p +- GBJ
@@ -1060,17 +1129,22 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
             b0[l * P + p] = o;
         }
         __syncthreads();
-        // pass 2, axis 2: (i -+ 1, j -+ 1) = p -+ (GBJ + 1); interior only
+        // pass 2, axis 2: (i -+ 1, j -+ 1) = p -+ (GBJ + 1); interior only; through b1 to the row-wise store
         if (r2) {
 #pragma unroll
             for (int l = 0; l < LH; ++l) {
-                if (lbase + l >= LP) break;
                 const f32x4_t c = b0[l * P + p], a = b0[l * P + p - GBJ - 1], b = b0[l * P + p + GBJ + 1];
                 f32x4_t o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
-                out[(unsigned)row * (unsigned)LP + lbase + l] = o;
+                b1[l * P + p] = o;
             }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LH; ++i) {
+            const int idx = i * P + p, pp = idx / LH, ll = idx - pp * LH;
+            if (prow[i] > 0 && lbase + ll < LP) out[(unsigned)prow[i] * (unsigned)LP + lbase + ll] = b1[ll * P + pp];
         }
     }
 }
@@ -1128,7 +1202,6 @@ struct UpdateArgs {
     SplatTab sg, sb;
 };
 
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int GATHER_SB = 256; // slot descriptors staged per batch
 constexpr int GATHER_ENT = TILE_PIX * 6;
 
@@ -1143,7 +1216,11 @@ __device__ __forceinline__ void tile_gather(const SplatTab &T, int tile, long lo
     const int nw = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6);
     const int ne = np * T.dp1;
     const uint2 *src = T.tent + ebase_pix * T.dp1;
-    for (int i = threadIdx.x; i < ne; i += blockDim.x) lent[i] = src[i];
+    for (int i = threadIdx.x; i < ne; i += blockDim.x) {
+        uint2 en = src[i];
+        en.x *= (unsigned)LP; // float4 index of the pixel's row in `stage`
+        lent[i] = en;
+    }
     for (int sb0 = s_beg; sb0 < s_end; sb0 += GATHER_SB) {
         const int nsb = min(GATHER_SB, s_end - sb0);
         if ((int)threadIdx.x < nsb) ldesc[threadIdx.x] = T.slot_desc[sb0 + threadIdx.x];
@@ -1162,7 +1239,7 @@ __device__ __forceinline__ void tile_gather(const SplatTab &T, int tile, long lo
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) en[jj] = lent[i0 + min(i + jj, n - 1)];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) in[jj] = stage[en[jj].x * (unsigned)LP + l];
+                for (int jj = 0; jj < 4; ++jj) in[jj] = stage[en[jj].x + l];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const float w = i + jj < n ? __uint_as_float(en[jj].y) : 0.f; // w * norm[pixel]
@@ -1211,42 +1288,46 @@ __global__ __launch_bounds__(256) void update_splat_kernel(UpdateArgs a) {
     const unsigned gofs = a.g_rows ? (unsigned)k * a.g_rows : 0u;
     const int ppt = (int)(blockDim.x >> 6) * gpw; // pixels per trip
     // pixel of the lane group in trip t0 (clamped to the tile: idle lanes re-read pixel 0)
-    auto pixel_of = [&](int t0) -> long long {
+    const unsigned cw_magic = tile_div_magic(tb.cw);
+    const unsigned pix0 = (unsigned)k * (unsigned)N + (unsigned)tb.y0 * (unsigned)a.tg.W + (unsigned)tb.x0; // B*N < 2^31 (checked)
+    auto pixel_of = [&](int t0) -> unsigned {
         const int t = t0 + g;
-        const int tc = (act && t < np) ? t : 0;
-        const int ty = tc / tb.cw, tx = tc - ty * tb.cw;
-        return (long long)k * N + (long long)(tb.y0 + ty) * a.tg.W + tb.x0 + tx;
+        const unsigned tc = (act && t < np) ? (unsigned)t : 0u;
+        const unsigned ty = (tc * cw_magic) >> 16, tx = tc - ty * (unsigned)tb.cw;
+        return pix0 + ty * (unsigned)a.tg.W + tx;
     };
     // the record and the unary of the NEXT trip are requested before this trip's lattice rows are gathered: two
     // trips of loads in flight per wave (the kernel runs at 4 waves per SIMD; record -> rows is a dependent chain)
     uint4 rq[5];
     f32x4_t un;
     {
-        const long long p = pixel_of((int)(threadIdx.x >> 6) * gpw);
+        const unsigned p = pixel_of((int)(threadIdx.x >> 6) * gpw);
         if (SLICE) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) rq[i] = a.pix_rec[p * 5 + i];
+            for (int i = 0; i < 5; ++i) rq[i] = a.pix_rec[p * 5u + i];
         }
-        un = u4[p * LP + l];
+        un = u4[p * (unsigned)LP + l];
     }
     for (int t0 = (int)(threadIdx.x >> 6) * gpw; t0 < np; t0 += ppt) {
         const int t = t0 + g;
         const bool ok = act && t < np;
-        const long long p = pixel_of(t0);
+        const unsigned p = pixel_of(t0);
         uint4 rqn[5];
         f32x4_t unn = un;
 #pragma unroll
         for (int i = 0; i < 5; ++i) rqn[i] = rq[i];
         if (t0 + ppt < np) {
-            const long long pn = pixel_of(t0 + ppt);
+            const unsigned pn = pixel_of(t0 + ppt);
             if (SLICE) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) rqn[i] = a.pix_rec[pn * 5 + i];
+                for (int i = 0; i < 5; ++i) rqn[i] = a.pix_rec[pn * 5u + i];
             }
-            unn = u4[pn * LP + l];
+            unn = u4[pn * (unsigned)LP + l];
         }
-        float e[4];
-        float mx = -3.0e38f;
+        // E = -U + sum_r (compat * alpha * norm * bary_r) * row_r : nine packed FMAs per class pair (this kernel is
+        // bound by VALU issue, not by memory: the weights are formed once per pixel and the row sums run as
+        // v_pk_fma_f32; exp and the normalisation use the hardware exp2 / reciprocal)
+        f32x2_t e01 = {-un[0], -un[1]}, e23 = {-un[2], -un[3]};
         if (SLICE) {
             // the pixel's record: 5 x 16 bytes, identical for the LP lanes of the pixel (broadcast loads)
             uint32_t rc[20];
@@ -1259,26 +1340,29 @@ __global__ __launch_bounds__(256) void update_splat_kernel(UpdateArgs a) {
             for (int r = 0; r < 3; ++r) vg[r] = vg4[(rc[r] + gofs) * (unsigned)LP + l];
 #pragma unroll
             for (int r = 0; r < 6; ++r) vb[r] = vb4[rc[3 + r] * (unsigned)LP + l];
-            const float ng = __uint_as_float(rc[18]), nbn = __uint_as_float(rc[19]);
+            const float wg = (a.compat_g * a.alpha_g) * __uint_as_float(rc[18]);
+            const float wb = (a.compat_b * a.alpha_b) * __uint_as_float(rc[19]);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float sg = 0.f, sb = 0.f;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) sg += __uint_as_float(rc[9 + r]) * vg[r][kk] * a.alpha_g;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) sb += __uint_as_float(rc[12 + r]) * vb[r][kk] * a.alpha_b;
-                float ek = -un[kk];
-                ek -= -a.compat_g * (sg * ng);
-                ek -= -a.compat_b * (sb * nbn);
-                e[kk] = (ok && 4 * l + kk < a.M) ? ek : -3.0e38f;
-                mx = fmaxf(mx, e[kk]);
+            for (int r = 0; r < 3; ++r) {
+                const float w = __uint_as_float(rc[9 + r]) * wg;
+                const f32x2_t w2 = {w, w}, lo = {vg[r][0], vg[r][1]}, hi = {vg[r][2], vg[r][3]};
+                e01 = __builtin_elementwise_fma(w2, lo, e01);
+                e23 = __builtin_elementwise_fma(w2, hi, e23);
             }
-        } else {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                e[kk] = (ok && 4 * l + kk < a.M) ? -un[kk] : -3.0e38f;
-                mx = fmaxf(mx, e[kk]);
+            for (int r = 0; r < 6; ++r) {
+                const float w = __uint_as_float(rc[12 + r]) * wb;
+                const f32x2_t w2 = {w, w}, lo = {vb[r][0], vb[r][1]}, hi = {vb[r][2], vb[r][3]};
+                e01 = __builtin_elementwise_fma(w2, lo, e01);
+                e23 = __builtin_elementwise_fma(w2, hi, e23);
             }
+        }
+        float e[4] = {e01[0], e01[1], e23[0], e23[1]};
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            e[kk] = (ok && 4 * l + kk < a.M) ? e[kk] : -3.0e38f;
+            mx = fmaxf(mx, e[kk]);
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i) rq[i] = rqn[i];
@@ -1289,9 +1373,11 @@ __global__ __launch_bounds__(256) void update_splat_kernel(UpdateArgs a) {
         }
         mx = __shfl(mx, seg0, 64);
         float ex[4], sum = 0.f;
+        const float mxl = mx * 1.44269504088896341f;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            ex[kk] = (ok && 4 * l + kk < a.M) ? expf(e[kk] - mx) : 0.f;
+            // exp(e - mx) as exp2(e * log2(e) - mx * log2(e)); masked classes give exp2(-huge) = 0
+            ex[kk] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[kk], 1.44269504088896341f, -mxl));
             sum += ex[kk];
         }
         for (int o = 4; o > 0; o >>= 1) {
@@ -1300,9 +1386,10 @@ __global__ __launch_bounds__(256) void update_splat_kernel(UpdateArgs a) {
         }
         sum = __shfl(sum, seg0, 64);
         if (ok) {
-            const f32x4_t o4 = {ex[0] / sum, ex[1] / sum, ex[2] / sum, ex[3] / sum};
+            const float rs = __builtin_amdgcn_rcpf(sum);
+            const f32x4_t o4 = {ex[0] * rs, ex[1] * rs, ex[2] * rs, ex[3] * rs};
             if (SPLAT) stage[t * LP + l] = o4;
-            if (q4) q4[p * LP + l] = o4;
+            if (q4) q4[p * (unsigned)LP + l] = o4;
         }
     }
     if (SPLAT) {
@@ -1439,8 +1526,12 @@ void splat_ones(wsc_ctx *ctx, const LatticeDev &L, const TileGeom &tg, float *va
 // rows of a lattice from the slot partials of the splat
 void combine4(wsc_ctx *ctx, const LatticeDev &L, const float *part, int LP, float *val) {
     WscKernelTimer timer(ctx, WSC_K_BLUR, ((double)L.n_slots + L.rows) * L.rep * L.M_cur * 4);
-    hipLaunchKernelGGL(combine4_kernel, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
-                       ctx->stream, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
+    if (L.sorted_dest)
+        hipLaunchKernelGGL(combine4_kernel<true>, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
+                           ctx->stream, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
+    else
+        hipLaunchKernelGGL(combine4_kernel<false>, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
+                           ctx->stream, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
 }
 
 // d+1 blur passes of the one-value-per-row normalisation lattice, ping-pong between a and b
@@ -1613,11 +1704,24 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
         L.n_slots = (int)ns;
         WSC_TRY(crf_alloc(crf, sizeof(int2) * (size_t)(L.n_slots + 1), (void **)&L.slot_desc));
         WSC_TRY(tmp.alloc(sizeof(int32_t) * (size_t)(L.n_slots + 1), (void **)&slot_row));
+        unsigned *slot_key = nullptr;
+        int32_t *dest_slot = nullptr;
+        if (D == 2) {
+            WSC_TRY(tmp.alloc(sizeof(unsigned) * (size_t)(L.n_slots + 1), (void **)&slot_key));
+            WSC_TRY(tmp.alloc(sizeof(int32_t) * (size_t)(L.n_slots + 1), (void **)&dest_slot));
+        }
         hipLaunchKernelGGL(tile_slots_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, srow, dp1, tg,
-                           L.tslot_start, L.slot_desc, slot_row, row_nslots);
+                           L.tslot_start, L.slot_desc, slot_row, slot_key, row_nslots);
         WSC_TRY(exclusive_scan(ctx, row_nslots, L.rows + 1, (unsigned *)L.row_slot_start, sums3));
         hipLaunchKernelGGL(slot_dest_kernel, dim3(grid1d(L.n_slots)), dim3(256), 0, ctx->stream, slot_row, L.n_slots,
                            L.row_slot_start, cursor, L.slot_desc);
+        if (D == 2) { // Gaussian lattice (built once per image size): deterministic partial-row order, plain fp32 combine
+            hipLaunchKernelGGL(dest_inverse_kernel, dim3(grid1d(L.n_slots)), dim3(256), 0, ctx->stream, L.slot_desc, L.n_slots,
+                               dest_slot);
+            hipLaunchKernelGGL(row_sort_dest_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream, slot_key, dest_slot,
+                               L.row_slot_start, L.rows, L.slot_desc);
+            L.sorted_dest = true;
+        }
     }
     hipLaunchKernelGGL(neighbors_kernel<D>, dim3(grid1d((long long)L.rows * dp1)), dim3(256), 0, ctx->stream, rowkey,
                        rowimg, table, slot2row, cap, (unsigned)(cap - 1), L.rows, L.nbr);
