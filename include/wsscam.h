@@ -264,6 +264,11 @@ int wsc_bilinear_resize(wsc_ctx *ctx, const float *src_dev, int C, int h, int w,
  *   rgb_dev uint8 [B][H][W][3] (HWC, as np.uint8(images[i])). */
 int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, float g_sxy,
                    float bi_sxy, float bi_srgb, wsc_crf **out);
+/* Ordering rule: the lattice memory goes back to the BUILD ctx's stream-ordered cache.  wsc_crf_inference may run on
+ * another ctx (stream); it records the end of its loop in the wsc_crf, and wsc_crf_destroy makes the build ctx's stream
+ * wait for that point before any later work of the build ctx can reuse the memory.  The caller only has to keep the
+ * wsc_crf alive until wsc_crf_inference has RETURNED (not until it has finished on the device), and must destroy it
+ * before the ctx it was created on. */
 void wsc_crf_destroy(wsc_crf *crf);
 /* number of occupied lattice vertices per image: v_gauss/v_bilat int32[B] host arrays (may be NULL) */
 int wsc_crf_lattice_sizes(wsc_ctx *ctx, const wsc_crf *crf, int32_t *v_gauss_host,

@@ -144,3 +144,28 @@ def test_eval_sem_seg_report(tmp_path):
     assert rows[0] == ",iou" and [r.split(",")[0] for r in rows[1:]] == ["background", "a", "b", "c", "miou"]
     log = open(tmp_path / "log.txt").read()
     assert "[eval_sem_seg, val] miou: " + str(np.nanmean(iou)) in log
+
+
+def test_grad_cam_alpha_closed_forms_vs_autograd():
+    """get_grad_cam_weights (02_cues/utilities.py:60-99, common_cnn.py:84-121) for BOTH classifier heads against
+    torch.autograd on the restated nets (oracle/cnn_ref.grad_cam_weights): GAP + Linear (VGG16) and
+    MaxPool + global max + Linear (M7 -- the all-zeros image ties every position; alpha does not depend on the winner),
+    incl. an odd feature-map size where MaxPool2d(2, 2) drops the last row / column."""
+    from oracle import cnn_ref
+    from wsscam.net import common
+
+    C = 7
+    for root, cfg, S in (("vgg16", cnn_ref.VGG16_CFG, 64), ("m7", cnn_ref.M7_CFG, 32), ("m7", cnn_ref.M7_CFG, 28)):
+        sd = cnn_ref.make_plain_state_dict(root, cfg, C, True, seed=11)
+        ref = cnn_ref.grad_cam_weights(sd, root, cfg, S, C)
+
+        class Model:  # what cues.get_grad_cam_weights reads from a wsscam CAM wrapper
+            _sd = {k: v.numpy() for k, v in sd.items()}
+
+        Model.root = root
+        alpha = cues.get_grad_cam_weights(Model, cues.find_final_layer(Model), np.zeros((1, S, S, 3), np.float32))
+        assert alpha.shape == ref.shape
+        assert np.abs(alpha - ref).max() <= 2e-5 * np.abs(ref).max(), (root, S, np.abs(alpha - ref).max())
+        h = S // (8 if root == "vgg16" else 4)
+        raw = common.grad_cam_alpha(Model._sd[root + ".classifier.0.weight"], h, h, "max" if root == "m7" else "avg", False)
+        assert np.allclose(raw, Model._sd[root + ".classifier.0.weight"].T / (h * h))

@@ -1,0 +1,113 @@
+"""GPU: BASELINE config 1 -- Grad-CAM on 16 VOC2012 `val` images with the modified VGG16 through the make_cam driver:
+the PREDICTED-label path (03b_irn/step/make_cam.py:49-52: `label = labels[0][args.use_cls]` on non-train splits;
+vgg16_cam.py:34-45: sigmoid score >= thresholds, forced arg-max when nothing passes), per-image `.npy` files, then
+eval_cam (eval_cam.py:48-62, 89-115) on them.  Everything is checked against the torch-fp32 oracle chain
+(oracle/cnn_ref.py: vgg16_cam_forward + make_cam_tail) on identical weights and inputs."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cnn_ref
+from wsscam import _lib
+from wsscam.step import eval_cam, make_cam
+
+pytestmark = pytest.mark.gpu
+
+VOC_FG = ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog", "horse",
+          "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]
+
+
+def test_config1_vgg16_val_predicted_labels_to_eval_cam(tmp_path):
+    C, S, n_img = 20, 321, 16
+    rng = np.random.default_rng(2012)
+    sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, True, seed=4)
+    sizes = [(120, 160), (160, 120), (107, 160), (160, 160)]
+    packs, ref = [], []
+    for i in range(n_img):
+        H0, W0 = sizes[i % len(sizes)]
+        img = cnn_ref.synth_image(rng, H0, W0)
+        x = cnn_ref.msf_pack(img, (S, S))
+        packs.append({"name": "2007_%06d" % i, "img": x, "size": (H0, W0), "label": np.zeros(C, np.float32)})  # GT unused on val
+        with torch.no_grad():
+            cam, score = cnn_ref.vgg16_cam_forward(torch.from_numpy(x), sd, C)
+        ref.append((cam, score.numpy()))
+    # thresholds (what common_cnn._load_pretrained leaves in the module: max(optimalScoreThresh, 1/3)): one image must fail
+    # every class (forced arg-max, vgg16_cam.py:41-42), the others pass some -- with a margin the device precision respects
+    scores = np.stack([r[1] for r in ref])                      # (16, C)
+    order = np.argsort(scores.max(axis=1))
+    j_none = int(order[0])
+    thr_val = 0.5 * (scores[order[0]].max() + scores[order[1]].max())
+    assert scores[order[1]].max() - scores[order[0]].max() > 2e-3, "synthetic scores too close for a robust threshold"
+    thresholds = np.full(C, max(thr_val, 1 / 3), np.float32)
+    margin = np.abs(scores - thresholds[None]).min()
+    sd_dev = {k: v.numpy() for k, v in sd.items()}
+    sd_dev["thresholds"] = thresholds
+
+    args = argparse.Namespace(cam_network="net.vgg16_cam", model_dir=None, dataset="voc12", tag="VOC2012_VGG16", num_classes=C,
+                              use_cls=list(range(C)), model_id="vgg16", state_dict=sd_dev, split="val", dataset_obj=packs,
+                              cam_out_dir=str(tmp_path / "cam_val"), outsize=(S, S), n_gpus=1, cam_batch_images=8,
+                              cam_precision=_lib.PREC_BF16X3, cam_weights_name=str(tmp_path / "unused"), norm_mode="int",
+                              val_list=None, dev_root=None, cam_scales=(1.0,), class_names={"bg": ["background"], "fg": VOC_FG})
+    make_cam.run(args)
+
+    n_forced = 0
+    pred_ref, gts = [], []
+    for i, p in enumerate(packs):
+        cam, score = ref[i]
+        y = score >= thresholds
+        if y.sum() == 0:  # vgg16_cam.py:41-42
+            y[np.argmax(score)] = True
+            n_forced += 1
+            assert i == j_none
+        if margin < 5e-4:  # a score this close to the threshold may legitimately flip on the device
+            continue
+        valid = torch.nonzero(torch.from_numpy(y))[:, 0]
+        strided, hi = cnn_ref.make_cam_tail(cam, p["size"], valid)
+        d = np.load(os.path.join(args.cam_out_dir, p["name"] + ".npy"), allow_pickle=True).item()
+        assert sorted(d) == ["cam", "high_res", "keys"]
+        assert d["keys"].dtype == np.int64 and np.array_equal(d["keys"], valid.numpy())
+        assert d["cam"].shape == tuple(strided.shape) and d["high_res"].shape == tuple(hi.shape)
+        assert np.abs(d["cam"] - strided.numpy()).max() <= 2e-4 and np.abs(d["high_res"] - hi.numpy()).max() <= 2e-4
+        cams = np.pad(hi.numpy(), ((1, 0), (0, 0), (0, 0)), mode="constant", constant_values=0.15)  # eval_cam.py:50
+        keys = np.pad(valid.numpy() + 1, (1, 0), mode="constant")                                   # eval_cam.py:51
+        pred_ref.append(keys[np.argmax(cams, axis=0)])
+    assert n_forced == 1 and margin >= 5e-4
+
+    # ---- eval_cam on the files ------------------------------------------------------------------------------
+    class Seg:
+        ids = [p["name"] for p in packs]
+
+        def __init__(self):
+            g = np.random.default_rng(5)
+            self.maps = [g.integers(0, 21, p["size"]).astype(np.uint8) for p in packs]
+            for m in self.maps:
+                m[g.random(m.shape) < 0.05] = 255
+
+        def label(self, i):
+            return self.maps[i]
+
+    seg = Seg()
+    eargs = argparse.Namespace(dataset="voc12", cam_out_dir=args.cam_out_dir, cam_eval_thres=0.15, split="val",
+                               class_names=args.class_names, eval_dir=str(tmp_path / "eval"), run_name="cfg1",
+                               logfile=str(tmp_path / "log.txt"), seg_labels=seg, cam_clr_out_dir=str(tmp_path / "clr"),
+                               class_colours={"bg": [(0, 0, 0)], "fg": [(8 * i + 7, 255 - 9 * i, 40 + 3 * i) for i in range(C)]})
+    conf, s = eval_cam.run(eargs)
+    # exact (integer work) against numpy on the SAME files
+    conf_np = np.zeros((21, 21), np.int64)
+    agree = []
+    for i, p in enumerate(packs):
+        d = np.load(os.path.join(args.cam_out_dir, p["name"] + ".npy"), allow_pickle=True).item()
+        cams = np.pad(d["high_res"], ((1, 0), (0, 0), (0, 0)), mode="constant", constant_values=0.15)
+        keys = np.pad(d["keys"] + 1, (1, 0), mode="constant")
+        cls = keys[np.argmax(cams, axis=0)]
+        m = seg.maps[i] != 255
+        conf_np += np.bincount(21 * seg.maps[i][m].astype(np.int64) + cls[m], minlength=441).reshape(21, 21)
+        agree.append((cls == pred_ref[i]).mean())
+    assert np.array_equal(conf, conf_np)
+    assert min(agree) >= 0.999  # label maps of the device CAMs vs the oracle chain's
+    assert "[eval_cam, val] miou: %s" % str(s["miou"]) in open(eargs.logfile).read()
+    assert os.path.exists(os.path.join(eargs.eval_dir, "cfg1_val_cam_iou.csv"))
+    assert os.path.exists(os.path.join(eargs.cam_clr_out_dir, packs[0]["name"] + ".png"))

@@ -120,6 +120,31 @@ def test_cam_tail_edge_cases(ctx):
         assert np.abs(s - rs.numpy()).max() <= 2e-6 and np.abs(hh - rh.numpy()).max() <= 2e-6
 
 
+def test_cam_tail_signed_maps(ctx):
+    """The ADP 'func' background channel is bg - max(exception CAMs) with no ReLU (common_cam.py:57-75): on an all-tissue
+    patch it is <= 0 everywhere and the reference divides by (negative max + 1e-5).  Maps of either sign and an
+    all-negative map against torch (make_cam.py:71-76), through both the tail and the fused unary path's maximum."""
+    rng = np.random.default_rng(19)
+    C, h, w = 5, 14, 14
+    cam = rng.normal(0.0, 1.0, (2, C, h, w)).astype(np.float32)
+    cam[0, 0] = -np.abs(cam[0, 0]) - 0.05      # all negative
+    cam[1, 3] = -0.75                           # constant negative
+    sizes = [(50, 37), (33, 64)]
+    keys = [[0, 1, 4], [3, 2]]
+    cam_dev = ctx.to_device(cam)
+    s_dev, h_dev, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, 2, C, h, w, sizes, keys)
+    s_all = ctx.to_host(s_dev, (sum(k * a * b for k, a, b, _, _ in shapes),), np.float32)
+    h_all = ctx.to_host(h_dev, (sum(k * a * b for k, _, _, a, b in shapes),), np.float32)
+    for b in range(2):
+        K, h4, w4, H0, W0 = shapes[b]
+        rs, rh = cnn_ref.make_cam_tail(torch.from_numpy(cam[b]), sizes[b], torch.tensor(keys[b]))
+        s = s_all[s_off[b]:s_off[b] + K * h4 * w4].reshape(K, h4, w4)
+        hh = h_all[h_off[b]:h_off[b] + K * H0 * W0].reshape(K, H0, W0)
+        tol = 2e-6 * max(1.0, float(np.abs(rh.numpy()).max()))
+        assert np.abs(s - rs.numpy()).max() <= tol and np.abs(hh - rh.numpy()).max() <= tol
+    assert h_all[h_off[0]:h_off[0] + 50 * 37].max() > 1e3  # all-negative map / (negative max + 1e-5): large positive values
+
+
 def test_bilinear_resize_vs_torch(ctx):
     rng = np.random.default_rng(2)
     src = rng.normal(0, 1, (5, 40, 40)).astype(np.float32)

@@ -48,6 +48,18 @@ __device__ __forceinline__ float bilerp(const float *src, int w, int y0, int y1,
     return __builtin_fmaf(ly0, top, ly1 * bot);
 }
 
+// Order-preserving float <-> uint code for atomicMax over floats of EITHER sign: the ADP background channel
+// (bg - max exception CAM, common_cam.py:57-75, no ReLU) can be <= 0 everywhere, and the reference then divides by
+// (negative max + 1e-5).  Code 0 (the memset value) is below every real number; it decodes to 0 (empty map).
+__device__ __forceinline__ unsigned int ord_enc(float f) {
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_dec(unsigned int u) {
+    if (u == 0u) return 0.f;
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
 // WRITE = false: atomicMax the per-job maxima; WRITE = true: write v / (max + 1e-5).
 template <bool WRITE>
 __global__ __launch_bounds__(256) void cam_tail_kernel(const float *__restrict__ cam, const TailJob *__restrict__ jobs,
@@ -66,10 +78,10 @@ __global__ __launch_bounds__(256) void cam_tail_kernel(const float *__restrict__
     const float sh_st = (float)h / (float)job.h4, sw_st = (float)w / (float)job.w4;
     float d_hi = 1.f, d_st = 1.f;
     if (WRITE) {
-        d_hi = __uint_as_float(mx[2 * blockIdx.y]) + 1e-5f;
-        d_st = __uint_as_float(mx[2 * blockIdx.y + 1]) + 1e-5f;
+        d_hi = ord_dec(mx[2 * blockIdx.y]) + 1e-5f;
+        d_st = ord_dec(mx[2 * blockIdx.y + 1]) + 1e-5f;
     }
-    float m_hi = 0.f, m_st = 0.f;
+    float m_hi = -3.0e38f, m_st = -3.0e38f;
     const int end = min(start + PIX_PER_BLOCK, n_hi + n_st);
     for (int i = start + threadIdx.x; i < end; i += blockDim.x) {
         int y0, y1, x0, x1;
@@ -92,14 +104,13 @@ __global__ __launch_bounds__(256) void cam_tail_kernel(const float *__restrict__
         }
     }
     if (!WRITE) {
-        // CAM values are >= 0 (ReLU + ReLU), so the uint order of the bits is the float order
         for (int o = 32; o > 0; o >>= 1) {
             m_hi = fmaxf(m_hi, __shfl_down(m_hi, o, 64));
             m_st = fmaxf(m_st, __shfl_down(m_st, o, 64));
         }
         if ((threadIdx.x & 63) == 0) {
-            if (m_hi > 0.f) atomicMax(&mx[2 * blockIdx.y], __float_as_uint(m_hi));
-            if (m_st > 0.f) atomicMax(&mx[2 * blockIdx.y + 1], __float_as_uint(m_st));
+            if (m_hi > -3.0e38f) atomicMax(&mx[2 * blockIdx.y], ord_enc(m_hi));
+            if (m_st > -3.0e38f) atomicMax(&mx[2 * blockIdx.y + 1], ord_enc(m_st));
         }
     }
 }
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(256) void cam_max_kernel(const float *__restrict__ 
     __syncthreads();
     const float sh = (float)h / (float)Hu, sw = (float)w / (float)Wu;
     const int n = H0 * W0;
-    float m = 0.f;
+    float m = -3.0e38f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int yy = i / W0, xx = i - yy * W0;
         int y0, y1, x0, x1;
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(256) void cam_max_kernel(const float *__restrict__ 
         m = fmaxf(m, bilerp(src, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1));
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&mx[bc], __float_as_uint(m)); // values >= 0: uint order = float order
+    if ((threadIdx.x & 63) == 0 && m > -3.0e38f) atomicMax(&mx[bc], ord_enc(m));
 }
 
 template <int CMAX>
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256) void cam_unary_kernel(const float *__restrict_
     const int hw = h * w;
     float *div = src + C * hw;
     for (int i = threadIdx.x; i < C * hw; i += blockDim.x) src[i] = cam[(long long)b * C * hw + i];
-    for (int c = threadIdx.x; c < C; c += blockDim.x) div[c] = __uint_as_float(mx[b * C + c]) + 1e-5f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) div[c] = ord_dec(mx[b * C + c]) + 1e-5f;
     __syncthreads();
     const float sh = (float)h / (float)Hu, sw = (float)w / (float)Wu;
     const int n = H0 * W0;
@@ -221,7 +232,8 @@ __global__ __launch_bounds__(256) void cam_eval_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ keys, float thres,
                                                        const uint8_t *__restrict__ gt, int n_class, int ignore_label,
                                                        uint8_t *__restrict__ pred,
-                                                       unsigned long long *__restrict__ confusion) {
+                                                       unsigned long long *__restrict__ confusion,
+                                                       unsigned *__restrict__ n_bad) {
     extern __shared__ unsigned hist[]; // n_class * n_class
     const EvalJob job = jobs[blockIdx.y];
     const int cells = n_class * n_class;
@@ -240,7 +252,12 @@ __global__ __launch_bounds__(256) void cam_eval_kernel(const float *__restrict__
         const int cls = idx == 0 ? 0 : keys[job.key_base + idx - 1] + 1;
         if (pred != nullptr) pred[job.pix_off + p] = (uint8_t)cls;
         const int g = gt != nullptr ? (int)gt[job.pix_off + p] : ignore_label;
-        if (g != ignore_label && g < n_class && cls < n_class) atomicAdd(&hist[g * n_class + cls], 1u);
+        if (g != ignore_label) {
+            // chainercv's calc_semantic_segmentation_confusion raises on labels outside [0, n_class): count them, the
+            // host turns a non-zero count into an error instead of a plausible but wrong mIoU
+            if (g < n_class && cls < n_class) atomicAdd(&hist[g * n_class + cls], 1u);
+            else atomicAdd(n_bad, 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < cells; i += blockDim.x)
@@ -275,19 +292,29 @@ int wsc_cam_eval_confusion(wsc_ctx *ctx, const float *highres_dev, int B, const 
         max_pix = std::max(max_pix, H0 * W0);
     }
     const int nkeys = key_off_host[B];
-    const size_t jb = (jobs.size() * sizeof(EvalJob) + 15) / 16 * 16, kb = (size_t)std::max(nkeys, 1) * sizeof(int32_t);
+    for (int i = 0; i < nkeys; ++i)
+        WSC_CHECK(keys_host[i] >= 0 && keys_host[i] + 1 < n_class, WSC_ERR_INVALID,
+                  "wsc_cam_eval_confusion: key %d outside [0, %d) (n_class counts the background)", keys_host[i], n_class - 1);
+    const size_t jb = (jobs.size() * sizeof(EvalJob) + 15) / 16 * 16,
+                 kb = ((size_t)std::max(nkeys, 1) * sizeof(int32_t) + 15) / 16 * 16;
     char *d = nullptr;
-    WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + kb, (void **)&d));
-    std::vector<char> stage(jb + kb, 0);
+    WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + kb + 16, (void **)&d));
+    std::vector<char> stage(jb + kb + 16, 0); // the last 16 bytes: out-of-range counter, zeroed
     memcpy(stage.data(), jobs.data(), jobs.size() * sizeof(EvalJob));
     if (nkeys > 0) memcpy(stage.data() + jb, keys_host, (size_t)nkeys * sizeof(int32_t));
     WSC_TRY(wsc_ctx_upload_small(ctx, d, stage.data(), stage.size()));
     const dim3 grid((unsigned)std::min((max_pix + 255) / 256, 64), (unsigned)B);
     hipLaunchKernelGGL(cam_eval_kernel, grid, dim3(256), (size_t)n_class * n_class * sizeof(unsigned), ctx->stream,
                        highres_dev, (const EvalJob *)d, (const int32_t *)(d + jb), bg_thres, gt_dev, n_class,
-                       ignore_label, pred_dev, (unsigned long long *)confusion_dev);
+                       ignore_label, pred_dev, (unsigned long long *)confusion_dev, (unsigned *)(d + jb + kb));
     WSC_HIP(hipGetLastError());
+    unsigned n_bad = 0;
+    WSC_HIP(hipMemcpyAsync(&n_bad, d + jb + kb, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
     wsc_ctx_cached_free(ctx, d);
+    WSC_CHECK(n_bad == 0, WSC_ERR_INVALID,
+              "wsc_cam_eval_confusion: %u pixels carry a ground-truth label outside [0, %d) (and != ignore_label %d)", n_bad,
+              n_class, ignore_label);
     return WSC_OK;
 }
 

@@ -124,6 +124,7 @@ struct wsc_crf {
     // per pixel, 20 dwords = five 16-byte loads: offG[3] offB[6] baryG[3] baryB[6] normG normB
     uint4 *pix_rec = nullptr;
     std::vector<void *> allocs;
+    std::vector<void *> persist_allocs; // blocks of a cached Gaussian lattice under construction (freed if the build fails)
     bool persist = false; // allocations made while set belong to the ctx (cached Gaussian lattice)
     // set by wsc_crf_inference on a ctx other than the build ctx: the last loop's completion on that stream
     hipEvent_t use_ev = nullptr;
@@ -1264,7 +1265,7 @@ __device__ __forceinline__ void tile_gather(const SplatTab &T, int tile, long lo
 // pixel's classes are reduced inside the lane, then across the pixel's LP lanes by shuffle-down with a segment
 // bound and a broadcast from the segment's first lane.  Between iterations Q exists only as the tile's LDS copy.
 template <bool SLICE, bool SPLAT>
-__global__ __launch_bounds__(256) void update_splat_kernel(UpdateArgs a) {
+__global__ __launch_bounds__(512) void update_splat_kernel(UpdateArgs a) {
     extern __shared__ f32x4_t stage[]; // [TILE_PIX][LP]
     const int LP = a.LP;
     const int gpw = 64 / LP;
@@ -1496,6 +1497,7 @@ int crf_alloc(wsc_crf *crf, size_t bytes, void **out) {
     void *p = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(crf->ctx, bytes, &p));
     if (!crf->persist) crf->allocs.push_back(p);
+    else crf->persist_allocs.push_back(p);
     *out = p;
     return WSC_OK;
 }
@@ -1797,7 +1799,9 @@ int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat) {
     // two messages the reference materialises (N*M*4 each); splat: read Q for both lattices + index+weight
     const double by = npix * (2.0 * a.M * 4 + (slice ? 9 * 8 + 2.0 * a.M * 4 : 0.0) + (splat ? 9 * 8 + 2.0 * a.M * 4 : 0.0));
     WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, by);
-    const dim3 grid((unsigned)(a.B * a.tg.tpi)), block(256);
+    const char *te = getenv("WSC_CRF_UPD_THREADS");
+    const int nthr = te ? atoi(te) : 256;
+    const dim3 grid((unsigned)(a.B * a.tg.tpi)), block(nthr == 512 ? 512 : (nthr == 128 ? 128 : 256));
     const size_t lds = splat ? sizeof(f32x4_t) * TILE_PIX * a.LP + sizeof(uint2) * GATHER_ENT + sizeof(int2) * GATHER_SB : 0;
     if (slice && splat) hipLaunchKernelGGL((update_splat_kernel<true, true>), grid, block, lds, ctx->stream, a);
     else if (slice) hipLaunchKernelGGL((update_splat_kernel<true, false>), grid, block, lds, ctx->stream, a);
@@ -1842,7 +1846,9 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
             GaussCache *g = new GaussCache{H, W, g_sxy, crf->lat[0]};
             ctx->attachments.emplace_back(g, &gauss_cache_delete);
         }
-        // on failure the partially built arrays stay with the ctx and are released at wsc_ctx_destroy
+        if (st != WSC_OK) // a failed build must not leave its arrays with the ctx for the rest of its life
+            for (void *p : crf->persist_allocs) wsc_ctx_cached_free(ctx, p);
+        crf->persist_allocs.clear();
         crf->persist = false;
     }
     crf->lat[0].rep = B;

@@ -16,25 +16,25 @@ def find_final_layer(model):
 
 
 def get_grad_cam_weights(input_model, final_layer, dummy_image, should_normalize=True):
-    """02_cues/utilities.py:60-99: alpha[:, c] = mean_{h,w} normalize(d y_c / d A) on `dummy_image`.
+    """02_cues/utilities.py:60-99 (twin: 03b_irn/net/common_cnn.py:84-121): alpha[:, c] = mean_{h,w} normalize(d y_c / d A)
+    on `dummy_image`, A = the final conv feature map (h x w x F), y_c the pre-sigmoid logit.
 
-    For the GAP + Linear classifier of the modified VGG16 the gradient of the pre-sigmoid logit y_c with
-    respect to the final feature map A (h x w x F) is the constant W[c, f] / (h w) at every position and
-    for every input image, so alpha has the closed form below (identical to K.gradients up to round-off).
-    Networks whose classifier pools with a max (M7 / X1.7) need a framework's tie-breaking on the
-    all-zeros image; pass their precomputed alpha instead."""
+    Both classifier heads of the reference's networks give a closed form (net.common.grad_cam_alpha):
+      * GAP + Linear (modified VGG16 / X1.7, net/vgg16.py:17-22): d y_c / d A = W[c, f] / (h w) at every position;
+      * MaxPool + global max + Linear (M7, net/m7.py:15-21): the gradient is W[c, f] at the ONE position the pooling
+        selected in channel f and zero elsewhere -- which position wins the ties of the all-zeros image does not
+        matter, because alpha is the spatial MEAN of the normalised gradient.
+    Identical to K.gradients / torch.autograd up to round-off (tests/test_cues_host.py)."""
+    from ..net.common import PLAIN_CFG, grad_cam_alpha
+
     sd = input_model._sd
     root = input_model.root
-    if getattr(input_model, "arch", None) != _lib.ARCH_VGG16_CAM:
-        raise NotImplementedError("get_grad_cam_weights: closed form only for GAP+Linear classifiers (vgg16)")
     W = np.asarray(sd[root + ".classifier.0.weight"], dtype=np.float64)  # (C, F)
     S = int(dummy_image.shape[1])
-    h = input_model.cam_size(S)
-    g = W / float(h * h)  # d y_c / d A[h, w, f], constant over (h, w)
-    if should_normalize:
-        rms = np.sqrt(np.mean(np.float32(g) ** 2, axis=1, keepdims=True, dtype=np.float64))
-        g = g / (rms + 1e-5)
-    return np.ascontiguousarray(g.T)  # (F, C); the spatial mean of a constant map is the constant
+    h = S
+    for _, layer in PLAIN_CFG[root]:
+        h //= 2 ** sum(1 for v in layer if v == "M")
+    return grad_cam_alpha(W, h, h, "max" if root == "m7" else "avg", should_normalize)
 
 
 def _to_nchw(images):

@@ -109,3 +109,135 @@ class DeviceCAMBase:
         cam = ctx.to_host(cam_dev, (B, self.num_classes, h, h), np.float32)
         score = ctx.to_host(score_dev, (B, self.num_classes), np.float32) if want_score else None
         return (cam, score) if want_score else cam
+
+
+# ---- Keras weight list -> state dict (03b_irn/net/common_cnn.py:25-82) ----------------------------------------
+# layer tables of the two plain stacks (net/vgg16.py:44, net/m7.py:41): 'M' MaxPool2d(2,2), 'D' Dropout
+PLAIN_CFG = {
+    "vgg16": [("layer1", [64, 64, "M"]), ("layer2", [128, 128, "M"]), ("layer3", [256, 256, 256, "M"]),
+              ("layer4", [512, 512, 512, 512, 512, 512]), ("layer5", [1024, "D", 1024, "D"])],
+    "m7": [("layer1", [64, 64, "M"]), ("layer2", [128, 128, "M"]), ("layer3_p1", [256, 256, 256])],
+}
+
+
+def plain_module_order(root, batchnorm):
+    """(kind, key prefix) of every parameterised module of VGG / MNet in `nn.Module.modules()` order, which is the
+    order load_weights_from_file pops the Keras list in (common_cnn.py:53-82): make_layers emits
+    conv -> ReLU -> BatchNorm per entry (common_cnn.py:137-141), the classifier's Linear comes last."""
+    order = []
+    for lname, layer in PLAIN_CFG[root]:
+        idx = 0
+        for v in layer:
+            if v in ("M", "D"):
+                idx += 1
+                continue
+            order.append(("conv", "%s.%s.%d" % (root, lname, idx)))
+            if batchnorm:
+                order.append(("bn", "%s.%s.%d" % (root, lname, idx + 2)))
+                idx += 3
+            else:
+                idx += 2
+    order.append(("linear", root + ".classifier.0"))
+    return order
+
+
+def state_dict_from_keras_weights(weights, tag, root="vgg16", batchnorm=True, thresholds_mat=None):
+    """`model.get_weights()` of the pretrained Keras CNN -> the state dict the device nets take.
+
+    Restates CommonCNN.load_weights_from_file / load_thresholds_from_file (common_cnn.py:25-82, 123-125):
+      * Conv2D kernels HWIO -> OIHW (`HWCD_to_DCHW`, :42-43), followed by their bias;
+      * BatchNormalization as [gamma, beta, moving_mean, moving_variance] -> weight, bias, running_mean, running_var;
+      * Dense kernel transposed to (classes, features); its bias is loaded only when 'VGG16' is NOT in the tag
+        (`use_bias`, :44 -- the Keras Dense of the VGG16 models has none).  The reference then keeps nn.Linear's
+        random-initialised bias (SURVEY Q2); here the key is simply absent and the device net uses a zero bias;
+      * the count check of :48-49 and every shape check are kept (AssertionError, as in the reference);
+      * thresholds = max(optimalScoreThresh, 1/3) (:39), stored under "thresholds".
+    `weights` is consumed front to back like the reference's `weights.pop(0)`; it is not modified.
+    """
+    weights = [np.asarray(w) for w in weights]
+    use_bias = "VGG16" not in tag
+    order = plain_module_order(root, batchnorm)
+    n_conv = sum(1 for k, _ in order if k == "conv")
+    n_bn = sum(1 for k, _ in order if k == "bn")
+    n_lin = sum(1 for k, _ in order if k == "linear")
+    assert 2 * n_conv + 4 * n_bn + (1 + use_bias) * n_lin == len(weights), \
+        "Sizes of PyTorch network and saved Keras network differ!"
+    sd = {}
+    pos = 0
+    cin = 3
+    for kind, key in order:
+        if kind == "conv":
+            w = np.transpose(weights[pos], (3, 2, 0, 1))
+            b = weights[pos + 1]
+            pos += 2
+            assert w.ndim == 4 and w.shape[1] == cin and w.shape[2:] == (3, 3), (key, w.shape)
+            assert b.shape == (w.shape[0],), (key, b.shape)
+            sd[key + ".weight"], sd[key + ".bias"] = w, b
+            cin = w.shape[0]
+        elif kind == "bn":
+            for name in ("weight", "bias", "running_mean", "running_var"):
+                w = weights[pos]
+                pos += 1
+                assert w.shape == (cin,), (key, name, w.shape)
+                sd[key + "." + name] = w
+        else:
+            w = np.transpose(weights[pos])
+            pos += 1
+            assert w.ndim == 2 and w.shape[1] == cin, (key, w.shape)
+            sd[key + ".weight"] = w
+            if use_bias:
+                b = weights[pos]
+                pos += 1
+                assert b.shape == (w.shape[0],), (key, b.shape)
+                sd[key + ".bias"] = b
+    if thresholds_mat is not None:
+        sd["thresholds"] = np.maximum(np.asarray(thresholds_mat, dtype=np.float64).reshape(-1), 1 / 3)
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in sd.items()}
+
+
+def keras_h5_weight_list(weights_path):
+    """The list `model.get_weights()` returns, read straight from a Keras 2 `.h5` weight file (layer_names /
+    weight_names attributes give the order): needs h5py, which is only required on this one path."""
+    try:
+        import h5py
+    except ImportError as e:  # no silent fallback: the caller asked for pretrained weights
+        raise RuntimeError("reading %s needs h5py (pass state_dict / a Keras weight list instead)" % weights_path) from e
+    out = []
+    with h5py.File(weights_path, "r") as f:
+        g = f["model_weights"] if "model_weights" in f else f
+        for lname in g.attrs["layer_names"]:
+            lname = lname.decode() if isinstance(lname, bytes) else lname
+            for wname in g[lname].attrs["weight_names"]:
+                wname = wname.decode() if isinstance(wname, bytes) else wname
+                out.append(np.asarray(g[lname][wname]))
+    return out
+
+
+def load_pretrained(model_dir, tag, root="vgg16", batchnorm=True):
+    """CommonCNN._load_pretrained (common_cnn.py:25-41): <model_dir>/<tag>/<tag>.h5 + <tag>.mat -> state dict."""
+    import os
+
+    import scipy.io
+
+    weights = keras_h5_weight_list(os.path.join(model_dir, tag, tag + ".h5"))
+    mat = scipy.io.loadmat(os.path.join(model_dir, tag, tag + ".mat")).get("optimalScoreThresh")[0]
+    return state_dict_from_keras_weights(weights, tag, root, batchnorm, mat)
+
+
+def grad_cam_alpha(W, h, w, pool, should_normalize=True):
+    """Grad-CAM weights alpha (F, C) of a `pool` + Linear classifier head on an h x w x F feature map
+    (02_cues/utilities.py:60-99): g = d y_c / d A, g <- g / (sqrt(mean(g^2)) + 1e-5), alpha[:, c] = mean_{h,w} g.
+    pool = "avg": g = W[c, f] / (h w) everywhere; "max": g = W[c, f] at one position per channel, else 0."""
+    W = np.asarray(W, dtype=np.float64)  # (C, F)
+    F = W.shape[1]
+    hw = float(h * w)
+    if pool == "avg":
+        mean_g = W / hw                                                     # spatial mean of a constant map
+        rms = np.sqrt(np.sum(np.float32(W / hw) ** 2, axis=1, keepdims=True, dtype=np.float64) / F)
+    elif pool == "max":
+        mean_g = W / hw                                                     # one entry W[c, f] averaged over h w positions
+        rms = np.sqrt(np.sum(np.float32(W) ** 2, axis=1, keepdims=True, dtype=np.float64) / (F * hw))
+    else:
+        raise ValueError("pool must be 'avg' or 'max'")
+    g = mean_g / (rms + 1e-5) if should_normalize else mean_g
+    return np.ascontiguousarray(g.T)

@@ -23,6 +23,20 @@ class CAM(DeviceCAMBase):
         self.tag = tag
         self.use_cls = use_cls
         self.thresholds = 0.5 * np.ones(num_classes, dtype=np.float32)  # common_cnn.py:22
+        self.batchnorm = dataset not in ("adp_morph", "adp_func")       # vgg16_cam.py:16-19 / m7_cam.py:15-18
+        if model_dir is not None and tag:
+            self._load_pretrained(model_dir, tag)
+
+    def _load_pretrained(self, model_dir, tag):
+        """CommonCNN._load_pretrained (common_cnn.py:25-41): Keras <tag>.h5 + <tag>.mat under <model_dir>/<tag>/.
+        When the files are absent the wrapper stays empty until load_state_dict() is called (the reference would
+        raise at construction; make_cam.run passes `args.state_dict` for weightless dry runs)."""
+        import os
+
+        from .common import load_pretrained
+
+        if os.path.exists(os.path.join(model_dir, tag, tag + ".h5")):
+            self.load_state_dict(load_pretrained(model_dir, tag, self.root, self.batchnorm), strict=True)
 
     def load_state_dict(self, state_dict, strict=True):
         super().load_state_dict(state_dict, strict)

@@ -55,6 +55,11 @@ def process_batch(model, packs, args, save=True):
     ctx = model.ctx
     B = len(packs)
     x = np.stack([np.asarray(p["img"], dtype=np.float32) for p in packs])  # (B,2,3,S,S)
+    if x.ndim != 5 or x.shape[1:3] != (2, 3) or x.shape[-2] != x.shape[-1]:
+        # wsc_net_forward_cam takes square S x S inputs: the reference's outsize=None configuration (native, non-square
+        # image sizes, func_sample.py:143-145) is not supported -- INTEGRATION.md, "limits"
+        raise ValueError("make_cam: network inputs must be (B, 2, 3, S, S) with one square size per run "
+                         "(args.outsize = (321, 321) or (224, 224)); got %s" % (x.shape,))
     S = x.shape[-1]
     C = model.num_classes
     h = model.cam_size(S)
@@ -139,6 +144,9 @@ def build_dataset(args):
 
 def run(args):
     """03b_irn/step/make_cam.py:95-124."""
+    if getattr(args, "outsize", (321, 321)) is None:
+        raise ValueError("make_cam: args.outsize=None (native, non-square network inputs) is not supported; "
+                         "use (321, 321) or (224, 224)")
     mod = args.cam_network
     if not mod.startswith("wsscam."):
         mod = "wsscam." + mod  # the reference passes 'net.resnet50_cam'
@@ -147,11 +155,13 @@ def run(args):
     if getattr(args, "cam_precision", None) is not None:  # optional: _lib.PREC_F16 (default) / BF16 / BF16X3
         model.precision = args.cam_precision
     if getattr(args, "state_dict", None) is not None:
-        model.load_state_dict(args.state_dict, strict=True)
-    else:
+        model.load_state_dict(args.state_dict, strict=True)  # weights handed over in memory (tests, dry runs)
+    elif getattr(args, "model_id", None) == "resnet50":      # make_cam.py:98-99: only resnet50 has a .pth
         import torch
 
         model.load_state_dict(torch.load(args.cam_weights_name + ".pth", map_location="cpu"), strict=True)
+    # the vgg16 / m7 / x1.7 wrappers transplanted their Keras weights from args.model_dir in the constructor
+    # (common_cnn._load_pretrained); a wrapper that is still empty fails loudly at the first forward pass
     model.eval()
 
     n_gpus = int(getattr(args, "n_gpus", 0)) or _device_count()
