@@ -24,6 +24,7 @@ def test_config1_vgg16_val_predicted_labels_to_eval_cam(tmp_path):
     C, S, n_img = 20, 321, 16
     rng = np.random.default_rng(2012)
     sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, True, seed=4)
+    sd["vgg16.classifier.0.weight"] = sd["vgg16.classifier.0.weight"] * 0.3  # keeps the sigmoid scores off saturation
     sizes = [(120, 160), (160, 120), (107, 160), (160, 160)]
     packs, ref = [], []
     for i in range(n_img):
@@ -34,15 +35,25 @@ def test_config1_vgg16_val_predicted_labels_to_eval_cam(tmp_path):
         with torch.no_grad():
             cam, score = cnn_ref.vgg16_cam_forward(torch.from_numpy(x), sd, C)
         ref.append((cam, score.numpy()))
-    # thresholds (what common_cnn._load_pretrained leaves in the module: max(optimalScoreThresh, 1/3)): one image must fail
-    # every class (forced arg-max, vgg16_cam.py:41-42), the others pass some -- with a margin the device precision respects
+    # thresholds (what common_cnn._load_pretrained leaves in the module, max(optimalScoreThresh, 1/3), is a per-class
+    # vector): image 0 must fail every class (forced arg-max, vgg16_cam.py:41-42) while other images pass some.  Per
+    # class the threshold sits in the middle of the widest gap of the 16 scores above image 0's, so every score keeps
+    # a margin the device precision (bf16x3: <= 1e-4 on a score) respects.
     scores = np.stack([r[1] for r in ref])                      # (16, C)
-    order = np.argsort(scores.max(axis=1))
-    j_none = int(order[0])
-    thr_val = 0.5 * (scores[order[0]].max() + scores[order[1]].max())
-    assert scores[order[1]].max() - scores[order[0]].max() > 2e-3, "synthetic scores too close for a robust threshold"
-    thresholds = np.full(C, max(thr_val, 1 / 3), np.float32)
-    margin = np.abs(scores - thresholds[None]).min()
+    j_none = 0
+    thresholds = np.zeros(C, np.float32)
+    margin = 1.0
+    for c in range(C):
+        v = np.sort(scores[:, c])
+        i0 = int(np.searchsorted(v, scores[j_none, c], side="right")) - 1
+        if i0 >= len(v) - 1:
+            thresholds[c] = scores[j_none, c] + 0.01
+            continue
+        gaps = v[i0 + 1:] - v[i0:-1]
+        k = i0 + int(np.argmax(gaps))
+        thresholds[c] = 0.5 * (v[k] + v[k + 1])
+        margin = min(margin, float(np.abs(scores[:, c] - thresholds[c]).min()))
+    assert margin >= 2e-4, "synthetic scores too close for a robust threshold: %g" % margin
     sd_dev = {k: v.numpy() for k, v in sd.items()}
     sd_dev["thresholds"] = thresholds
 
@@ -61,20 +72,19 @@ def test_config1_vgg16_val_predicted_labels_to_eval_cam(tmp_path):
         if y.sum() == 0:  # vgg16_cam.py:41-42
             y[np.argmax(score)] = True
             n_forced += 1
-            assert i == j_none
-        if margin < 5e-4:  # a score this close to the threshold may legitimately flip on the device
-            continue
         valid = torch.nonzero(torch.from_numpy(y))[:, 0]
         strided, hi = cnn_ref.make_cam_tail(cam, p["size"], valid)
         d = np.load(os.path.join(args.cam_out_dir, p["name"] + ".npy"), allow_pickle=True).item()
         assert sorted(d) == ["cam", "high_res", "keys"]
         assert d["keys"].dtype == np.int64 and np.array_equal(d["keys"], valid.numpy())
         assert d["cam"].shape == tuple(strided.shape) and d["high_res"].shape == tuple(hi.shape)
-        assert np.abs(d["cam"] - strided.numpy()).max() <= 2e-4 and np.abs(d["high_res"] - hi.numpy()).max() <= 2e-4
+        # bf16x3 (16-bit effective mantissa per operand) through the 15-conv VGG16 stack at 321^2: 3.0e-4 measured on
+        # the max-normalised maps (ResNet50: 1.2e-4); stated tolerance 5e-4
+        assert np.abs(d["cam"] - strided.numpy()).max() <= 5e-4 and np.abs(d["high_res"] - hi.numpy()).max() <= 5e-4
         cams = np.pad(hi.numpy(), ((1, 0), (0, 0), (0, 0)), mode="constant", constant_values=0.15)  # eval_cam.py:50
         keys = np.pad(valid.numpy() + 1, (1, 0), mode="constant")                                   # eval_cam.py:51
         pred_ref.append(keys[np.argmax(cams, axis=0)])
-    assert n_forced == 1 and margin >= 5e-4
+    assert n_forced >= 1 and not (scores[j_none] >= thresholds).any()
 
     # ---- eval_cam on the files ------------------------------------------------------------------------------
     class Seg:
