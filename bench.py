@@ -16,6 +16,12 @@ in HBM (BASELINE config 2/3: ResNet50 CAM + dense-CRF, 321x321, batch 32 images 
 N > 1: one process per GPU (torch.distributed.run), every rank owns its own batch (the dataset is
 image-sharded, images[g::G]); no data-path collective, only the timing barrier.  scaling = weak.
 
+Besides the headline (`value`: inputs resident in HBM, f16 operands) the same JSON line carries, under `stages`
+(rank 0, N = 1; --quick skips them): `value_bf16x3` (the fp32-class precision mode), `value_M_eq_Kplus1` (SURVEY
+config 3's other variant: one CRF per group of images with the same K, M = K+1), `value_end_to_end` (pageable host
+batch -> pinned staging -> H2D, D2H of cam / high_res / labels, np.save through writer threads).
+--scaling strong: the K steps are a FIXED set of K*batch images sharded over the ranks (rank g runs ceil(K/N) steps).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -54,6 +60,12 @@ def parse():
                     help="CAM network (resnet50 is the BASELINE.json configuration; vgg16 / m7 are extra "
                          "measurements of the other conv stacks of the reference, 03b_irn/net/{vgg16,m7}.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="skip the extra stage measurements (bf16x3, M=K+1, end-to-end)")
+    ap.add_argument("--seconds", type=float, default=0.0,
+                    help="steady-state run: raise --steps so that the timed region lasts at least this long")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank runs --steps steps on its own batch; strong: --steps x --batch images in total, "
+                         "image-sharded over the ranks")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish each step before starting the next (default: the mean-field loop of step i "
                          "overlaps the conv stack + lattice build of step i+1 on separate streams)")
@@ -78,11 +90,10 @@ def crf_bytes_per_image(N, M, T, vg, vb):
 
 
 class Workload:
-    def __init__(self, device, batch, precision, workload, seed, arch="resnet50"):
+    def __init__(self, device, batch, precision, workload, seed, arch="resnet50", share=None):
         import numpy as np
 
-        from oracle import cnn_ref  # synthetic-input generator only (no compute of the product path)
-        from wsscam import _lib
+        from wsscam import _lib, synth
 
         global S, GFLOP_PER_IMAGE
         S = INPUT_SIZE_BY_ARCH[arch]
@@ -99,45 +110,37 @@ class Workload:
         self.ctx_crf = _lib.Context(device)
         self.pending = None  # lattices of the step whose mean-field loop is still in flight
         prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3}[precision]
+        # seeded random weights of the named architecture (no checkpoints offline), wsscam.synth
         if arch == "resnet50":
-            sd = {k: v.numpy() for k, v in cnn_ref.make_resnet50_cam_state_dict(NUM_CLASSES, seed=0).items()}
-            self.net = _lib.Net(self.ctx, _lib.ARCH_RESNET50_CAM, sd, NUM_CLASSES, prec)
+            self.sd = synth.resnet50_cam_state_dict(NUM_CLASSES, seed=0)
+            self.net = _lib.Net(self.ctx, _lib.ARCH_RESNET50_CAM, self.sd, NUM_CLASSES, prec)
         elif arch == "vgg16":
-            sd = {k: v.numpy() for k, v in cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, NUM_CLASSES, True,
-                                                                       seed=0).items()}
-            self.net = _lib.Net(self.ctx, _lib.ARCH_VGG16_CAM, sd, NUM_CLASSES, prec)
+            self.sd = synth.plain_state_dict("vgg16", NUM_CLASSES, True, seed=0)
+            self.net = _lib.Net(self.ctx, _lib.ARCH_VGG16_CAM, self.sd, NUM_CLASSES, prec)
         else:
-            sd = {k: v.numpy() for k, v in cnn_ref.make_plain_state_dict("m7", cnn_ref.M7_CFG, NUM_CLASSES, True,
-                                                                       seed=0).items()}
+            self.sd = synth.plain_state_dict("m7", NUM_CLASSES, True, seed=0)
             rngw = np.random.default_rng(5)
-            sd["gradcam_weights"] = rngw.normal(0, 0.05, (256, NUM_CLASSES)).astype(np.float32)
-            self.net = _lib.Net(self.ctx, _lib.ARCH_M7_CAM, sd, NUM_CLASSES, prec)
+            self.sd["gradcam_weights"] = rngw.normal(0, 0.05, (256, NUM_CLASSES)).astype(np.float32)
+            self.net = _lib.Net(self.ctx, _lib.ARCH_M7_CAM, self.sd, NUM_CLASSES, prec)
         self.arch = arch
         self.h = self.net.cam_size(S)
-        rng = np.random.default_rng(20121 + seed)
-        gold = np.load(os.path.join(ROOT, "tests", "golden", "resnet50_cam.npz"))
-        labels = gold["trainaug_labels"]
-        xs, rgbs, self.sizes, self.keys = [], [], [], []
-        for i in range(batch):
-            H0, W0 = cnn_ref.VOC_SIZES[(i + seed) % len(cnn_ref.VOC_SIZES)]
-            img = cnn_ref.synth_image(rng, H0, W0)
-            r = cnn_ref.resize_bilinear_f64(img, (S, S))
-            x = np.transpose(cnn_ref.normalize_int(r), (2, 0, 1))
-            xs.append(np.stack([x, np.flip(x, -1)], 0))
-            rgbs.append(np.clip(np.rint(r), 0, 255).astype(np.uint8))
-            self.sizes.append((H0, W0))
-            self.keys.append(np.nonzero(labels[(i + seed * batch) % len(labels)])[0].astype(np.int32))
-        self.x_host = np.ascontiguousarray(np.stack(xs), dtype=np.float32)
-        self.rgb_host = np.ascontiguousarray(np.stack(rgbs))
+        if share is not None:  # same images / labels as another workload (other precision)
+            self.x_host, self.rgb_host, self.sizes, self.keys = share.x_host, share.rgb_host, share.sizes, share.keys
+        else:
+            # real image-level labels (rows of the reference's voc12/cls_labels.npy in train_aug.txt order: the K
+            # distribution of the dataset), synthetic VOC-like images
+            labels = np.load(os.path.join(ROOT, "tests", "golden", "resnet50_cam.npz"))["trainaug_labels"]
+            self.x_host, self.rgb_host, self.sizes = synth.image_batch(batch, S, seed)
+            self.keys = [np.nonzero(labels[(i + seed * batch) % len(labels)])[0].astype(np.int32) for i in range(batch)]
         ctx = self.ctx
         self.x_dev = ctx.to_device(self.x_host)
         self.rgb_dev = ctx.to_device(self.rgb_host)
         self.cam_dev = ctx.alloc(batch * NUM_CLASSES * self.h * self.h * 4)
         # native-size make_cam outputs
-        s_tot = sum(len(k) * ((H - 1) // 4 + 1) * ((W - 1) // 4 + 1) for k, (H, W) in zip(self.keys, self.sizes))
-        h_tot = sum(len(k) * H * W for k, (H, W) in zip(self.keys, self.sizes))
-        self.strided_dev = ctx.alloc(max(s_tot, 1) * 4)
-        self.highres_dev = ctx.alloc(max(h_tot, 1) * 4)
+        self.s_tot = sum(len(k) * ((H - 1) // 4 + 1) * ((W - 1) // 4 + 1) for k, (H, W) in zip(self.keys, self.sizes))
+        self.h_tot = sum(len(k) * H * W for k, (H, W) in zip(self.keys, self.sizes))
+        self.strided_dev = ctx.alloc(max(self.s_tot, 1) * 4)
+        self.highres_dev = ctx.alloc(max(self.h_tot, 1) * 4)
         # CRF stack
         N = S * S
         # unaries / labels are double-buffered: step i+1 writes its unaries while step i's loop reads its own
@@ -146,14 +149,21 @@ class Workload:
         self.unary_dev, self.label_dev = self.unary_bufs[0], self.label_bufs[0]
         self.parity = 0
         self.vg = self.vb = None
+        self.e2e = None
+
+    def close(self):
+        self.drain()
+        for c in (self.ctx, self.ctx_build, self.ctx_crf):
+            c.sync()
+        self.net.close()
 
     # -- pieces ------------------------------------------------------------------------------
     def run_cnn(self):
         self.net.forward_cam(self.x_dev, self.B, S, self.cam_dev, None)
 
     def run_tail(self):
-        self._lib.cam_postprocess(self.ctx, self.cam_dev, self.B, NUM_CLASSES, self.h, self.h, self.sizes, self.keys,
-                                  self.strided_dev, self.highres_dev)
+        self.tail_meta = self._lib.cam_postprocess(self.ctx, self.cam_dev, self.B, NUM_CLASSES, self.h, self.h, self.sizes,
+                                                   self.keys, self.strided_dev, self.highres_dev)
 
     def run_unary(self):
         # upsample all 20 class maps to S x S, x /= max + 1e-5, [bg = 0.15 | maps] -> unaries: one fused call
@@ -217,6 +227,120 @@ class Workload:
         self.ctx.sync()  # the lattice memory goes back to the build ctx's cache only when inference is done
         crf.close()
 
+    # -- SURVEY config 3, second variant: M = K + 1 ---------------------------------------------------------
+    def setup_kplus1(self):
+        """Images grouped by K = number of positive classes; one CRF batch per group with M = K + 1 (background + the
+        image's own classes: what cam_to_ir_label / eval_cam work with, 03b_irn/step/cam_to_ir_label.py:27-41)."""
+        np = self.np
+        order = sorted(range(self.B), key=lambda b: len(self.keys[b]))
+        self.kp_rgb_dev = self.ctx.to_device(self.rgb_host[order])
+        self.kp_x_dev = self.ctx.to_device(self.x_host[order])
+        self.kp_keys = [self.keys[b] for b in order]
+        self.kp_groups = []
+        b0 = 0
+        while b0 < self.B:
+            K = len(self.kp_keys[b0])
+            b1 = b0
+            while b1 < self.B and len(self.kp_keys[b1]) == K:
+                b1 += 1
+            if K > 0:
+                self.kp_groups.append((b0, b1 - b0, K))
+            b0 = b1
+        N = S * S
+        self.kp_maps_dev = self.ctx.alloc(self.B * 6 * N * 4 + 4)
+        self.kp_strided_dev = self.ctx.alloc(self.B * 6 * ((S - 1) // 4 + 1) ** 2 * 4 + 4)
+        self.kp_unary_dev = self.ctx.alloc(self.B * 7 * N * 4)
+        self.kp_label_dev = self.ctx.alloc(self.B * N * 4)
+        assert max(len(k) for k in self.kp_keys) <= 6
+
+    def step_kplus1(self):
+        N = S * S
+        self.net.forward_cam(self.kp_x_dev, self.B, S, self.cam_dev, None)
+        for (b0, nb, K) in self.kp_groups:
+            cam_g = self.cam_dev.ptr + b0 * NUM_CLASSES * self.h * self.h * 4
+            crf = self._lib.Crf(self.ctx_build, self.kp_rgb_dev.ptr + b0 * N * 3, nb, S, S, CRF_CFG[0], CRF_CFG[2], CRF_CFG[3])
+            self._lib.cam_postprocess(self.ctx, cam_g, nb, NUM_CLASSES, self.h, self.h, [(S, S)] * nb, self.kp_keys[b0:b0 + nb],
+                                      self.kp_strided_dev, self.kp_maps_dev)
+            self._lib.unary_from_maps(self.ctx, self.kp_maps_dev, nb, K, N, 0.15, self.kp_unary_dev)
+            self.ctx.wait_for(self.ctx_build)
+            crf.inference(self.kp_unary_dev, K + 1, CRF_CFG[1], CRF_CFG[4], CRF_CFG[5], None,
+                          self.kp_label_dev.ptr + b0 * N * 4, ctx=self.ctx)
+            self.ctx.sync()
+            crf.close()
+
+    # -- end to end: host batch in, files out ---------------------------------------------------------------
+    def setup_e2e(self, out_dir, n_writers=8):
+        from concurrent.futures import ThreadPoolExecutor
+
+        np = self.np
+        self.e2e = {"dir": out_dir, "pool": ThreadPoolExecutor(n_writers), "futs": [[], []],
+                    "pin_in": [self.ctx.host_alloc(self.x_host.nbytes) for _ in range(2)],
+                    "pin_out": [self.ctx.host_alloc((max(self.s_tot, 1) + max(self.h_tot, 1)) * 4) for _ in range(2)],
+                    "pin_lab": [self.ctx_crf.host_alloc(self.B * S * S * 4) for _ in range(2)], "prev": None}
+        os.makedirs(out_dir, exist_ok=True)
+
+    def _e2e_save(self, p, b, s_off, h_off, shapes):
+        np = self.np
+        e = self.e2e
+        K, h4, w4, H0, W0 = shapes[b]
+        st = e["pin_out"][p].view((max(self.s_tot, 1),), np.float32)
+        hi = e["pin_out"][p].view((max(self.h_tot, 1),), np.float32, offset_bytes=max(self.s_tot, 1) * 4)
+        np.save(os.path.join(e["dir"], "img%03d.npy" % b),
+                {"keys": self.keys[b].astype(np.int64), "cam": st[s_off[b]:s_off[b] + K * h4 * w4].reshape(K, h4, w4),
+                 "high_res": hi[h_off[b]:h_off[b] + K * H0 * W0].reshape(K, H0, W0)})  # make_cam.py:80-82
+        lab = e["pin_lab"][p].view((self.B, S, S), np.int32)[b]
+        np.save(os.path.join(e["dir"], "img%03d_crf.npy" % b), lab.astype(np.uint8))
+
+    def _e2e_finish(self, prev):
+        """The step whose mean-field loop was still in flight: labels to the host, then the writer threads."""
+        p, s_off, h_off, shapes = prev
+        e = self.e2e
+        self.ctx_crf.d2h_async(e["pin_lab"][p], self.label_bufs[p], self.B * S * S * 4)
+        self.ctx_crf.sync()
+        self.pending.close()
+        self.pending = None
+        e["futs"][p] = [e["pool"].submit(self._e2e_save, p, b, s_off, h_off, shapes) for b in range(self.B)]
+
+    def step_e2e(self):
+        """step_pipelined() with the host boundary of the reference around it: a pageable float32 batch (what the
+        DataLoader hands over) is staged through page-locked memory and copied in; cam / high_res and the label maps
+        are copied out and written as .npy files by writer threads while the next step computes."""
+        np = self.np
+        e = self.e2e
+        self.parity ^= 1
+        p = self.parity
+        for f in e["futs"][p]:
+            f.result()  # the files of step i-2 are on disk: its staging buffers are free again
+        e["futs"][p] = []
+        np.copyto(e["pin_in"][p].view(self.x_host.shape, np.float32), self.x_host)
+        self.unary_dev, self.label_dev = self.unary_bufs[p], self.label_bufs[p]
+        self.ctx.h2d_async(self.x_dev, e["pin_in"][p], self.x_host.nbytes)
+        self.run_cnn()
+        crf = self.crf_create()
+        self.run_tail()
+        _, _, s_off, h_off, shapes = self.tail_meta
+        self.ctx.d2h_async(e["pin_out"][p], self.strided_dev, max(self.s_tot, 1) * 4)
+        self.ctx.d2h_async(e["pin_out"][p], self.highres_dev, max(self.h_tot, 1) * 4, dst_offset=max(self.s_tot, 1) * 4)
+        self.run_unary()
+        if e["prev"] is not None:
+            self._e2e_finish(e["prev"])
+        self.ctx_crf.wait_for(self.ctx)
+        self.ctx_crf.wait_for(self.ctx_build)
+        self.crf_infer(crf, ctx=self.ctx_crf)
+        self.pending = crf
+        e["prev"] = (p, s_off, h_off, shapes)
+
+    def drain_e2e(self):
+        e = self.e2e
+        if e["prev"] is not None:
+            self._e2e_finish(e["prev"])
+            e["prev"] = None
+        self.ctx.sync()
+        for fl in e["futs"]:
+            for f in fl:
+                f.result()
+        e["futs"] = [[], []]
+
     def timed(self, fn, reps):
         """Average device time of fn() over reps, HIP events on the ctx stream."""
         fn()  # untimed: the first call on this ctx may grow its workspace arena (a hipMalloc of a few GB)
@@ -228,16 +352,19 @@ class Workload:
 
 
 def cpu_baseline(wl, budget_s):
-    """Oracle on the host cores: torch-CPU fp32 restatement of make_cam._work (batch = 1 image, as the
-    reference runs it) + the single-threaded C dense-CRF restatement (pydensecrf is single-threaded).
-    kind = "port": the reference itself cannot travel to the GPU box."""
+    """Oracle on the host cores (the only place bench.py touches oracle/): torch-CPU fp32 restatement of
+    make_cam._work (batch = 1 image, as the reference runs it) + the C dense-CRF restatement, once single-threaded
+    (pydensecrf is single-threaded per image) and once over images in parallel (one image per thread: what an
+    OpenMP-over-images loop around the reference's per-image CRF gives).  kind = "port": the reference itself cannot
+    travel to the GPU box."""
     import numpy as np
     import torch
+    from concurrent.futures import ThreadPoolExecutor
 
     from oracle import cnn_ref
     from tests import helpers
 
-    sd = cnn_ref.make_resnet50_cam_state_dict(NUM_CLASSES, seed=0)
+    sd = {k: torch.from_numpy(v) for k, v in wl.sd.items()}  # the product run's own weights
     # pick the thread count the way a user of the reference would: the fastest of a few settings
     # (all cores of a many-core host is slower than 16-64 threads on these small batch-1 convolutions)
     ncpu = os.cpu_count() or 1
@@ -256,8 +383,7 @@ def cpu_baseline(wl, budget_s):
     torch.set_num_threads(cores)
     n_cam, t_cam = 0, 0.0
     cams = []
-    t_budget = budget_s * 0.5
-    while n_cam < wl.B and (n_cam < 2 or t_cam < t_budget):
+    while n_cam < wl.B and (n_cam < 2 or t_cam < budget_s * 0.4):
         x = torch.from_numpy(wl.x_host[n_cam])
         lab = torch.zeros(NUM_CLASSES)
         lab[torch.from_numpy(wl.keys[n_cam].astype(np.int64))] = 1
@@ -269,23 +395,33 @@ def cpu_baseline(wl, budget_s):
         t_cam += time.perf_counter() - t0
         cams.append(cam)
         n_cam += 1
-    n_crf, t_crf = 0, 0.0
-    if wl.workload == "cam_crf":
-        while n_crf < n_cam and (n_crf < 1 or t_crf < budget_s * 0.5):
-            t0 = time.perf_counter()
-            with torch.no_grad():
-                _, hi = cnn_ref.make_cam_tail(cams[n_crf], (S, S), torch.arange(NUM_CLASSES))
-            v = np.concatenate([np.full((1, S * S), 0.15, np.float32), hi.numpy().reshape(NUM_CLASSES, -1)], 0)
-            p = v / v.sum(0, keepdims=True)
-            U = -np.log(np.clip(p, 1e-5, 1.0)).astype(np.float32)
-            helpers.crf_oracle(wl.rgb_host[n_crf], U, CRF_CFG)
-            t_crf += time.perf_counter() - t0
-            n_crf += 1
-    per_img = t_cam / n_cam + (t_crf / n_crf if n_crf else 0.0)
-    return {"value": round(1.0 / per_img, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d images torch-CPU fp32 ResNet50-CAM+tail (%.2f s/img, %d threads) + %d images C dense-CRF "
-                      "M=21 T=10 (%.2f s/img, 1 thread)" % (n_cam, t_cam / n_cam, cores, n_crf,
-                                                            t_crf / n_crf if n_crf else 0.0)}
+    if wl.workload != "cam_crf":
+        return {"value": round(n_cam / t_cam, 4), "unit": "images/s", "cores": cores, "kind": "port",
+                "sample": "%d images torch-CPU fp32 ResNet50-CAM+tail (%.2f s/img, %d threads)" % (n_cam, t_cam / n_cam, cores)}
+
+    def unary_of(i):
+        with torch.no_grad():
+            _, hi = cnn_ref.make_cam_tail(cams[i % n_cam], (S, S), torch.arange(NUM_CLASSES))
+        v = np.concatenate([np.full((1, S * S), 0.15, np.float32), hi.numpy().reshape(NUM_CLASSES, -1)], 0)
+        return -np.log(np.clip(v / v.sum(0, keepdims=True), 1e-5, 1.0)).astype(np.float32)
+
+    t0 = time.perf_counter()
+    helpers.crf_oracle(wl.rgb_host[0], unary_of(0), CRF_CFG)
+    t_crf1 = time.perf_counter() - t0                                   # one image, one thread
+    threads = max(1, min(ncpu, 64))
+    n_par = max(threads, int(budget_s * 0.4 / max(t_crf1, 1e-3)) * threads)
+    n_par = min(n_par, 4 * threads)
+    us = [unary_of(i) for i in range(min(n_cam, 4))]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C oracle
+        list(ex.map(lambda i: helpers.crf_oracle(wl.rgb_host[i % wl.B], us[i % len(us)], CRF_CFG), range(n_par)))
+    crf_rate = n_par / (time.perf_counter() - t0)                       # images/s, `threads` images in flight
+    per_img = t_cam / n_cam + 1.0 / crf_rate
+    return {"value": round(1.0 / per_img, 4), "unit": "images/s", "cores": max(cores, threads), "kind": "port",
+            "value_crf_single_thread": round(1.0 / (t_cam / n_cam + t_crf1), 4),
+            "sample": "%d images torch-CPU fp32 ResNet50-CAM+tail (%.3f s/img, %d threads) + C dense-CRF M=21 T=10: %d images over "
+                      "%d threads, one image per thread (%.1f images/s; %.2f s/img on one thread)"
+                      % (n_cam, t_cam / n_cam, cores, n_par, threads, crf_rate, t_crf1)}
 
 
 def main():
@@ -316,27 +452,42 @@ def main():
 
     wl = Workload(device, args.batch, args.precision, args.workload, seed=rank, arch=args.arch)
 
-    def barrier():
-        wl.ctx.sync()
-        wl.ctx_build.sync()
-        wl.ctx_crf.sync()
+    def barrier(w):
+        w.ctx.sync()
+        w.ctx_build.sync()
+        w.ctx_crf.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
     pipelined = args.workload == "cam_crf" and not args.no_pipeline
+
+    def timed_run(w, do_step, steps, warmup, drain):
+        """W warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides -> seconds."""
+        for _ in range(warmup):
+            do_step()
+        drain()
+        barrier(w)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            do_step()
+        drain()
+        w.ctx.sync()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
     do_step = wl.step_pipelined if pipelined else wl.step
-    for _ in range(args.warmup):
-        do_step()
-    wl.drain()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        do_step()
-    wl.drain()
-    wl.ctx.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    steps = args.steps
+    if args.seconds > 0:  # steady state: size the timed region from a short probe (same K on every rank)
+        probe = timed_run(wl, do_step, 3, max(args.warmup, 1), wl.drain) / 3
+        steps = max(steps, int(args.seconds / probe) + 1)
+        if dist is not None:
+            t = torch.tensor([steps], dtype=torch.int64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            steps = int(t.item())
+    # strong scaling: the K steps are one fixed image set, sharded -- rank g owns ceil(K / N) of them
+    my_steps = (steps + world - 1) // world if args.scaling == "strong" else steps
+    elapsed = timed_run(wl, do_step, my_steps, args.warmup, wl.drain)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -389,9 +540,9 @@ def main():
     roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
     roofline["kernel"] = dom
     roofline["algorithmic_bytes_per_launch" if roofline["bound"] == "hbm" else "flop_per_launch"] = round(work / calls)
-    # HBM bytes per launch of that kernel class from the committed PMC passes (profiles/collect.sh ->
-    # profiles/hbm_traffic.json; FETCH_SIZE / WRITE_SIZE cannot be read from inside the process).  Only the
-    # default workload is profiled there; anything else reports null.
+    # HBM bytes per launch of that kernel class: NOT observed in this run -- FETCH_SIZE / WRITE_SIZE cannot be read from
+    # inside the process; the figure is the one committed under profiles/ from the PMC passes of the same command
+    # (profiles/collect.sh -> profiles/hbm_traffic.json).  Only the default workload is profiled there.
     tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
     default_wl = (args.workload == "cam_crf" and args.arch == "resnet50" and args.batch == 32 and args.precision == "f16")
     if default_wl and os.path.exists(tj):
@@ -399,23 +550,53 @@ def main():
             cls = json.load(fh).get("classes", {}).get(dom)
         if cls:
             roofline["traffic"] = cls["bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+            roofline["traffic_source"] = ("committed: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE "
+                                          "passes of this command, %s); not re-measured in this run" % cls.get("round", "r02"))
     roofline["avg_launch_us"] = round(ms / calls * 1e3, 2)
     roofline["launches_per_step"] = calls // 2
     stages["kernels"] = kernels
 
+    # ---- the other numbers SURVEY 8(d) asks for, same images (rank 0 of a 1-GPU run) ---------------------------
+    if world == 1 and args.workload == "cam_crf" and args.arch == "resnet50" and not args.quick:
+        k_extra = max(3, min(args.steps, 10))
+        if args.precision != "bf16x3":  # fp32-class mode: split-bf16 operands, three MFMA products per term
+            w3 = Workload(device, args.batch, "bf16x3", args.workload, seed=rank, arch=args.arch, share=wl)
+            t3 = timed_run(w3, w3.step_pipelined if pipelined else w3.step, k_extra, 2, w3.drain)
+            stages["value_bf16x3"] = round(args.batch * k_extra / t3, 3)
+            stages["cnn_ms_bf16x3"] = round(w3.timed(w3.run_cnn, 3), 4)
+            w3.close()
+            del w3
+        wl.setup_kplus1()
+        tk = timed_run(wl, wl.step_kplus1, k_extra, 2, lambda: None)
+        stages["value_M_eq_Kplus1"] = round(args.batch * k_extra / tk, 3)
+        stages["M_eq_Kplus1_groups"] = ["K=%d x %d images" % (K, nb) for (_, nb, K) in wl.kp_groups]
+        import shutil
+        import tempfile
+
+        tmp = tempfile.mkdtemp(prefix="wsc_bench_", dir=os.environ.get("WSC_BENCH_TMP", None))
+        try:
+            wl.setup_e2e(tmp)
+            te = timed_run(wl, wl.step_e2e, k_extra, 2, wl.drain_e2e)
+            stages["value_end_to_end"] = round(args.batch * k_extra / te, 3)
+            stages["end_to_end"] = ("per step: 79 MB pageable float32 batch -> pinned -> H2D; D2H of cam + high_res (%.1f MB) and "
+                                    "label maps (%.1f MB); %d .npy files through 8 writer threads; overlapped with the next step"
+                                    % ((wl.s_tot + wl.h_tot) * 4 / 1e6, args.batch * S * S * 4 / 1e6, 2 * args.batch))
+            wl.e2e["pool"].shutdown(wait=True)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
     if rank == 0:
-        images = args.batch * args.steps * world
+        images = args.batch * (steps if args.scaling == "strong" else steps * world)
         out = {
             "metric": "images/sec CAM+CRF pseudo-labels, VOC2012 321x321",
             "value": round(images / elapsed, 3),
             "unit": "images/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(elapsed / my_steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
@@ -426,6 +607,7 @@ def main():
                        "%s CAM (make_cam), %dx%d, batch %d images per GPU" % (args.arch, S, S, args.batch),
                        "batch_images": args.batch, "num_classes": NUM_CLASSES, "crf_config": list(CRF_CFG),
                        "parallelism": "image-sharded x%d, no collective" % world,
+                       "steps_per_rank": my_steps,
                        "step_overlap": "mean-field loop of step i overlaps conv stack + lattice build of step i+1 "
                                        "(3 HIP streams)" if pipelined else "none"},
             "roofline": roofline,

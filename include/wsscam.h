@@ -102,6 +102,13 @@ int wsc_free(wsc_ctx *ctx, void *dptr);
 int wsc_memcpy_h2d(wsc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes); /* async on ctx stream */
 int wsc_memcpy_d2h(wsc_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* synchronises */
 int wsc_memset(wsc_ctx *ctx, void *dst_dev, int value, size_t bytes);
+/* Page-locked host staging for the batch pipeline (replaces DataLoader(pin_memory=...) + .cuda(non_blocking=True),
+ * make_cam.py:29,45-48, and the .cpu() copies of :81-85): copies between pinned memory and the device are truly
+ * asynchronous on the ctx stream; the host buffer must stay untouched until a later wsc_sync(ctx) returns. */
+int wsc_host_alloc(wsc_ctx *ctx, size_t bytes, void **host_out);
+int wsc_host_free(wsc_ctx *ctx, void *host);
+int wsc_memcpy_h2d_async(wsc_ctx *ctx, void *dst_dev, const void *src_pinned_host, size_t bytes);
+int wsc_memcpy_d2h_async(wsc_ctx *ctx, void *dst_pinned_host, const void *src_dev, size_t bytes);
 
 /* timing on the ctx stream with HIP events (bench.py's roofline leg):
  * wsc_timer_begin/_end bracket a region; _end synchronises and returns ms. */

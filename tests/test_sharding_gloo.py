@@ -54,6 +54,7 @@ def _rank_main(rank, world, port, out_dir, n_items):
             dataset = "voc12"
             cam_out_dir = out_dir
             cam_batch_images = 4
+            cam_pipeline = False  # the overlapped host pipeline needs a device; the shard bookkeeping is the same
 
         seen = []
 

@@ -118,8 +118,8 @@ WscKernelTimer::~WscKernelTimer() {
 
 static const char *kClassNames[WSC_K_COUNT] = {
     "conv_igemm_kernel<256-row tiles,glds>", "conv_igemm_kernel<128x128,glds>", "conv_igemm_kernel<128x64,glds>", "conv_igemm_kernel<small-Cin>",
-    "pool/layout/flip-add", "cam_tail+unary", "crf_build(all)", "splat4+combine", "blur4+blur3_tile",
-    "slice_update_kernel", "crf init/finish"};
+    "pool/layout/flip-add", "cam_tail+unary", "crf_build(all)", "(unused)", "combine4+blur4+blur3_tile",
+    "update_splat_kernel", "crf init/finish"};
 
 extern "C" {
 
@@ -227,6 +227,7 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
 
 int wsc_sync(wsc_ctx *ctx) {
     WSC_CHECK(ctx, WSC_ERR_INVALID, "wsc_sync: null ctx");
+    WSC_HIP(hipSetDevice(ctx->device)); // may be called from a helper thread whose current device is still 0
     WSC_HIP(hipStreamSynchronize(ctx->stream));
     return WSC_OK;
 }
@@ -289,6 +290,39 @@ int wsc_memset(wsc_ctx *ctx, void *dst_dev, int value, size_t bytes) {
     WSC_CHECK(ctx && (bytes == 0 || dst_dev), WSC_ERR_INVALID, "wsc_memset: null argument");
     if (bytes == 0) return WSC_OK;
     WSC_HIP(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    return WSC_OK;
+}
+
+int wsc_host_alloc(wsc_ctx *ctx, size_t bytes, void **host_out) {
+    WSC_CHECK(ctx && host_out, WSC_ERR_INVALID, "wsc_host_alloc: null argument");
+    WSC_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(host_out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        wsc_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return WSC_ERR_NOMEM;
+    }
+    return WSC_OK;
+}
+
+int wsc_host_free(wsc_ctx *ctx, void *host) {
+    WSC_CHECK(ctx, WSC_ERR_INVALID, "wsc_host_free: null ctx");
+    if (!host) return WSC_OK;
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    WSC_HIP(hipHostFree(host));
+    return WSC_OK;
+}
+
+int wsc_memcpy_h2d_async(wsc_ctx *ctx, void *dst_dev, const void *src_pinned_host, size_t bytes) {
+    WSC_CHECK(ctx && (bytes == 0 || (dst_dev && src_pinned_host)), WSC_ERR_INVALID, "wsc_memcpy_h2d_async: null argument");
+    if (bytes == 0) return WSC_OK;
+    WSC_HIP(hipMemcpyAsync(dst_dev, src_pinned_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return WSC_OK;
+}
+
+int wsc_memcpy_d2h_async(wsc_ctx *ctx, void *dst_pinned_host, const void *src_dev, size_t bytes) {
+    WSC_CHECK(ctx && (bytes == 0 || (dst_pinned_host && src_dev)), WSC_ERR_INVALID, "wsc_memcpy_d2h_async: null argument");
+    if (bytes == 0) return WSC_OK;
+    WSC_HIP(hipMemcpyAsync(dst_pinned_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return WSC_OK;
 }
 

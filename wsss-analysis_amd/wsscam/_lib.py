@@ -71,6 +71,10 @@ _SIGNATURES = {
     "wsc_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "wsc_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "wsc_memset": (_i, [_vp, _vp, _i, _sz]),
+    "wsc_host_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "wsc_host_free": (_i, [_vp, _vp]),
+    "wsc_memcpy_h2d_async": (_i, [_vp, _vp, _vp, _sz]),
+    "wsc_memcpy_d2h_async": (_i, [_vp, _vp, _vp, _sz]),
     "wsc_profile_begin": (_i, [_vp]),
     "wsc_profile_end": (_i, [_vp, _i, _vp, _vp, _vp, ctypes.POINTER(_i)]),
     "wsc_profile_class_name": (ctypes.c_char_p, [_i]),
@@ -207,6 +211,16 @@ class Context:
         check(self._lib.wsc_memcpy_d2h(self.h, out.ctypes.data, _ptr(buf) + offset_bytes, out.nbytes))
         return out
 
+    def host_alloc(self, nbytes):
+        """Page-locked host buffer (wsc_host_alloc) for asynchronous copies."""
+        return PinnedBuffer(self, int(nbytes))
+
+    def h2d_async(self, dst_dev, pinned, nbytes, dst_offset=0, src_offset=0):
+        check(self._lib.wsc_memcpy_h2d_async(self.h, _ptr(dst_dev) + dst_offset, pinned.ptr + src_offset, int(nbytes)))
+
+    def d2h_async(self, pinned, src_dev, nbytes, dst_offset=0, src_offset=0):
+        check(self._lib.wsc_memcpy_d2h_async(self.h, pinned.ptr + dst_offset, _ptr(src_dev) + src_offset, int(nbytes)))
+
     def profile_begin(self):
         check(self._lib.wsc_profile_begin(self.h))
 
@@ -243,6 +257,34 @@ class DeviceBuffer:
     def free(self):
         if getattr(self, "ptr", None) and self.ctx.h:
             self.ctx._lib.wsc_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PinnedBuffer:
+    """hipHostMalloc'ed bytes; `.view(shape, dtype, offset)` is a numpy array over them (no copy)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = nbytes
+        p = _vp()
+        check(ctx._lib.wsc_host_alloc(ctx.h, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+        self._raw = (ctypes.c_char * max(nbytes, 1)).from_address(self.ptr)
+
+    def view(self, shape, dtype, offset_bytes=0):
+        n = int(np.prod(shape)) if len(shape) else 1
+        return np.frombuffer(self._raw, dtype=dtype, count=n, offset=offset_bytes).reshape(shape)
+
+    def free(self):
+        if getattr(self, "ptr", None) and self.ctx.h:
+            self._raw = None
+            self.ctx._lib.wsc_host_free(self.ctx.h, self.ptr)
         self.ptr = None
 
     def __del__(self):
@@ -308,8 +350,10 @@ class Net:
         check(self.ctx._lib.wsc_net_feat_channels(self.h, ctypes.byref(n)))
         return n.value
 
-    def forward_cam(self, x_dev, B, S, cam_dev, score_dev=None):
-        check(self.ctx._lib.wsc_net_forward_cam(self.ctx.h, self.h, _ptr(x_dev), B, S, _ptr(cam_dev),
+    def forward_cam(self, x_dev, B, S, cam_dev, score_dev=None, ctx=None):
+        """ctx: the context (stream, activation arena) to run on; the packed weights are read-only and shared."""
+        run = ctx or self.ctx
+        check(self.ctx._lib.wsc_net_forward_cam(run.h, self.h, _ptr(x_dev), B, S, _ptr(cam_dev),
                                                 _ptr(score_dev)))
 
     def forward_gradcam(self, x_dev, N, S, relu, cams_dev, score_dev=None):

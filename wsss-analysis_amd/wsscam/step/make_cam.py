@@ -98,14 +98,43 @@ def process_batch(model, packs, args, save=True):
 def _work(process_id, model, dataset, args):
     """Per-GPU worker (make_cam.py:25-93): shard `process_id` of the dataset on device `process_id`."""
     databin = dataset[process_id]
-    model.cuda(process_id)
+    # device of this worker: process_id as in the reference (cuda.device(process_id), make_cam.py:31); `cam_device_ids`
+    # remaps it (e.g. two workers on one GPU)
+    ids = getattr(args, "cam_device_ids", None)
+    device = int(ids[process_id]) if ids is not None else process_id
+    model.cuda(device)
     bs = int(getattr(args, "cam_batch_images", 32))
     n = len(databin)
-    for i0 in range(0, n, bs):
-        packs = [databin[i] for i in range(i0, min(i0 + bs, n))]
-        # images in one batch must share the network input size (outsize is fixed per run)
-        process_batch(model, packs, args, save=True)
-    model.ctx.sync()
+    if n == 0:
+        return
+    adp = args.dataset in ("adp_morph", "adp_func")
+    if adp or not getattr(args, "cam_pipeline", True):
+        # ADP: the background / 'other' channels are synthesised on the host between the CAM head and the tail
+        # (common_cam.py:31-92), so the batches run one after the other
+        for i0 in range(0, n, bs):
+            packs = [databin[i] for i in range(i0, min(i0 + bs, n))]
+            process_batch(model, packs, args, save=True)
+        model.ctx.sync()
+        return
+    from .pipeline import CamPipeline
+
+    first = databin[0]
+    S = int(np.asarray(first["img"]).shape[-1])
+    if np.asarray(first["img"]).shape != (2, 3, S, S):
+        raise ValueError("make_cam: network inputs must be (2, 3, S, S) with one square size per run; got %s"
+                         % (np.asarray(first["img"]).shape,))
+    has_cls = model.arch != _lib.ARCH_RESNET50_CAM
+    needs_score = "train" not in args.split
+    if needs_score and not has_cls:
+        raise ValueError("split %r needs predicted labels but %s has no classifier branch" % (args.split, type(model).__name__))
+    pipe = CamPipeline(model, device, bs, S, keys_fn=lambda pack, score: _valid_cat(args, pack, score, model),
+                       save_fn=lambda name, keys, sc, hc: _save(args, name, keys, sc, hc), needs_score=needs_score,
+                       n_lanes=int(getattr(args, "cam_pipeline_lanes", 3)), n_loaders=int(getattr(args, "cam_loader_threads", 8)),
+                       n_writers=int(getattr(args, "cam_writer_threads", 8)))
+    try:
+        pipe.run(databin)
+    finally:
+        pipe.close()
 
 
 def _device_count():

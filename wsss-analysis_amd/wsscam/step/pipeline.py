@@ -1,0 +1,145 @@
+"""Host pipeline of the make_cam worker (03b_irn/step/make_cam.py:25-93 is a serial loop: DataLoader item ->
+.cuda() -> model -> two interpolates -> .cpu() x3 -> np.save, one image at a time).
+
+Here a worker keeps the GPU fed from several directions at once:
+  loader threads   dataset[i] (decode, resize, normalise) written straight into a lane's page-locked input buffer
+  lanes            n_lanes x (wsc_ctx = one HIP stream, pinned input + output staging, device buffers): batch i runs on
+                   lane i % n_lanes -- pinned H2D, conv stack, CAM head, make_cam tail, pinned D2H, all asynchronous
+  finisher threads wait for a lane's stream (wsc_sync releases the GIL), then hand the images to the
+  writer threads   np.save of the pickled {"keys", "cam", "high_res"} dicts (the reference's format, unchanged)
+Per-image outputs stay idempotent: a rerun rewrites the same files.  No collective, no shared state between GPUs.
+"""
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from .. import _lib
+
+
+class _Lane:
+    def __init__(self, device, B, S, C, h):
+        self.ctx = _lib.Context(device)
+        self.B, self.S, self.C, self.h = B, S, C, h
+        self.in_bytes = B * 2 * 3 * S * S * 4
+        self.pin_in = self.ctx.host_alloc(self.in_bytes)
+        self.x_view = self.pin_in.view((B, 2, 3, S, S), np.float32)
+        self.x_dev = self.ctx.alloc(self.in_bytes)
+        self.cam_dev = self.ctx.alloc(B * C * h * h * 4)
+        self.score_dev = self.ctx.alloc(B * C * 4)
+        self.pin_score = self.ctx.host_alloc(B * C * 4)
+        self.out_cap = 0
+        self.pin_out = None
+        self.s_dev = self.h_dev = None
+        self.free = threading.Event()
+        self.free.set()
+
+    def ensure_out(self, s_tot, h_tot):
+        need = (max(s_tot, 1) + max(h_tot, 1)) * 4
+        if need > self.out_cap:
+            cap = int(need * 1.5) + (1 << 20)
+            for b in (self.pin_out, self.s_dev, self.h_dev):
+                if b is not None:
+                    b.free()
+            self.pin_out = self.ctx.host_alloc(cap)
+            self.s_dev = self.ctx.alloc(cap)
+            self.h_dev = self.ctx.alloc(cap)
+            self.out_cap = cap
+
+    def close(self):
+        self.ctx.sync()
+        for b in (self.pin_in, self.pin_out, self.pin_score, self.x_dev, self.cam_dev, self.score_dev, self.s_dev, self.h_dev):
+            if b is not None:
+                b.free()
+        self.ctx.close()
+
+
+class CamPipeline:
+    """Batched, overlapped make_cam worker for one GPU.  `keys_fn(pack, score_row_or_None) -> int64 keys`,
+    `save_fn(name, keys, strided, highres)` are the driver's own (make_cam._valid_cat / _save)."""
+
+    def __init__(self, model, device, batch_images, S, keys_fn, save_fn, needs_score, n_lanes=3, n_loaders=8, n_writers=8):
+        self.model, self.device, self.B, self.S = model, device, batch_images, S
+        self.keys_fn, self.save_fn, self.needs_score = keys_fn, save_fn, needs_score
+        self.C = model.num_classes
+        self.h = model.cam_size(S)
+        self.lanes = [_Lane(device, batch_images, S, self.C, self.h) for _ in range(n_lanes)]
+        self.loaders = ThreadPoolExecutor(n_loaders, thread_name_prefix="wsc-load")
+        self.writers = ThreadPoolExecutor(n_writers, thread_name_prefix="wsc-save")
+        self.finishers = ThreadPoolExecutor(n_lanes, thread_name_prefix="wsc-finish")
+        self.errors = []
+        self.images_done = 0
+
+    # -- stages --------------------------------------------------------------------------------------------
+    def _load_into(self, lane, k, dataset, idx):
+        pack = dataset[idx]
+        img = np.asarray(pack["img"], dtype=np.float32)
+        if img.shape != lane.x_view.shape[1:]:
+            raise ValueError("make_cam: network inputs must be (2, 3, %d, %d) for every image of a run; %s has %s"
+                             % (self.S, self.S, pack.get("name"), img.shape))
+        lane.x_view[k] = img  # page-locked: the H2D below is a straight DMA
+        return {key: v for key, v in pack.items() if key != "img"}
+
+    def _finish(self, lane, metas, keys, shapes, s_off, h_off, s_tot):
+        try:
+            lane.ctx.sync()  # this lane's stream only; the other lanes keep running
+            strided = lane.pin_out.view((max(s_tot, 1),), np.float32)
+            highres = lane.pin_out.view((lane.out_cap // 4 - max(s_tot, 1),), np.float32, offset_bytes=max(s_tot, 1) * 4)
+            futs = []
+            for b, meta in enumerate(metas):
+                K, h4, w4, H0, W0 = shapes[b]
+                sc = strided[s_off[b]:s_off[b] + K * h4 * w4].reshape(K, h4, w4)
+                hc = highres[h_off[b]:h_off[b] + K * H0 * W0].reshape(K, H0, W0)
+                futs.append(self.writers.submit(self.save_fn, meta["name"], keys[b], sc, hc))
+            for f in futs:
+                f.result()
+            self.images_done += len(metas)
+        except Exception as e:  # surfaced by run()
+            self.errors.append(e)
+        finally:
+            lane.free.set()
+
+    def _start(self, lane, dataset, indices):
+        n = len(indices)
+        metas = [f.result() for f in [self.loaders.submit(self._load_into, lane, k, dataset, i) for k, i in enumerate(indices)]]
+        ctx = lane.ctx
+        ctx.h2d_async(lane.x_dev, lane.pin_in, n * 2 * 3 * self.S * self.S * 4)
+        self.model._ensure_net().forward_cam(lane.x_dev, n, self.S, lane.cam_dev, lane.score_dev if self.needs_score else None,
+                                             ctx=ctx)
+        score = None
+        if self.needs_score:  # predicted labels decide which maps are produced: one small read-back
+            ctx.d2h_async(lane.pin_score, lane.score_dev, n * self.C * 4)
+            ctx.sync()
+            score = lane.pin_score.view((n, self.C), np.float32).copy()
+        keys = [self.keys_fn(m, None if score is None else score[b]) for b, m in enumerate(metas)]
+        sizes = [tuple(int(v) for v in m["size"]) for m in metas]
+        s_tot = sum(len(k) * ((H - 1) // 4 + 1) * ((W - 1) // 4 + 1) for k, (H, W) in zip(keys, sizes))
+        h_tot = sum(len(k) * H * W for k, (H, W) in zip(keys, sizes))
+        lane.ensure_out(s_tot, h_tot)
+        _, _, s_off, h_off, shapes = _lib.cam_postprocess(ctx, lane.cam_dev, n, self.C, self.h, self.h, sizes, keys,
+                                                          lane.s_dev, lane.h_dev)
+        ctx.d2h_async(lane.pin_out, lane.s_dev, max(s_tot, 1) * 4)
+        ctx.d2h_async(lane.pin_out, lane.h_dev, max(h_tot, 1) * 4, dst_offset=max(s_tot, 1) * 4)
+        lane.free.clear()
+        self.finishers.submit(self._finish, lane, metas, keys, shapes, s_off, h_off, s_tot)
+
+    # -- driver --------------------------------------------------------------------------------------------
+    def run(self, dataset, indices=None):
+        idx = list(range(len(dataset))) if indices is None else list(indices)
+        for bi, i0 in enumerate(range(0, len(idx), self.B)):
+            lane = self.lanes[bi % len(self.lanes)]
+            lane.free.wait()
+            if self.errors:
+                break
+            self._start(lane, dataset, idx[i0:i0 + self.B])
+        for lane in self.lanes:
+            lane.free.wait()
+        if self.errors:
+            raise self.errors[0]
+
+    def close(self):
+        for ex in (self.loaders, self.writers, self.finishers):
+            ex.shutdown(wait=True)
+        for lane in self.lanes:
+            lane.close()
