@@ -260,6 +260,39 @@ int wsc_cam_unary(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w
 int wsc_bilinear_resize(wsc_ctx *ctx, const float *src_dev, int C, int h, int w, float *dst_dev, int H,
                         int W);
 
+/* ---- HistoSegNet post-processing (03c_hsn/utilities.py:231-397), device resident ---------- */
+
+/* HSN grad_cam after the einsum (utilities.py:262-277), for the NHWC maps of wsc_net_forward_gradcam(relu = 0):
+ *   per (image, class) cv2.resize(map, (S, S)) (bilinear) then max(., 0); cams /= max(max_{h,w,c} cams, 1e-7) per
+ *   image; cams *= gate[b][c]  (gate = conf_scores * is_pass_threshold).
+ *   cams_nhwc_dev float32 [B][h][w][C];  gate_dev float32 [B][C];  out_dev float32 [B][C][S*S]  (class-major). */
+int wsc_hsn_gradcam_post(wsc_ctx *ctx, const float *cams_nhwc_dev, int B, int h, int w, int C, int S,
+                         const float *gate_dev, float *out_dev);
+/* modify_by_htt's background activation (utilities.py:341-347; twins 02_cues/adp_cues.py:279-285,
+ * 03b_irn/net/common_cam.py:36-44): 0.75 * expit(4 * (mean_rgb - 240)) smoothed by scipy.ndimage.gaussian_filter(
+ * sigma = 2) (truncate 4 sigma, mode 'reflect', axis 0 then axis 1), then cv2.resize (bilinear) to Ho x Wo when the
+ * CAM grid differs from the image (:345-347).
+ *   rgb_dev uint8 [B][H][W][3];  bg_dev FLOAT64 [B][Ho*Wo] (on tissue the activation is far below the fp32 range and
+ *   still decides whether the Background class has mass). */
+int wsc_hsn_background(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, int Ho, int Wo, double *bg_dev);
+/* The valid-class stack of one HTT type, modify_by_htt (utilities.py:348-363) and get_cs_gradcam (:367-397) in one pass:
+ *   Y[v] = H[src_of_valid[v]] (0 where src_of_valid[v] < 0);  Y[bg_ind] = bg - max_{v in exceptions} Y[v];
+ *   functional types (other_ind >= 0): Y[other_ind] = max(0.05 * (1 - max_v Y[v]), max_k H[adipose_src[k]]);
+ *   cs[v] = (top1 - top2)(Y) where argmax(Y) == v else 0;  cs[other_ind] = Y[other_ind];
+ *   mass[b][v] = 1 if cs[b][v] has a positive entry (dcrf_process keeps the classes whose sum is > 0, :425; every
+ *   entry of cs is >= 0).
+ *   bg_dev == NULL skips the modify_by_htt step (get_cs_gradcam alone on an already modified stack).
+ *   H_dev float32 [B][C_all][N] (wsc_hsn_gradcam_post);  bg_dev float64 [B][N];  cs_dev, y_dev (may be NULL) [B][Cv][N];
+ *   mass_dev uint32 [B][Cv];  Cv <= 32, at most 4 exception / adipose classes. */
+int wsc_hsn_cs_gradcam(wsc_ctx *ctx, const float *H_dev, int B, int C_all, int N, const double *bg_dev,
+                       const int32_t *src_of_valid_host, int Cv, int bg_ind, int other_ind,
+                       const int32_t *exception_inds_host, int n_exc, const int32_t *adipose_src_host, int n_adip,
+                       float *cs_dev, float *y_dev, uint32_t *mass_dev);
+/* unary_from_softmax of a gathered channel list (utilities.py:431): unary[i][p] = -log(clip(maps[chan_off[i] + p],
+ * 1e-5, 1)), i < n_chan; chan_off_host = float offsets of the channels inside maps_dev. */
+int wsc_hsn_gather_unary(wsc_ctx *ctx, const float *maps_dev, const int64_t *chan_off_host, int n_chan, int N,
+                         float *unary_dev);
+
 /* ---- dense CRF (pydensecrf replacement) -------------------------------- */
 
 /* DenseCRF2D(W,H,M) + addPairwiseGaussian(sxy=g_sxy) + addPairwiseBilateral(

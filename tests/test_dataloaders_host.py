@@ -113,3 +113,64 @@ def test_label_table_lookup_order(tmp_path, monkeypatch):
     monkeypatch.setenv("WSSCAM_CLS_LABELS_ROOT", str(root))
     assert find_cls_labels(os.path.join("voc12", "t.npy")) == str(root / "voc12" / "t.npy")
     assert find_cls_labels(os.path.join("voc12", "t.npy"), "/explicit/path.npy") == "/explicit/path.npy"
+
+
+def _cv2_inter_linear_ref(img, out_hw):
+    """INDEPENDENT statement of cv2.resize(..., interpolation=INTER_LINEAR) on float images, scalar loops, straight from
+    OpenCV's documented coordinate rule (imgproc resize, `fx = (dx + 0.5) * scale_x - 0.5; sx = floor(fx); fx -= sx;
+    sx < 0 -> (sx, fx) = (0, 0); sx >= W - 1 -> (sx, fx) = (W - 1, 0)`; same for y): out = sum of the four taps."""
+    H, W = img.shape[:2]
+    oh, ow = out_hw
+    out = np.zeros((oh, ow) + img.shape[2:], np.float64)
+    sy_, sx_ = H / oh, W / ow
+    for dy in range(oh):
+        fy = (dy + 0.5) * sy_ - 0.5
+        y0 = int(np.floor(fy))
+        fy -= y0
+        if y0 < 0:
+            y0, fy = 0, 0.0
+        if y0 >= H - 1:
+            y0, fy = H - 1, 0.0
+        y1 = min(y0 + 1, H - 1)
+        for dx in range(ow):
+            fx = (dx + 0.5) * sx_ - 0.5
+            x0 = int(np.floor(fx))
+            fx -= x0
+            if x0 < 0:
+                x0, fx = 0, 0.0
+            if x0 >= W - 1:
+                x0, fx = W - 1, 0.0
+            x1 = min(x0 + 1, W - 1)
+            out[dy, dx] = ((1 - fy) * (1 - fx) * img[y0, x0] + (1 - fy) * fx * img[y0, x1] +
+                           fy * (1 - fx) * img[y1, x0] + fy * fx * img[y1, x1])
+    return out
+
+
+def test_resize_bilinear_f64_against_cv2_rule():
+    """TorchvisionResize (03b_irn/voc12/dataloader.py:68-78: float64 cv2.resize, bilinear) -- cv2 itself is absent
+    offline, so the vectorised resize of the dataloaders is checked against an independent scalar statement of OpenCV's
+    INTER_LINEAR rule (up- and down-scaling, non-square, 1-pixel sides), plus closed forms: a linear ramp stays the
+    same ramp away from the clamped border, an impulse spreads with the documented hat weights, constants are kept."""
+    rng = np.random.default_rng(8)
+    for (H, W), out in (((7, 5), (11, 13)), ((20, 31), (9, 8)), ((1, 6), (4, 4)), ((6, 1), (3, 7)), ((12, 12), (12, 12)),
+                        ((37, 50), (64, 64))):
+        img = rng.normal(size=(H, W, 3)) * 50 + 100
+        got = voc_dl.resize_bilinear_f64(img, out)
+        ref = _cv2_inter_linear_ref(img, out)
+        assert got.shape == ref.shape and got.dtype == np.float64
+        assert np.abs(got - ref).max() <= 1e-10, ((H, W), out, np.abs(got - ref).max())
+    # ramp: f(x) = a x + b sampled at the half-pixel source coordinate, exact where no clamping happens
+    W, ow = 40, 100
+    ramp = (3.0 * np.arange(W) + 2.0)[None, :, None].repeat(4, 0)
+    r = voc_dl.resize_bilinear_f64(ramp, (4, ow))[0, :, 0]
+    src = (np.arange(ow) + 0.5) * W / ow - 0.5
+    inner = (src >= 0) & (src <= W - 1)
+    assert np.abs(r[inner] - (3.0 * src[inner] + 2.0)).max() <= 1e-10
+    assert r[0] == ramp[0, 0, 0] and r[-1] == ramp[0, -1, 0]  # clamped ends
+    # impulse at column 5 of 16, upscaled x2: hat weights max(0, 1 - |src - 5|)
+    imp = np.zeros((1, 16, 1))
+    imp[0, 5, 0] = 1.0
+    r = voc_dl.resize_bilinear_f64(imp, (1, 32))[0, :, 0]
+    src = (np.arange(32) + 0.5) / 2 - 0.5
+    assert np.abs(r - np.maximum(0, 1 - np.abs(src - 5))).max() <= 1e-12
+    assert np.all(voc_dl.resize_bilinear_f64(np.full((9, 7, 3), 4.25), (15, 3)) == 4.25)

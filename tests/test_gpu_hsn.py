@@ -1,0 +1,111 @@
+"""GPU: the device HistoSegNet chain (csrc/hsn.hip: wsc_hsn_gradcam_post / _background / _cs_gradcam / _gather_unary)
+against the numpy / scipy restatement of 03c_hsn/utilities.py:231-445 in oracle/hsn_ref.py.  fp32 on the device,
+float64 in the oracle: stated tolerance 1e-5 absolute on maps that are O(1) (fp32 source coordinates and bilinear weights:
+4e-6 measured at 40 -> 321), 2e-6 for the element-wise stages."""
+import numpy as np
+import pytest
+
+from oracle import hsn_ref
+from wsscam import _lib
+from wsscam.hsn import demo as hsn_demo
+from wsscam.hsn import utilities as hsn
+
+pytestmark = pytest.mark.gpu
+
+
+def _adp_like(rng, H, W):
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = np.full((H, W, 3), 235.0, np.float32) + rng.normal(0, 6, (H, W, 3))
+    for _ in range(5):
+        cy, cx, r = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(0.1, 0.3) * min(H, W)
+        a = 1 / (1 + np.exp(np.minimum((((yy - cy) ** 2 + (xx - cx) ** 2) / r ** 2 - 1) * 5, 50)))
+        img = img * (1 - a[..., None]) + rng.uniform([150, 60, 120], [230, 140, 200]) * a[..., None]
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_hsn_gradcam_post_vs_oracle(ctx):
+    rng = np.random.default_rng(1)
+    for (B, h, C, S) in ((3, 10, 7, 33), (2, 40, 31, 321), (1, 1, 2, 5)):
+        cams = rng.normal(0.1, 1.0, (B, h, h, C)).astype(np.float32)
+        cams[0, :, :, 0] = -1.0  # a class that is negative everywhere: zero after max(., 0)
+        scores = rng.uniform(0, 1, (B, C))
+        is_pass = scores >= 0.4
+        out_dev = ctx.alloc(B * C * S * S * 4)
+        _lib.hsn_gradcam_post(ctx, ctx.to_device(cams), B, h, h, C, S, ctx.to_device((scores * is_pass).astype(np.float32)), out_dev)
+        got = ctx.to_host(out_dev, (B, C, S, S), np.float32)
+        ref = np.transpose(hsn_ref.grad_cam_post(cams, scores, is_pass, (S, S)), (0, 3, 1, 2))
+        assert np.abs(got - ref).max() <= 1e-5, (B, h, C, S, np.abs(got - ref).max())
+    # the numpy-signature mirror goes through the same kernels (needs a network: covered by test_hsn_segment_adp_driver)
+
+
+def test_hsn_background_vs_scipy(ctx):
+    import scipy.ndimage
+    import scipy.special
+
+    rng = np.random.default_rng(2)
+    for (B, H, W) in ((2, 64, 48), (1, 321, 321), (1, 5, 3), (1, 1, 20)):
+        rgb = np.stack([_adp_like(rng, H, W) for _ in range(B)])
+        rgb[0, : H // 2, : W // 2] = 250  # a white (background) region
+        bg_dev = ctx.alloc(B * H * W * 8)
+        _lib.hsn_background(ctx, ctx.to_device(rgb), B, H, W, bg_dev)
+        got = ctx.to_host(bg_dev, (B, H, W), np.float64)
+        ref = np.stack([scipy.ndimage.gaussian_filter(0.75 * scipy.special.expit(4 * (np.mean(rgb[i], axis=-1) - 240)), sigma=2)
+                        for i in range(B)])
+        assert np.abs(got - ref).max() <= 1e-12 and np.all((got > 0) == (ref > 0)), ((B, H, W), np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("htt", ["morph", "func"])
+def test_hsn_modify_and_cs_gradcam_vs_oracle(ctx, htt):
+    rng = np.random.default_rng(3 if htt == "morph" else 4)
+    B, S = 2, 57
+    N = S * S
+    ac = hsn_demo.ADPClasses()
+    C_all = len(ac.classes["all"])
+    H = np.maximum(rng.normal(0.0, 0.4, (B, C_all, S, S)), 0).astype(np.float32)
+    H[0, 5] = 0  # a class without mass
+    H[:, :, :4, :4] = 0  # a corner where everything ties at zero (np.argmax's first-maximum rule)
+    raw = np.stack([_adp_like(rng, S, S) for _ in range(B)])
+    raw[1, 20:40, 10:50] = 252
+    valid = ac.classes["valid_" + htt]
+    Cv = len(valid)
+    Y = np.zeros((B, Cv, S, S))
+    Y[:, ac.classinds[htt + "2valid"]] = H[:, ac.classinds["all2" + htt]]
+    adipose_all = [i for i, x in enumerate(ac.classes["all"]) if x in ["A.W", "A.B", "A.M"]]
+    Yr = hsn_ref.modify_by_htt(Y, raw, valid, gradcam_adipose=H[:, adipose_all].astype(np.float64) if htt == "func" else None)
+    csr = hsn_ref.get_cs_gradcam(Yr, valid, htt)
+    # device, fused, from the gated Grad-CAM stack
+    H_dev = ctx.to_device(H.reshape(B, C_all, N))
+    bg_dev = ctx.alloc(B * N * 8)
+    _lib.hsn_background(ctx, ctx.to_device(raw), B, S, S, bg_dev)
+    src_of = [-1] * Cv
+    for v, a in zip(ac.classinds[htt + "2valid"], ac.classinds["all2" + htt]):
+        src_of[v] = a
+    bg_ind, other_ind, ex = hsn._htt_tables(valid, htt == "func")
+    cs_dev, y_dev, mass_dev = ctx.alloc(B * Cv * N * 4), ctx.alloc(B * Cv * N * 4), ctx.alloc(B * Cv * 4)
+    _lib.hsn_cs_gradcam(ctx, H_dev, B, C_all, N, bg_dev, src_of, bg_ind, other_ind, ex, adipose_all if htt == "func" else None,
+                        cs_dev, y_dev, mass_dev)
+    y = ctx.to_host(y_dev, (B, Cv, S, S), np.float32)
+    cs = ctx.to_host(cs_dev, (B, Cv, S, S), np.float32)
+    mass = ctx.to_host(mass_dev, (B, Cv), np.uint32)
+    assert np.abs(y - Yr).max() <= 2e-6
+    # the margin map: identical arg-max except where the two largest values are closer than the fp32 resolution
+    srt = np.sort(Yr, axis=1)
+    safe = (srt[:, -1] - srt[:, -2]) > 1e-5
+    tie = (srt[:, -1] - srt[:, -2]) == 0
+    assert np.abs(cs - csr)[np.broadcast_to((safe | tie)[:, None], cs.shape)].max() <= 4e-6
+    assert (safe | tie).mean() > 0.99
+    for b in range(B):
+        keep = hsn_ref.pass_classes(csr[b])
+        assert list(np.nonzero(mass[b])[0]) == list(keep), (b, np.nonzero(mass[b])[0], keep)
+    # numpy-signature mirrors (03c_hsn/utilities.py:306, :367) run the same kernels
+    Ym = hsn.modify_by_htt(Y.copy(), raw, valid, gradcam_adipose=H[:, adipose_all] if htt == "func" else None, ctx=ctx)
+    assert np.abs(Ym - Yr).max() <= 2e-6
+    cm = hsn.get_cs_gradcam(Yr, valid, htt, ctx=ctx)
+    assert np.abs(cm - csr)[np.broadcast_to((safe | tie)[:, None], cs.shape)].max() <= 4e-6
+    # unaries of the passing classes (unary_from_softmax, utilities.py:431)
+    keep = np.nonzero(mass[1])[0]
+    u_dev = ctx.alloc(len(keep) * N * 4)
+    _lib.hsn_gather_unary(ctx, cs_dev, [(1 * Cv + int(c)) * N for c in keep], N, u_dev)
+    U = ctx.to_host(u_dev, (len(keep), N), np.float32)
+    Ur = -np.log(np.clip(cs[1, keep].reshape(len(keep), N), 1e-5, 1.0))
+    assert np.abs(U - Ur).max() <= 2e-6

@@ -96,6 +96,10 @@ _SIGNATURES = {
     "wsc_unary_from_maps": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "wsc_cam_unary": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
+    "wsc_hsn_gradcam_post": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "wsc_hsn_background": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "wsc_hsn_cs_gradcam": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "wsc_hsn_gather_unary": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "wsc_crf_create": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _f, ctypes.POINTER(_vp)]),
     "wsc_crf_destroy": (None, [_vp]),
     "wsc_crf_lattice_sizes": (_i, [_vp, _vp, _vp, _vp]),
@@ -518,3 +522,28 @@ def rw_propagate_batch(ctx, x_dev, edge_dev, Ks, hs, ws, dirs, path_start, path_
                                           int(dirs.shape[0]), float(beta), int(n_steps), _ptr(rw_dev)))
     return rw_dev
 
+
+
+# ---- HistoSegNet post-processing (csrc/hsn.hip) -------------------------------------------------------------------
+def hsn_gradcam_post(ctx, cams_nhwc_dev, B, h, w, C, S, gate_dev, out_dev):
+    check(ctx._lib.wsc_hsn_gradcam_post(ctx.h, _ptr(cams_nhwc_dev), B, h, w, C, S, _ptr(gate_dev), _ptr(out_dev)))
+
+
+def hsn_background(ctx, rgb_dev, B, H, W, bg_dev, out_hw=None):
+    Ho, Wo = (H, W) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
+    check(ctx._lib.wsc_hsn_background(ctx.h, _ptr(rgb_dev), B, H, W, Ho, Wo, _ptr(bg_dev)))
+
+
+def hsn_cs_gradcam(ctx, H_dev, B, C_all, N, bg_dev, src_of_valid, bg_ind, other_ind, exception_inds, adipose_src, cs_dev,
+                   y_dev, mass_dev):
+    sv = np.ascontiguousarray(src_of_valid, dtype=np.int32)
+    ex = np.ascontiguousarray(exception_inds, dtype=np.int32)
+    ad = np.ascontiguousarray(adipose_src if adipose_src is not None else [], dtype=np.int32)
+    check(ctx._lib.wsc_hsn_cs_gradcam(ctx.h, _ptr(H_dev), B, C_all, N, _ptr(bg_dev), sv.ctypes.data, len(sv), int(bg_ind),
+                                      int(other_ind), ex.ctypes.data if len(ex) else None, len(ex),
+                                      ad.ctypes.data if len(ad) else None, len(ad), _ptr(cs_dev), _ptr(y_dev), _ptr(mass_dev)))
+
+
+def hsn_gather_unary(ctx, maps_dev, chan_off, N, unary_dev):
+    co = np.ascontiguousarray(chan_off, dtype=np.int64)
+    check(ctx._lib.wsc_hsn_gather_unary(ctx.h, _ptr(maps_dev), co.ctypes.data, len(co), N, _ptr(unary_dev)))

@@ -84,31 +84,39 @@ def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size
     HTT type {morph, func}: scatter into the valid-class stack, modify_by_htt (background / other channels),
     get_cs_gradcam, dense CRF with that type's configuration.  `images` are uint8 RGB (any size; resized like
     ADPCues.read_batch), `dcrf_configs` {'morph': 6-vector, 'func': 6-vector} (the reference reads
-    `<htt>_optimal_pcc.npy`).  Returns {'morph': [label maps], 'func': [label maps]} at (size, size)."""
+    `<htt>_optimal_pcc.npy`).  Returns {'morph': [label maps], 'func': [label maps]} at (size, size).
+
+    Device resident between the batch upload and the label maps: wsc_net_forward_gradcam -> wsc_hsn_gradcam_post ->
+    wsc_hsn_background -> wsc_hsn_cs_gradcam -> wsc_hsn_gather_unary -> wsc_crf_*; the host sees the (B, C) scores, the
+    (B, Cv) class-mass flags and the final labels."""
+    from .. import _lib
+
     ac = ADPClasses(all_classes)
     out = {"morph": [], "func": []}
-    thr = np.asarray(thresholds).reshape(1, -1)
+    N = size * size
+    C_all = len(ac.classes["all"])
+    adipose_all = [i for i, x in enumerate(ac.classes["all"]) if x in ["A.W", "A.B", "A.M"]]
     for lo in range(0, len(images), batch_size):
         hi = min(lo + batch_size, len(images))
+        B = hi - lo
         _, raw = read_batch(images[lo:hi], (size, size), [0, 0, 0], [1, 1, 1])
         raw = np.clip(np.rint(raw), 0, 255).astype(np.uint8)  # ADPCues.read_batch keeps the resized batch as uint8
         norm = (raw - 193.09203) / 56.450138                  # adp_cues.py:130
-        _, scores = cu.conv_and_cams(model, np.asarray(alpha), norm, relu=False, want_scores=True)
-        is_pass = np.greater_equal(scores, thr)
-        H = np.transpose(hu.grad_cam(model, alpha, norm, is_pass, "final", scores, orig_sz=[size, size],
-                                     should_upsample=True), (0, 3, 1, 2))
-        Y = {}
+        H_dev, scores, is_pass, ctx = hu.grad_cam_device(model, alpha, norm, thresholds, [size, size])
+        bg_dev = ctx.alloc(B * N * 8)
+        _lib.hsn_background(ctx, ctx.to_device(raw), B, size, size, bg_dev)
         for htt in ("morph", "func"):
             valid = ac.classes["valid_" + htt]
-            Y[htt] = np.zeros((hi - lo, len(valid), size, size))
-            Y[htt][:, ac.classinds[htt + "2valid"]] = H[:, ac.classinds["all2" + htt]]
-            if htt == "morph":
-                Y[htt] = hu.modify_by_htt(Y[htt], raw, valid)
-            else:
-                adipose = [i for i, x in enumerate(ac.classes["morph"]) if x in ["A.W", "A.B", "A.M"]]
-                Y[htt] = hu.modify_by_htt(Y[htt], raw, valid, gradcam_adipose=Y["morph"][:, adipose])
-            cs = hu.get_cs_gradcam(Y[htt], valid, htt)
-            out[htt].extend(list(hu.dcrf_process(cs, raw, dcrf_configs[htt], ctx=model.ctx)))
+            Cv = len(valid)
+            src_of = [-1] * Cv
+            for v, a_ in zip(ac.classinds[htt + "2valid"], ac.classinds["all2" + htt]):
+                src_of[v] = a_
+            bg_ind, other_ind, ex_inds = hu._htt_tables(valid, htt == "func")
+            cs_dev, mass_dev = ctx.alloc(B * Cv * N * 4), ctx.alloc(B * Cv * 4)
+            _lib.hsn_cs_gradcam(ctx, H_dev, B, C_all, N, bg_dev, src_of, bg_ind, other_ind, ex_inds,
+                                adipose_all if htt == "func" else None, cs_dev, None, mass_dev)
+            mass = ctx.to_host(mass_dev, (B, Cv), np.uint32)
+            out[htt].extend(list(hu.dcrf_process_device(ctx, cs_dev, mass, raw, Cv, size, size, dcrf_configs[htt])))
         if is_verbose:
             print("\tBatch %d-%d" % (lo, hi))
     return out

@@ -9,56 +9,134 @@ from ..cues import utilities as cues_utilities
 from ..misc.imutils import default_context, unary_from_softmax
 
 
+def grad_cam_device(input_model, weights, images, thresholds, orig_sz, rgb_dev=None):
+    """HSN grad_cam with everything after the batch upload on the device: one CNN pass (einsum maps + scores,
+    SURVEY Q9), score gate, per-map upsample + max(., 0), per-image normalisation (03c_hsn/utilities.py:258-277 with
+    the class gating of demo.py:127-131 / :335-341).  Returns (H_dev [B][C][S*S] device buffer, scores (B, C),
+    is_pass (B, C), ctx); H stays in HBM for wsc_hsn_cs_gradcam / the CRF."""
+    net, ctx = input_model.gradcam_net(np.asarray(weights))
+    x = cues_utilities._to_nchw(images)
+    B, S_in = x.shape[0], x.shape[2]
+    h = net.cam_size(S_in)
+    C = np.asarray(weights).shape[1]
+    S = int(orig_sz[0])
+    assert int(orig_sz[1]) == S, "square output size"
+    x_dev = ctx.to_device(x)
+    cams_dev = ctx.alloc(B * h * h * C * 4)
+    score_dev = ctx.alloc(B * C * 4)
+    net.forward_gradcam(x_dev, B, S_in, False, cams_dev, score_dev)
+    scores = ctx.to_host(score_dev, (B, C), np.float32)  # 4 B C bytes: the gate is a host decision in the reference too
+    is_pass = np.greater_equal(scores, np.asarray(thresholds).reshape(1, -1))
+    gate_dev = ctx.to_device((scores * is_pass).astype(np.float32))
+    H_dev = ctx.alloc(B * C * S * S * 4)
+    _lib.hsn_gradcam_post(ctx, cams_dev, B, h, h, C, S, gate_dev, H_dev)
+    return H_dev, scores, is_pass, ctx
+
+
 def grad_cam(input_model, weights, images, is_pass_threshold, final_layer, conf_scores, orig_sz=[224, 224],
              should_upsample=False):
     """03c_hsn/utilities.py:231-278 -> (B, S, S, C): einsum (no ReLU before the resize), per-map bilinear
-    upsample then max(., 0), division by the per-image maximum over all classes, gating by score x pass."""
-    cams, _ = cues_utilities.conv_and_cams(input_model, np.asarray(weights), images, relu=False)
-    if should_upsample:
-        cams = np.maximum(cues_utilities._upsample_nhwc(input_model.ctx, cams, (int(orig_sz[0]), int(orig_sz[1]))), 0)
-    cams = cams.astype(np.float64)
-    cams = cams / np.maximum(np.max(cams, axis=(1, 2, 3), keepdims=True), 1e-7)
-    return cams * np.expand_dims(np.expand_dims(conf_scores * is_pass_threshold, axis=1), axis=2)
+    upsample then max(., 0), division by the per-image maximum over all classes, gating by score x pass.
+    numpy in / numpy out like the reference; the arithmetic runs in wsc_net_forward_gradcam + wsc_hsn_gradcam_post."""
+    net, ctx = input_model.gradcam_net(np.asarray(weights))
+    x = cues_utilities._to_nchw(images)
+    B, S_in = x.shape[0], x.shape[2]
+    h = net.cam_size(S_in)
+    C = np.asarray(weights).shape[1]
+    cams_dev = ctx.alloc(B * h * h * C * 4)
+    net.forward_gradcam(ctx.to_device(x), B, S_in, False, cams_dev, None)
+    if not should_upsample:  # (no reference caller; kept for the signature) normalise at the CNN resolution
+        cams = ctx.to_host(cams_dev, (B, h, h, C), np.float32).astype(np.float64)
+        cams = cams / np.maximum(np.max(cams, axis=(1, 2, 3), keepdims=True), 1e-7)
+        return cams * np.expand_dims(np.expand_dims(conf_scores * is_pass_threshold, axis=1), axis=2)
+    S = int(orig_sz[0])
+    gate_dev = ctx.to_device(np.ascontiguousarray(np.asarray(conf_scores) * np.asarray(is_pass_threshold), dtype=np.float32))
+    out_dev = ctx.alloc(B * C * S * S * 4)
+    _lib.hsn_gradcam_post(ctx, cams_dev, B, h, h, C, S, gate_dev, out_dev)
+    out = ctx.to_host(out_dev, (B, C, S, S), np.float32)
+    return np.transpose(out, (0, 2, 3, 1)).astype(np.float64)
 
 
-def modify_by_htt(gradcam, images, classes, gradcam_adipose=None):
+def _htt_tables(classes, func):
+    exceptions = ["G.O", "G.N", "T"] if func else ["A.W", "A.B", "A.M"]
+    return classes.index("Background"), (classes.index("Other") if func else -1), \
+        [i for i, c in enumerate(classes) if c in exceptions]
+
+
+def modify_by_htt(gradcam, images, classes, gradcam_adipose=None, ctx=None):
     """03c_hsn/utilities.py:306-364: synthesise the 'Background' (and, for functional types, 'Other')
     channels of an ADP Grad-CAM stack in place and return it.
 
-    background = 0.75 * sigmoid(4 * (mean_rgb - 240)), Gaussian-smoothed (sigma 2), resized to the CAM
-    size if needed, minus the strongest exception-class activation; other = max(0.05 * (1 - max_c cam),
-    adipose cam)."""
-    import scipy.ndimage
-    import scipy.special
-
+    background = 0.75 * sigmoid(4 * (mean_rgb - 240)), Gaussian-smoothed (sigma 2), minus the strongest
+    exception-class activation; other = max(0.05 * (1 - max_c cam), adipose cam).  numpy in / numpy out; the work is
+    wsc_hsn_background + wsc_hsn_cs_gradcam on the device (the drivers call those directly and never come here)."""
+    ctx = ctx or default_context()
+    gradcam = np.asarray(gradcam)
+    B, Cv, Hh, Ww = gradcam.shape
+    Hi, Wi = int(np.asarray(images).shape[1]), int(np.asarray(images).shape[2])
     func = gradcam_adipose is not None
-    exceptions = ["G.O", "G.N", "T"] if func else ["A.W", "A.B", "A.M"]
-    bg_ind = classes.index("Background")
-    ex_inds = [i for i, c in enumerate(classes) if c in exceptions]
-    bg = 0.75 * scipy.special.expit(4 * (np.mean(images, axis=-1) - 240))
-    for i in range(bg.shape[0]):
-        bg[i] = scipy.ndimage.gaussian_filter(bg[i], sigma=2)
-    if bg.shape[1:] != gradcam.shape[2:]:
-        bg = cues_utilities.resize_stack(bg[:, None], (gradcam.shape[2], gradcam.shape[3]))[:, 0]
-    gradcam[:, bg_ind] = bg - np.max(gradcam[:, ex_inds], axis=1)
+    bg_ind, other_ind, ex_inds = _htt_tables(list(classes), func)
+    stack = gradcam.astype(np.float32)
+    adip = None
     if func:
-        other_ind = classes.index("Other")
-        other = 0.05 * (1 - np.max(gradcam, axis=1))
-        gradcam[:, other_ind] = np.max(np.concatenate((other[:, None], gradcam_adipose), axis=1), axis=1)
+        na = gradcam_adipose.shape[1]
+        stack = np.concatenate((stack, np.asarray(gradcam_adipose, dtype=np.float32)), axis=1)
+        adip = list(range(Cv, Cv + na))
+    N = Hh * Ww
+    H_dev = ctx.to_device(np.ascontiguousarray(stack.reshape(B, -1, N)))
+    bg_dev = ctx.alloc(B * N * 8)
+    _lib.hsn_background(ctx, ctx.to_device(np.ascontiguousarray(np.uint8(images))), B, Hi, Wi, bg_dev, out_hw=(Hh, Ww))
+    cs_dev, y_dev, mass_dev = ctx.alloc(B * Cv * N * 4), ctx.alloc(B * Cv * N * 4), ctx.alloc(B * Cv * 4)
+    _lib.hsn_cs_gradcam(ctx, H_dev, B, stack.shape[1], N, bg_dev, list(range(Cv)), bg_ind, other_ind, ex_inds, adip, cs_dev,
+                        y_dev, mass_dev)
+    y = ctx.to_host(y_dev, (B, Cv, Hh, Ww), np.float32)
+    gradcam[:, bg_ind] = y[:, bg_ind]  # only the synthesised channels are written, as in the reference (:349, :362)
+    if func:
+        gradcam[:, other_ind] = y[:, other_ind]
     return gradcam
 
 
-def get_cs_gradcam(gradcam, classes, htt_class):
+def get_cs_gradcam(gradcam, classes, htt_class, ctx=None):
     """03c_hsn/utilities.py:367-397: class-specific Grad-CAM = (top1 - top2 margin) on the arg-max class,
-    zero elsewhere; the functional/glas 'Other' channel passes through unchanged."""
-    top2 = np.partition(gradcam, gradcam.shape[1] - 2, axis=1)[:, -2:]
-    maxdiff = top2[:, 1] - top2[:, 0]
-    maxind = np.argmax(gradcam, axis=1)
-    cs = np.zeros_like(gradcam)
-    other_ind = classes.index("Other") if htt_class in ("func", "glas") else -1
-    for c in range(gradcam.shape[1]):
-        cs[:, c] = gradcam[:, c] if c == other_ind else maxdiff * (maxind == c)
-    return cs
+    zero elsewhere; the functional/glas 'Other' channel passes through unchanged.  (wsc_hsn_cs_gradcam, modify step off.)"""
+    ctx = ctx or default_context()
+    gradcam = np.asarray(gradcam)
+    B, Cv, Hh, Ww = gradcam.shape
+    N = Hh * Ww
+    other_ind = list(classes).index("Other") if htt_class in ("func", "glas") else -1
+    H_dev = ctx.to_device(np.ascontiguousarray(gradcam.reshape(B, Cv, N), dtype=np.float32))
+    cs_dev, mass_dev = ctx.alloc(B * Cv * N * 4), ctx.alloc(B * Cv * 4)
+    _lib.hsn_cs_gradcam(ctx, H_dev, B, Cv, N, None, list(range(Cv)), 0, other_ind, [], None, cs_dev, None, mass_dev)
+    return ctx.to_host(cs_dev, (B, Cv, Hh, Ww), np.float32).astype(gradcam.dtype if gradcam.dtype.kind == "f" else np.float64)
+
+
+def dcrf_process_device(ctx, cs_dev, mass, rgb_host, Cv, H, W, config):
+    """dcrf_process (03c_hsn/utilities.py:399-445) on class-specific maps that are already in HBM: per image the
+    classes with positive mass (`mass` (B, Cv) from wsc_hsn_cs_gradcam, :425), unaries gathered on the device (:431),
+    one CRF batch per distinct class count, arg-max mapped back through each image's class list.  -> (B, H, W) int64."""
+    gauss_sxy, gauss_compat, bilat_sxy, bilat_srgb, bilat_compat, n_infer = config
+    B = mass.shape[0]
+    N = H * W
+    out = np.zeros((B, H, W), np.int64)  # an image without a passing class: arg-max of an all-zero stack = 0
+    pass_inds = [np.nonzero(mass[i])[0] for i in range(B)]
+    groups = {}
+    for i, p in enumerate(pass_inds):
+        if len(p) > 0:
+            groups.setdefault(len(p), []).append(i)
+    for M, idxs in groups.items():
+        Bg = len(idxs)
+        chan = [(i * Cv + int(c)) * N for i in idxs for c in pass_inds[i]]
+        u_dev = ctx.alloc(Bg * M * N * 4)
+        _lib.hsn_gather_unary(ctx, cs_dev, chan, N, u_dev)
+        rgb_dev = ctx.to_device(np.ascontiguousarray(rgb_host[idxs]))
+        a_dev = ctx.alloc(Bg * N * 4)
+        d = _lib.Crf(ctx, rgb_dev, Bg, H, W, gauss_sxy, bilat_sxy, bilat_srgb)
+        d.inference(u_dev, M, gauss_compat, bilat_compat, int(n_infer), None, a_dev)
+        lab = ctx.to_host(a_dev, (Bg, H, W), np.int32)
+        d.close()
+        for j, i in enumerate(idxs):
+            out[i] = pass_inds[i][lab[j]]
+    return out
 
 
 def dcrf_process(probs, images, config, ctx=None):
