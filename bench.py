@@ -55,7 +55,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="images per step per GPU")
     ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "bf16x3"])
-    ap.add_argument("--workload", default="cam_crf", choices=["cam_crf", "cam"])
+    ap.add_argument("--workload", default="cam_crf", choices=["cam_crf", "cam", "hsn"],
+                    help="cam_crf: the BASELINE.json metric; cam: make_cam only; hsn: BASELINE config 5 (HistoSegNet on ADP-like "
+                         "321x321 patches: VGG16 Grad-CAM -> modify_by_htt -> cs-gradcam -> dense CRF for the 29 morphological "
+                         "and the 5 functional classes, 03c_hsn/demo.py:271-380), an extra measurement")
     ap.add_argument("--arch", default="resnet50", choices=["resnet50", "vgg16", "m7"],
                     help="CAM network (resnet50 is the BASELINE.json configuration; vgg16 / m7 are extra "
                          "measurements of the other conv stacks of the reference, 03b_irn/net/{vgg16,m7}.py)")
@@ -126,11 +129,12 @@ class Workload:
         self.h = self.net.cam_size(S)
         if share is not None:  # same images / labels as another workload (other precision)
             self.x_host, self.rgb_host, self.sizes, self.keys = share.x_host, share.rgb_host, share.sizes, share.keys
+            self.native = share.native
         else:
             # real image-level labels (rows of the reference's voc12/cls_labels.npy in train_aug.txt order: the K
             # distribution of the dataset), synthetic VOC-like images
             labels = np.load(os.path.join(ROOT, "tests", "golden", "resnet50_cam.npz"))["trainaug_labels"]
-            self.x_host, self.rgb_host, self.sizes = synth.image_batch(batch, S, seed)
+            self.x_host, self.rgb_host, self.sizes, self.native = synth.image_batch(batch, S, seed, with_native=True)
             self.keys = [np.nonzero(labels[(i + seed * batch) % len(labels)])[0].astype(np.int32) for i in range(batch)]
         ctx = self.ctx
         self.x_dev = ctx.to_device(self.x_host)
@@ -269,11 +273,16 @@ class Workload:
             crf.close()
 
     # -- end to end: host batch in, files out ---------------------------------------------------------------
-    def setup_e2e(self, out_dir, n_writers=8):
+    def setup_e2e(self, out_dir, n_writers=8, u8=False):
         from concurrent.futures import ThreadPoolExecutor
 
         np = self.np
-        self.e2e = {"dir": out_dir, "pool": ThreadPoolExecutor(n_writers), "futs": [[], []],
+        if self.e2e is not None:
+            self.e2e["pool"].shutdown(wait=True)
+        self.u8_offs = np.concatenate(([0], np.cumsum([im.size for im in self.native]))).astype(np.int64)
+        self.u8_dev = self.ctx.alloc(int(self.u8_offs[-1]))
+        self.e2e = {"dir": out_dir, "pool": ThreadPoolExecutor(n_writers), "futs": [[], []], "u8": u8,
+                    "pin_u8": [self.ctx.host_alloc(int(self.u8_offs[-1])) for _ in range(2)],
                     "pin_in": [self.ctx.host_alloc(self.x_host.nbytes) for _ in range(2)],
                     "pin_out": [self.ctx.host_alloc((max(self.s_tot, 1) + max(self.h_tot, 1)) * 4) for _ in range(2)],
                     "pin_lab": [self.ctx_crf.host_alloc(self.B * S * S * 4) for _ in range(2)], "prev": None}
@@ -312,9 +321,17 @@ class Workload:
         for f in e["futs"][p]:
             f.result()  # the files of step i-2 are on disk: its staging buffers are free again
         e["futs"][p] = []
-        np.copyto(e["pin_in"][p].view(self.x_host.shape, np.float32), self.x_host)
         self.unary_dev, self.label_dev = self.unary_bufs[p], self.label_bufs[p]
-        self.ctx.h2d_async(self.x_dev, e["pin_in"][p], self.x_host.nbytes)
+        if e["u8"]:  # decoded images in: the dataset transform (resize, normalise, flip pair) runs on the device
+            buf = e["pin_u8"][p].view((int(self.u8_offs[-1]),), np.uint8)
+            for k, im in enumerate(self.native):
+                buf[self.u8_offs[k]:self.u8_offs[k + 1]] = im.reshape(-1)
+            self.ctx.h2d_async(self.u8_dev, e["pin_u8"][p], int(self.u8_offs[-1]))
+            self._lib.msf_input_u8(self.ctx, self.u8_dev, [im.shape[:2] for im in self.native], self.u8_offs[:-1], S,
+                                   (104.0, 117.0, 123.0), (255.0, 255.0, 255.0), self.x_dev, pre_div255=False, pair=True)
+        else:
+            np.copyto(e["pin_in"][p].view(self.x_host.shape, np.float32), self.x_host)
+            self.ctx.h2d_async(self.x_dev, e["pin_in"][p], self.x_host.nbytes)
         self.run_cnn()
         crf = self.crf_create()
         self.run_tail()
@@ -424,6 +441,56 @@ def cpu_baseline(wl, budget_s):
                       % (n_cam, t_cam / n_cam, cores, n_par, threads, crf_rate, t_crf1)}
 
 
+def run_hsn(args, device):
+    """BASELINE config 5 on one GPU: `segment_adp` (03c_hsn/demo.py:271-380) on batches of ADP-like patches, device
+    resident from the batch upload to the label maps.  One step = one batch of --batch images (reference: 16)."""
+    import numpy as np
+
+    from wsscam import _lib, synth
+    from wsscam.hsn import demo as hsn_demo
+    from wsscam.net import vgg16_cam
+    from wsscam.net.common import grad_cam_alpha
+
+    C, S_ = 31, 321
+    prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3}[args.precision]
+    sd = synth.plain_state_dict("vgg16", C, batchnorm=False, seed=0)  # ADP models have no BatchNorm (vgg16_cam.py:16-19)
+    model = vgg16_cam.CAM(None, "adp_morph", "ADP_VGG16", C, None, precision=prec)
+    model.load_state_dict(sd)
+    model.cuda(device)
+    alpha = grad_cam_alpha(sd["vgg16.classifier.0.weight"], S_ // 8, S_ // 8, "avg")
+    rng = np.random.default_rng(4242)
+    images = [synth.adp_image(rng, S_, S_) for _ in range(args.batch)]
+    thr = np.full((1, C), 0.5)
+    cfgs = {"morph": np.array([3 / 2, 3, 80 / 2, 13, 10, 10]), "func": np.array([3 / 2, 3, 80 / 2, 13, 10, 10])}
+
+    def step():
+        return hsn_demo.segment_adp(model, alpha, thr, images, cfgs, S_, args.batch)
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    model.ctx.sync()
+    ctx = model.ctx
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_begin()
+    step()
+    prof = ctx.profile_end()
+    kernels = {n: {"launches_per_step": c, "ms_per_step": round(ms, 4)} for n, (c, ms, w) in prof.items()}
+    m_classes = {h: sorted({int(len(np.unique(lab))) for lab in out[h]}) for h in out}
+    print(json.dumps({
+        "metric": "images/sec HistoSegNet CAM+CRF (BASELINE config 5, ADP-like 321x321 patches, morph + func label maps)",
+        "value": round(args.batch * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "vgg16 (31 classes, no BN) HSN Grad-CAM + modify_by_htt + cs-gradcam + dense-CRF x2 (morph 29 / "
+                               "func 5 classes, 10 iters), 321x321, batch %d" % args.batch, "batch_images": args.batch,
+                   "distinct_labels_per_image": m_classes},
+        "stages": {"kernel_classes": kernels}}))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -450,6 +517,13 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
+    if args.workload == "hsn":
+        if rank == 0:
+            run_hsn(args, device)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     wl = Workload(device, args.batch, args.precision, args.workload, seed=rank, arch=args.arch)
 
     def barrier(w):
@@ -581,6 +655,12 @@ def main():
             stages["end_to_end"] = ("per step: 79 MB pageable float32 batch -> pinned -> H2D; D2H of cam + high_res (%.1f MB) and "
                                     "label maps (%.1f MB); %d .npy files through 8 writer threads; overlapped with the next step"
                                     % ((wl.s_tot + wl.h_tot) * 4 / 1e6, args.batch * S * S * 4 / 1e6, 2 * args.batch))
+            wl.setup_e2e(tmp, u8=True)
+            te = timed_run(wl, wl.step_e2e, k_extra, 2, wl.drain_e2e)
+            stages["value_end_to_end_u8_input"] = round(args.batch * k_extra / te, 3)
+            stages["end_to_end_u8_input"] = ("as value_end_to_end, but the host hands over the DECODED native-size images (%.1f MB "
+                                             "per step); float64 resize + normalise + flip pair on the device, bit-identical"
+                                             % (wl.u8_offs[-1] / 1e6))
             wl.e2e["pool"].shutdown(wait=True)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)

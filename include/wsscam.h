@@ -254,6 +254,18 @@ int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N
 int wsc_cam_unary(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
                   float *unary_dev);
 
+/* The MSF dataset transform of a batch of DECODED images (03b_irn/voc12/dataloader.py:68-106, 225-246; constants of
+ * adp/dataloader.py:64-80, deepglobe/dataloader.py:60-66): float64 bilinear resize to S x S (cv2.resize INTER_LINEAR
+ * on the float64 image, skipped when the image already has that size), float32 normalisation
+ * (x - mean[c]) / std[c] (pre_div255: (x / 255 - mean[c]) / std[c], norm_mode 'float'), HWC -> CHW, and with
+ * pair = 1 the [x, flip(x, -1)] stack make_cam feeds the network; pair = 0 gives the plain batch of
+ * 02_cues/utilities.py:146-181.  Bit-identical to the numpy path of wsscam.voc12.dataloader (same float64 expression).
+ *   images_dev uint8: image b is the HWC block [H0_b][W0_b][3] at byte offset_host[b];  size_hw_host int32 [B][2];
+ *   x_dev float32 [B][2][3][S][S] (pair) or [B][3][S][S]. */
+int wsc_msf_input_u8(wsc_ctx *ctx, const uint8_t *images_dev, int B, const int32_t *size_hw_host,
+                     const int64_t *offset_host, int S, const float *mean3_host, const float *std3_host,
+                     int pre_div255, int pair, float *x_dev);
+
 /* F.interpolate(mode='bilinear', align_corners=False) on float32 [C][h][w] -> [C][H][W]
  * (make_cam.py:64-69; also resize_stack 02_cues/utilities.py:20-40 up to the
  * cv2/torch border convention). */

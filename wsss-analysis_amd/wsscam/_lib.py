@@ -96,6 +96,7 @@ _SIGNATURES = {
     "wsc_unary_from_maps": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "wsc_cam_unary": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
+    "wsc_msf_input_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "wsc_hsn_gradcam_post": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "wsc_hsn_background": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "wsc_hsn_cs_gradcam": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
@@ -178,6 +179,12 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            pool = self.__dict__.pop("_pool", None)
+            if pool:
+                for lst in pool.values():
+                    for buf in lst:
+                        self._lib.wsc_free(self.h, buf.ptr)
+                        buf.ptr = None
             self._lib.wsc_ctx_destroy(self.h)
             self.h = None
 
@@ -200,12 +207,27 @@ class Context:
         check(self._lib.wsc_device_info(self.h, buf, 128, ctypes.byref(n)))
         return buf.value.decode(), n.value
 
-    def alloc(self, nbytes):
-        return DeviceBuffer(self, int(nbytes))
+    def alloc(self, nbytes, pooled=False):
+        """pooled=True: the block comes from / returns to a per-context free list instead of hipMalloc / hipFree (both
+        synchronise the device).  Only for buffers that are used on THIS context's stream alone: reuse is ordered by
+        the stream, exactly like the library's internal cached allocator."""
+        nbytes = int(nbytes)
+        if pooled:
+            size = 1 << max(16, (max(nbytes, 1) - 1).bit_length())
+            pool = self.__dict__.setdefault("_pool", {})
+            lst = pool.get(size)
+            if lst:
+                buf = lst.pop()
+                buf.nbytes = nbytes
+                return buf
+            buf = DeviceBuffer(self, size)
+            buf.nbytes, buf._pool_size = nbytes, size
+            return buf
+        return DeviceBuffer(self, nbytes)
 
-    def to_device(self, arr):
+    def to_device(self, arr, pooled=False):
         arr = np.ascontiguousarray(arr)
-        buf = DeviceBuffer(self, arr.nbytes)
+        buf = self.alloc(arr.nbytes, pooled=pooled)
         check(self._lib.wsc_memcpy_h2d(self.h, buf.ptr, arr.ctypes.data, arr.nbytes))
         self.sync()  # arr may be a temporary
         return buf
@@ -260,6 +282,13 @@ class DeviceBuffer:
 
     def free(self):
         if getattr(self, "ptr", None) and self.ctx.h:
+            size = getattr(self, "_pool_size", None)
+            if size is not None and getattr(self.ctx, "_pool", None) is not None:
+                twin = DeviceBuffer.__new__(DeviceBuffer)  # the block lives on in the pool under a fresh handle
+                twin.ctx, twin.nbytes, twin.ptr, twin._pool_size = self.ctx, size, self.ptr, size
+                self.ctx._pool.setdefault(size, []).append(twin)
+                self.ptr = None
+                return
             self.ctx._lib.wsc_free(self.ctx.h, self.ptr)
         self.ptr = None
 
@@ -547,3 +576,14 @@ def hsn_cs_gradcam(ctx, H_dev, B, C_all, N, bg_dev, src_of_valid, bg_ind, other_
 def hsn_gather_unary(ctx, maps_dev, chan_off, N, unary_dev):
     co = np.ascontiguousarray(chan_off, dtype=np.int64)
     check(ctx._lib.wsc_hsn_gather_unary(ctx.h, _ptr(maps_dev), co.ctypes.data, len(co), N, _ptr(unary_dev)))
+
+
+def msf_input_u8(ctx, images_dev, sizes, offsets, S, mean, std, x_dev, pre_div255=False, pair=True):
+    """wsc_msf_input_u8: decoded uint8 images (packed HWC blocks at byte `offsets`) -> float32 network input."""
+    B = len(sizes)
+    size_hw = np.ascontiguousarray(sizes, dtype=np.int32).reshape(B, 2)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    m = np.ascontiguousarray(mean, dtype=np.float32)
+    sd = np.ascontiguousarray(std, dtype=np.float32)
+    check(ctx._lib.wsc_msf_input_u8(ctx.h, _ptr(images_dev), B, size_hw.ctypes.data, off.ctypes.data, int(S), m.ctypes.data,
+                                    sd.ctypes.data, int(bool(pre_div255)), int(bool(pair)), _ptr(x_dev)))

@@ -99,12 +99,17 @@ def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size
     for lo in range(0, len(images), batch_size):
         hi = min(lo + batch_size, len(images))
         B = hi - lo
-        _, raw = read_batch(images[lo:hi], (size, size), [0, 0, 0], [1, 1, 1])
-        raw = np.clip(np.rint(raw), 0, 255).astype(np.uint8)  # ADPCues.read_batch keeps the resized batch as uint8
-        norm = (raw - 193.09203) / 56.450138                  # adp_cues.py:130
-        H_dev, scores, is_pass, ctx = hu.grad_cam_device(model, alpha, norm, thresholds, [size, size])
-        bg_dev = ctx.alloc(B * N * 8)
-        _lib.hsn_background(ctx, ctx.to_device(raw), B, size, size, bg_dev)
+        chunk = images[lo:hi]
+        if all(np.asarray(im).shape == (size, size, 3) and np.asarray(im).dtype == np.uint8 for im in chunk):
+            raw = np.ascontiguousarray(np.stack(chunk))       # already at the network size: nothing to resize
+        else:
+            _, raw = read_batch(chunk, (size, size), [0, 0, 0], [1, 1, 1])
+            raw = np.clip(np.rint(raw), 0, 255).astype(np.uint8)  # ADPCues.read_batch keeps the resized batch as uint8
+        # (raw - 193.09203) / 56.450138 (adp_cues.py:130) and the NHWC -> NCHW layout on the device
+        H_dev, scores, is_pass, ctx, raw_dev = hu.grad_cam_device(model, alpha, None, thresholds, [size, size], raw_u8=raw,
+                                                                  mean_std=(193.09203, 56.450138))
+        bg_dev = ctx.alloc(B * N * 8, pooled=True)
+        _lib.hsn_background(ctx, raw_dev, B, size, size, bg_dev)
         for htt in ("morph", "func"):
             valid = ac.classes["valid_" + htt]
             Cv = len(valid)
@@ -112,7 +117,7 @@ def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size
             for v, a_ in zip(ac.classinds[htt + "2valid"], ac.classinds["all2" + htt]):
                 src_of[v] = a_
             bg_ind, other_ind, ex_inds = hu._htt_tables(valid, htt == "func")
-            cs_dev, mass_dev = ctx.alloc(B * Cv * N * 4), ctx.alloc(B * Cv * 4)
+            cs_dev, mass_dev = ctx.alloc(B * Cv * N * 4, pooled=True), ctx.alloc(B * Cv * 4, pooled=True)
             _lib.hsn_cs_gradcam(ctx, H_dev, B, C_all, N, bg_dev, src_of, bg_ind, other_ind, ex_inds,
                                 adipose_all if htt == "func" else None, cs_dev, None, mass_dev)
             mass = ctx.to_host(mass_dev, (B, Cv), np.uint32)

@@ -9,27 +9,39 @@ from ..cues import utilities as cues_utilities
 from ..misc.imutils import default_context, unary_from_softmax
 
 
-def grad_cam_device(input_model, weights, images, thresholds, orig_sz, rgb_dev=None):
+def grad_cam_device(input_model, weights, images, thresholds, orig_sz, raw_u8=None, mean_std=None):
     """HSN grad_cam with everything after the batch upload on the device: one CNN pass (einsum maps + scores,
     SURVEY Q9), score gate, per-map upsample + max(., 0), per-image normalisation (03c_hsn/utilities.py:258-277 with
-    the class gating of demo.py:127-131 / :335-341).  Returns (H_dev [B][C][S*S] device buffer, scores (B, C),
-    is_pass (B, C), ctx); H stays in HBM for wsc_hsn_cs_gradcam / the CRF."""
+    the class gating of demo.py:127-131 / :335-341).  `images`: normalised (B,S,S,3) floats, or None with `raw_u8`
+    (B,S,S,3) uint8 + `mean_std` = (mean, std): the normalisation runs on the device as well (wsc_msf_input_u8).
+    Returns (H_dev [B][C][S*S] device buffer, scores (B, C), is_pass (B, C), ctx[, raw_dev]); H stays in HBM for
+    wsc_hsn_cs_gradcam / the CRF."""
     net, ctx = input_model.gradcam_net(np.asarray(weights))
-    x = cues_utilities._to_nchw(images)
-    B, S_in = x.shape[0], x.shape[2]
+    raw_dev = None
+    if images is None:
+        B, S_in = raw_u8.shape[0], raw_u8.shape[1]
+        raw_dev = ctx.to_device(raw_u8, pooled=True)
+        x_dev = ctx.alloc(B * 3 * S_in * S_in * 4, pooled=True)
+        _lib.msf_input_u8(ctx, raw_dev, [(S_in, S_in)] * B, np.arange(B, dtype=np.int64) * (S_in * S_in * 3), S_in,
+                          (mean_std[0],) * 3, (mean_std[1],) * 3, x_dev, pre_div255=False, pair=False)
+    else:
+        x = cues_utilities._to_nchw(images)
+        B, S_in = x.shape[0], x.shape[2]
+        x_dev = ctx.to_device(x, pooled=True)
     h = net.cam_size(S_in)
     C = np.asarray(weights).shape[1]
     S = int(orig_sz[0])
     assert int(orig_sz[1]) == S, "square output size"
-    x_dev = ctx.to_device(x)
-    cams_dev = ctx.alloc(B * h * h * C * 4)
-    score_dev = ctx.alloc(B * C * 4)
+    cams_dev = ctx.alloc(B * h * h * C * 4, pooled=True)
+    score_dev = ctx.alloc(B * C * 4, pooled=True)
     net.forward_gradcam(x_dev, B, S_in, False, cams_dev, score_dev)
     scores = ctx.to_host(score_dev, (B, C), np.float32)  # 4 B C bytes: the gate is a host decision in the reference too
     is_pass = np.greater_equal(scores, np.asarray(thresholds).reshape(1, -1))
-    gate_dev = ctx.to_device((scores * is_pass).astype(np.float32))
-    H_dev = ctx.alloc(B * C * S * S * 4)
+    gate_dev = ctx.to_device((scores * is_pass).astype(np.float32), pooled=True)
+    H_dev = ctx.alloc(B * C * S * S * 4, pooled=True)
     _lib.hsn_gradcam_post(ctx, cams_dev, B, h, h, C, S, gate_dev, H_dev)
+    if raw_dev is not None:
+        return H_dev, scores, is_pass, ctx, raw_dev
     return H_dev, scores, is_pass, ctx
 
 
@@ -43,15 +55,15 @@ def grad_cam(input_model, weights, images, is_pass_threshold, final_layer, conf_
     B, S_in = x.shape[0], x.shape[2]
     h = net.cam_size(S_in)
     C = np.asarray(weights).shape[1]
-    cams_dev = ctx.alloc(B * h * h * C * 4)
-    net.forward_gradcam(ctx.to_device(x), B, S_in, False, cams_dev, None)
+    cams_dev = ctx.alloc(B * h * h * C * 4, pooled=True)
+    net.forward_gradcam(ctx.to_device(x, pooled=True), B, S_in, False, cams_dev, None)
     if not should_upsample:  # (no reference caller; kept for the signature) normalise at the CNN resolution
         cams = ctx.to_host(cams_dev, (B, h, h, C), np.float32).astype(np.float64)
         cams = cams / np.maximum(np.max(cams, axis=(1, 2, 3), keepdims=True), 1e-7)
         return cams * np.expand_dims(np.expand_dims(conf_scores * is_pass_threshold, axis=1), axis=2)
     S = int(orig_sz[0])
-    gate_dev = ctx.to_device(np.ascontiguousarray(np.asarray(conf_scores) * np.asarray(is_pass_threshold), dtype=np.float32))
-    out_dev = ctx.alloc(B * C * S * S * 4)
+    gate_dev = ctx.to_device(np.ascontiguousarray(np.asarray(conf_scores) * np.asarray(is_pass_threshold), dtype=np.float32), pooled=True)
+    out_dev = ctx.alloc(B * C * S * S * 4, pooled=True)
     _lib.hsn_gradcam_post(ctx, cams_dev, B, h, h, C, S, gate_dev, out_dev)
     out = ctx.to_host(out_dev, (B, C, S, S), np.float32)
     return np.transpose(out, (0, 2, 3, 1)).astype(np.float64)
@@ -83,10 +95,10 @@ def modify_by_htt(gradcam, images, classes, gradcam_adipose=None, ctx=None):
         stack = np.concatenate((stack, np.asarray(gradcam_adipose, dtype=np.float32)), axis=1)
         adip = list(range(Cv, Cv + na))
     N = Hh * Ww
-    H_dev = ctx.to_device(np.ascontiguousarray(stack.reshape(B, -1, N)))
-    bg_dev = ctx.alloc(B * N * 8)
-    _lib.hsn_background(ctx, ctx.to_device(np.ascontiguousarray(np.uint8(images))), B, Hi, Wi, bg_dev, out_hw=(Hh, Ww))
-    cs_dev, y_dev, mass_dev = ctx.alloc(B * Cv * N * 4), ctx.alloc(B * Cv * N * 4), ctx.alloc(B * Cv * 4)
+    H_dev = ctx.to_device(np.ascontiguousarray(stack.reshape(B, -1, N)), pooled=True)
+    bg_dev = ctx.alloc(B * N * 8, pooled=True)
+    _lib.hsn_background(ctx, ctx.to_device(np.ascontiguousarray(np.uint8(images)), pooled=True), B, Hi, Wi, bg_dev, out_hw=(Hh, Ww))
+    cs_dev, y_dev, mass_dev = ctx.alloc(B * Cv * N * 4, pooled=True), ctx.alloc(B * Cv * N * 4, pooled=True), ctx.alloc(B * Cv * 4, pooled=True)
     _lib.hsn_cs_gradcam(ctx, H_dev, B, stack.shape[1], N, bg_dev, list(range(Cv)), bg_ind, other_ind, ex_inds, adip, cs_dev,
                         y_dev, mass_dev)
     y = ctx.to_host(y_dev, (B, Cv, Hh, Ww), np.float32)
@@ -104,8 +116,8 @@ def get_cs_gradcam(gradcam, classes, htt_class, ctx=None):
     B, Cv, Hh, Ww = gradcam.shape
     N = Hh * Ww
     other_ind = list(classes).index("Other") if htt_class in ("func", "glas") else -1
-    H_dev = ctx.to_device(np.ascontiguousarray(gradcam.reshape(B, Cv, N), dtype=np.float32))
-    cs_dev, mass_dev = ctx.alloc(B * Cv * N * 4), ctx.alloc(B * Cv * 4)
+    H_dev = ctx.to_device(np.ascontiguousarray(gradcam.reshape(B, Cv, N), dtype=np.float32), pooled=True)
+    cs_dev, mass_dev = ctx.alloc(B * Cv * N * 4, pooled=True), ctx.alloc(B * Cv * 4, pooled=True)
     _lib.hsn_cs_gradcam(ctx, H_dev, B, Cv, N, None, list(range(Cv)), 0, other_ind, [], None, cs_dev, None, mass_dev)
     return ctx.to_host(cs_dev, (B, Cv, Hh, Ww), np.float32).astype(gradcam.dtype if gradcam.dtype.kind == "f" else np.float64)
 
@@ -126,10 +138,10 @@ def dcrf_process_device(ctx, cs_dev, mass, rgb_host, Cv, H, W, config):
     for M, idxs in groups.items():
         Bg = len(idxs)
         chan = [(i * Cv + int(c)) * N for i in idxs for c in pass_inds[i]]
-        u_dev = ctx.alloc(Bg * M * N * 4)
+        u_dev = ctx.alloc(Bg * M * N * 4, pooled=True)
         _lib.hsn_gather_unary(ctx, cs_dev, chan, N, u_dev)
-        rgb_dev = ctx.to_device(np.ascontiguousarray(rgb_host[idxs]))
-        a_dev = ctx.alloc(Bg * N * 4)
+        rgb_dev = ctx.to_device(np.ascontiguousarray(rgb_host[idxs]), pooled=True)
+        a_dev = ctx.alloc(Bg * N * 4, pooled=True)
         d = _lib.Crf(ctx, rgb_dev, Bg, H, W, gauss_sxy, bilat_sxy, bilat_srgb)
         d.inference(u_dev, M, gauss_compat, bilat_compat, int(n_infer), None, a_dev)
         lab = ctx.to_host(a_dev, (Bg, H, W), np.int32)
@@ -165,9 +177,9 @@ def dcrf_process(probs, images, config, ctx=None):
     for M, idxs in groups.items():
         Bg = len(idxs)
         U = np.stack([np.ascontiguousarray(unary_from_softmax(probs[i, pass_inds[i]])) for i in idxs])
-        rgb_dev = ctx.to_device(rgb[idxs])
-        u_dev = ctx.to_device(U.astype(np.float32))
-        q_dev = ctx.alloc(Bg * M * H * W * 4)
+        rgb_dev = ctx.to_device(rgb[idxs], pooled=True)
+        u_dev = ctx.to_device(U.astype(np.float32), pooled=True)
+        q_dev = ctx.alloc(Bg * M * H * W * 4, pooled=True)
         d = _lib.Crf(ctx, rgb_dev, Bg, H, W, gauss_sxy, bilat_sxy, bilat_srgb)
         d.inference(u_dev, M, gauss_compat, bilat_compat, int(n_infer), q_dev, None)
         Q = ctx.to_host(q_dev, (Bg, M, H, W), np.float32)

@@ -119,10 +119,20 @@ def _work(process_id, model, dataset, args):
     from .pipeline import CamPipeline
 
     first = databin[0]
-    S = int(np.asarray(first["img"]).shape[-1])
-    if np.asarray(first["img"]).shape != (2, 3, S, S):
-        raise ValueError("make_cam: network inputs must be (2, 3, S, S) with one square size per run; got %s"
-                         % (np.asarray(first["img"]).shape,))
+    norm = None
+    if "img" in first:
+        S = int(np.asarray(first["img"]).shape[-1])
+        if np.asarray(first["img"]).shape != (2, 3, S, S):
+            raise ValueError("make_cam: network inputs must be (2, 3, S, S) with one square size per run; got %s"
+                             % (np.asarray(first["img"]).shape,))
+    else:  # dataset built with device_transform=True: items carry the decoded image, the transform runs on the GPU
+        S = int(args.outsize[0])
+        base = getattr(databin, "dataset", databin)
+        norm = getattr(base, "norm", None)
+        if norm is None:
+            from ..voc12.dataloader import TorchvisionNormalize
+
+            norm = TorchvisionNormalize(args.norm_mode)
     has_cls = model.arch != _lib.ARCH_RESNET50_CAM
     needs_score = "train" not in args.split
     if needs_score and not has_cls:
@@ -130,7 +140,7 @@ def _work(process_id, model, dataset, args):
     pipe = CamPipeline(model, device, bs, S, keys_fn=lambda pack, score: _valid_cat(args, pack, score, model),
                        save_fn=lambda name, keys, sc, hc: _save(args, name, keys, sc, hc), needs_score=needs_score,
                        n_lanes=int(getattr(args, "cam_pipeline_lanes", 3)), n_loaders=int(getattr(args, "cam_loader_threads", 8)),
-                       n_writers=int(getattr(args, "cam_writer_threads", 8)))
+                       n_writers=int(getattr(args, "cam_writer_threads", 8)), norm=norm)
     try:
         pipe.run(databin)
     finally:
@@ -152,7 +162,8 @@ def build_dataset(args):
         return dataloader.VOC12ClassificationDatasetMSF(args.val_list, norm_mode=args.norm_mode,
                                                         outsize=args.outsize, dev_root=args.dev_root,
                                                         scales=args.cam_scales,
-                                                        cls_labels_path=getattr(args, "cls_labels_path", None))
+                                                        cls_labels_path=getattr(args, "cls_labels_path", None),
+                                                        device_transform=bool(getattr(args, "cam_device_transform", False)))
     if args.dataset in ("adp_morph", "adp_func"):
         from ..adp import dataloader
 

@@ -32,6 +32,8 @@ class _Lane:
         self.out_cap = 0
         self.pin_out = None
         self.s_dev = self.h_dev = None
+        self.u8_cap = 0
+        self.pin_u8 = self.u8_dev = None
         self.free = threading.Event()
         self.free.set()
 
@@ -47,9 +49,20 @@ class _Lane:
             self.h_dev = self.ctx.alloc(cap)
             self.out_cap = cap
 
+    def ensure_u8(self, nbytes):
+        if nbytes > self.u8_cap:
+            cap = int(nbytes * 1.5) + (1 << 20)
+            for b in (self.pin_u8, self.u8_dev):
+                if b is not None:
+                    b.free()
+            self.pin_u8 = self.ctx.host_alloc(cap)
+            self.u8_dev = self.ctx.alloc(cap)
+            self.u8_cap = cap
+
     def close(self):
         self.ctx.sync()
-        for b in (self.pin_in, self.pin_out, self.pin_score, self.x_dev, self.cam_dev, self.score_dev, self.s_dev, self.h_dev):
+        for b in (self.pin_in, self.pin_out, self.pin_score, self.x_dev, self.cam_dev, self.score_dev, self.s_dev, self.h_dev,
+                  self.pin_u8, self.u8_dev):
             if b is not None:
                 b.free()
         self.ctx.close()
@@ -59,8 +72,10 @@ class CamPipeline:
     """Batched, overlapped make_cam worker for one GPU.  `keys_fn(pack, score_row_or_None) -> int64 keys`,
     `save_fn(name, keys, strided, highres)` are the driver's own (make_cam._valid_cat / _save)."""
 
-    def __init__(self, model, device, batch_images, S, keys_fn, save_fn, needs_score, n_lanes=3, n_loaders=8, n_writers=8):
+    def __init__(self, model, device, batch_images, S, keys_fn, save_fn, needs_score, n_lanes=3, n_loaders=8, n_writers=8,
+                 norm=None):
         self.model, self.device, self.B, self.S = model, device, batch_images, S
+        self.norm = norm  # TorchvisionNormalize of the dataset (device transform of "img_u8" items)
         self.keys_fn, self.save_fn, self.needs_score = keys_fn, save_fn, needs_score
         self.C = model.num_classes
         self.h = model.cam_size(S)
@@ -74,6 +89,8 @@ class CamPipeline:
     # -- stages --------------------------------------------------------------------------------------------
     def _load_into(self, lane, k, dataset, idx):
         pack = dataset[idx]
+        if "img" not in pack:  # device transform: the decoded uint8 image travels, wsc_msf_input_u8 does the rest
+            return dict(pack)
         img = np.asarray(pack["img"], dtype=np.float32)
         if img.shape != lane.x_view.shape[1:]:
             raise ValueError("make_cam: network inputs must be (2, 3, %d, %d) for every image of a run; %s has %s"
@@ -104,7 +121,21 @@ class CamPipeline:
         n = len(indices)
         metas = [f.result() for f in [self.loaders.submit(self._load_into, lane, k, dataset, i) for k, i in enumerate(indices)]]
         ctx = lane.ctx
-        ctx.h2d_async(lane.x_dev, lane.pin_in, n * 2 * 3 * self.S * self.S * 4)
+        if "img_u8" in metas[0]:
+            # decoded images: (sum H0 W0 3) bytes over PCIe instead of n x 2.47 MB of float32; resize + normalise + flip
+            # pair on the device, bit-identical to the host transform (csrc/input.hip)
+            sizes_u8 = [tuple(int(v) for v in np.asarray(m["img_u8"]).shape[:2]) for m in metas]
+            offs = np.concatenate(([0], np.cumsum([h * w * 3 for h, w in sizes_u8]))).astype(np.int64)
+            lane.ensure_u8(int(offs[-1]))
+            buf = lane.pin_u8.view((lane.u8_cap,), np.uint8)
+            for k, m in enumerate(metas):
+                buf[offs[k]:offs[k + 1]] = np.ascontiguousarray(m.pop("img_u8"), dtype=np.uint8).reshape(-1)
+            ctx.h2d_async(lane.u8_dev, lane.pin_u8, int(offs[-1]))
+            norm = self.norm
+            _lib.msf_input_u8(ctx, lane.u8_dev, sizes_u8, offs[:-1], self.S, norm.mean, norm.std, lane.x_dev,
+                              pre_div255=norm.norm_mode == "float", pair=True)
+        else:
+            ctx.h2d_async(lane.x_dev, lane.pin_in, n * 2 * 3 * self.S * self.S * 4)
         self.model._ensure_net().forward_cam(lane.x_dev, n, self.S, lane.cam_dev, lane.score_dev if self.needs_score else None,
                                              ctx=ctx)
         score = None

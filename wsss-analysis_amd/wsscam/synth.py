@@ -98,17 +98,32 @@ def plain_state_dict(root, num_classes=20, batchnorm=True, seed=0):
     return sd
 
 
-def image_batch(batch, S, seed=0):
-    """-> (x float32 (B,2,3,S,S) MSF items, rgb uint8 (B,S,S,3) resized images, native sizes [(H0,W0)])."""
+def image_batch(batch, S, seed=0, with_native=False):
+    """-> (x float32 (B,2,3,S,S) MSF items, rgb uint8 (B,S,S,3) resized images, native sizes [(H0,W0)]
+    [, the native-size uint8 images])."""
     rng = np.random.default_rng(20121 + seed)
     norm = TorchvisionNormalize("int")
-    xs, rgbs, sizes = [], [], []
+    xs, rgbs, sizes, native = [], [], [], []
     for i in range(batch):
         H0, W0 = VOC_SIZES[(i + seed) % len(VOC_SIZES)]
         img = synth_image(rng, H0, W0)
+        native.append(img)
         r = resize_bilinear_f64(img, (S, S))
         x = np.transpose(norm(r), (2, 0, 1))
         xs.append(np.stack([x, np.flip(x, -1)], 0))
         rgbs.append(np.clip(np.rint(r), 0, 255).astype(np.uint8))
         sizes.append((H0, W0))
-    return np.ascontiguousarray(np.stack(xs), dtype=np.float32), np.ascontiguousarray(np.stack(rgbs)), sizes
+    out = (np.ascontiguousarray(np.stack(xs), dtype=np.float32), np.ascontiguousarray(np.stack(rgbs)), sizes)
+    return out + (native,) if with_native else out
+
+
+def adp_image(rng, H, W):
+    """ADP-like histology patch: pink / purple blobs on a near-white slide background, so the
+    0.75 * expit(4 * (mean_rgb - 240)) background activation of modify_by_htt is exercised."""
+    img = np.full((H, W, 3), 244.0) + rng.normal(0, 3, (H, W, 3))
+    yy, xx = np.mgrid[:H, :W]
+    for _ in range(max(4, H * W // 12000)):
+        cy, cx, r = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(0.04, 0.18) * min(H, W)
+        m = ((yy - cy) ** 2 + (xx - cx) ** 2) < r * r
+        img[m] = rng.uniform([150, 60, 130], [220, 130, 200]) + rng.normal(0, 6, (int(m.sum()), 3))
+    return np.clip(img, 0, 255).astype(np.uint8)

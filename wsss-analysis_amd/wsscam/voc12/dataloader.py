@@ -79,7 +79,7 @@ def msf_pack(img_u8, outsize, norm):
 
 class VOC12ClassificationDatasetMSF:
     def __init__(self, img_name_list_path, dev_root, norm_mode="float", outsize=None, scales=(1.0,),
-                 cls_labels_path=None):
+                 cls_labels_path=None, device_transform=False):
         assert norm_mode in ["float", "int"]
         assert outsize in [(321, 321), (224, 224), None]
         assert tuple(scales) == (1.0,), "multi-scale inference (pil_rescale) is not implemented"
@@ -87,6 +87,9 @@ class VOC12ClassificationDatasetMSF:
         self.dev_root = dev_root
         self.outsize = outsize
         self.norm = TorchvisionNormalize(norm_mode)
+        # device_transform: items carry the decoded image ("img_u8") instead of the float32 pair ("img"); make_cam's
+        # pipeline then runs resize + normalise + flip on the GPU (wsc_msf_input_u8, bit-identical to msf_pack)
+        self.device_transform = device_transform and outsize is not None
         from ..adp.dataloader import find_cls_labels
 
         cls = np.load(find_cls_labels(os.path.join("voc12", "cls_labels.npy"), cls_labels_path),
@@ -101,5 +104,7 @@ class VOC12ClassificationDatasetMSF:
 
         name_str = decode_int_filename(self.img_name_list[idx])
         img = np.asarray(Image.open(get_img_path(name_str, self.dev_root)).convert("RGB"))
+        if self.device_transform:
+            return {"name": name_str, "img_u8": img, "size": (img.shape[0], img.shape[1]), "label": self.label_list[idx]}
         return {"name": name_str, "img": msf_pack(img, self.outsize, self.norm), "size": (img.shape[0], img.shape[1]),
                 "label": self.label_list[idx]}
