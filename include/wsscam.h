@@ -272,6 +272,19 @@ int wsc_msf_input_u8(wsc_ctx *ctx, const uint8_t *images_dev, int B, const int32
 int wsc_bilinear_resize(wsc_ctx *ctx, const float *src_dev, int C, int h, int w, float *dst_dev, int H,
                         int W);
 
+/* ---- cam_to_ir_label (03b_irn/step/cam_to_ir_label.py:26-75) ------------------------------- */
+
+/* labels = np.argmax(np.pad(high_res, ((1,0),(0,0),(0,0)), constant_values=thres), axis=0) and the unary energy of
+ * imutils.crf_inference_label: pydensecrf.utils.unary_from_labels(labels, n_labels = K + 1, gt_prob, zero_unsure=False).
+ *   highres_dev float32 [B][K][N];  unary_dev float32 [B][K+1][N];  labels_dev int32 [B][N] or NULL. */
+int wsc_label_unary_from_cam(wsc_ctx *ctx, const float *highres_dev, int B, int K, int N, float thres, float gt_prob,
+                             float *unary_dev, int32_t *labels_dev);
+/* conf = keys[fg_pred]; with bg_pred_dev (VOC, :54-57): conf[fg_conf == 0] = 255, conf[bg_conf + fg_conf == 0] = 0;
+ * without (ADP / DeepGlobe, keys[0] = -1, :38-40 / :71-73): conf[fg_conf == -1] = 255.
+ *   fg_pred_dev / bg_pred_dev int32 [B][N] (CRF arg-max);  keys_host int32 [B][M];  conf_dev uint8 [B][N]. */
+int wsc_ir_label_combine(wsc_ctx *ctx, const int32_t *fg_pred_dev, const int32_t *bg_pred_dev, const int32_t *keys_host,
+                         int B, int M, int N, uint8_t *conf_dev);
+
 /* ---- HistoSegNet post-processing (03c_hsn/utilities.py:231-397), device resident ---------- */
 
 /* HSN grad_cam after the einsum (utilities.py:262-277), for the NHWC maps of wsc_net_forward_gradcam(relu = 0):

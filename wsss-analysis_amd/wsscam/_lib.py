@@ -97,6 +97,8 @@ _SIGNATURES = {
     "wsc_cam_unary": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     "wsc_msf_input_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "wsc_label_unary_from_cam": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
+    "wsc_ir_label_combine": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "wsc_hsn_gradcam_post": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "wsc_hsn_background": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "wsc_hsn_cs_gradcam": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
@@ -587,3 +589,14 @@ def msf_input_u8(ctx, images_dev, sizes, offsets, S, mean, std, x_dev, pre_div25
     sd = np.ascontiguousarray(std, dtype=np.float32)
     check(ctx._lib.wsc_msf_input_u8(ctx.h, _ptr(images_dev), B, size_hw.ctypes.data, off.ctypes.data, int(S), m.ctypes.data,
                                     sd.ctypes.data, int(bool(pre_div255)), int(bool(pair)), _ptr(x_dev)))
+
+
+def label_unary_from_cam(ctx, highres_dev, B, K, N, thres, gt_prob, unary_dev, labels_dev=None):
+    check(ctx._lib.wsc_label_unary_from_cam(ctx.h, _ptr(highres_dev), B, K, N, float(thres), float(gt_prob), _ptr(unary_dev),
+                                            _ptr(labels_dev)))
+
+
+def ir_label_combine(ctx, fg_pred_dev, bg_pred_dev, keys, N, conf_dev):
+    k = np.ascontiguousarray(keys, dtype=np.int32)
+    B, M = k.shape
+    check(ctx._lib.wsc_ir_label_combine(ctx.h, _ptr(fg_pred_dev), _ptr(bg_pred_dev), k.ctypes.data, B, M, N, _ptr(conf_dev)))

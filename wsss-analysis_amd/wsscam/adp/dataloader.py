@@ -115,3 +115,22 @@ class ADPClassificationDatasetMSF:
         x, orig = msf_item(img, self.outsize, self.norm)
         return {"name": name, "img": x, "orig_img": orig, "size": (img.shape[0], img.shape[1]),
                 "label": self.label_list[idx]}
+
+
+class ADPImageDataset:
+    """adp/dataloader.py:121-180 as cam_to_ir_label uses it (`norm_mode=None, to_torch=False`): {"name", "img": uint8 HWC}."""
+
+    def __init__(self, img_name_list_path, dev_root, htt_type, is_eval, norm_mode=None, to_torch=False, **augment):
+        if any(v for v in augment.values()) or norm_mode is not None or to_torch:
+            raise NotImplementedError("ADPImageDataset: only the plain image reader of the inference steps is provided")
+        self.img_name_list = load_img_name_list(img_name_list_path)
+        self.dev_root, self.htt_type, self.is_eval = dev_root, htt_type, is_eval
+
+    def __len__(self):
+        return len(self.img_name_list)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+
+        name = self.img_name_list[idx]
+        return {"name": name, "img": np.asarray(Image.open(get_img_path(name, self.dev_root, self.is_eval)).convert("RGB"))}

@@ -68,3 +68,24 @@ class DeepGlobeClassificationDatasetMSF:
         x, orig = msf_item(img, self.outsize, self.norm)
         return {"name": name, "img": x, "orig_img": orig, "size": (img.shape[0], img.shape[1]),
                 "label": self.label_list[idx]}
+
+
+class DeepGlobeImageDataset:
+    """deepglobe/dataloader.py:117-176 as cam_to_ir_label uses it (`norm_mode=None, to_torch=False`): {"name", "img": uint8 HWC}."""
+
+    def __init__(self, img_name_list_path, dev_root, is_balanced, norm_mode=None, to_torch=False, **augment):
+        if any(v for v in augment.values()) or norm_mode is not None or to_torch:
+            raise NotImplementedError("DeepGlobeImageDataset: only the plain image reader of the inference steps is provided")
+        from ..adp.dataloader import load_img_name_list
+
+        self.img_name_list = load_img_name_list(img_name_list_path)
+        self.dev_root, self.is_balanced = dev_root, is_balanced
+
+    def __len__(self):
+        return len(self.img_name_list)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+
+        name = self.img_name_list[idx]
+        return {"name": name, "img": np.asarray(Image.open(get_img_path(name, self.dev_root)).convert("RGB"))}

@@ -108,3 +108,24 @@ class VOC12ClassificationDatasetMSF:
             return {"name": name_str, "img_u8": img, "size": (img.shape[0], img.shape[1]), "label": self.label_list[idx]}
         return {"name": name_str, "img": msf_pack(img, self.outsize, self.norm), "size": (img.shape[0], img.shape[1]),
                 "label": self.label_list[idx]}
+
+
+class VOC12ImageDataset:
+    """voc12/dataloader.py:137-190 as cam_to_ir_label uses it (`norm_mode=None, to_torch=False`, cam_to_ir_label.py:100-101):
+    items {"name", "img": uint8 HWC}.  The training-time augmentations of the class (resize_long, rescale, crops, flips)
+    belong to train_cam / train_irn, which are out of scope."""
+
+    def __init__(self, img_name_list_path, dev_root, norm_mode=None, to_torch=False, **augment):
+        if any(v for v in augment.values()) or norm_mode is not None or to_torch:
+            raise NotImplementedError("VOC12ImageDataset: only the plain image reader of the inference steps is provided")
+        self.img_name_list = load_img_name_list(img_name_list_path)
+        self.dev_root = dev_root
+
+    def __len__(self):
+        return len(self.img_name_list)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+
+        name_str = decode_int_filename(self.img_name_list[idx])
+        return {"name": name_str, "img": np.asarray(Image.open(get_img_path(name_str, self.dev_root)).convert("RGB"))}
