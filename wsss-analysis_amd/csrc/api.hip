@@ -217,6 +217,12 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_ev) (void)hipEventDestroy(ctx->pinned_ev);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    if (ctx->aux_done_ev) (void)hipEventDestroy(ctx->aux_done_ev);
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+    }
     for (auto &r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

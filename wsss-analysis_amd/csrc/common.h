@@ -141,6 +141,10 @@ struct wsc_ctx {
     bool pinned_busy = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t join_ev = nullptr; // wsc_ctx_wait
+    // side stream for work that is independent inside one call (crf.hip: the bilateral lattice's combine + blur passes run
+    // beside the Gaussian lattice's fused blur); forked from / joined into `stream` with the two events
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t fork_ev = nullptr, aux_done_ev = nullptr;
     bool profiling = false;
     std::vector<WscProfRecord> prof;
     std::vector<hipEvent_t> prof_pool;

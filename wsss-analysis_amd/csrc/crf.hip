@@ -1041,7 +1041,10 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
     // part != null: the input rows are not in memory yet -- every box point sums its row from the slot partials
     // of the splat (combine_slots4, consecutive partial rows) while loading; `in` is unused
     constexpr int P = GBI * GBJ; // one thread per point of the halo box
-    __shared__ f32x4_t b0[LH * P], b1[LH * P];
+    // plane stride P + 1: the row-wise load / store phases address (point, float4) with the float4 index fastest, and a
+    // stride of exactly P float4s (4096 B) would put a row's LH float4s on one bank
+    constexpr int PS = P + 1;
+    __shared__ f32x4_t b0[LH * PS], b1[LH * PS];
     // XCD-contiguous logical block id: neighbouring tiles of one replica (which share halo rows) on one L2
     const int nb = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qq = nb >> 3, rr = nb & 7;
@@ -1102,7 +1105,7 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
                 const int idx = i * P + p, pp = idx / LH, ll = idx - pp * LH;
                 if (part && pse[i] - psb[i] > 1 && lbase + ll < LP)
                     v[i] = combine_slots4<true>(part, psb[i], pse[i], (unsigned)LP, (unsigned)(lbase + ll));
-                b0[ll * P + pp] = v[i];
+                b0[ll * PS + pp] = v[i];
             }
         }
         __syncthreads();
@@ -1111,11 +1114,11 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
         for (int l = 0; l < LH; ++l) {
             f32x4_t o = zero;
             if (r0) {
-                const f32x4_t c = b0[l * P + p], a = b0[l * P + p + GBJ], b = b0[l * P + p - GBJ];
+                const f32x4_t c = b0[l * PS + p], a = b0[l * PS + p + GBJ], b = b0[l * PS + p - GBJ];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
             }
-            b1[l * P + p] = o;
+            b1[l * PS + p] = o;
         }
         __syncthreads();
         // pass 1, axis 1: (i, j +- 1) = p +- 1
@@ -1123,29 +1126,29 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
         for (int l = 0; l < LH; ++l) {
             f32x4_t o = zero;
             if (r1) {
-                const f32x4_t c = b1[l * P + p], a = b1[l * P + p - 1], b = b1[l * P + p + 1];
+                const f32x4_t c = b1[l * PS + p], a = b1[l * PS + p - 1], b = b1[l * PS + p + 1];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
             }
-            b0[l * P + p] = o;
+            b0[l * PS + p] = o;
         }
         __syncthreads();
         // pass 2, axis 2: (i -+ 1, j -+ 1) = p -+ (GBJ + 1); interior only; through b1 to the row-wise store
         if (r2) {
 #pragma unroll
             for (int l = 0; l < LH; ++l) {
-                const f32x4_t c = b0[l * P + p], a = b0[l * P + p - GBJ - 1], b = b0[l * P + p + GBJ + 1];
+                const f32x4_t c = b0[l * PS + p], a = b0[l * PS + p - GBJ - 1], b = b0[l * PS + p + GBJ + 1];
                 f32x4_t o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = c[q] + 0.5f * (a[q] + b[q]);
-                b1[l * P + p] = o;
+                b1[l * PS + p] = o;
             }
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < LH; ++i) {
             const int idx = i * P + p, pp = idx / LH, ll = idx - pp * LH;
-            if (prow[i] > 0 && lbase + ll < LP) out[(unsigned)prow[i] * (unsigned)LP + lbase + ll] = b1[ll * P + pp];
+            if (prow[i] > 0 && lbase + ll < LP) out[(unsigned)prow[i] * (unsigned)LP + lbase + ll] = b1[ll * PS + pp];
         }
     }
 }
@@ -1935,6 +1938,13 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
         hipLaunchKernelGGL(init_q_kernel, tgrid, dim3(TP), 2 * (size_t)M * (TP + 1) * sizeof(float), ctx->stream,
                            unary_dev, M, Mp, N, u, n_iters == 0 ? q : (float *)nullptr);
     }
+    const char *nf = getenv("WSC_CRF_NO_FORK");
+    const bool no_fork = (nf && atoi(nf) != 0) || ctx->profiling; // per-kernel timing wants the launches one after the other
+    if (!no_fork && !ctx->aux_stream) {
+        WSC_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        WSC_HIP(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+        WSC_HIP(hipEventCreateWithFlags(&ctx->aux_done_ev, hipEventDisableTiming));
+    }
     UpdateArgs a;
     a.pix_rec = crf->pix_rec; a.val_g = nullptr; a.val_b = nullptr;
     a.u = u; a.q = nullptr;
@@ -1953,8 +1963,22 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
         a.q = last ? q : nullptr;
         WSC_TRY(launch_update(ctx, a, it > 0, !last));
         if (last) break;
-        a.val_g = combine_blur_all4(ctx, G, LP, partg, vg0, vg1);
+        // The two lattices are independent until the next update: the bilateral one (seven short launches on ~1 MB per
+        // image) runs on the ctx's side stream beside the Gaussian lattice's fused blur.
+        const bool fork = !no_fork;
+        hipStream_t main_stream = ctx->stream;
+        if (fork) {
+            WSC_HIP(hipEventRecord(ctx->fork_ev, main_stream));
+            WSC_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->fork_ev, 0));
+            ctx->stream = ctx->aux_stream; // launches and timers of the bilateral path go to the side stream
+        }
         a.val_b = combine_blur_all4(ctx, Bl, LP, partb, vb0, vb1);
+        if (fork) {
+            WSC_HIP(hipEventRecord(ctx->aux_done_ev, ctx->aux_stream));
+            ctx->stream = main_stream;
+        }
+        a.val_g = combine_blur_all4(ctx, G, LP, partg, vg0, vg1);
+        if (fork) WSC_HIP(hipStreamWaitEvent(main_stream, ctx->aux_done_ev, 0));
     }
     {
         WscKernelTimer ftimer(ctx, WSC_K_CRF_MISC, (double)npix * M * 8);
