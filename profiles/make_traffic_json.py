@@ -12,10 +12,11 @@ import sys
 from collections import defaultdict
 
 CLASSES = {  # bench.py kernel-class label -> (kernel-name substrings, substring whose dispatches count as launches)
-    "splat4+combine": (("splat4_kernel", "splat_combine_kernel"), "splat4_kernel"),
-    "blur4+blur3_tile": (("blur4_kernel", "blur3_tile_kernel"), ("blur4_kernel", "blur3_tile_kernel")),
+    "update_splat_kernel": (("update_splat_kernel",), "update_splat_kernel"),
+    "combine4+blur4+blur3_tile": (("combine4_kernel", "blur4_kernel", "blur3_tile_kernel"),
+                                  ("combine4_kernel", "blur4_kernel", "blur3_tile_kernel")),
     "blur3_tile_kernel": (("blur3_tile_kernel",), "blur3_tile_kernel"),
-    "slice_update_kernel": (("slice_update_kernel",), "slice_update_kernel"),
+    "update_splat_kernel<true, true>": (("update_splat_kernel<true, true>",), "update_splat_kernel<true, true>"),
 }
 
 
@@ -30,11 +31,14 @@ def per_kernel(db, counter):
     return tot, {k: len(v) for k, v in disp.items()}
 
 
+ROUND = "r02"
+
+
 def main(fetch_db, write_db):
     f, fd = per_kernel(fetch_db, "FETCH_SIZE")
     w, wd = per_kernel(write_db, "WRITE_SIZE")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 "
-                     "--no-cpu-baseline --no-pipeline; FETCH_SIZE doubled (gfx950 correction)", "classes": {}}
+                     "--no-cpu-baseline --no-pipeline --quick; FETCH_SIZE doubled (gfx950 correction)", "round": ROUND, "classes": {}}
     for label, (subs, launch_sub) in CLASSES.items():
         fb = sum(v for k, v in f.items() if any(s in k for s in subs)) * 1024.0 * 2.0
         wb = sum(v for k, v in w.items() if any(s in k for s in subs)) * 1024.0
@@ -44,7 +48,7 @@ def main(fetch_db, write_db):
         if nf == 0 or nw == 0:
             continue
         out["classes"][label] = {"read_bytes_per_launch": round(fb / nf), "write_bytes_per_launch": round(wb / nw),
-                                 "bytes_per_launch": round(fb / nf + wb / nw), "launches_profiled": nf}
+                                 "bytes_per_launch": round(fb / nf + wb / nw), "launches_profiled": nf, "round": ROUND}
     json.dump(out, sys.stdout, indent=1)
     print()
 

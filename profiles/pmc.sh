@@ -1,5 +1,5 @@
 #!/bin/bash
-# bash scratch/pmc.sh <tag> "<counters>" "<kernel regex>" [bench args]
+# bash profiles/pmc.sh <tag> "<counters>" "<kernel regex>" [bench args]
 tag=$1; C=$2; RX=$3; shift 3
 out=gpurun_out
 mkdir -p $out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick per-kernel stats of the bench: bash scratch/prof_stats.sh <tag> [bench args]
+# quick per-kernel stats of the bench: bash profiles/prof_stats.sh <tag> [bench args]
 tag=$1; shift
 out=gpurun_out
 mkdir -p $out
