@@ -158,25 +158,47 @@ __global__ void unary_from_maps_kernel(const float *__restrict__ maps, float bg,
 // recomputes the C bilinear samples from the image's C source maps in LDS (C*h*w floats), divides by
 // (max + 1e-5), and applies the unary formula.  Same float operations in the same order as the two-step
 // path (cam_tail_kernel<true> then unary_from_maps_kernel), so the results are bit-identical.
-__global__ __launch_bounds__(256) void cam_max_kernel(const float *__restrict__ cam, int C, int h, int w, int H0, int W0,
-                                                      int Hu, int Wu, unsigned int *__restrict__ mx) {
-    extern __shared__ float src[]; // h*w
-    const int bc = blockIdx.y;     // b*C + c
+__global__ __launch_bounds__(1024) void cam_max_kernel(const float *__restrict__ cam, int C, int h, int w, int H0, int W0,
+                                                       int Hu, int Wu, unsigned int *__restrict__ mx) {
+    // One block per (image, class), a thread per output COLUMN: the column's source taps are computed once, the row's
+    // taps are uniform over the block, and a sample costs four LDS reads + bilerp -- the per-sample index arithmetic (a
+    // division and two src_index calls) made the first version instruction-bound at 190-360 us for 640 maps at 321 x 321.
+    // bilerp gets the same operands as in cam_unary_kernel: the maximum is the maximum of exactly the values written there.
+    extern __shared__ float src[]; // h*w, then 16 wave maxima, then the row taps {y0*w, y1*w, ly0, ly1} of every output row
+    const int bc = blockIdx.x;     // b*C + c
+    float4 *rows = reinterpret_cast<float4 *>(src + ((h * w + 16 + 3) & ~3));
     for (int i = threadIdx.x; i < h * w; i += blockDim.x) src[i] = cam[(long long)bc * h * w + i];
-    __syncthreads();
     const float sh = (float)h / (float)Hu, sw = (float)w / (float)Wu;
-    const int n = H0 * W0;
-    float m = -3.0e38f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int yy = i / W0, xx = i - yy * W0;
-        int y0, y1, x0, x1;
-        float ly0, ly1, lx0, lx1;
+    for (int yy = threadIdx.x; yy < H0; yy += blockDim.x) {
+        int y0, y1;
+        float ly0, ly1;
         src_index(yy, sh, h, y0, y1, ly0, ly1);
+        rows[yy] = make_float4(__int_as_float(y0 * w), __int_as_float(y1 * w), ly0, ly1);
+    }
+    __syncthreads();
+    float m = -3.0e38f;
+    for (int xx = threadIdx.x; xx < W0; xx += blockDim.x) {
+        int x0, x1;
+        float lx0, lx1;
         src_index(xx, sw, w, x0, x1, lx0, lx1);
-        m = fmaxf(m, bilerp(src, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1));
+#pragma unroll 4
+        for (int yy = 0; yy < H0; ++yy) {
+            const float4 r = rows[yy]; // uniform over the block
+            // bilerp(src, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1) with the row offsets taken from the table
+            const float *r0 = src + __float_as_int(r.x), *r1 = src + __float_as_int(r.y);
+            const float top = __builtin_fmaf(lx0, r0[x0], lx1 * r0[x1]);
+            const float bot = __builtin_fmaf(lx0, r1[x0], lx1 * r1[x1]);
+            m = fmaxf(m, __builtin_fmaf(r.z, top, r.w * bot));
+        }
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > -3.0e38f) atomicMax(&mx[bc], ord_enc(m));
+    float *wm = src + h * w;
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, wm[i]);
+        mx[bc] = m > -3.0e38f ? ord_enc(m) : 0u;
+    }
 }
 
 template <int CMAX>
@@ -350,8 +372,8 @@ int wsc_cam_unary(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w
     WSC_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned int) * (size_t)B * C, ctx->stream));
     const int n = H0 * W0;
     WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, (double)B * (C + 1) * n * 4);
-    hipLaunchKernelGGL(cam_max_kernel, dim3((unsigned)std::min((n + 255) / 256, 64), (unsigned)(B * C)), dim3(256),
-                       (size_t)h * w * sizeof(float), ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu, mx);
+    hipLaunchKernelGGL(cam_max_kernel, dim3((unsigned)(B * C)), dim3((unsigned)std::min(1024, (W0 + 63) / 64 * 64)),
+                       ((size_t)h * w + 20 + 4 * (size_t)H0) * sizeof(float), ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu, mx);
     // each block re-reads its image's C source maps (35 KB for 20 x 21 x 21): a few pixels per thread amortise that
     const dim3 ugrid((unsigned)std::min((n + 1023) / 1024, 512), (unsigned)B);
     if (C <= 20)

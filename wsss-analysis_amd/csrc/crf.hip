@@ -1206,6 +1206,12 @@ struct UpdateArgs {
     SplatTab sg, sb;
 };
 
+// load through a uniform base + 32-bit byte offset: the compiler can use the SGPR-base addressing form and the
+// per-lane address arithmetic stays 32-bit (the 64-bit pointer adds were a fifth of the update loop's VALU work)
+template <class T>
+__device__ __forceinline__ T ld_off(const void *base, unsigned byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
 constexpr int GATHER_SB = 256; // slot descriptors staged per batch
 constexpr int GATHER_ENT = TILE_PIX * 6;
 
@@ -1308,9 +1314,9 @@ __global__ __launch_bounds__(512) void update_splat_kernel(UpdateArgs a) {
         const unsigned p = pixel_of((int)(threadIdx.x >> 6) * gpw);
         if (SLICE) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) rq[i] = a.pix_rec[p * 5u + i];
+            for (int i = 0; i < 5; ++i) rq[i] = ld_off<uint4>(a.pix_rec, p * 80u + 16u * i);
         }
-        un = u4[p * (unsigned)LP + l];
+        un = ld_off<f32x4_t>(u4, (p * (unsigned)LP + l) * 16u);
     }
     for (int t0 = (int)(threadIdx.x >> 6) * gpw; t0 < np; t0 += ppt) {
         const int t = t0 + g;
@@ -1324,9 +1330,9 @@ __global__ __launch_bounds__(512) void update_splat_kernel(UpdateArgs a) {
             const unsigned pn = pixel_of(t0 + ppt);
             if (SLICE) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) rqn[i] = a.pix_rec[pn * 5u + i];
+                for (int i = 0; i < 5; ++i) rqn[i] = ld_off<uint4>(a.pix_rec, pn * 80u + 16u * i);
             }
-            unn = u4[pn * (unsigned)LP + l];
+            unn = ld_off<f32x4_t>(u4, (pn * (unsigned)LP + l) * 16u);
         }
         // E = -U + sum_r (compat * alpha * norm * bary_r) * row_r : nine packed FMAs per class pair (this kernel is
         // bound by VALU issue, not by memory: the weights are formed once per pixel and the row sums run as
@@ -1341,9 +1347,9 @@ __global__ __launch_bounds__(512) void update_splat_kernel(UpdateArgs a) {
             }
             f32x4_t vg[3], vb[6];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) vg[r] = vg4[(rc[r] + gofs) * (unsigned)LP + l];
+            for (int r = 0; r < 3; ++r) vg[r] = ld_off<f32x4_t>(vg4, ((rc[r] + gofs) * (unsigned)LP + l) * 16u);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) vb[r] = vb4[rc[3 + r] * (unsigned)LP + l];
+            for (int r = 0; r < 6; ++r) vb[r] = ld_off<f32x4_t>(vb4, (rc[3 + r] * (unsigned)LP + l) * 16u);
             const float wg = (a.compat_g * a.alpha_g) * __uint_as_float(rc[18]);
             const float wb = (a.compat_b * a.alpha_b) * __uint_as_float(rc[19]);
 #pragma unroll
@@ -1911,9 +1917,10 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     const LatticeDev &G = crf->lat[0], &Bl = crf->lat[1];
     const int LP = (M + 3) / 4, Mp = 4 * LP; // rows padded to 16-byte multiples
     const long long g_rows = (long long)G.rows * G.rep, g_slots = (long long)G.n_slots * G.rep;
-    WSC_CHECK(npix * Mp < (1ll << 31) && g_rows * Mp < (1ll << 31) && (long long)Bl.rows * Mp < (1ll << 31) &&
-                  g_slots * Mp < (1ll << 31) && (long long)Bl.n_slots * Mp < (1ll << 31),
-              WSC_ERR_CAPACITY, "CRF batch too large for 32-bit element indices (B*N*Mp = %lld)", npix * Mp);
+    // the iteration kernels address with 32-bit BYTE offsets: every array below 4 GiB
+    WSC_CHECK(npix * Mp < (1ll << 30) && g_rows * Mp < (1ll << 30) && (long long)Bl.rows * Mp < (1ll << 30) &&
+                  g_slots * Mp < (1ll << 30) && (long long)Bl.n_slots * Mp < (1ll << 30) && npix * 80 < (1ll << 32),
+              WSC_ERR_CAPACITY, "CRF batch too large for 32-bit byte offsets (B*N*Mp = %lld elements; split the batch)", npix * Mp);
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t qb = al(sizeof(float) * npix * Mp);
     const size_t vg = al(sizeof(float) * (size_t)g_rows * Mp), vb = al(sizeof(float) * (size_t)Bl.rows * Mp);
