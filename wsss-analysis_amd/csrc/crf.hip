@@ -277,16 +277,11 @@ struct EmbedArgs {
     int *err;        // key range error flag
 };
 
-// Step 1 of the lattice build: elevate every pixel's feature vector, find its simplex and
-// barycentric weights (exactly as Permutohedral::init does), insert the d+1 vertex keys
-// into the image's hash table.
+// Elevate a pixel's feature vector, find its simplex and barycentric weights (exactly as Permutohedral::init does):
+// the d+1 packed vertex keys and weights of pixel gp = (x, y).  Returns false when a key leaves the packed range.
 template <int D>
-__global__ __launch_bounds__(256) void lattice_embed_kernel(EmbedArgs a) {
-    const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x; // global pixel
-    if (gp >= (long long)a.B * a.N) return;
-    const int b = (int)(gp / a.N);
-    const int n = (int)(gp - (long long)b * a.N);
-    const int y = n / a.W, x = n - y * a.W;
+__device__ __forceinline__ bool embed_pixel(const EmbedArgs &a, long long gp, int x, int y, unsigned long long *pk_out,
+                                            float *bary_out) {
 
     float f[D];
     f[0] = (float)x / a.inv_sxy_den;
@@ -359,9 +354,7 @@ __global__ __launch_bounds__(256) void lattice_embed_kernel(EmbedArgs a) {
     }
     bary[0] = (float)((double)bary[0] + (1.0 + (double)bary[D + 1]));
 
-    unsigned long long *table = a.table + (long long)b * a.cap;
-    int32_t *first = a.first + (long long)b * a.cap;
-    const long long e0 = gp * (D + 1);
+    bool ok = true;
 #pragma unroll
     for (int r = 0; r <= D; ++r) {
         int key[D];
@@ -371,29 +364,10 @@ __global__ __launch_bounds__(256) void lattice_embed_kernel(EmbedArgs a) {
             const int can = rank[i] <= D - r ? r : r - (D + 1);
             key[i] = (int)(short)(rem0[i] + (float)can);
         }
-        unsigned long long pk;
-        if (!pack_key<D>(key, pk)) atomicOr(a.err, 1);
-        int slot;
-        if (true) {
-            // lanes = consecutive pixels: the group leader (lowest lane = lowest pixel) inserts for all
-            const unsigned long long grp = wave_match(pk, b);
-            const int leader = __ffsll((long long)grp) - 1;
-            slot = 0;
-            if (lane_id() == leader) {
-                slot = hash_insert(table, a.cap_mask, pk);
-                if (slot >= 0) atomicMin(&first[slot], n * (D + 1) + r);
-                else atomicOr(a.err, 2); // table too small
-            }
-            slot = __shfl(slot, leader, 64);
-        } else {
-            slot = hash_insert(table, a.cap_mask, pk);
-            if (slot >= 0) atomicMin(&first[slot], n * (D + 1) + r);
-            else atomicOr(a.err, 2);
-        }
-        if (slot < 0) slot = 0; // keeps the bookkeeping kernels in range; the build is discarded
-        a.eslot[e0 + r] = slot;
-        a.bary[e0 + r] = bary[r];
+        ok = pack_key<D>(key, pk_out[r]) && ok;
+        bary_out[r] = bary[r];
     }
+    return ok;
 }
 
 // flag[e] = 1 if entry e is the first (raster order) toucher of its vertex
@@ -567,21 +541,27 @@ __device__ __forceinline__ void tile_slot_flags(const int *srow, int ne, int *au
     block_scan_lds<false>(aux, ne, wtot);
 }
 
-// Pass 1, one block per tile: bring the tile's entries (pixel t of the tile, vertex rank r; index e = t*(d+1)+r) into
-// groups of equal lattice row, keeping the entries of a group in index order, and write them out tile-major.  That
-// makes the summation order of every slot a function of the image alone -- not of the batch it is in, nor of an
-// atomic's arrival order.  (The ORDER OF THE GROUPS within the tile is that of an LDS hash table and may differ from
-// run to run: it only decides where a slot's partial row lives, never a value.)
-//   A  rows -> slots of an LDS hash table (compare-and-swap insert);   B  stable rank of every entry inside its group:
-//   wave q walks the q-th quarter of the index range in order, 64 entries at a time -- equal slots are matched with
-//   ballots, the running per-(wave, slot) count gives the rank within the quarter;   C  group sizes, scan -> group
-//   starts; position = start + entries of the group in earlier quarters + rank.
-constexpr int GROUP_HT = SORT_MAX; // hash slots (load <= 0.75 even when every entry has its own row)
-__global__ __launch_bounds__(256) void tile_group_kernel(const int32_t *__restrict__ offset, const float *__restrict__ bary,
-                                                         int dp1, TileGeom tg, uint2 *__restrict__ tent,
-                                                         int32_t *__restrict__ srow_out, unsigned *__restrict__ tile_nslots) {
-    __shared__ unsigned table[GROUP_HT];
-    __shared__ int start[GROUP_HT];          // group size, then group start
+// Pass 1 of the lattice build, one block per pixel tile (one thread per pixel): embed the tile's pixels, bring their
+// d+1 entries each (pixel t of the tile, vertex rank r; index e = t*(d+1)+r) into groups of equal lattice vertex, keeping
+// the entries of a group in index order, write them out tile-major, and insert every DISTINCT vertex of the tile into
+// the image's global hash table once (a 16 x 16 tile touches ~120 bilateral vertices with its 1536 entries: 13x fewer
+// global compare-and-swaps / atomicMins than one per entry).  The index order inside a group makes the summation
+// order of every splat slot a function of the image alone -- not of the batch it is in, nor of an atomic's arrival
+// order.  (The ORDER OF THE GROUPS within the tile is that of an LDS hash table and may differ from run to run: it only
+// decides where a slot's partial row lives, never a value.)
+//   A  keys -> slots of an LDS hash table (64-bit compare-and-swap), per slot the smallest global entry index
+//   B  stable rank of every entry inside its group: wave q walks the q-th quarter of the index range in order, 64
+//      entries at a time -- equal slots are matched with ballots, the running per-(wave, slot) count gives the rank
+//   C  per occupied slot: group size; global insert + atomicMin of the first-touch index (vertex ids are assigned in
+//      first-touch raster order, the CPU reference's insertion order)
+//   D  scan -> group starts; position = start + entries of the group in earlier quarters + rank
+constexpr int GROUP_HT = SORT_MAX; // hash slots (load <= 0.75 even when every entry has its own vertex)
+template <int D>
+__global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom tg, uint2 *__restrict__ tent,
+                                                         int32_t *__restrict__ sslot_out, unsigned *__restrict__ tile_nslots) {
+    constexpr int dp1 = D + 1;
+    __shared__ unsigned long long table[GROUP_HT]; // vertex key, later the vertex's global hash slot
+    __shared__ int start[GROUP_HT];                // first-touch entry index, then group size, then group start
     __shared__ unsigned short wcnt[4][GROUP_HT];
     __shared__ unsigned short eslot[SORT_MAX], erank[SORT_MAX];
     __shared__ int wtot[4];
@@ -591,32 +571,42 @@ __global__ __launch_bounds__(256) void tile_group_kernel(const int32_t *__restri
     const int N = tg.H * tg.W;
     const int np = tb.cw * tb.ch, ne = np * dp1;
     for (int i = threadIdx.x; i < GROUP_HT; i += 256) {
-        table[i] = 0xFFFFFFFFu;
+        table[i] = EMPTY_KEY;
+        start[i] = 0x7fffffff;
         wcnt[0][i] = 0; wcnt[1][i] = 0; wcnt[2][i] = 0; wcnt[3][i] = 0;
     }
     __syncthreads();
-    const long long pbase = (long long)b * N;
-    for (int e = threadIdx.x; e < ne; e += 256) {
-        const int t = e / dp1, r = e - t * dp1;
-        const int ty = t / tb.cw, tx = t - ty * tb.cw;
-        const long long p = pbase + (long long)(tb.y0 + ty) * tg.W + tb.x0 + tx;
-        const unsigned row = (unsigned)offset[p * dp1 + r];
-        unsigned sl = (row * 2654435761u) >> 21 & (GROUP_HT - 1);
-        for (;;) {
-            const unsigned old = atomicCAS(&table[sl], 0xFFFFFFFFu, row);
-            if (old == 0xFFFFFFFFu || old == row) break;
-            sl = (sl + 1) & (GROUP_HT - 1);
+    // ---- A: this thread's pixel
+    const int t = threadIdx.x;
+    const bool have = t < np;
+    const int ty = have ? t / tb.cw : 0, tx = have ? t - ty * tb.cw : 0;
+    const int y = tb.y0 + ty, x = tb.x0 + tx;
+    const int n = y * tg.W + x;
+    const long long gp = (long long)b * N + n;
+    unsigned long long pk[dp1];
+    float bary[dp1];
+    if (have) {
+        if (!embed_pixel<D>(a, gp, x, y, pk, bary)) atomicOr(a.err, 1);
+#pragma unroll
+        for (int r = 0; r < dp1; ++r) {
+            unsigned sl = (unsigned)(mix64(pk[r]) >> 40) & (GROUP_HT - 1);
+            for (;;) {
+                const unsigned long long old = atomicCAS(&table[sl], EMPTY_KEY, pk[r]);
+                if (old == EMPTY_KEY || old == pk[r]) break;
+                sl = (sl + 1) & (GROUP_HT - 1);
+            }
+            eslot[t * dp1 + r] = (unsigned short)sl;
+            atomicMin(&start[sl], n * dp1 + r);
         }
-        eslot[e] = (unsigned short)sl;
     }
     __syncthreads();
+    // ---- B: stable ranks
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int Q = ((ne + 3) / 4 + 63) / 64 * 64; // entries per quarter, whole wave trips
     for (int c = q * Q; c < min(ne, (q + 1) * Q); c += 64) {
         const int e = c + lane;
         const bool valid = e < ne;
         const unsigned sl = valid ? eslot[e] : 0u;
-        // match equal slots among the valid lanes
         unsigned long long remaining = __ballot(valid);
         unsigned long long mine = 0;
         while (remaining) {
@@ -638,10 +628,22 @@ __global__ __launch_bounds__(256) void tile_group_kernel(const int32_t *__restri
         }
     }
     __syncthreads();
+    // ---- C: groups -> global table
+    unsigned long long *gtable = a.table + (long long)b * a.cap;
+    int32_t *gfirst = a.first + (long long)b * a.cap;
     int my_slots = 0;
     for (int i = threadIdx.x; i < GROUP_HT; i += 256) {
         const int c0 = wcnt[0][i], c1 = wcnt[1][i], c2 = wcnt[2][i], c3 = wcnt[3][i];
         const int tot = c0 + c1 + c2 + c3;
+        if (tot > 0) {
+            int gs = hash_insert(gtable, a.cap_mask, table[i]);
+            if (gs >= 0) atomicMin(&gfirst[gs], start[i]);
+            else {
+                atomicOr(a.err, 2); // table too small: the build is repeated with the worst-case size
+                gs = 0;
+            }
+            table[i] = (unsigned long long)(unsigned)gs;
+        }
         start[i] = tot;
         wcnt[0][i] = 0;
         wcnt[1][i] = (unsigned short)c0;
@@ -655,24 +657,28 @@ __global__ __launch_bounds__(256) void tile_group_kernel(const int32_t *__restri
     __syncthreads();
     if (threadIdx.x == 0) tile_nslots[tile] = (unsigned)(wtot[0] + wtot[1] + wtot[2] + wtot[3]);
     __syncthreads();
+    // ---- D: positions
     block_scan_lds<false>(start, GROUP_HT, wtot); // inclusive
-    const long long ebase = (pbase + tb.ebase) * dp1;
-    for (int e = threadIdx.x; e < ne; e += 256) {
-        const int sl = eslot[e];
-        const int qq = e / Q;
-        const int cnt = (int)wcnt[qq][sl];
-        const int prev = sl > 0 ? start[sl - 1] : 0; // exclusive start of the group
-        const int pos = prev + cnt + (int)erank[e];
-        const int t = e / dp1, r = e - t * dp1;
-        const int ty = t / tb.cw, tx = t - ty * tb.cw;
-        const long long p = pbase + (long long)(tb.y0 + ty) * tg.W + tb.x0 + tx;
-        srow_out[ebase + pos] = (int32_t)table[sl];
-        tent[ebase + pos] = make_uint2((unsigned)t, __float_as_uint(bary[p * dp1 + r]));
+    if (have) {
+        const long long ebase = ((long long)b * N + tb.ebase) * dp1;
+#pragma unroll
+        for (int r = 0; r < dp1; ++r) {
+            const int e = t * dp1 + r;
+            const int sl = eslot[e];
+            const int prev = sl > 0 ? start[sl - 1] : 0; // exclusive start of the group
+            const int pos = prev + (int)wcnt[e / Q][sl] + (int)erank[e];
+            const int gs = (int)(unsigned)table[sl];
+            tent[ebase + pos] = make_uint2((unsigned)t, __float_as_uint(bary[r]));
+            sslot_out[ebase + pos] = gs;
+            a.eslot[gp * dp1 + r] = gs;
+            a.bary[gp * dp1 + r] = bary[r];
+        }
     }
 }
 
 // Pass 2, one block per tile: slot descriptors at their final (compact) index; slots per row counted.
-__global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restrict__ srow_in, int dp1, TileGeom tg,
+__global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restrict__ sslot_in, const int32_t *__restrict__ slot2row,
+                                                         long long cap, int dp1, TileGeom tg,
                                                          const int32_t *__restrict__ tslot_start, int2 *__restrict__ slot_desc,
                                                          int32_t *__restrict__ slot_row, unsigned *__restrict__ slot_key,
                                                          unsigned *__restrict__ row_nslots) {
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restri
     const int N = tg.H * tg.W;
     const int ne = tb.cw * tb.ch * dp1;
     const long long ebase = ((long long)b * N + tb.ebase) * dp1;
-    for (int i = threadIdx.x; i < ne; i += 256) rows_s[i] = srow_in[ebase + i];
+    for (int i = threadIdx.x; i < ne; i += 256) rows_s[i] = slot2row[(long long)b * cap + sslot_in[ebase + i]];
     __syncthreads();
     tile_slot_flags(rows_s, ne, aux, flag, seg, wtot);
     const int ns = aux[ne - 1];
@@ -1653,7 +1659,14 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     }
     ea.table = table; ea.cap_mask = (unsigned)(cap - 1); ea.cap = cap;
     ea.eslot = eslot; ea.bary = L.bary; ea.first = first; ea.err = err;
-    hipLaunchKernelGGL(lattice_embed_kernel<D>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ea);
+    const TileGeom tg = make_geom(crf->H, crf->W);
+    L.n_tiles = B * tg.tpi;
+    int32_t *sslot;
+    unsigned *tile_nslots;
+    WSC_TRY(tmp.alloc(sizeof(int32_t) * total, (void **)&sslot));
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.n_tiles + 1), (void **)&tile_nslots));
+    WSC_HIP(hipMemsetAsync(tile_nslots, 0, sizeof(unsigned) * (L.n_tiles + 1), ctx->stream));
+    hipLaunchKernelGGL(tile_embed_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent, sslot, tile_nslots);
     hipLaunchKernelGGL(flag_first_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, first, cap, N, dp1,
                        total, flag);
     WSC_TRY(exclusive_scan(ctx, flag, total, prefix, sums));
@@ -1689,25 +1702,18 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
                        cap, N, dp1, total, slot2row, rowkey, rowimg);
     hipLaunchKernelGGL(remap_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, slot2row, cap, N, dp1, total,
                        L.offset);
-    {   // splat tables: entries sorted per pixel tile, slots, slots of each row
-        const TileGeom tg = make_geom(crf->H, crf->W);
-        L.n_tiles = B * tg.tpi;
-        int32_t *srow, *slot_row;
-        unsigned *tile_nslots, *sums2, *row_nslots, *cursor, *sums3;
+    {   // splat tables: slots of the grouped tile entries, partial rows of each lattice row
+        int32_t *slot_row;
+        unsigned *sums2, *row_nslots, *cursor, *sums3;
         const int nb2 = (L.n_tiles + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK, nb3 = (L.rows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        WSC_TRY(tmp.alloc(sizeof(int32_t) * total, (void **)&srow));
-        WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.n_tiles + 1), (void **)&tile_nslots));
         WSC_TRY(tmp.alloc(sizeof(unsigned) * (nb2 + 2), (void **)&sums2));
         WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&row_nslots));
         WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&cursor));
         WSC_TRY(tmp.alloc(sizeof(unsigned) * (nb3 + 2), (void **)&sums3));
         WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (L.n_tiles + 2), (void **)&L.tslot_start));
         WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (L.rows + 2), (void **)&L.row_slot_start));
-        WSC_HIP(hipMemsetAsync(tile_nslots, 0, sizeof(unsigned) * (L.n_tiles + 1), ctx->stream));
         WSC_HIP(hipMemsetAsync(row_nslots, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
         WSC_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
-        hipLaunchKernelGGL(tile_group_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1, tg,
-                           L.tent, srow, tile_nslots);
         WSC_TRY(exclusive_scan(ctx, tile_nslots, L.n_tiles + 1, (unsigned *)L.tslot_start, sums2));
         unsigned ns = 0;
         WSC_HIP(hipMemcpyAsync(&ns, sums2 + nb2, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
@@ -1721,7 +1727,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
             WSC_TRY(tmp.alloc(sizeof(unsigned) * (size_t)(L.n_slots + 1), (void **)&slot_key));
             WSC_TRY(tmp.alloc(sizeof(int32_t) * (size_t)(L.n_slots + 1), (void **)&dest_slot));
         }
-        hipLaunchKernelGGL(tile_slots_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, srow, dp1, tg,
+        hipLaunchKernelGGL(tile_slots_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, sslot, slot2row, cap, dp1, tg,
                            L.tslot_start, L.slot_desc, slot_row, slot_key, row_nslots);
         WSC_TRY(exclusive_scan(ctx, row_nslots, L.rows + 1, (unsigned *)L.row_slot_start, sums3));
         hipLaunchKernelGGL(slot_dest_kernel, dim3(grid1d(L.n_slots)), dim3(256), 0, ctx->stream, slot_row, L.n_slots,
