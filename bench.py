@@ -148,7 +148,7 @@ class Workload:
         # CRF stack
         N = S * S
         # unaries / labels are double-buffered: step i+1 writes its unaries while step i's loop reads its own
-        self.unary_bufs = [ctx.alloc(batch * (NUM_CLASSES + 1) * N * 4) for _ in range(2)]
+        self.unary_bufs = [ctx.alloc(batch * ((NUM_CLASSES + 1 + 3) // 4 * 4) * N * 4) for _ in range(2)]
         self.label_bufs = [ctx.alloc(batch * N * 4) for _ in range(2)]
         self.unary_dev, self.label_dev = self.unary_bufs[0], self.label_bufs[0]
         self.parity = 0
@@ -172,14 +172,16 @@ class Workload:
     def run_unary(self):
         # upsample all 20 class maps to S x S, x /= max + 1e-5, [bg = 0.15 | maps] -> unaries: one fused call
         # (wsc_cam_postprocess + wsc_unary_from_maps give the same bits through 0.5 GB of intermediate maps)
-        self._lib.cam_unary(self.ctx, self.cam_dev, self.B, NUM_CLASSES, self.h, self.h, S, S, 0.15, self.unary_dev)
+        # written pixel-major ([B][N][24]): the layout the mean-field loop reads, no transpose pass in wsc_crf_inference
+        self._lib.cam_unary(self.ctx, self.cam_dev, self.B, NUM_CLASSES, self.h, self.h, S, S, 0.15, self.unary_dev,
+                            pixel_major=True)
 
     def crf_create(self):
         return self._lib.Crf(self.ctx_build, self.rgb_dev, self.B, S, S, CRF_CFG[0], CRF_CFG[2], CRF_CFG[3])
 
     def crf_infer(self, crf, ctx=None):
         crf.inference(self.unary_dev, NUM_CLASSES + 1, CRF_CFG[1], CRF_CFG[4], CRF_CFG[5], None, self.label_dev,
-                      ctx=ctx or self.ctx)
+                      ctx=ctx or self.ctx, pixel_major=True)
 
     def drain(self):
         """Wait for the mean-field loop still in flight (pipelined mode) and release its lattices."""

@@ -253,6 +253,11 @@ int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N
  *   cam_dev float32 [B][C][h][w] (wsc_net_forward_cam)  ->  unary_dev float32 [B][C+1][H0*W0] */
 int wsc_cam_unary(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
                   float *unary_dev);
+/* The same with the unaries written PIXEL-major, rows padded to Mp = 4 * ceil((C+1)/4) floats (padding = 0): the layout
+ * the mean-field loop reads, for wsc_crf_inference_pm (saves the class-major -> pixel-major pass of wsc_crf_inference).
+ *   unary_pm_dev float32 [B][H0*W0][Mp] */
+int wsc_cam_unary_pm(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
+                     float *unary_pm_dev);
 
 /* The MSF dataset transform of a batch of DECODED images (03b_irn/voc12/dataloader.py:68-106, 225-246; constants of
  * adp/dataloader.py:64-80, deepglobe/dataloader.py:60-66): float64 bilinear resize to S x S (cv2.resize INTER_LINEAR
@@ -347,6 +352,10 @@ int wsc_crf_lattice_sizes(wsc_ctx *ctx, const wsc_crf *crf, int32_t *v_gauss_hos
  * M <= 32. */
 int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M, float g_compat,
                       float bi_compat, int n_iters, float *q_dev, int32_t *argmax_dev);
+/* wsc_crf_inference on pixel-major unaries: unary_pm_dev float32 [B][H*W][Mp], Mp = 4 * ceil(M/4), padding classes 0
+ * (wsc_cam_unary_pm).  The buffer is read in place during the whole loop and never written. */
+int wsc_crf_inference_pm(wsc_ctx *ctx, wsc_crf *crf, const float *unary_pm_dev, int M, float g_compat,
+                         float bi_compat, int n_iters, float *q_dev, int32_t *argmax_dev);
 
 #ifdef __cplusplus
 }

@@ -255,3 +255,36 @@ def test_crf_labels_only_call_matches_full_call(ctx):
         crf.close()
         assert np.array_equal(a, a_full)
         assert np.array_equal(a, q.argmax(1).astype(np.int32))  # numpy's argmax also takes the first maximum
+
+
+def test_pixel_major_unary_path_is_bit_identical(ctx):
+    """wsc_cam_unary_pm + wsc_crf_inference_pm (unaries written pixel-major by the producer, read in place by the loop)
+    against wsc_cam_unary + wsc_crf_inference: same labels and same Q bits, for a class count that needs row padding
+    (C + 1 = 21 -> Mp = 24) and one that does not (C + 1 = 8), incl. the n_iters = 0 soft-max."""
+    rng = np.random.default_rng(41)
+    for (B, C, h, S, iters) in ((2, 20, 9, 45, 3), (1, 7, 5, 32, 0), (1, 7, 5, 32, 2)):
+        cam = np.maximum(rng.normal(0.2, 1.0, (B, C, h, h)), 0).astype(np.float32)
+        rgbs = np.stack([helpers.synth_crf_case(rng, S, S, 2)[0] for _ in range(B)])
+        M, N = C + 1, S * S
+        Mp = (M + 3) // 4 * 4
+        cam_dev, rgb_dev = ctx.to_device(cam), ctx.to_device(rgbs)
+        u_cm, u_pm = ctx.alloc(B * M * N * 4), ctx.alloc(B * N * Mp * 4)
+        _lib.cam_unary(ctx, cam_dev, B, C, h, h, S, S, 0.15, u_cm)
+        _lib.cam_unary(ctx, cam_dev, B, C, h, h, S, S, 0.15, u_pm, pixel_major=True)
+        U = ctx.to_host(u_cm, (B, M, N), np.float32)
+        Upm = ctx.to_host(u_pm, (B, N, Mp), np.float32)
+        assert np.array_equal(np.transpose(Upm[:, :, :M], (0, 2, 1)), U) and np.all(Upm[:, :, M:] == 0)
+        crf = _lib.Crf(ctx, rgb_dev, B, S, S, 1.5, 40.0, 13.0)
+        q1, q2 = ctx.alloc(B * M * N * 4), ctx.alloc(B * M * N * 4)
+        a1, a2, a3 = ctx.alloc(B * N * 4), ctx.alloc(B * N * 4), ctx.alloc(B * N * 4)
+        crf.inference(u_cm, M, 3.0, 10.0, iters, q1, a1)
+        crf.inference(u_pm, M, 3.0, 10.0, iters, q2, a2, pixel_major=True)
+        crf.inference(u_pm, M, 3.0, 10.0, iters, None, a3, pixel_major=True)  # labels only
+        Q1, Q2 = ctx.to_host(q1, (B, M, N), np.float32), ctx.to_host(q2, (B, M, N), np.float32)
+        A1, A2, A3 = (ctx.to_host(x, (B, N), np.int32) for x in (a1, a2, a3))
+        crf.close()
+        if iters == 0:  # the class-major path takes soft-max(-U) in its layout pass (expf, divide), the other in the update kernel
+            assert np.abs(Q1 - Q2).max() <= 1e-6 and np.array_equal(A2, A3) and (A1 == A2).mean() >= 0.999
+        else:
+            assert np.array_equal(Q1, Q2) and np.array_equal(A1, A2) and np.array_equal(A1, A3)
+        assert np.array_equal(ctx.to_host(u_pm, (B, N, Mp), np.float32), Upm)  # read in place, never written

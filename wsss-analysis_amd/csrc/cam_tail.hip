@@ -201,7 +201,7 @@ __global__ __launch_bounds__(1024) void cam_max_kernel(const float *__restrict__
     }
 }
 
-template <int CMAX>
+template <int CMAX, bool PM>
 __global__ __launch_bounds__(256) void cam_unary_kernel(const float *__restrict__ cam, int C, int h, int w, int H0, int W0,
                                                         int Hu, int Wu, const unsigned int *__restrict__ mx, float bg,
                                                         float *__restrict__ unary) {
@@ -231,11 +231,25 @@ __global__ __launch_bounds__(256) void cam_unary_kernel(const float *__restrict_
             }
         }
         const float inv = 1.f / sum;
+        if (PM) {
+            // pixel-major, rows padded to Mp = 4 * ceil((C+1)/4) floats: the layout the mean-field loop reads (no transpose pass)
+            const int Mp = (C + 1 + 3) / 4 * 4;
+            float uu[CMAX + 4];
+            uu[0] = -logf(fminf(fmaxf(bg * inv, 1e-5f), 1.f));
+#pragma unroll
+            for (int c = 0; c < CMAX + 3; ++c)
+                uu[c + 1] = (c < CMAX && c < C) ? -logf(fminf(fmaxf(v[c < CMAX ? c : 0] * inv, 1e-5f), 1.f)) : 0.f;
+            float4 *dst = reinterpret_cast<float4 *>(unary + ((long long)b * n + i) * Mp);
+#pragma unroll
+            for (int q = 0; q < (CMAX + 4) / 4; ++q)
+                if (4 * q < Mp) dst[q] = make_float4(uu[4 * q], uu[4 * q + 1], uu[4 * q + 2], uu[4 * q + 3]);
+        } else {
         float *dst = unary + (long long)b * (C + 1) * n + i;
         dst[0] = -logf(fminf(fmaxf(bg * inv, 1e-5f), 1.f));
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
             if (c < C) dst[(long long)(c + 1) * n] = -logf(fminf(fmaxf(v[c] * inv, 1e-5f), 1.f));
+        }
     }
 }
 
@@ -354,8 +368,21 @@ int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N
     return WSC_OK;
 }
 
+static int cam_unary_impl(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
+                          float *unary_dev, bool pixel_major);
+
 int wsc_cam_unary(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
                   float *unary_dev) {
+    return cam_unary_impl(ctx, cam_dev, B, C, h, w, H0, W0, bg_value, unary_dev, false);
+}
+
+int wsc_cam_unary_pm(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
+                     float *unary_pm_dev) {
+    return cam_unary_impl(ctx, cam_dev, B, C, h, w, H0, W0, bg_value, unary_pm_dev, true);
+}
+
+static int cam_unary_impl(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
+                          float *unary_dev, bool pixel_major) {
     WSC_CHECK(ctx && cam_dev && unary_dev, WSC_ERR_INVALID, "wsc_cam_unary: null argument");
     WSC_CHECK(B > 0 && C > 0 && h > 0 && w > 0 && H0 > 0 && W0 > 0 && bg_value > 0.f, WSC_ERR_INVALID,
               "wsc_cam_unary: bad argument");
@@ -376,11 +403,17 @@ int wsc_cam_unary(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w
                        ((size_t)h * w + 20 + 4 * (size_t)H0) * sizeof(float), ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu, mx);
     // each block re-reads its image's C source maps (35 KB for 20 x 21 x 21): a few pixels per thread amortise that
     const dim3 ugrid((unsigned)std::min((n + 1023) / 1024, 512), (unsigned)B);
-    if (C <= 20)
-        hipLaunchKernelGGL(cam_unary_kernel<20>, ugrid, dim3(256), lds, ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu,
+    if (C <= 20 && !pixel_major)
+        hipLaunchKernelGGL((cam_unary_kernel<20, false>), ugrid, dim3(256), lds, ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu,
+                           (const unsigned int *)mx, bg_value, unary_dev);
+    else if (C <= 20)
+        hipLaunchKernelGGL((cam_unary_kernel<20, true>), ugrid, dim3(256), lds, ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu,
+                           (const unsigned int *)mx, bg_value, unary_dev);
+    else if (!pixel_major)
+        hipLaunchKernelGGL((cam_unary_kernel<32, false>), ugrid, dim3(256), lds, ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu,
                            (const unsigned int *)mx, bg_value, unary_dev);
     else
-        hipLaunchKernelGGL(cam_unary_kernel<32>, ugrid, dim3(256), lds, ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu,
+        hipLaunchKernelGGL((cam_unary_kernel<32, true>), ugrid, dim3(256), lds, ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu,
                            (const unsigned int *)mx, bg_value, unary_dev);
     WSC_HIP(hipGetLastError());
     wsc_ctx_cached_free(ctx, mx); // stream-ordered reuse

@@ -1204,6 +1204,7 @@ struct UpdateArgs {
     const float *val_g, *val_b;
     const float *u; // [pixel][Mp]
     float *q;       // [pixel][Mp] or null (only the last iteration's Q leaves the chip)
+    int32_t *argmax; // [pixel] or null: labels-only call, the last iteration writes the arg-max instead of Q
     float alpha_g, alpha_b, compat_g, compat_b;
     int M, LP;
     int B;
@@ -1401,11 +1402,31 @@ __global__ __launch_bounds__(512) void update_splat_kernel(UpdateArgs a) {
             if (l + o < LP) sum += other;
         }
         sum = __shfl(sum, seg0, 64);
+        const float rs = __builtin_amdgcn_rcpf(sum);
+        const f32x4_t o4 = {ex[0] * rs, ex[1] * rs, ex[2] * rs, ex[3] * rs};
         if (ok) {
-            const float rs = __builtin_amdgcn_rcpf(sum);
-            const f32x4_t o4 = {ex[0] * rs, ex[1] * rs, ex[2] * rs, ex[3] * rs};
             if (SPLAT) stage[t * LP + l] = o4;
             if (q4) q4[p * (unsigned)LP + l] = o4;
+        }
+        if (!SPLAT && a.argmax != nullptr) {
+            // np.argmax(Q, axis=0) on the very values a full call would have written: first maximum in class order
+            float bv = o4[0];
+            int bi = 4 * l;
+#pragma unroll
+            for (int kk = 1; kk < 4; ++kk)
+                if (4 * l + kk < a.M && o4[kk] > bv) {
+                    bv = o4[kk];
+                    bi = 4 * l + kk;
+                }
+            for (int o = 4; o > 0; o >>= 1) {
+                const float ov = __shfl_down(bv, o, 64);
+                const int oi = __shfl_down(bi, o, 64);
+                if (l + o < LP && ov > bv) { // the other lane holds HIGHER classes: it wins only when strictly larger
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            if (ok && l == 0) a.argmax[p] = bi;
         }
     }
     if (SPLAT) {
@@ -1912,8 +1933,21 @@ int wsc_crf_lattice_sizes(wsc_ctx *ctx, const wsc_crf *crf, int32_t *v_gauss_hos
     return WSC_OK;
 }
 
+static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, bool pixel_major, int M, float g_compat,
+                              float bi_compat, int n_iters, float *q_dev, int32_t *argmax_dev);
+
 int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M, float g_compat, float bi_compat,
                       int n_iters, float *q_dev, int32_t *argmax_dev) {
+    return crf_inference_impl(ctx, crf, unary_dev, false, M, g_compat, bi_compat, n_iters, q_dev, argmax_dev);
+}
+
+int wsc_crf_inference_pm(wsc_ctx *ctx, wsc_crf *crf, const float *unary_pm_dev, int M, float g_compat, float bi_compat,
+                         int n_iters, float *q_dev, int32_t *argmax_dev) {
+    return crf_inference_impl(ctx, crf, unary_pm_dev, true, M, g_compat, bi_compat, n_iters, q_dev, argmax_dev);
+}
+
+static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, bool pixel_major, int M, float g_compat,
+                              float bi_compat, int n_iters, float *q_dev, int32_t *argmax_dev) {
     WSC_CHECK(ctx && crf && unary_dev, WSC_ERR_INVALID, "wsc_crf_inference: null argument");
     WSC_CHECK(M >= 1 && M <= 32, WSC_ERR_INVALID, "wsc_crf_inference: M=%d outside [1,32]", M);
     WSC_CHECK(n_iters >= 0, WSC_ERR_INVALID, "wsc_crf_inference: n_iters=%d", n_iters);
@@ -1946,10 +1980,12 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     crf->lat[0].M_cur = M;
     crf->lat[1].M_cur = M;
     const dim3 tgrid((N + TP - 1) / TP, B);
-    {
+    if (!pixel_major) {
         WscKernelTimer timer(ctx, WSC_K_CRF_MISC, (double)npix * M * 12);
         hipLaunchKernelGGL(init_q_kernel, tgrid, dim3(TP), 2 * (size_t)M * (TP + 1) * sizeof(float), ctx->stream,
                            unary_dev, M, Mp, N, u, n_iters == 0 ? q : (float *)nullptr);
+    } else {
+        u = const_cast<float *>(unary_dev); // already [pixel][Mp] (wsc_cam_unary_pm): read in place, never written
     }
     const char *nf = getenv("WSC_CRF_NO_FORK");
     const bool no_fork = (nf && atoi(nf) != 0) || ctx->profiling; // per-kernel timing wants the launches one after the other
@@ -1960,7 +1996,7 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     }
     UpdateArgs a;
     a.pix_rec = crf->pix_rec; a.val_g = nullptr; a.val_b = nullptr;
-    a.u = u; a.q = nullptr;
+    a.u = u; a.q = nullptr; a.argmax = nullptr;
     a.alpha_g = G.alpha; a.alpha_b = Bl.alpha; a.compat_g = g_compat; a.compat_b = bi_compat;
     a.M = M; a.LP = LP; a.B = B;
     a.tg = make_geom(crf->H, crf->W);
@@ -1971,9 +2007,15 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     a.sb.n_slots = Bl.n_slots; a.sb.shared = 0; a.sb.dp1 = 6;
     // Q(0) = softmax(-U) is splatted straight from the kernel that computes it; iteration t slices the blurred
     // lattices, forms Q(t) and splats it for iteration t+1; the last iteration writes Q(T) instead.
+    if (n_iters == 0 && pixel_major) { // Q = softmax(-U): the update kernel without messages and without the splat
+        a.q = q;
+        WSC_TRY(launch_update(ctx, a, false, false));
+    }
     for (int it = 0; it <= n_iters && n_iters > 0; ++it) {
         const bool last = it == n_iters;
-        a.q = last ? q : nullptr;
+        const bool labels_only = last && q_dev == nullptr && argmax_dev != nullptr;
+        a.q = last && !labels_only ? q : nullptr;
+        a.argmax = labels_only ? argmax_dev : nullptr;
         WSC_TRY(launch_update(ctx, a, it > 0, !last));
         if (last) break;
         // The two lattices are independent until the next update: the bilateral one (seven short launches on ~1 MB per
@@ -1995,7 +2037,7 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
     }
     {
         WscKernelTimer ftimer(ctx, WSC_K_CRF_MISC, (double)npix * M * 8);
-        if (q_dev || argmax_dev)
+        if (q_dev || (argmax_dev && n_iters == 0))
             hipLaunchKernelGGL(finish_kernel, tgrid, dim3(TP), (size_t)M * (TP + 1) * sizeof(float), ctx->stream, q, M, Mp,
                                N, q_dev, argmax_dev);
     }

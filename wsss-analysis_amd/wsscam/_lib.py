@@ -95,6 +95,7 @@ _SIGNATURES = {
     "wsc_cam_eval_confusion": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _vp]),
     "wsc_unary_from_maps": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "wsc_cam_unary": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "wsc_cam_unary_pm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     "wsc_msf_input_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "wsc_label_unary_from_cam": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
@@ -107,6 +108,7 @@ _SIGNATURES = {
     "wsc_crf_destroy": (None, [_vp]),
     "wsc_crf_lattice_sizes": (_i, [_vp, _vp, _vp, _vp]),
     "wsc_crf_inference": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
+    "wsc_crf_inference_pm": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
 }
 
 
@@ -477,9 +479,11 @@ def unary_from_maps(ctx, maps_dev, B, C, N, bg_value, unary_dev):
     check(ctx._lib.wsc_unary_from_maps(ctx.h, _ptr(maps_dev), B, C, N, float(bg_value), _ptr(unary_dev)))
 
 
-def cam_unary(ctx, cam_dev, B, C, h, w, H0, W0, bg_value, unary_dev):
-    """cam_postprocess (all classes at H0 x W0) + unary_from_maps without the intermediate maps in HBM."""
-    check(ctx._lib.wsc_cam_unary(ctx.h, _ptr(cam_dev), B, C, h, w, H0, W0, float(bg_value), _ptr(unary_dev)))
+def cam_unary(ctx, cam_dev, B, C, h, w, H0, W0, bg_value, unary_dev, pixel_major=False):
+    """cam_postprocess (all classes at H0 x W0) + unary_from_maps without the intermediate maps in HBM.
+    pixel_major: unaries as [B][H0*W0][Mp] (Mp = 4 ceil((C+1)/4)) for Crf.inference(..., pixel_major=True)."""
+    fn = ctx._lib.wsc_cam_unary_pm if pixel_major else ctx._lib.wsc_cam_unary
+    check(fn(ctx.h, _ptr(cam_dev), B, C, h, w, H0, W0, float(bg_value), _ptr(unary_dev)))
 
 
 def bilinear_resize(ctx, src_dev, C, h, w, dst_dev, H, W):
@@ -514,12 +518,14 @@ class Crf:
         check(self.ctx._lib.wsc_crf_lattice_sizes(self.ctx.h, self.h, vg.ctypes.data, vb.ctypes.data))
         return vg, vb
 
-    def inference(self, unary_dev, M, g_compat, bi_compat, n_iters, q_dev=None, argmax_dev=None, ctx=None):
+    def inference(self, unary_dev, M, g_compat, bi_compat, n_iters, q_dev=None, argmax_dev=None, ctx=None, pixel_major=False):
         """ctx: the context (stream, workspace) to run the mean-field loop on; defaults to the one the
-        lattices were built on.  When it differs, the caller orders the two with ctx.wait_for(build_ctx)."""
+        lattices were built on.  When it differs, the caller orders the two with ctx.wait_for(build_ctx).
+        pixel_major: unary_dev is [B][H*W][Mp] (cam_unary(..., pixel_major=True)), read in place."""
         run = ctx or self.ctx
-        check(self.ctx._lib.wsc_crf_inference(run.h, self.h, _ptr(unary_dev), M, float(g_compat),
-                                              float(bi_compat), int(n_iters), _ptr(q_dev), _ptr(argmax_dev)))
+        fn = self.ctx._lib.wsc_crf_inference_pm if pixel_major else self.ctx._lib.wsc_crf_inference
+        check(fn(run.h, self.h, _ptr(unary_dev), M, float(g_compat), float(bi_compat), int(n_iters), _ptr(q_dev),
+                 _ptr(argmax_dev)))
 
 
 def rw_propagate(ctx, x_dev, edge_dev, K, h, w, dirs, path_start, path_yx, beta, n_steps, rw_dev=None):
