@@ -297,7 +297,16 @@ int wsc_ir_label_combine(wsc_ctx *ctx, const int32_t *fg_pred_dev, const int32_t
  *   image; cams *= gate[b][c]  (gate = conf_scores * is_pass_threshold).
  *   cams_nhwc_dev float32 [B][h][w][C];  gate_dev float32 [B][C];  out_dev float32 [B][C][S*S]  (class-major). */
 int wsc_hsn_gradcam_post(wsc_ctx *ctx, const float *cams_nhwc_dev, int B, int h, int w, int C, int S,
-                         const float *gate_dev, float *out_dev);
+                         const float *gate_dev, float *out_dev, int out_channels, int out_first);
+/* (out_channels > C: the maps go to channels [out_first, out_first + C) of a wider [B][out_channels][S*S] stack, e.g. behind
+ * the background channel of the VOC branch; out_channels <= 0 means a plain [B][C][S*S] output.) */
+/* VOC background channel (03c_hsn/demo.py:145-147): X_bg = sum over the bg model's class maps; channel 0 of the stack =
+ * 0.15 * expit(max over the WHOLE batch of X_bg - X_bg)  (SURVEY Q6).
+ *   Hbg_dev float32 [B][Cb][N];  y_dev float32 [B][Ctot][N] (channel 0 is written). */
+int wsc_hsn_voc_background(wsc_ctx *ctx, const float *Hbg_dev, int B, int Cb, int N, float *y_dev, int Ctot);
+/* mass[i] = 1 if map i has a positive entry (dcrf_process keeps the classes whose sum is > 0, utilities.py:425; the maps
+ * are >= 0).  maps_dev float32 [n_maps][N];  mass_dev uint32 [n_maps]. */
+int wsc_hsn_class_mass(wsc_ctx *ctx, const float *maps_dev, int n_maps, int N, uint32_t *mass_dev);
 /* modify_by_htt's background activation (utilities.py:341-347; twins 02_cues/adp_cues.py:279-285,
  * 03b_irn/net/common_cam.py:36-44): 0.75 * expit(4 * (mean_rgb - 240)) smoothed by scipy.ndimage.gaussian_filter(
  * sigma = 2) (truncate 4 sigma, mode 'reflect', axis 0 then axis 1), then cv2.resize (bilinear) to Ho x Wo when the

@@ -35,7 +35,7 @@ __device__ __forceinline__ void src_index_hp(int dst, float scale, int n, int &i
 template <bool WRITE>
 __global__ __launch_bounds__(256) void hsn_gradcam_post_kernel(const float *__restrict__ cams, int h, int w, int C, int S,
                                                                const float *__restrict__ gate, unsigned int *__restrict__ mx,
-                                                               float *__restrict__ out) {
+                                                               float *__restrict__ out, int Ctot, int c0) {
     extern __shared__ float src[]; // h*w
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
     const float *base = cams + (long long)b * h * w * C + c;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void hsn_gradcam_post_kernel(const float *__re
         src_index_hp(xx, sw, w, x0, x1, lx0, lx1);
         float v = ly0 * (lx0 * src[y0 * w + x0] + lx1 * src[y0 * w + x1]) + ly1 * (lx0 * src[y1 * w + x0] + lx1 * src[y1 * w + x1]);
         v = fmaxf(v, 0.f);
-        if (WRITE) out[(long long)bc * n + i] = v * scale;
+        if (WRITE) out[((long long)b * Ctot + c0 + c) * n + i] = v * scale;
         else m = fmaxf(m, v);
     }
     if (!WRITE) {
@@ -218,6 +218,40 @@ __global__ void hsn_gather_unary_kernel(const float *__restrict__ maps, const lo
     }
 }
 
+// VOC background channel of 03c_hsn/demo.py:145-147 (Q6: the maximum runs over the WHOLE batch):
+//   X_bg = sum_c H_bg[b][c];  Y[b][0] = 0.15 * expit(max_batch(X_bg) - X_bg)
+__global__ void hsn_sum_max_kernel(const float *__restrict__ Hbg, int Cb, int N, long long total, float *__restrict__ xbg,
+                                   unsigned int *__restrict__ mx) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / N;
+        const int p = (int)(i - b * N);
+        const float *src = Hbg + b * Cb * N + p;
+        float acc = 0.f;
+        for (int c = 0; c < Cb; ++c) acc += src[(long long)c * N];
+        xbg[i] = acc;
+        m = fmaxf(m, acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(mx, __float_as_uint(m)); // X_bg >= 0: uint order = float order
+}
+__global__ void hsn_voc_bg_kernel(const float *__restrict__ xbg, const unsigned int *__restrict__ mx, int Ctot, int N,
+                                  long long total, float *__restrict__ y) {
+    const float m = __uint_as_float(*mx);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / N;
+        const int p = (int)(i - b * N);
+        y[b * Ctot * N + p] = 0.15f / (1.0f + expf(-(m - xbg[i])));
+    }
+}
+// mass[b][c] = 1 if maps[b][c] has a positive entry (all entries >= 0: the sum of dcrf_process :425 is > 0 exactly then)
+__global__ __launch_bounds__(256) void hsn_mass_kernel(const float *__restrict__ maps, int N, unsigned int *__restrict__ mass) {
+    const float *src = maps + (long long)blockIdx.y * N;
+    bool any = false;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) any = any || src[p] > 0.f;
+    if (__ballot(any) != 0ull && (threadIdx.x & 63) == 0) mass[blockIdx.y] = 1u;
+}
+
 inline int grid_for(long long total, int cap = 8192) {
     long long g = (total + 255) / 256;
     if (g > cap) g = cap;
@@ -230,8 +264,11 @@ inline int grid_for(long long total, int cap = 8192) {
 extern "C" {
 
 int wsc_hsn_gradcam_post(wsc_ctx *ctx, const float *cams_nhwc_dev, int B, int h, int w, int C, int S, const float *gate_dev,
-                         float *out_dev) {
+                         float *out_dev, int out_channels, int out_first) {
     WSC_CHECK(ctx && cams_nhwc_dev && gate_dev && out_dev, WSC_ERR_INVALID, "wsc_hsn_gradcam_post: null argument");
+    if (out_channels <= 0) { out_channels = C; out_first = 0; }
+    WSC_CHECK(out_first >= 0 && out_first + C <= out_channels, WSC_ERR_INVALID,
+              "wsc_hsn_gradcam_post: channels [%d, %d) do not fit a stack of %d", out_first, out_first + C, out_channels);
     WSC_CHECK(B > 0 && h > 0 && w > 0 && C > 0 && S > 0 && (long long)B * C <= 65535, WSC_ERR_INVALID,
               "wsc_hsn_gradcam_post: bad shape B=%d h=%d w=%d C=%d S=%d", B, h, w, C, S);
     const size_t lds = (size_t)h * w * sizeof(float);
@@ -243,9 +280,9 @@ int wsc_hsn_gradcam_post(wsc_ctx *ctx, const float *cams_nhwc_dev, int B, int h,
     const dim3 grid((unsigned)std::min((S * S + 255) / 256, 64), (unsigned)(B * C));
     WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, (double)B * C * S * S * 4);
     hipLaunchKernelGGL(hsn_gradcam_post_kernel<false>, grid, dim3(256), lds, ctx->stream, cams_nhwc_dev, h, w, C, S, gate_dev, mx,
-                       out_dev);
+                       out_dev, out_channels, out_first);
     hipLaunchKernelGGL(hsn_gradcam_post_kernel<true>, grid, dim3(256), lds, ctx->stream, cams_nhwc_dev, h, w, C, S, gate_dev, mx,
-                       out_dev);
+                       out_dev, out_channels, out_first);
     WSC_HIP(hipGetLastError());
     wsc_ctx_cached_free(ctx, mx); // stream-ordered reuse
     return WSC_OK;
@@ -318,6 +355,34 @@ int wsc_hsn_cs_gradcam(wsc_ctx *ctx, const float *H_dev, int B, int C_all, int N
     const dim3 grid((unsigned)std::min((N + 255) / 256, 128), (unsigned)B);
     WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, (double)B * N * 4 * (2.0 * Cv + 1));
     hipLaunchKernelGGL(hsn_cs_kernel, grid, dim3(256), 0, ctx->stream, a);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+int wsc_hsn_voc_background(wsc_ctx *ctx, const float *Hbg_dev, int B, int Cb, int N, float *y_dev, int Ctot) {
+    WSC_CHECK(ctx && Hbg_dev && y_dev, WSC_ERR_INVALID, "wsc_hsn_voc_background: null argument");
+    WSC_CHECK(B > 0 && Cb > 0 && N > 0 && Ctot > 0, WSC_ERR_INVALID, "wsc_hsn_voc_background: bad shape");
+    WSC_HIP(hipSetDevice(ctx->device));
+    const long long total = (long long)B * N;
+    float *xbg = nullptr;
+    WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(float) * (size_t)total + 256, (void **)&xbg));
+    unsigned int *mx = reinterpret_cast<unsigned int *>(xbg + total);
+    WSC_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(hsn_sum_max_kernel, dim3(grid_for(total, 2048)), dim3(256), 0, ctx->stream, Hbg_dev, Cb, N, total, xbg, mx);
+    hipLaunchKernelGGL(hsn_voc_bg_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float *)xbg,
+                       (const unsigned int *)mx, Ctot, N, total, y_dev);
+    WSC_HIP(hipGetLastError());
+    wsc_ctx_cached_free(ctx, xbg);
+    return WSC_OK;
+}
+
+int wsc_hsn_class_mass(wsc_ctx *ctx, const float *maps_dev, int n_maps, int N, uint32_t *mass_dev) {
+    WSC_CHECK(ctx && maps_dev && mass_dev, WSC_ERR_INVALID, "wsc_hsn_class_mass: null argument");
+    WSC_CHECK(n_maps > 0 && n_maps <= 65535 && N > 0, WSC_ERR_INVALID, "wsc_hsn_class_mass: n_maps=%d N=%d", n_maps, N);
+    WSC_HIP(hipSetDevice(ctx->device));
+    WSC_HIP(hipMemsetAsync(mass_dev, 0, sizeof(uint32_t) * (size_t)n_maps, ctx->stream));
+    hipLaunchKernelGGL(hsn_mass_kernel, dim3((unsigned)std::min((N + 255) / 256, 64), (unsigned)n_maps), dim3(256), 0, ctx->stream,
+                       maps_dev, N, mass_dev);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }

@@ -100,7 +100,9 @@ _SIGNATURES = {
     "wsc_msf_input_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "wsc_label_unary_from_cam": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
     "wsc_ir_label_combine": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "wsc_hsn_gradcam_post": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "wsc_hsn_gradcam_post": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i]),
+    "wsc_hsn_voc_background": (_i, [_vp, _vp, _i, _i, _i, _vp, _i]),
+    "wsc_hsn_class_mass": (_i, [_vp, _vp, _i, _i, _vp]),
     "wsc_hsn_background": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "wsc_hsn_cs_gradcam": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "wsc_hsn_gather_unary": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -393,8 +395,9 @@ class Net:
         check(self.ctx._lib.wsc_net_forward_cam(run.h, self.h, _ptr(x_dev), B, S, _ptr(cam_dev),
                                                 _ptr(score_dev)))
 
-    def forward_gradcam(self, x_dev, N, S, relu, cams_dev, score_dev=None):
-        check(self.ctx._lib.wsc_net_forward_gradcam(self.ctx.h, self.h, _ptr(x_dev), N, S, int(relu), _ptr(cams_dev),
+    def forward_gradcam(self, x_dev, N, S, relu, cams_dev, score_dev=None, ctx=None):
+        run = ctx or self.ctx
+        check(self.ctx._lib.wsc_net_forward_gradcam(run.h, self.h, _ptr(x_dev), N, S, int(relu), _ptr(cams_dev),
                                                     _ptr(score_dev)))
 
     def forward_features(self, x_dev, N, S, feat_dev):
@@ -562,8 +565,17 @@ def rw_propagate_batch(ctx, x_dev, edge_dev, Ks, hs, ws, dirs, path_start, path_
 
 
 # ---- HistoSegNet post-processing (csrc/hsn.hip) -------------------------------------------------------------------
-def hsn_gradcam_post(ctx, cams_nhwc_dev, B, h, w, C, S, gate_dev, out_dev):
-    check(ctx._lib.wsc_hsn_gradcam_post(ctx.h, _ptr(cams_nhwc_dev), B, h, w, C, S, _ptr(gate_dev), _ptr(out_dev)))
+def hsn_gradcam_post(ctx, cams_nhwc_dev, B, h, w, C, S, gate_dev, out_dev, out_channels=0, out_first=0):
+    check(ctx._lib.wsc_hsn_gradcam_post(ctx.h, _ptr(cams_nhwc_dev), B, h, w, C, S, _ptr(gate_dev), _ptr(out_dev),
+                                        int(out_channels), int(out_first)))
+
+
+def hsn_voc_background(ctx, Hbg_dev, B, Cb, N, y_dev, Ctot):
+    check(ctx._lib.wsc_hsn_voc_background(ctx.h, _ptr(Hbg_dev), B, Cb, N, _ptr(y_dev), Ctot))
+
+
+def hsn_class_mass(ctx, maps_dev, n_maps, N, mass_dev):
+    check(ctx._lib.wsc_hsn_class_mass(ctx.h, _ptr(maps_dev), n_maps, N, _ptr(mass_dev)))
 
 
 def hsn_background(ctx, rgb_dev, B, H, W, bg_dev, out_hw=None):

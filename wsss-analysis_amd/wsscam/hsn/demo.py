@@ -23,34 +23,54 @@ def dcrf_config_for(dataset, model_type):
 
 def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True, is_verbose=True, *, models, alphas,
             images, n_seg_classes=None):
+    """Device resident between the batch upload and the label maps, like segment_adp: both models' Grad-CAM stacks are
+    written straight into one [B][1 + C][S*S] stack (wsc_hsn_gradcam_post with a channel offset), the VOC background
+    channel comes from wsc_hsn_voc_background (max over the whole batch, Q6), class mass flags from wsc_hsn_class_mass,
+    unaries from wsc_hsn_gather_unary; the host sees scores, flags and labels."""
+    from .. import _lib
+
     assert dataset in ["VOC2012", "DeepGlobe", "DeepGlobe_balanced"], "ADP: segment_adp"
     assert model_type in ["VGG16", "M7"]
     img_size = 321 if model_type == "VGG16" else 224
-    fgbg_modes = ["fg", "bg"] if dataset == "VOC2012" else ["fg"]
-    mean, std = ([104, 117, 123], [255, 255, 255]) if dataset == "VOC2012" else ([0, 0, 0], [255, 255, 255])
+    voc = dataset == "VOC2012"
+    mean, std = ([104, 117, 123], [255, 255, 255]) if voc else ([0, 0, 0], [255, 255, 255])
     cfg = dcrf_config_for(dataset, model_type)
     out = []
+    N = img_size * img_size
     n_batches = math.ceil(len(images) / batch_size)
+    ctx = models["fg"].ctx
+    thr_of = lambda a: np.full((1, np.asarray(a).shape[1]), 1.0 / 3.0)  # max(min(thr, 0), 1/3): demo.py:83, Q5
     for ib in range(n_batches):
         lo, hi = ib * batch_size, min((ib + 1) * batch_size, len(images))
-        norm, raw = read_batch(images[lo:hi], (img_size, img_size), mean, std)
-        H = {}
-        for m in fgbg_modes:
-            _, scores = cu.conv_and_cams(models[m], np.asarray(alphas[m]), norm, relu=False, want_scores=True)
-            thr = np.full((1, scores.shape[1]), 1.0 / 3.0)  # max(min(thr, 0), 1/3)
-            is_pass = np.greater_equal(scores, thr)
-            g = hu.grad_cam(models[m], alphas[m], norm, is_pass, "final", scores, orig_sz=[img_size, img_size],
-                            should_upsample=True)
-            H[m] = np.transpose(g, (0, 3, 1, 2))
-        if dataset == "VOC2012":
-            C = H["fg"].shape[1]
-            Y = np.zeros((hi - lo, (n_seg_classes or C + 1), img_size, img_size))
-            X_bg = np.sum(H["bg"], axis=1)
-            Y[:, 0] = 0.15 * scipy.special.expit(np.max(X_bg) - X_bg)  # max over the whole batch (Q6)
-            Y[:, 1:] = H["fg"]
+        B = hi - lo
+        chunk = images[lo:hi]
+        if all(np.asarray(im).shape == (img_size, img_size, 3) and np.asarray(im).dtype == np.uint8 for im in chunk):
+            norm, raw, raw_u8 = None, None, np.ascontiguousarray(np.stack(chunk))
+        else:  # the resize of read_batch stays on the host (float64, kept un-rounded like the reference's batch)
+            norm, raw = read_batch(chunk, (img_size, img_size), mean, std)
+            raw_u8 = raw.astype(np.uint8)
+        C = np.asarray(alphas["fg"]).shape[1]
+        if voc:
+            Cv = n_seg_classes or C + 1
+            y_dev = ctx.alloc(B * Cv * N * 4, pooled=True)
+            kw = dict(raw_u8=raw_u8, mean_std=(mean, std)) if norm is None else {}
+            hu.grad_cam_device(models["fg"], alphas["fg"], norm, thr_of(alphas["fg"]), [img_size, img_size], out=(y_dev, Cv, 1),
+                               ctx=ctx, **kw)
+            Cb = np.asarray(alphas["bg"]).shape[1]
+            hb = hu.grad_cam_device(models["bg"], alphas["bg"], norm, thr_of(alphas["bg"]), [img_size, img_size], ctx=ctx, **kw)
+            _lib.hsn_voc_background(ctx, hb[0], B, Cb, N, y_dev, Cv)
+            valid = list(range(Cv))
         else:
-            Y = H["fg"][:, :-1, :, :]
-        out.extend(list(hu.dcrf_process(Y, raw.astype(np.uint8), cfg, ctx=models["fg"].ctx)))
+            Cv = C
+            kw = dict(raw_u8=raw_u8, mean_std=(mean, std)) if norm is None else {}
+            y_dev = hu.grad_cam_device(models["fg"], alphas["fg"], norm, thr_of(alphas["fg"]), [img_size, img_size], ctx=ctx,
+                                       **kw)[0]
+            valid = list(range(C - 1))  # Y = H_fg[:, :-1]: the 'unknown' class is dropped (demo.py:153)
+        mass_dev = ctx.alloc(B * Cv * 4, pooled=True)
+        _lib.hsn_class_mass(ctx, y_dev, B * Cv, N, mass_dev)
+        mass = ctx.to_host(mass_dev, (B, Cv), np.uint32)
+        mass[:, [c for c in range(Cv) if c not in valid]] = 0
+        out.extend(list(hu.dcrf_process_device(ctx, y_dev, mass, raw_u8, Cv, img_size, img_size, cfg)))
         if is_verbose:
             print("\tBatch #%d of %d" % (ib + 1, n_batches))
     return out

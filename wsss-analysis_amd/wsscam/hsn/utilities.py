@@ -9,21 +9,25 @@ from ..cues import utilities as cues_utilities
 from ..misc.imutils import default_context, unary_from_softmax
 
 
-def grad_cam_device(input_model, weights, images, thresholds, orig_sz, raw_u8=None, mean_std=None):
+def grad_cam_device(input_model, weights, images, thresholds, orig_sz, raw_u8=None, mean_std=None, out=None, ctx=None):
     """HSN grad_cam with everything after the batch upload on the device: one CNN pass (einsum maps + scores,
     SURVEY Q9), score gate, per-map upsample + max(., 0), per-image normalisation (03c_hsn/utilities.py:258-277 with
     the class gating of demo.py:127-131 / :335-341).  `images`: normalised (B,S,S,3) floats, or None with `raw_u8`
-    (B,S,S,3) uint8 + `mean_std` = (mean, std): the normalisation runs on the device as well (wsc_msf_input_u8).
-    Returns (H_dev [B][C][S*S] device buffer, scores (B, C), is_pass (B, C), ctx[, raw_dev]); H stays in HBM for
-    wsc_hsn_cs_gradcam / the CRF."""
-    net, ctx = input_model.gradcam_net(np.asarray(weights))
+    (B,S,S,3) uint8 + `mean_std` = (mean[3] or scalar, std[3] or scalar): the normalisation runs on the device as well
+    (wsc_msf_input_u8).  `out` = (buffer, channels, first): write the maps into channels [first, first + C) of a wider
+    [B][channels][S*S] stack.  Returns (H_dev [B][C][S*S] device buffer, scores (B, C), is_pass (B, C), ctx[, raw_dev]);
+    H stays in HBM for wsc_hsn_cs_gradcam / the CRF."""
+    net, nctx = input_model.gradcam_net(np.asarray(weights), ctx=ctx)
+    ctx = nctx
     raw_dev = None
     if images is None:
         B, S_in = raw_u8.shape[0], raw_u8.shape[1]
         raw_dev = ctx.to_device(raw_u8, pooled=True)
         x_dev = ctx.alloc(B * 3 * S_in * S_in * 4, pooled=True)
+        mean = np.broadcast_to(np.asarray(mean_std[0], np.float32), (3,))
+        std = np.broadcast_to(np.asarray(mean_std[1], np.float32), (3,))
         _lib.msf_input_u8(ctx, raw_dev, [(S_in, S_in)] * B, np.arange(B, dtype=np.int64) * (S_in * S_in * 3), S_in,
-                          (mean_std[0],) * 3, (mean_std[1],) * 3, x_dev, pre_div255=False, pair=False)
+                          mean, std, x_dev, pre_div255=False, pair=False)
     else:
         x = cues_utilities._to_nchw(images)
         B, S_in = x.shape[0], x.shape[2]
@@ -34,12 +38,16 @@ def grad_cam_device(input_model, weights, images, thresholds, orig_sz, raw_u8=No
     assert int(orig_sz[1]) == S, "square output size"
     cams_dev = ctx.alloc(B * h * h * C * 4, pooled=True)
     score_dev = ctx.alloc(B * C * 4, pooled=True)
-    net.forward_gradcam(x_dev, B, S_in, False, cams_dev, score_dev)
+    net.forward_gradcam(x_dev, B, S_in, False, cams_dev, score_dev, ctx=ctx)
     scores = ctx.to_host(score_dev, (B, C), np.float32)  # 4 B C bytes: the gate is a host decision in the reference too
     is_pass = np.greater_equal(scores, np.asarray(thresholds).reshape(1, -1))
     gate_dev = ctx.to_device((scores * is_pass).astype(np.float32), pooled=True)
-    H_dev = ctx.alloc(B * C * S * S * 4, pooled=True)
-    _lib.hsn_gradcam_post(ctx, cams_dev, B, h, h, C, S, gate_dev, H_dev)
+    if out is None:
+        H_dev = ctx.alloc(B * C * S * S * 4, pooled=True)
+        _lib.hsn_gradcam_post(ctx, cams_dev, B, h, h, C, S, gate_dev, H_dev)
+    else:
+        H_dev = out[0]
+        _lib.hsn_gradcam_post(ctx, cams_dev, B, h, h, C, S, gate_dev, H_dev, out_channels=out[1], out_first=out[2])
     if raw_dev is not None:
         return H_dev, scores, is_pass, ctx, raw_dev
     return H_dev, scores, is_pass, ctx

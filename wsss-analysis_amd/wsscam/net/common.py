@@ -74,8 +74,9 @@ class DeviceCAMBase:
     def cam_size(self, S):
         return self._ensure_net().cam_size(S)
 
-    def gradcam_net(self, weights):
-        """(wsc_net with `weights` (F x C Grad-CAM alpha) as its 1x1 head, ctx); cached per alpha."""
+    def gradcam_net(self, weights, ctx=None):
+        """(wsc_net with `weights` (F x C Grad-CAM alpha) as its 1x1 head, ctx); cached per alpha.  `ctx`: run on
+        this context instead of the model's own (two models of one driver share a stream and its buffers)."""
         w = np.ascontiguousarray(weights, dtype=np.float32)
         key = (w.shape, hash(w.tobytes()))
         cache = self.__dict__.setdefault("_gradcam_nets", {})
@@ -85,7 +86,7 @@ class DeviceCAMBase:
             sd = dict(self._sd)
             sd["gradcam_weights"] = w
             cache[key] = _lib.Net(self._ctx, self.arch, sd, w.shape[1], self.precision)
-        return cache[key], self._ctx
+        return cache[key], (ctx or self._ctx)
 
     # -- batched device forward ---------------------------------------------------------------
     def forward_batch_device(self, x_dev, B, S, cam_dev, score_dev=None):
