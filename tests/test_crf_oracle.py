@@ -25,7 +25,11 @@ def test_lattice_vs_exact_meanfield(built, cfg, seed):
     agree = (Qe.argmax(0) == am).mean()
     kl = (Qe * np.log((Qe + 1e-12) / (q + 1e-12))).sum(0).mean()
     narrow = cfg[3] < 10
-    assert agree >= (0.96 if narrow else 0.975), agree
+    # SURVEY 8(c) bar for the pin: >= 98 % arg-max agreement, mean KL <= 5e-2 -- met by the two configurations with the
+    # wide colour kernel.  The narrow one (srgb = 5 against sigma = 8 image noise, sxy = 50 > the image) is where the
+    # lattice is a coarse approximation of the Gaussian whatever the unaries or a denoised image (KL 0.07-0.35 measured
+    # over sharpness 2-5 and smoothing 0-2 px): its bound is stated separately.
+    assert agree >= (0.96 if narrow else 0.98), agree
     assert kl <= (0.2 if narrow else 5e-2), kl
     assert ls[0] > 0 and ls[1] > 0
     # the CRF really did something: it is not the unary arg-max that is being compared
