@@ -56,6 +56,7 @@ struct ConvKArgs {
     int Kbase;       // elements of one weight plane per row
     int ntiles_n, nblocks;
     const bf16_t *zero; // >= 16 bytes of zeros in HBM: source of padded taps for the LDS-DMA path
+    int fast;           // host side only: FAST variant of the kernel this launch may use (0 = generic)
     int debug;          // WSC_CONV_DEBUG ablations (timing only, results are wrong): 1 = no DMA after the
                         // first two stages, 2 = no fragment reads / MFMAs
 };
@@ -69,8 +70,19 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 //   256-row tile: 8 waves, 3 stages (144 KB), 1 block per CU: 0.73x the L2->LDS bytes per FLOP and a
 //   prefetch distance of two K-steps, with counted s_waitcnt vmcnt + raw s_barrier so a stage stays in
 //   flight across the barrier (a __syncthreads() would drain the LDS DMA every K-step).
-template <int BM, int BN, int MODE, bool SPLIT, int ET, bool GLDS, int STAGES, int WMT = 64>
-__global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
+//
+// FAST (f16, single precision plane, LDS-DMA layers only) removes per-element case handling the common layers do not need:
+//   bit 0  epilogue: fp16 output only, every column tile full (Cout % BN == 0), no post-ReLU affine, 32-bit output
+//          offsets -- scale / shift as float4 loads, no per-channel predicates, residual rows read at a clamped row
+//          (no predicate), only the final store is masked by the row bound.  Same arithmetic, operation for operation.
+//   bit 1  pointwise: 1x1, stride 1, no padding -- output row m reads activation row m: no (n, ho, wo) decode in the
+//          prologue, no tap bounds test per DMA piece (rows past the end are clamped to the last row; their results
+//          are never stored).
+// One-K-step FAST tiles are compiled for 4 waves per SIMD (<= 128 VGPRs) so that 4 blocks of 34 KB share a CU.
+template <int BM, int BN, int MODE, bool SPLIT, int ET, bool GLDS, int STAGES, int WMT = 64, int FAST = 0>
+__global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void conv_igemm_kernel(ConvKArgs p) {
+    constexpr bool FEPI = (FAST & 1) != 0, PW = (FAST & 2) != 0;
+    static_assert(FAST == 0 || (GLDS && MODE == 0 && !SPLIT && ET == 1), "FAST paths exist for the f16 LDS-DMA layers");
     constexpr int NT = BM * 2;   // threads
     constexpr int NW = BM / 32;  // waves
     // waves are laid out WR (along M) x WC (along N); a wave owns a WMT x WN tile = MI x NI MFMA tiles.
@@ -124,7 +136,12 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + lrow + RSTEP * i;
-        if (m < p.m_end) {
+        if (PW) {
+            const int mc = m < p.m_end ? m : p.m_end - 1;
+            hb[i] = 0;
+            wb[i] = 0;
+            base[i] = (long long)mc * p.Cin;
+        } else if (m < p.m_end) {
             const unsigned t1 = __umulhi(p.div_howo_mul, (unsigned)m);
             const int n = (int)((t1 + (((unsigned)m - t1) >> p.div_howo_s1)) >> p.div_howo_s2);
             const int rem = m - n * p.HoWo;
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             const int r = lrow + RSTEP * i;
             const int ks = slot ^ ((r >> 1) & 7);
             const int hi = hb[i] + khi, wi = wb[i] + kwi;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const bool ok = PW || ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
             const bf16_t *g = ok ? src + base[i] + tap_off + ks * 8 : p.zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                              (__attribute__((address_space(3))) void *)(sa + i * 1024), 16, 0, 0);
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
         };
         auto issue_a = [&](int i, int buf) {
             const int hi = hb[i] + n_khi, wi = wb[i] + n_kwi;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const bool ok = PW || ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
             const bf16_t *g = ok ? n_src + (aoff[i] + n_tap) : p.zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                              (__attribute__((address_space(3))) void *)(smem + buf * A_BYTES + wv * 4096 + i * 1024),
@@ -470,7 +487,8 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     const bool has_res = p.res != nullptr && full;
     // (the 256 x 256 tile requests them per 128-row group: 16 passes of residual rows next to 128 accumulator
     // registers would not fit the 256-VGPR budget of 2 waves per SIMD)
-    constexpr bool PRE_ALL = WMT == 64;
+    // (the one-K-step FAST tile, compiled for 128 VGPRs, requests them per 64-row group as well)
+    constexpr bool PRE_ALL = WMT == 64 && !(STAGES == 1 && FEPI);
     constexpr int NHALF_R = STAGES == 1 ? BM / 64 : (WMT == 128 ? BM / 128 : 1);
     constexpr int NRES = PRE_ALL ? NPASS : NPASS / NHALF_R;
     uint4 rres[NRES], rres_lo[NRES];
@@ -480,7 +498,12 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             const int m = m0 + (first_pass + i) * RPP + r0;
             rres[i] = make_uint4(0, 0, 0, 0);
             rres_lo[i] = make_uint4(0, 0, 0, 0);
-            if (has_res && m < p.m_end) {
+            if (FEPI) {
+                if (has_res) {
+                    const int mc = m < p.m_end ? m : p.m_end - 1; // clamped: always a valid row, never stored past the end
+                    rres[i] = *reinterpret_cast<const uint4 *>(p.res + ((unsigned)mc * (unsigned)p.Cout + (unsigned)c));
+                }
+            } else if (has_res && m < p.m_end) {
                 const long long o = (long long)m * p.Cout + c;
                 rres[i] = *reinterpret_cast<const uint4 *>(p.res + o);
                 if (SPLIT) rres_lo[i] = *reinterpret_cast<const uint4 *>(p.res_lo + o);
@@ -488,14 +511,26 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
         }
     };
     if (PRE_ALL) fetch_res(0);
-    float s1[8], b1[8], s2[8], b2[8];
-    const bool post = p.s2 != nullptr;
+    float s1[8], b1[8], s2[FEPI ? 1 : 8], b2[FEPI ? 1 : 8];
+    const bool post = !FEPI && p.s2 != nullptr;
+    if (FEPI) {
+        const f32x4_t sa = *reinterpret_cast<const f32x4_t *>(p.s1 + c), sb = *reinterpret_cast<const f32x4_t *>(p.s1 + c + 4);
+        const f32x4_t ba = *reinterpret_cast<const f32x4_t *>(p.b1 + c), bb = *reinterpret_cast<const f32x4_t *>(p.b1 + c + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        s1[j] = cok ? p.s1[c + j] : 0.f;
-        b1[j] = cok ? p.b1[c + j] : 0.f;
-        s2[j] = (cok && post) ? p.s2[c + j] : 1.f;
-        b2[j] = (cok && post) ? p.b2[c + j] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            s1[j] = sa[j];
+            s1[4 + j] = sb[j];
+            b1[j] = ba[j];
+            b1[4 + j] = bb[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s1[j] = cok ? p.s1[c + j] : 0.f;
+            b1[j] = cok ? p.b1[c + j] : 0.f;
+            s2[j] = (cok && post) ? p.s2[c + j] : 1.f;
+            b2[j] = (cok && post) ? p.b2[c + j] : 0.f;
+        }
     }
 
     // fp32 transpose through LDS.  Multi-K-step variants move the whole BM x BN tile at once (one barrier).
@@ -533,6 +568,35 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
             const int pass = half * PPH + pp;
             const int lrow_e = pp * RPP + r0; // row inside the group
             const int m = m0 + half * GR + lrow_e;
+            if (FEPI) {
+                float v[8];
+                const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(ct + lrow_e * CT_STRIDE + c8 * 8);
+                const f32x4_t q1 = *reinterpret_cast<const f32x4_t *>(ct + lrow_e * CT_STRIDE + c8 * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = q0[j] * s1[j] + b1[j];
+                    v[4 + j] = q1[j] * s1[4 + j] + b1[4 + j];
+                }
+                if (has_res) {
+                    const int ri = PRE_ALL ? pass : pp;
+                    const uint32_t rw[4] = {rres[ri].x, rres[ri].y, rres[ri].z, rres[ri].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[2 * j] += f16_to_f32((bf16_t)(rw[j] & 0xffffu));
+                        v[2 * j + 1] += f16_to_f32((bf16_t)(rw[j] >> 16));
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                uint32_t hw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hw[j] = (uint32_t)f32_to_f16(v[2 * j]) | ((uint32_t)f32_to_f16(v[2 * j + 1]) << 16);
+                if (m < p.m_end)
+                    *reinterpret_cast<uint4 *>(p.y + ((unsigned)m * (unsigned)p.Cout + (unsigned)c)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                continue;
+            }
             if (m < p.m_end) {
                 float v[8];
                 const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(ct + lrow_e * CT_STRIDE + c8 * 8);
@@ -599,7 +663,7 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_igemm_kernel(ConvKArgs p) {
     }
 }
 
-template <int BM, int BN, int MODE, bool SPLIT, int ET, int STAGES, int WMT = 64>
+template <int BM, int BN, int MODE, bool SPLIT, int ET, int STAGES, int WMT = 64, int FAST = 0>
 int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     constexpr bool GLDS = MODE == 0; // LDS-DMA staging for every generic layer; small-Cin layers stage via registers
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -610,7 +674,7 @@ int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
     // the attribute belongs to the (function, device) pair: a process may hold contexts on several GPUs
     static bool attr_set[64] = {};
-    auto kern = conv_igemm_kernel<BM, BN, MODE, SPLIT, ET, GLDS, STAGES, WMT>;
+    auto kern = conv_igemm_kernel<BM, BN, MODE, SPLIT, ET, GLDS, STAGES, WMT, FAST>;
     const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
     if (!attr_set[dev] || ctx->device != dev) {
         WSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -625,21 +689,28 @@ int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     return WSC_OK;
 }
 
-template <int BM, int BN, int MODE, bool SPLIT, int ET>
+template <int BM, int BN, int MODE, bool SPLIT, int ET, int FAST = 0>
 int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
     if constexpr (BM == 256 && BN == 256) {
-        return launch_stages<BM, BN, MODE, SPLIT, ET, 2, 128>(ctx, a);
+        return launch_stages<BM, BN, MODE, SPLIT, ET, 2, 128, FAST>(ctx, a);
     } else if constexpr (BM == 256) {
-        return launch_stages<BM, BN, MODE, SPLIT, ET, 3>(ctx, a);
+        return launch_stages<BM, BN, MODE, SPLIT, ET, 3, 64, FAST>(ctx, a);
     } else if constexpr (MODE == 0) {
         // a one-K-step layer (1x1 conv, 64 input channels) needs one LDS buffer: 34 KB per block, 4 blocks per CU
-        if (a.nk == 1) return launch_stages<BM, BN, MODE, SPLIT, ET, 1>(ctx, a);
-        return launch_stages<BM, BN, MODE, SPLIT, ET, 2>(ctx, a);
+        if (a.nk == 1) return launch_stages<BM, BN, MODE, SPLIT, ET, 1, 64, FAST>(ctx, a);
+        return launch_stages<BM, BN, MODE, SPLIT, ET, 2, 64, FAST>(ctx, a);
     } else {
         // one-K-step small-Cin layer (3x3 on <= 4 channels: VGG16 / M7 first conv): single LDS buffer, 64-row epilogue
         if (a.nk == 1) return launch_stages<BM, BN, MODE, SPLIT, ET, 1>(ctx, a);
         return launch_stages<BM, BN, MODE, SPLIT, ET, 2>(ctx, a);
     }
+}
+
+// f16 LDS-DMA layer on its FAST variant (fast = 1: epilogue, 3: epilogue + pointwise)
+template <int BM, int BN>
+int launch_fast(wsc_ctx *ctx, const ConvKArgs &a, int fast) {
+    if (fast == 3) return launch_variant<BM, BN, 0, false, 1, 3>(ctx, a);
+    return launch_variant<BM, BN, 0, false, 1, 1>(ctx, a);
 }
 
 template <int BN>
@@ -650,6 +721,7 @@ int launch_bn(wsc_ctx *ctx, const ConvKArgs &a, int small_cin, int split, int fm
         return launch_variant<128, BN, 2, true, 0>(ctx, a);
     }
     if (fmt) {
+        if (small_cin == 0 && a.fast) return launch_fast<128, BN>(ctx, a, a.fast);
         if (small_cin == 0) return launch_variant<128, BN, 0, false, 1>(ctx, a);
         if (small_cin == 1) return launch_variant<128, BN, 1, false, 1>(ctx, a);
         return launch_variant<128, BN, 2, false, 1>(ctx, a);
@@ -662,12 +734,14 @@ int launch_bn(wsc_ctx *ctx, const ConvKArgs &a, int small_cin, int split, int fm
 // 256 x 128 tile (generic layers only)
 int launch_big(wsc_ctx *ctx, const ConvKArgs &a, int split, int fmt) {
     if (split) return launch_variant<256, 128, 0, true, 0>(ctx, a);
+    if (fmt && a.fast) return launch_fast<256, 128>(ctx, a, a.fast);
     if (fmt) return launch_variant<256, 128, 0, false, 1>(ctx, a);
     return launch_variant<256, 128, 0, false, 0>(ctx, a);
 }
 // 256 x 256 tile, 128 x 64 per wave (generic layers with CoutPad % 256 == 0 only)
 int launch_square(wsc_ctx *ctx, const ConvKArgs &a, int split, int fmt) {
     if (split) return launch_variant<256, 256, 0, true, 0>(ctx, a);
+    if (fmt && a.fast) return launch_fast<256, 256>(ctx, a, a.fast);
     if (fmt) return launch_variant<256, 256, 0, false, 1>(ctx, a);
     return launch_variant<256, 256, 0, false, 0>(ctx, a);
 }
@@ -720,6 +794,14 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
         return (e && ok && atoi(ok) == 1) ? atoi(e) : 0;
     }();
     a.debug = debug;
+    // FAST variants (see the kernel): f16, one precision plane, fp16 output only, full column tiles, no post-ReLU affine
+    static const int nofast = [] { const char *e = getenv("WSC_CONV_NOFAST"); return e ? atoi(e) : 0; }();
+    a.fast = 0;
+    if (!nofast && p.fmt && !p.split && p.small_cin == 0 && p.y != nullptr && p.y_f32 == nullptr && p.s2 == nullptr &&
+        p.Cout == p.CoutPad && (long long)a.M * p.Cout < (1ll << 31)) {
+        a.fast = 1;
+        if (p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1) a.fast = 3;
+    }
     if (a.M == 0) return WSC_OK;
     // tile choice.  Measured on the ResNet50-CAM stack (64 samples @321^2, f16): 128-row tiles 4.31 ms,
     // 256-row 3-stage tiles on the K >= 512 layers 4.37 ms, everywhere 4.45 ms -- the stack is bound by
