@@ -279,6 +279,12 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b),
                                                        c, 0, 0, 0);
     };
+    auto mfma0 = [&](const u32x4_t &a, const u32x4_t &b) -> f32x16_t {
+        const f32x16_t z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ET == 0)
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), z, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), z, 0, 0, 0);
+    };
     // LDS byte address of the (only) LDS object
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
 
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
     };
 
     // ---- main loop ------------------------------------------------------------------
-    const int nk = p.nk;
+    const int nk = STAGES == 1 ? 1 : p.nk; // (the single-buffer variant is launched for one-K-step layers only)
     if (GLDS && MODE == 0 && STAGES == 3) {
         // three LDS buffers, prefetch distance two K-steps.  Every wave issues PER = 4 + NB DMA
         // instructions per stage; vmcnt(PER) therefore means "everything but the newest stage has
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
 #pragma unroll
                 for (int i = 0; i < NB; ++i) issue_b(i, cur ^ 1);
             }
-            if (!(p.debug & 2)) {
+            if (STAGES == 1 || !(p.debug & 2)) {
                 const unsigned sa = lds0 + cur * A_BYTES, sb = lds0 + STAGES * A_BYTES + cur * B_BYTES;
                 u32x4_t fa[2][MI], fb[2][NI];
                 auto rd = [&](int set, int ks) {
@@ -451,7 +457,11 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) mfma(fa[set][mi], fb[set][ni], acc[mi][ni]);
+                        for (int ni = 0; ni < NI; ++ni) {
+                            // one-K-step layers: the first k-slice takes C = 0 as an inline constant (no 64 v_mov per wave)
+                            if (STAGES == 1 && ks == 0) acc[mi][ni] = mfma0(fa[set][mi], fb[set][ni]);
+                            else mfma(fa[set][mi], fb[set][ni], acc[mi][ni]);
+                        }
                 }
             }
             if (more) advance();
@@ -511,6 +521,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
         }
     };
     if (PRE_ALL) fetch_res(0);
+    const float sat_lo = p.relu ? 0.f : -65504.f;
     float s1[8], b1[8], s2[FEPI ? 1 : 8], b2[FEPI ? 1 : 8];
     const bool post = !FEPI && p.s2 != nullptr;
     if (FEPI) {
@@ -586,13 +597,16 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                         v[2 * j + 1] += f16_to_f32((bf16_t)(rw[j] >> 16));
                     }
                 }
-                if (p.relu) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
+                // ReLU and the saturation of f32_to_f16 (+-65504, no infinities) in ONE median: med3(v, lo, 65504) with
+                // lo = 0 under ReLU (max(v, 0) then min(., 65504)) and -65504 otherwise -- same values as fmaxf + the clamp,
+                // a quarter of the instructions (each fmaxf / fminf costs a canonicalising v_max on top)
                 uint32_t hw[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) hw[j] = (uint32_t)f32_to_f16(v[2 * j]) | ((uint32_t)f32_to_f16(v[2 * j + 1]) << 16);
+                for (int j = 0; j < 4; ++j) {
+                    const _Float16 h0 = (_Float16)__builtin_amdgcn_fmed3f(v[2 * j], sat_lo, 65504.f);
+                    const _Float16 h1 = (_Float16)__builtin_amdgcn_fmed3f(v[2 * j + 1], sat_lo, 65504.f);
+                    hw[j] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+                }
                 if (m < p.m_end)
                     *reinterpret_cast<uint4 *>(p.y + ((unsigned)m * (unsigned)p.Cout + (unsigned)c)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
                 continue;
