@@ -30,6 +30,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -82,7 +83,8 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 template <int BM, int BN, int MODE, bool SPLIT, int ET, bool GLDS, int STAGES, int WMT = 64, int FAST = 0>
 __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void conv_igemm_kernel(ConvKArgs p) {
     constexpr bool FEPI = (FAST & 1) != 0, PW = (FAST & 2) != 0;
-    static_assert(FAST == 0 || (GLDS && MODE == 0 && !SPLIT && ET == 1), "FAST paths exist for the f16 LDS-DMA layers");
+    static_assert(FAST == 0 || (!SPLIT && ET == 1 && ((GLDS && MODE == 0) || FAST == 1)),
+                  "FAST paths: f16, one precision plane; the pointwise prologue belongs to the LDS-DMA layers");
     constexpr int NT = BM * 2;   // threads
     constexpr int NW = BM / 32;  // waves
     // waves are laid out WR (along M) x WC (along N); a wave owns a WMT x WN tile = MI x NI MFMA tiles.
@@ -421,8 +423,19 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
         for (int i = 0; i < NB; ++i) issue_b(i, 0);
         advance();
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
+        // Fragment read addresses: lds_off(row + 32 mi, sl) = lds_off(row, sl) + 4096 mi (the swizzle term (row >> 1) & 7 does not
+        // see multiples of 32), so one VGPR per k-slice and operand serves every mi / ni through the instruction's immediate
+        // offset, which also carries the buffer (the K loop is unrolled by two so that `cur` is a constant): no address VALU
+        // inside the loop (it was 20 v_add per K-step).
+        unsigned offA[4], offB[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            offA[ks] = lds0 + lds_off(wm * WMT + l31, ks * 2 + kgrp);
+            offB[ks] = lds0 + STAGES * A_BYTES + lds_off(wn * WN + l31, ks * 2 + kgrp);
+        }
+        auto kstep = [&](auto cur_c, int kt) __attribute__((always_inline)) {
+            constexpr int cur = decltype(cur_c)::value;
+            const unsigned(&oA)[4] = offA, (&oB)[4] = offB; // (named here: the nested lambda below must not be the first use)
             const bool more = kt + 1 < nk && !(p.debug & 1);
             if (more) {
                 prep();
@@ -432,16 +445,14 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                 for (int i = 0; i < NB; ++i) issue_b(i, cur ^ 1);
             }
             if (STAGES == 1 || !(p.debug & 2)) {
-                const unsigned sa = lds0 + cur * A_BYTES, sb = lds0 + STAGES * A_BYTES + cur * B_BYTES;
                 u32x4_t fa[2][MI], fb[2][NI];
                 auto rd = [&](int set, int ks) {
-                    const int sl = ks * 2 + kgrp;
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][mi]) : "v"(sa + lds_off(wm * WMT + mi * 32 + l31, sl)) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[set][mi]) : "v"(oA[ks]), "n"(cur * A_BYTES + mi * 4096) : "memory");
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][ni]) : "v"(sb + lds_off(wn * WN + ni * 32 + l31, sl)) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][ni]) : "v"(oB[ks]), "n"(cur * B_BYTES + ni * 4096) : "memory");
                 };
                 rd(0, 0);
 #pragma unroll
@@ -466,6 +477,11 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
             }
             if (more) advance();
             __syncthreads();
+        };
+        static_assert(A_BYTES + (MI - 1) * 4096 < 65536 && B_BYTES + (NI - 1) * 4096 < 65536, "ds_read immediate offset range");
+        for (int kt = 0; kt < nk; kt += 2) {
+            kstep(std::integral_constant<int, 0>{}, kt);
+            if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
         }
     } else {
         load_tile(0);
@@ -715,8 +731,8 @@ int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
         return launch_stages<BM, BN, MODE, SPLIT, ET, 2, 64, FAST>(ctx, a);
     } else {
         // one-K-step small-Cin layer (3x3 on <= 4 channels: VGG16 / M7 first conv): single LDS buffer, 64-row epilogue
-        if (a.nk == 1) return launch_stages<BM, BN, MODE, SPLIT, ET, 1>(ctx, a);
-        return launch_stages<BM, BN, MODE, SPLIT, ET, 2>(ctx, a);
+        if (a.nk == 1) return launch_stages<BM, BN, MODE, SPLIT, ET, 1, 64, FAST>(ctx, a);
+        return launch_stages<BM, BN, MODE, SPLIT, ET, 2, 64, FAST>(ctx, a);
     }
 }
 
@@ -736,6 +752,8 @@ int launch_bn(wsc_ctx *ctx, const ConvKArgs &a, int small_cin, int split, int fm
     }
     if (fmt) {
         if (small_cin == 0 && a.fast) return launch_fast<128, BN>(ctx, a, a.fast);
+        if (small_cin == 1 && a.fast) return launch_variant<128, BN, 1, false, 1, 1>(ctx, a);
+        if (small_cin == 2 && a.fast) return launch_variant<128, BN, 2, false, 1, 1>(ctx, a);
         if (small_cin == 0) return launch_variant<128, BN, 0, false, 1>(ctx, a);
         if (small_cin == 1) return launch_variant<128, BN, 1, false, 1>(ctx, a);
         return launch_variant<128, BN, 2, false, 1>(ctx, a);
@@ -811,10 +829,10 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     // FAST variants (see the kernel): f16, one precision plane, fp16 output only, full column tiles, no post-ReLU affine
     static const int nofast = [] { const char *e = getenv("WSC_CONV_NOFAST"); return e ? atoi(e) : 0; }();
     a.fast = 0;
-    if (!nofast && p.fmt && !p.split && p.small_cin == 0 && p.y != nullptr && p.y_f32 == nullptr && p.s2 == nullptr &&
+    if (!nofast && p.fmt && !p.split && p.y != nullptr && p.y_f32 == nullptr && p.s2 == nullptr &&
         p.Cout == p.CoutPad && (long long)a.M * p.Cout < (1ll << 31)) {
         a.fast = 1;
-        if (p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1) a.fast = 3;
+        if (p.small_cin == 0 && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1) a.fast = 3;
     }
     if (a.M == 0) return WSC_OK;
     // tile choice.  Measured on the ResNet50-CAM stack (64 samples @321^2, f16): 128-row tiles 4.31 ms,
