@@ -1250,16 +1250,36 @@ __device__ __forceinline__ void tile_gather(const SplatTab &T, int tile, long lo
             // explicit packed FMAs (this file is compiled with -ffp-contract=off for the simplex search): the gather
             // is VALU/LDS-issue bound, 8 v_pk_fma_f32 per 4 entries instead of 16 mul + 16 add
             f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-            for (int i = 0; i < n; i += 4) {
+            // whole groups of four entries without any per-entry predicate (no index clamp, no weight mask: 3 VALU per
+            // entry next to the two packed FMAs instead of 5), then at most one masked group for the remainder; the
+            // entries are summed in the same order as before
+            const uint2 *le = lent + i0;
+            int i = 0;
+            for (; i + 4 <= n; i += 4) {
                 uint2 en[4];
                 f32x4_t in[4];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) en[jj] = lent[i0 + min(i + jj, n - 1)];
+                for (int jj = 0; jj < 4; ++jj) en[jj] = le[i + jj];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) in[jj] = stage[en[jj].x + l];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const float w = i + jj < n ? __uint_as_float(en[jj].y) : 0.f; // w * norm[pixel]
+                    const float w = __uint_as_float(en[jj].y); // w * norm[pixel]
+                    const f32x2_t w2 = {w, w}, lo = {in[jj][0], in[jj][1]}, hi = {in[jj][2], in[jj][3]};
+                    a01 = __builtin_elementwise_fma(w2, lo, a01);
+                    a23 = __builtin_elementwise_fma(w2, hi, a23);
+                }
+            }
+            if (i < n) {
+                uint2 en[3];
+                f32x4_t in[3];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) en[jj] = le[min(i + jj, n - 1)];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) in[jj] = stage[en[jj].x + l];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    const float w = i + jj < n ? __uint_as_float(en[jj].y) : 0.f;
                     const f32x2_t w2 = {w, w}, lo = {in[jj][0], in[jj][1]}, hi = {in[jj][2], in[jj][3]};
                     a01 = __builtin_elementwise_fma(w2, lo, a01);
                     a23 = __builtin_elementwise_fma(w2, hi, a23);
