@@ -73,7 +73,7 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 //   flight across the barrier (a __syncthreads() would drain the LDS DMA every K-step).
 //
 // FAST (f16, single precision plane, LDS-DMA layers only) removes per-element case handling the common layers do not need:
-//   bit 0  epilogue: fp16 output only, every column tile full (Cout % BN == 0), no post-ReLU affine, 32-bit output
+//   bit 0  epilogue: fp16 output only, every column tile full (Cout % BN == 0), 32-bit output
 //          offsets -- scale / shift as float4 loads, no per-channel predicates, residual rows read at a clamped row
 //          (no predicate), only the final store is masked by the row bound.  Same arithmetic, operation for operation.
 //   bit 1  pointwise: 1x1, stride 1, no padding -- output row m reads activation row m: no (n, ho, wo) decode in the
@@ -537,7 +537,8 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
         }
     };
     if (PRE_ALL) fetch_res(0);
-    const float sat_lo = p.relu ? 0.f : -65504.f;
+    const bool fpost = FEPI && p.s2 != nullptr;
+    const float sat_lo = (p.relu && !fpost) ? 0.f : -65504.f;
     float s1[8], b1[8], s2[FEPI ? 1 : 8], b2[FEPI ? 1 : 8];
     const bool post = !FEPI && p.s2 != nullptr;
     if (FEPI) {
@@ -616,6 +617,18 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                 // ReLU and the saturation of f32_to_f16 (+-65504, no infinities) in ONE median: med3(v, lo, 65504) with
                 // lo = 0 under ReLU (max(v, 0) then min(., 65504)) and -65504 otherwise -- same values as fmaxf + the clamp,
                 // a quarter of the instructions (each fmaxf / fminf costs a canonicalising v_max on top)
+                if (fpost) {
+                    // conv -> ReLU -> BatchNorm layers (net/common_cnn.py make_layers): ReLU, then the affine; its scale / shift
+                    // are re-read per pass (L1 hits) instead of holding 16 more VGPRs through the K loop
+                    const f32x4_t s2a = *reinterpret_cast<const f32x4_t *>(p.s2 + c), s2b = *reinterpret_cast<const f32x4_t *>(p.s2 + c + 4);
+                    const f32x4_t b2a = *reinterpret_cast<const f32x4_t *>(p.b2 + c), b2b = *reinterpret_cast<const f32x4_t *>(p.b2 + c + 4);
+                    const float rl = p.relu ? 0.f : -3.0e38f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = __builtin_amdgcn_fmed3f(v[j], rl, 3.0e38f) * s2a[j] + b2a[j];
+                        v[4 + j] = __builtin_amdgcn_fmed3f(v[4 + j], rl, 3.0e38f) * s2b[j] + b2b[j];
+                    }
+                }
                 uint32_t hw[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -829,7 +842,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     // FAST variants (see the kernel): f16, one precision plane, fp16 output only, full column tiles, no post-ReLU affine
     static const int nofast = [] { const char *e = getenv("WSC_CONV_NOFAST"); return e ? atoi(e) : 0; }();
     a.fast = 0;
-    if (!nofast && p.fmt && !p.split && p.y != nullptr && p.y_f32 == nullptr && p.s2 == nullptr &&
+    if (!nofast && p.fmt && !p.split && p.y != nullptr && p.y_f32 == nullptr &&
         p.Cout == p.CoutPad && (long long)a.M * p.Cout < (1ll << 31)) {
         a.fast = 1;
         if (p.small_cin == 0 && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1) a.fast = 3;
