@@ -1301,7 +1301,7 @@ __device__ __forceinline__ void tile_gather(const SplatTab &T, int tile, long lo
 // pixel's classes are reduced inside the lane, then across the pixel's LP lanes by shuffle-down with a segment
 // bound and a broadcast from the segment's first lane.  Between iterations Q exists only as the tile's LDS copy.
 template <bool SLICE, bool SPLAT>
-__global__ __launch_bounds__(512) void update_splat_kernel(UpdateArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void update_splat_kernel(UpdateArgs a) {
     extern __shared__ f32x4_t stage[]; // [TILE_PIX][LP]
     const int LP = a.LP;
     const int gpw = 64 / LP;
@@ -1318,81 +1318,110 @@ __global__ __launch_bounds__(512) void update_splat_kernel(UpdateArgs a) {
     const TileBox tb = tile_box(a.tg, j);
     const int np = tb.cw * tb.ch;
     const int N = a.tg.H * a.tg.W;
-    const f32x4_t *vg4 = reinterpret_cast<const f32x4_t *>(a.val_g);
-    const f32x4_t *vb4 = reinterpret_cast<const f32x4_t *>(a.val_b);
-    const f32x4_t *u4 = reinterpret_cast<const f32x4_t *>(a.u);
-    f32x4_t *q4 = reinterpret_cast<f32x4_t *>(a.q);
-    const unsigned gofs = a.g_rows ? (unsigned)k * a.g_rows : 0u;
     const int ppt = (int)(blockDim.x >> 6) * gpw; // pixels per trip
-    // pixel of the lane group in trip t0 (clamped to the tile: idle lanes re-read pixel 0)
+    // Addressing: a uniform (SGPR) base per array -- the tile's first pixel, the image's replica of the Gaussian rows --
+    // plus a 32-bit per-lane byte offset formed with 24-bit multiplies (v_mad_u32_u24, full rate; a 32-bit v_mul_lo_u32
+    // is a quarter-rate instruction and there were 15 of them per trip): the tile-local pixel offset is below N < 2^24
+    // and a row id below 2^24 (both checked by the host).
     const unsigned cw_magic = tile_div_magic(tb.cw);
-    const unsigned pix0 = (unsigned)k * (unsigned)N + (unsigned)tb.y0 * (unsigned)a.tg.W + (unsigned)tb.x0; // B*N < 2^31 (checked)
+    const size_t pix0 = (size_t)k * (size_t)N + (size_t)tb.y0 * (size_t)a.tg.W + (size_t)tb.x0;
+    const unsigned LP16 = (unsigned)LP * 16u, l16 = (unsigned)l * 16u;
+    const char *rec_b = reinterpret_cast<const char *>(a.pix_rec) + pix0 * 80;
+    const char *u_b = reinterpret_cast<const char *>(a.u) + pix0 * LP16;
+    char *q_b = reinterpret_cast<char *>(a.q) + pix0 * LP16;
+    const char *vg_b = reinterpret_cast<const char *>(a.val_g) + (a.g_rows ? (size_t)k * a.g_rows * LP16 : (size_t)0);
+    const char *vb_b = reinterpret_cast<const char *>(a.val_b);
+    // pixel of the lane group in trip t0 as an offset from the tile's first pixel (clamped to the tile: idle lanes
+    // re-read pixel 0)
     auto pixel_of = [&](int t0) -> unsigned {
         const int t = t0 + g;
         const unsigned tc = (act && t < np) ? (unsigned)t : 0u;
-        const unsigned ty = (tc * cw_magic) >> 16, tx = tc - ty * (unsigned)tb.cw;
-        return pix0 + ty * (unsigned)a.tg.W + tx;
+        const unsigned ty = (tc * cw_magic) >> 16, tx = tc - __umul24(ty, (unsigned)tb.cw);
+        return __umul24(ty, (unsigned)a.tg.W) + tx;
     };
-    // the record and the unary of the NEXT trip are requested before this trip's lattice rows are gathered: two
-    // trips of loads in flight per wave (the kernel runs at 4 waves per SIMD; record -> rows is a dependent chain)
-    uint4 rq[5];
-    f32x4_t un;
-    {
-        const unsigned p = pixel_of((int)(threadIdx.x >> 6) * gpw);
-        if (SLICE) {
+    // Software pipeline over the trips of a wave, two deep: at the top of trip t the lattice rows of trip t+1 are
+    // requested (its record arrived during trip t-1) together with the record + unary of trip t+2; trip t's softmax runs
+    // on an energy that is already complete; at the bottom the rows of trip t+1 are folded into ITS energy.  record ->
+    // rows is a dependent chain and the kernel runs at 4 waves per SIMD: a wave now keeps a trip of row gathers in
+    // flight across the whole update of the trip before it (same FMA order per pixel as before: bit-identical).
+    uint4 rq[5];          // record of the trip whose rows are not requested yet
+    f32x4_t unn;          // unary of the trip after the next one to be folded
+    f32x2_t e01, e23;     // energy of the current trip
+    const float cag = a.compat_g * a.alpha_g, cab = a.compat_b * a.alpha_b;
+    auto load_rec = [&](unsigned p, uint4(&r)[5]) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) rq[i] = ld_off<uint4>(a.pix_rec, p * 80u + 16u * i);
+        for (int i = 0; i < 5; ++i) r[i] = ld_off<uint4>(rec_b, __umul24(p, 80u) + 16u * i);
+    };
+    // the pixel's record: 5 x 16 bytes, identical for the LP lanes of the pixel (broadcast loads)
+    auto issue_rows = [&](const uint4(&r)[5], f32x4_t(&g3)[3], f32x4_t(&b6)[6], float(&w9)[9]) {
+        uint32_t rc[20];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            rc[4 * i] = r[i].x; rc[4 * i + 1] = r[i].y; rc[4 * i + 2] = r[i].z; rc[4 * i + 3] = r[i].w;
         }
-        un = ld_off<f32x4_t>(u4, (p * (unsigned)LP + l) * 16u);
-    }
-    for (int t0 = (int)(threadIdx.x >> 6) * gpw; t0 < np; t0 += ppt) {
-        const int t = t0 + g;
-        const bool ok = act && t < np;
-        const unsigned p = pixel_of(t0);
-        uint4 rqn[5];
-        f32x4_t unn = un;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) rqn[i] = rq[i];
-        if (t0 + ppt < np) {
-            const unsigned pn = pixel_of(t0 + ppt);
-            if (SLICE) {
+        for (int i = 0; i < 3; ++i) g3[i] = ld_off<f32x4_t>(vg_b, __umul24(rc[i], LP16) + l16);
 #pragma unroll
-                for (int i = 0; i < 5; ++i) rqn[i] = ld_off<uint4>(a.pix_rec, pn * 80u + 16u * i);
-            }
-            unn = ld_off<f32x4_t>(u4, (pn * (unsigned)LP + l) * 16u);
-        }
-        // E = -U + sum_r (compat * alpha * norm * bary_r) * row_r : nine packed FMAs per class pair (this kernel is
-        // bound by VALU issue, not by memory: the weights are formed once per pixel and the row sums run as
-        // v_pk_fma_f32; exp and the normalisation use the hardware exp2 / reciprocal)
-        f32x2_t e01 = {-un[0], -un[1]}, e23 = {-un[2], -un[3]};
+        for (int i = 0; i < 6; ++i) b6[i] = ld_off<f32x4_t>(vb_b, __umul24(rc[3 + i], LP16) + l16);
+        const float wg = cag * __uint_as_float(rc[18]);
+        const float wb = cab * __uint_as_float(rc[19]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w9[i] = __uint_as_float(rc[9 + i]) * wg;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w9[3 + i] = __uint_as_float(rc[12 + i]) * wb;
+    };
+    // E = -U + sum_r (compat * alpha * norm * bary_r) * row_r : nine packed FMAs per class pair (the weights are formed
+    // once per pixel, the row sums run as v_pk_fma_f32)
+    auto fold = [&](const f32x4_t &u, const f32x4_t(&g3)[3], const f32x4_t(&b6)[6], const float(&w9)[9], f32x2_t &o01, f32x2_t &o23) {
+        o01 = f32x2_t{-u[0], -u[1]};
+        o23 = f32x2_t{-u[2], -u[3]};
         if (SLICE) {
-            // the pixel's record: 5 x 16 bytes, identical for the LP lanes of the pixel (broadcast loads)
-            uint32_t rc[20];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                rc[4 * i] = rq[i].x; rc[4 * i + 1] = rq[i].y; rc[4 * i + 2] = rq[i].z; rc[4 * i + 3] = rq[i].w;
-            }
-            f32x4_t vg[3], vb[6];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) vg[r] = ld_off<f32x4_t>(vg4, ((rc[r] + gofs) * (unsigned)LP + l) * 16u);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) vb[r] = ld_off<f32x4_t>(vb4, (rc[3 + r] * (unsigned)LP + l) * 16u);
-            const float wg = (a.compat_g * a.alpha_g) * __uint_as_float(rc[18]);
-            const float wb = (a.compat_b * a.alpha_b) * __uint_as_float(rc[19]);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const float w = __uint_as_float(rc[9 + r]) * wg;
-                const f32x2_t w2 = {w, w}, lo = {vg[r][0], vg[r][1]}, hi = {vg[r][2], vg[r][3]};
-                e01 = __builtin_elementwise_fma(w2, lo, e01);
-                e23 = __builtin_elementwise_fma(w2, hi, e23);
+                const f32x2_t w2 = {w9[r], w9[r]}, lo = {g3[r][0], g3[r][1]}, hi = {g3[r][2], g3[r][3]};
+                o01 = __builtin_elementwise_fma(w2, lo, o01);
+                o23 = __builtin_elementwise_fma(w2, hi, o23);
             }
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                const float w = __uint_as_float(rc[12 + r]) * wb;
-                const f32x2_t w2 = {w, w}, lo = {vb[r][0], vb[r][1]}, hi = {vb[r][2], vb[r][3]};
-                e01 = __builtin_elementwise_fma(w2, lo, e01);
-                e23 = __builtin_elementwise_fma(w2, hi, e23);
+                const f32x2_t w2 = {w9[3 + r], w9[3 + r]}, lo = {b6[r][0], b6[r][1]}, hi = {b6[r][2], b6[r][3]};
+                o01 = __builtin_elementwise_fma(w2, lo, o01);
+                o23 = __builtin_elementwise_fma(w2, hi, o23);
             }
+        }
+    };
+    const int t_first = (int)(threadIdx.x >> 6) * gpw;
+    {
+        const unsigned p = pixel_of(t_first);
+        const f32x4_t u0 = ld_off<f32x4_t>(u_b, __umul24(p, LP16) + l16);
+        f32x4_t g3[3], b6[6];
+        float w9[9];
+        if (SLICE) {
+            load_rec(p, rq);
+            issue_rows(rq, g3, b6, w9);
+        }
+        unn = u0;
+        if (t_first + ppt < np) {
+            const unsigned pn = pixel_of(t_first + ppt);
+            if (SLICE) load_rec(pn, rq);
+            unn = ld_off<f32x4_t>(u_b, __umul24(pn, LP16) + l16);
+        }
+        fold(u0, g3, b6, w9, e01, e23);
+    }
+    for (int t0 = t_first; t0 < np; t0 += ppt) {
+        const int t = t0 + g;
+        const bool ok = act && t < np;
+        const unsigned p = pixel_of(t0);
+        // next trip's rows (its record was requested one trip ago), then the record + unary of the trip after it
+        const bool has_next = t0 + ppt < np;
+        f32x4_t vgn[3], vbn[6];
+        float wrn[9];
+        const f32x4_t un1 = unn;
+        if (SLICE && has_next) issue_rows(rq, vgn, vbn, wrn);
+        if (t0 + 2 * ppt < np) {
+            const unsigned p2 = pixel_of(t0 + 2 * ppt);
+            if (SLICE) load_rec(p2, rq);
+            unn = ld_off<f32x4_t>(u_b, __umul24(p2, LP16) + l16);
         }
         float e[4] = {e01[0], e01[1], e23[0], e23[1]};
         float mx = -3.0e38f;
@@ -1401,9 +1430,6 @@ __global__ __launch_bounds__(512) void update_splat_kernel(UpdateArgs a) {
             e[kk] = (ok && 4 * l + kk < a.M) ? e[kk] : -3.0e38f;
             mx = fmaxf(mx, e[kk]);
         }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) rq[i] = rqn[i];
-        un = unn;
         for (int o = 4; o > 0; o >>= 1) {
             const float other = __shfl_down(mx, o, 64);
             if (l + o < LP) mx = fmaxf(mx, other);
@@ -1426,7 +1452,7 @@ __global__ __launch_bounds__(512) void update_splat_kernel(UpdateArgs a) {
         const f32x4_t o4 = {ex[0] * rs, ex[1] * rs, ex[2] * rs, ex[3] * rs};
         if (ok) {
             if (SPLAT) stage[t * LP + l] = o4;
-            if (q4) q4[p * (unsigned)LP + l] = o4;
+            if (a.q) *reinterpret_cast<f32x4_t *>(q_b + (__umul24(p, LP16) + l16)) = o4;
         }
         if (!SPLAT && a.argmax != nullptr) {
             // np.argmax(Q, axis=0) on the very values a full call would have written: first maximum in class order
@@ -1446,8 +1472,9 @@ __global__ __launch_bounds__(512) void update_splat_kernel(UpdateArgs a) {
                     bi = oi;
                 }
             }
-            if (ok && l == 0) a.argmax[p] = bi;
+            if (ok && l == 0) a.argmax[pix0 + p] = bi;
         }
+        if (has_next) fold(un1, vgn, vbn, wrn, e01, e23); // the next trip's energy: its rows have had this trip to arrive
     }
     if (SPLAT) {
         uint2 *lent = reinterpret_cast<uint2 *>(stage + TILE_PIX * LP);
@@ -1981,6 +2008,9 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     WSC_CHECK(npix * Mp < (1ll << 30) && g_rows * Mp < (1ll << 30) && (long long)Bl.rows * Mp < (1ll << 30) &&
                   g_slots * Mp < (1ll << 30) && (long long)Bl.n_slots * Mp < (1ll << 30) && npix * 80 < (1ll << 32),
               WSC_ERR_CAPACITY, "CRF batch too large for 32-bit byte offsets (B*N*Mp = %lld elements; split the batch)", npix * Mp);
+    // ... and forms them with 24-bit multiplies: pixels of one image and row ids below 2^24
+    WSC_CHECK(N < (1 << 24) && G.rows < (1 << 24) && Bl.rows < (1 << 24), WSC_ERR_CAPACITY,
+              "CRF image / lattice too large for 24-bit row arithmetic (N = %d, rows = %d / %d)", N, G.rows, Bl.rows);
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t qb = al(sizeof(float) * npix * Mp);
     const size_t vg = al(sizeof(float) * (size_t)g_rows * Mp), vb = al(sizeof(float) * (size_t)Bl.rows * Mp);
