@@ -371,15 +371,15 @@ __device__ __forceinline__ bool embed_pixel(const EmbedArgs &a, long long gp, in
 }
 
 // flag[e] = 1 if entry e is the first (raster order) toucher of its vertex
+// (blockIdx.y = image: the per-entry image index used to be a 64-bit division, ~60 slow VALU instructions per entry)
 __global__ void flag_first_kernel(const int32_t *__restrict__ eslot, const int32_t *__restrict__ first, long long cap,
-                                  int N, int dp1, long long total, unsigned *__restrict__ flag) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        const long long per_img = (long long)N * dp1;
-        const int b = (int)(e / per_img);
-        const int local = (int)(e - b * per_img);
-        flag[e] = first[(long long)b * cap + eslot[e]] == local ? 1u : 0u;
-    }
+                                  int per_img, unsigned *__restrict__ flag) {
+    const int b = blockIdx.y;
+    const int32_t *es = eslot + (long long)b * per_img;
+    const int32_t *fi = first + (long long)b * cap;
+    unsigned *fl = flag + (long long)b * per_img;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_img; i += gridDim.x * blockDim.x)
+        fl[i] = fi[es[i]] == i ? 1u : 0u;
 }
 
 // ---- flat exclusive scan (3 kernels), unsigned 32-bit -------------------------------
@@ -467,14 +467,14 @@ int exclusive_scan(wsc_ctx *ctx, const unsigned *in, long long n, unsigned *out,
 // first-toucher entries publish the row id of their slot and the slot's key
 __global__ void assign_ids_kernel(const int32_t *__restrict__ eslot, const unsigned *__restrict__ flag,
                                   const unsigned *__restrict__ prefix, const unsigned long long *__restrict__ table,
-                                  long long cap, int N, int dp1, long long total, int32_t *__restrict__ slot2row,
+                                  long long cap, int per_img, int32_t *__restrict__ slot2row,
                                   unsigned long long *__restrict__ rowkey, int32_t *__restrict__ rowimg) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        if (!flag[e]) continue;
-        const int b = (int)(e / ((long long)N * dp1));
-        const long long s = (long long)b * cap + eslot[e];
-        const int row = 1 + (int)prefix[e];
+    const int b = blockIdx.y;
+    const long long e0 = (long long)b * per_img;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_img; i += gridDim.x * blockDim.x) {
+        if (!flag[e0 + i]) continue;
+        const long long s = (long long)b * cap + eslot[e0 + i];
+        const int row = 1 + (int)prefix[e0 + i];
         slot2row[s] = row;
         rowkey[row] = table[s];
         rowimg[row] = b;
@@ -483,13 +483,13 @@ __global__ void assign_ids_kernel(const int32_t *__restrict__ eslot, const unsig
 
 // offset[e] = row of entry e
 __global__ __launch_bounds__(256) void remap_kernel(const int32_t *__restrict__ eslot,
-                                                    const int32_t *__restrict__ slot2row, long long cap, int N,
-                                                    int dp1, long long total, int32_t *__restrict__ offset) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(e / ((long long)N * dp1));
-        offset[e] = slot2row[(long long)b * cap + eslot[e]];
-    }
+                                                    const int32_t *__restrict__ slot2row, long long cap,
+                                                    int per_img, int32_t *__restrict__ offset) {
+    const int b = blockIdx.y;
+    const int32_t *es = eslot + (long long)b * per_img;
+    const int32_t *s2r = slot2row + (long long)b * cap;
+    int32_t *of = offset + (long long)b * per_img;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_img; i += gridDim.x * blockDim.x) of[i] = s2r[es[i]];
 }
 
 // ---- splat tables of a pixel tile (lattice build) -------------------------------------------------------
@@ -773,10 +773,11 @@ __global__ __launch_bounds__(256) void tile_scale_entries_kernel(const float *__
     const int N = tg.H * tg.W;
     const int ne = tb.cw * tb.ch * dp1;
     const long long ebase = ((long long)b * N + tb.ebase) * dp1;
+    const unsigned cw_magic = tile_div_magic(tb.cw);
     for (int i = threadIdx.x; i < ne; i += 256) {
         uint2 en = tent[ebase + i];
         const int t = (int)en.x;
-        const int ty = t / tb.cw, tx = t - ty * tb.cw;
+        const int ty = (int)(((unsigned)t * cw_magic) >> 16), tx = t - ty * tb.cw;
         const long long p = (long long)b * N + (long long)(tb.y0 + ty) * tg.W + tb.x0 + tx;
         en.y = __float_as_uint(__uint_as_float(en.y) * norm[p]);
         tent[ebase + i] = en;
@@ -788,11 +789,9 @@ template <int D>
 __global__ void neighbors_kernel(const unsigned long long *__restrict__ rowkey, const int32_t *__restrict__ rowimg,
                                  const unsigned long long *__restrict__ table, const int32_t *__restrict__ slot2row,
                                  long long cap, unsigned cap_mask, int rows, int2 *__restrict__ nbr) {
-    const long long total = (long long)rows * (D + 1);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(i / rows);
-        const int row = (int)(i - (long long)j * rows);
+    const int j = blockIdx.y; // blur axis
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+        const long long i = (long long)j * rows + row;
         if (row == 0) {
             nbr[i] = make_int2(0, 0);
             continue;
@@ -1171,21 +1170,31 @@ __global__ void slice_norm_kernel(const int32_t *__restrict__ offset, const floa
     }
 }
 
-// everything slice_update needs to know about a pixel in 80 contiguous bytes
+// everything the update kernel needs to know about a pixel in 80 contiguous bytes: one thread per 16-byte piece
+// (coalesced stores; blockIdx.y = image, so no per-pixel 64-bit modulo for the shared Gaussian lattice's pixel)
 __global__ void pack_pixels_kernel(const int32_t *__restrict__ off_g, const float *__restrict__ bary_g,
                                    const float *__restrict__ norm_g, const int32_t *__restrict__ off_b,
-                                   const float *__restrict__ bary_b, const float *__restrict__ norm_b, long long npix,
-                                   long long g_pix, uint32_t *__restrict__ rec) {
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
-         p += (long long)gridDim.x * blockDim.x) {
-        uint32_t *r = rec + p * 20;
-        const long long pg = p % g_pix; // the Gaussian lattice arrays describe one image
-        for (int i = 0; i < 3; ++i) r[i] = (uint32_t)off_g[pg * 3 + i];
-        for (int i = 0; i < 6; ++i) r[3 + i] = (uint32_t)off_b[p * 6 + i];
-        for (int i = 0; i < 3; ++i) r[9 + i] = __float_as_uint(bary_g[pg * 3 + i]);
-        for (int i = 0; i < 6; ++i) r[12 + i] = __float_as_uint(bary_b[p * 6 + i]);
-        r[18] = __float_as_uint(norm_g[pg]);
-        r[19] = __float_as_uint(norm_b[p]);
+                                   const float *__restrict__ bary_b, const float *__restrict__ norm_b, int N,
+                                   int g_shared, uint4 *__restrict__ rec) {
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * 5; i += gridDim.x * blockDim.x) {
+        const int n = i / 5, piece = i - n * 5;
+        const long long p = (long long)b * N + n;
+        const long long pg = g_shared ? (long long)n : p; // the Gaussian lattice arrays describe one image
+        uint32_t w[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = piece * 4 + c; // word of the record: 3 + 6 row ids, 3 + 6 barycentric weights, 2 norms
+            uint32_t v;
+            if (k < 3) v = (uint32_t)off_g[pg * 3 + k];
+            else if (k < 9) v = (uint32_t)off_b[p * 6 + (k - 3)];
+            else if (k < 12) v = __float_as_uint(bary_g[pg * 3 + (k - 9)]);
+            else if (k < 18) v = __float_as_uint(bary_b[p * 6 + (k - 12)]);
+            else if (k == 18) v = __float_as_uint(norm_g[pg]);
+            else v = __float_as_uint(norm_b[p]);
+            w[c] = v;
+        }
+        rec[p * 5 + piece] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -1735,8 +1744,9 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.n_tiles + 1), (void **)&tile_nslots));
     WSC_HIP(hipMemsetAsync(tile_nslots, 0, sizeof(unsigned) * (L.n_tiles + 1), ctx->stream));
     hipLaunchKernelGGL(tile_embed_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent, sslot, tile_nslots);
-    hipLaunchKernelGGL(flag_first_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, first, cap, N, dp1,
-                       total, flag);
+    const int per_img = N * dp1; // entries of one image (total < 2^31 checked above)
+    const dim3 grid_img((unsigned)grid1d(per_img, 256, B >= 32 ? 256 : 8192 / (B > 0 ? B : 1)), (unsigned)B);
+    hipLaunchKernelGGL(flag_first_kernel, grid_img, dim3(256), 0, ctx->stream, eslot, first, cap, per_img, flag);
     WSC_TRY(exclusive_scan(ctx, flag, total, prefix, sums));
     // vertex counts: grand total and per-image boundaries
     int herr = 0;
@@ -1766,10 +1776,9 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(tmp.alloc(sizeof(int32_t) * L.rows, (void **)&rowimg));
     WSC_TRY(crf_alloc(crf, sizeof(int2) * (size_t)dp1 * L.rows, (void **)&L.nbr));
 
-    hipLaunchKernelGGL(assign_ids_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, flag, prefix, table,
-                       cap, N, dp1, total, slot2row, rowkey, rowimg);
-    hipLaunchKernelGGL(remap_kernel, dim3(grid1d(total)), dim3(256), 0, ctx->stream, eslot, slot2row, cap, N, dp1, total,
-                       L.offset);
+    hipLaunchKernelGGL(assign_ids_kernel, grid_img, dim3(256), 0, ctx->stream, eslot, flag, prefix, table, cap, per_img,
+                       slot2row, rowkey, rowimg);
+    hipLaunchKernelGGL(remap_kernel, grid_img, dim3(256), 0, ctx->stream, eslot, slot2row, cap, per_img, L.offset);
     {   // splat tables: slots of the grouped tile entries, partial rows of each lattice row
         int32_t *slot_row;
         unsigned *sums2, *row_nslots, *cursor, *sums3;
@@ -1808,7 +1817,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
             L.sorted_dest = true;
         }
     }
-    hipLaunchKernelGGL(neighbors_kernel<D>, dim3(grid1d((long long)L.rows * dp1)), dim3(256), 0, ctx->stream, rowkey,
+    hipLaunchKernelGGL(neighbors_kernel<D>, dim3((unsigned)grid1d(L.rows, 256, 4096), (unsigned)dp1), dim3(256), 0, ctx->stream, rowkey,
                        rowimg, table, slot2row, cap, (unsigned)(cap - 1), L.rows, L.nbr);
     WSC_HIP(hipGetLastError());
     if (D == 2) { // tile tables of the fused blur (one-off per cached Gaussian lattice: the host syncs are fine)
@@ -1949,9 +1958,10 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
     if (st == WSC_OK) st = crf_alloc(crf, sizeof(uint4) * 5 * (size_t)B * crf->N, (void **)&crf->pix_rec);
     if (st == WSC_OK) {
         const long long npix = (long long)B * crf->N;
-        hipLaunchKernelGGL(pack_pixels_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, crf->lat[0].offset,
-                           crf->lat[0].bary, crf->lat[0].norm, crf->lat[1].offset, crf->lat[1].bary, crf->lat[1].norm,
-                           npix, (long long)crf->lat[0].n_pix, (uint32_t *)crf->pix_rec);
+        (void)npix;
+        hipLaunchKernelGGL(pack_pixels_kernel, dim3((unsigned)grid1d((long long)crf->N * 5, 256, 2048), (unsigned)B), dim3(256), 0,
+                           ctx->stream, crf->lat[0].offset, crf->lat[0].bary, crf->lat[0].norm, crf->lat[1].offset,
+                           crf->lat[1].bary, crf->lat[1].norm, crf->N, crf->lat[0].rep > 1 ? 1 : 0, crf->pix_rec);
     }
     if (st != WSC_OK) {
         wsc_crf_destroy(crf);
