@@ -882,11 +882,17 @@ __global__ __launch_bounds__(256) void slot_ones_kernel(const int32_t *__restric
     const int b = tile / tg.tpi, j = tile - b * tg.tpi;
     const TileBox tb = tile_box(tg, j);
     const long long ebase = ((long long)b * tg.H * tg.W + tb.ebase) * dp1;
+    // the tile's entry weights through LDS (one coalesced pass): a thread then walks its slot's entries at LDS latency
+    // instead of <= 32 dependent trips to L2 (a tile has ~120 slots: half the block's threads each own a chain)
+    __shared__ float w[TILE_PIX * 6];
+    const int ne = tb.cw * tb.ch * dp1;
+    for (int i = threadIdx.x; i < ne; i += 256) w[i] = __uint_as_float(tent[ebase + i].y);
+    __syncthreads();
     for (int s = tslot_start[tile] + threadIdx.x; s < tslot_start[tile + 1]; s += 256) {
         const int2 d = slot_desc[s];
         const int i0 = d.x & 0xffff, n = d.x >> 16;
         float acc = 0.f;
-        for (int i = 0; i < n; ++i) acc += __uint_as_float(tent[ebase + i0 + i].y);
+        for (int i = 0; i < n; ++i) acc += w[i0 + i];
         part[d.y] = acc;
     }
 }
