@@ -150,3 +150,28 @@ def test_conv_square_tile_large_layer(ctx, precision):
     err = np.abs(y - ref)
     bound = 2.0 ** -11 * np.abs(ref) + 3e-4 * mx if precision == _lib.PREC_F16 else np.full_like(ref, 1e-4 * mx)
     assert not (err > bound).any(), "max err %.4g (max|ref| %.3g)" % (err.max(), mx)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 65, 65, 64, 7, 2, 3), (3, 64, 21, 23, 256, 1, 1, 0), (2, 256, 17, 17, 64, 1, 1, 0),
+                                   (2, 64, 19, 19, 64, 3, 1, 1), (2, 128, 21, 21, 128, 3, 2, 1), (2, 256, 16, 16, 512, 1, 2, 0),
+                                   (3, 512, 13, 11, 512, 3, 1, 1), (2, 1024, 9, 9, 256, 1, 1, 0)])
+def test_conv_fast_variants_equal_generic_path(ctx, shape, monkeypatch):
+    """The FAST kernel variants (case-free epilogue with ReLU + saturation as one median, pointwise prologue, one-K-step
+    tiles at 128 VGPRs, unrolled K loop) against the generic path of the same kernel (WSC_CONV_NOFAST=1, read per call):
+    the same fp16 values (0.0 == -0.0), with and without residual / ReLU, including outputs that saturate at 65504."""
+    N, Cin, H, W, Cout, k, stride, pad = shape
+    rng = np.random.default_rng(Cin * 7 + Cout + k)
+    x = rng.normal(0, 1, (N, Cin, H, W)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, Cin, k, k)) * np.sqrt(2.0 / (Cin * k * k))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    scale[:4] = 3.0e4  # a few channels overflow the fp16 range: the saturation path is compared too
+    shift = rng.normal(0, 0.2, Cout).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = rng.normal(0, 1, (N, Cout, Ho, Wo)).astype(np.float32)
+    for use_res, relu in [(False, True), (True, True), (True, False)]:
+        monkeypatch.setenv("WSC_CONV_NOFAST", "1")
+        y_ref = _run(ctx, x, w, stride, pad, scale, shift, res if use_res else None, relu, _lib.PREC_F16)
+        monkeypatch.setenv("WSC_CONV_NOFAST", "0")
+        y = _run(ctx, x, w, stride, pad, scale, shift, res if use_res else None, relu, _lib.PREC_F16)
+        assert np.isfinite(y).all() and np.abs(y).max() == 65504.0
+        assert np.array_equal(y, y_ref), (shape, use_res, relu, np.abs(y - y_ref).max())

@@ -840,7 +840,8 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     }();
     a.debug = debug;
     // FAST variants (see the kernel): f16, one precision plane, fp16 output only, full column tiles, no post-ReLU affine
-    static const int nofast = [] { const char *e = getenv("WSC_CONV_NOFAST"); return e ? atoi(e) : 0; }();
+    const char *nfe = getenv("WSC_CONV_NOFAST"); // read per call, so a test can compare the two paths
+    const int nofast = nfe ? atoi(nfe) : 0;
     a.fast = 0;
     if (!nofast && p.fmt && !p.split && p.y != nullptr && p.y_f32 == nullptr &&
         p.Cout == p.CoutPad && (long long)a.M * p.Cout < (1ll << 31)) {
