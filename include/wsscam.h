@@ -259,6 +259,14 @@ int wsc_cam_unary(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w
 int wsc_cam_unary_pm(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
                      float *unary_pm_dev);
 
+/* Multi-scale inference (args.cam_scales, 03b_irn/step/make_cam.py:62-69: `torch.sum(torch.stack([F.interpolate(o, size) for
+ * o in outputs]), 0)` for the strided and the high-resolution maps): every scale of the MSF dataset is resized to the same
+ * network input (voc12/dataloader.py:232-240), so the per-scale CAMs have one size and, bilinear interpolation being linear,
+ * the sum of the interpolated maps is the interpolation of the summed map (up to fp32 rounding, ~1e-7 relative).  The scales
+ * of an image are consecutive "images" of one wsc_net_forward_cam batch; this adds them in scale order:
+ *   cam_dev float32 [n_images * n_scales][map_elems]  ->  out_dev float32 [n_images][map_elems]   (out_dev != cam_dev) */
+int wsc_cam_sum_scales(wsc_ctx *ctx, const float *cam_dev, int n_images, int n_scales, long long map_elems, float *out_dev);
+
 /* The MSF dataset transform of a batch of DECODED images (03b_irn/voc12/dataloader.py:68-106, 225-246; constants of
  * adp/dataloader.py:64-80, deepglobe/dataloader.py:60-66): float64 bilinear resize to S x S (cv2.resize INTER_LINEAR
  * on the float64 image, skipped when the image already has that size), float32 normalisation

@@ -213,14 +213,15 @@ def get_strided_up_size(orig_size, stride):
 
 
 def make_cam_tail(cam, size, valid_cat):
-    """make_cam._work, 03b_irn/step/make_cam.py:41-42,62-76 for one scale.
+    """make_cam._work, 03b_irn/step/make_cam.py:41-42,62-76.
 
-    cam: (C,h,w) tensor; size: (H0,W0); valid_cat: LongTensor of class indices.
+    cam: (C,h,w) tensor, or a list of them (one per args.cam_scales entry: every scale is interpolated, THEN summed, the
+    reference's order); size: (H0,W0); valid_cat: LongTensor of class indices.
     Returns (strided_cam (K,h4,w4), highres_cam (K,H0,W0)) float32 tensors.
     """
     strided_size = get_strided_size(size, 4)
     strided_up_size = get_strided_up_size(size, 16)
-    outputs = [cam]
+    outputs = list(cam) if isinstance(cam, (list, tuple)) else [cam]
     strided_cam = torch.sum(torch.stack(
         [F.interpolate(torch.unsqueeze(o, 0), strided_size, mode="bilinear", align_corners=False)[0]
          for o in outputs]), 0)

@@ -92,6 +92,23 @@ def test_voc_dataset_item(tmp_path, monkeypatch):
     r = voc_dl.resize_bilinear_f64(x, (224, 224))
     assert np.allclose(it["img"][0, 0], (np.float32(r[..., 0]) - 104.0) / 255.0, atol=1e-6)
     assert np.allclose(it["img"][0, 2], (np.float32(r[..., 2]) - 123.0) / 255.0, atol=1e-6)
+    # args.cam_scales with several entries (voc12/dataloader.py:231-242): a LIST of pairs, every scale PIL-bicubic rescaled to
+    # round(H s) x round(W s) and then resized to the same outsize; scale 1 is the plain item; device_transform hands over
+    # the rescaled uint8 images instead
+    from wsscam.misc import imutils
+
+    ms = voc_dl.VOC12ClassificationDatasetMSF(str(lst), str(tmp_path), norm_mode="int", outsize=(224, 224), scales=(1.0, 0.5, 1.5))[0]
+    assert isinstance(ms["img"], list) and [a.shape for a in ms["img"]] == [(2, 3, 224, 224)] * 3
+    assert np.array_equal(ms["img"][0], it["img"]) and ms["size"] == (50, 70)
+    raw = np.asarray(PIL_Image.open(voc_dl.get_img_path("2007_000032", str(tmp_path))).convert("RGB"))
+    half = imutils.pil_rescale(raw, 0.5, order=3)
+    assert half.shape == (25, 35, 3) and imutils.pil_rescale(raw, 1.5, order=3).shape == (75, 105, 3)
+    assert np.array_equal(half, np.asarray(PIL_Image.fromarray(raw).resize((35, 25), PIL_Image.BICUBIC)))
+    assert np.array_equal(ms["img"][1], voc_dl.msf_pack(half, (224, 224), voc_dl.TorchvisionNormalize("int")))
+    assert imutils.pil_resize(raw, (50, 70), 3) is raw
+    u8 = voc_dl.VOC12ClassificationDatasetMSF(str(lst), str(tmp_path), norm_mode="int", outsize=(224, 224), scales=(1.0, 0.5),
+                                              device_transform=True)[0]
+    assert "img" not in u8 and [a.shape for a in u8["img_u8"]] == [(50, 70, 3), (25, 35, 3)]
 
 
 def test_label_table_lookup_order(tmp_path, monkeypatch):

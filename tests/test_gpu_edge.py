@@ -68,6 +68,54 @@ def test_make_cam_run_end_to_end(tmp_path):
         assert np.abs(rec["cam"] - ref["cam"]).max() <= 2e-4
 
 
+@pytest.mark.parametrize("mode", ["batch", "pipeline", "pipeline_u8"])
+def test_make_cam_multi_scale(tmp_path, mode):
+    """args.cam_scales with several entries (make_cam.py:62-69 sums the per-scale interpolated maps; the MSF dataset rescales
+    with PIL bicubic and resizes every scale to the same network input, voc12/dataloader.py:231-240): dataset items with a
+    LIST of pairs through the serial path, the overlapped pipeline and the device-side input transform, against the oracle
+    in the reference's order (interpolate each scale, then sum).  Summing before the (linear) interpolation differs by
+    fp32 rounding only: the bound is the single-scale one."""
+    from wsscam.misc import imutils
+    from wsscam.voc12 import dataloader as voc_dl
+
+    sd = cnn_ref.make_resnet50_cam_state_dict(20, seed=0)
+    rng = np.random.default_rng(5)
+    sizes = [(60, 80), (97, 64), (64, 72), (50, 50), (33, 47)]
+    scales = (1.0, 0.5, 1.5)
+    labels = [np.zeros(20, np.float32) for _ in sizes]
+    for i, cls in enumerate([[1, 4], [7], [], [0, 19], [12]]):
+        labels[i][cls] = 1
+    norm = voc_dl.TorchvisionNormalize("float")
+    raws = [cnn_ref.synth_image(rng, *sz) for sz in sizes]
+    data, data_u8 = [], []
+    for i, (raw, sz, lb) in enumerate(zip(raws, sizes, labels)):
+        s_imgs = imutils.scale_images(raw, scales)
+        assert s_imgs[1].shape[:2] == (int(np.round(sz[0] * 0.5)), int(np.round(sz[1] * 0.5))) and s_imgs[0] is raw
+        data.append({"name": "2008_%06d" % i, "img": [voc_dl.msf_pack(si, (65, 65), norm) for si in s_imgs], "size": sz, "label": lb})
+        data_u8.append({"name": "2008_%06d" % i, "img_u8": s_imgs, "size": sz, "label": lb})
+    args = types.SimpleNamespace(cam_network="net.resnet50_cam", model_dir=None, dataset="voc12", tag="", num_classes=20,
+                                 use_cls=None, model_id="resnet50", cam_weights_name=None, state_dict=sd,
+                                 dataset_obj=data_u8 if mode == "pipeline_u8" else data, split="train_aug",
+                                 cam_out_dir=str(tmp_path), n_gpus=1, cam_batch_images=2, cam_precision=_lib.PREC_BF16X3,
+                                 cam_pipeline=mode != "batch", outsize=(65, 65), norm_mode="float", cam_scales=scales)
+    make_cam.run(args)
+    contrib = 0.0
+    for d in data:
+        rec = np.load(os.path.join(tmp_path, d["name"] + ".npy"), allow_pickle=True).item()
+        if d["label"].sum() == 0:
+            assert all(rec[k].shape == (0,) for k in rec)
+            continue
+        valid = torch.nonzero(torch.from_numpy(d["label"]))[:, 0]
+        with torch.no_grad():
+            cams = [cnn_ref.resnet50_cam_forward(torch.from_numpy(x), sd) for x in d["img"]]
+            rs, rh = cnn_ref.make_cam_tail(cams, d["size"], valid)
+            one, _ = cnn_ref.make_cam_tail(cams[0], d["size"], valid)
+        assert np.array_equal(rec["keys"], valid.numpy())
+        assert np.abs(rec["cam"] - rs.numpy()).max() <= 2e-4 and np.abs(rec["high_res"] - rh.numpy()).max() <= 2e-4
+        contrib = max(contrib, float(np.abs(rs.numpy() - one.numpy()).max()))
+    assert contrib > 1e-2  # the other scales really contribute (a random-init class map can be all zero: checked over the set)
+
+
 def test_cam_tail_large_native_size(ctx):
     """ADP evaluation size 1088x1088 (eval_cam.py:28): 1.18 M pixels per class map."""
     rng = np.random.default_rng(3)

@@ -371,6 +371,32 @@ int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N
 static int cam_unary_impl(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
                           float *unary_dev, bool pixel_major);
 
+// out[b] = sum over the n_scales consecutive maps of image b, added in scale order (fp32)
+__global__ void cam_sum_scales_kernel(const float *__restrict__ cam, long long n_out, int n_scales, long long elems,
+                                      float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / elems, e = i - b * elems;
+        const float *src = cam + (b * n_scales) * elems + e;
+        float acc = src[0];
+        for (int sidx = 1; sidx < n_scales; ++sidx) acc += src[(long long)sidx * elems];
+        out[i] = acc;
+    }
+}
+
+int wsc_cam_sum_scales(wsc_ctx *ctx, const float *cam_dev, int n_images, int n_scales, long long map_elems, float *out_dev) {
+    WSC_CHECK(ctx && cam_dev && out_dev, WSC_ERR_INVALID, "wsc_cam_sum_scales: null argument");
+    WSC_CHECK(n_images > 0 && n_scales > 0 && map_elems > 0, WSC_ERR_INVALID, "wsc_cam_sum_scales: bad argument");
+    WSC_CHECK(cam_dev != out_dev || n_scales == 1, WSC_ERR_INVALID, "wsc_cam_sum_scales: in-place call with several scales");
+    WSC_HIP(hipSetDevice(ctx->device));
+    const long long n_out = (long long)n_images * map_elems;
+    long long g = (n_out + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(cam_sum_scales_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, cam_dev, n_out, n_scales, map_elems,
+                       out_dev);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
 int wsc_cam_unary(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h, int w, int H0, int W0, float bg_value,
                   float *unary_dev) {
     return cam_unary_impl(ctx, cam_dev, B, C, h, w, H0, W0, bg_value, unary_dev, false);

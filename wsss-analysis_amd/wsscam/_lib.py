@@ -96,6 +96,7 @@ _SIGNATURES = {
     "wsc_unary_from_maps": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "wsc_cam_unary": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wsc_cam_unary_pm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "wsc_cam_sum_scales": (_i, [_vp, _vp, _i, _i, ctypes.c_longlong, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     "wsc_msf_input_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "wsc_label_unary_from_cam": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
@@ -487,6 +488,11 @@ def cam_unary(ctx, cam_dev, B, C, h, w, H0, W0, bg_value, unary_dev, pixel_major
     pixel_major: unaries as [B][H0*W0][Mp] (Mp = 4 ceil((C+1)/4)) for Crf.inference(..., pixel_major=True)."""
     fn = ctx._lib.wsc_cam_unary_pm if pixel_major else ctx._lib.wsc_cam_unary
     check(fn(ctx.h, _ptr(cam_dev), B, C, h, w, H0, W0, float(bg_value), _ptr(unary_dev)))
+
+
+def cam_sum_scales(ctx, cam_dev, n_images, n_scales, map_elems, out_dev):
+    """out[b] = sum_s cam[b * n_scales + s] (make_cam.py:62-69 for equal-size scales; see include/wsscam.h)."""
+    check(ctx._lib.wsc_cam_sum_scales(ctx.h, _ptr(cam_dev), int(n_images), int(n_scales), int(map_elems), _ptr(out_dev)))
 
 
 def bilinear_resize(ctx, src_dev, C, h, w, dst_dev, H, W):

@@ -50,7 +50,7 @@ class DeepGlobeClassificationDatasetMSF:
                  cls_labels_path=None):
         assert norm_mode in ["float", "int"]
         assert outsize in [(321, 321), (224, 224), None]
-        assert tuple(scales) == (1.0,), "multi-scale inference (pil_rescale) is not implemented"
+        self.scales = tuple(scales)
         self.img_name_list = load_img_name_list(img_name_list_path)
         self.dev_root = dev_root
         self.outsize = outsize
@@ -65,7 +65,11 @@ class DeepGlobeClassificationDatasetMSF:
 
         name = str(self.img_name_list[idx])
         img = np.asarray(Image.open(get_img_path(name, self.dev_root)).convert("RGB"))
-        x, orig = msf_item(img, self.outsize, self.norm)
+        from ..misc import imutils
+
+        items = [msf_item(si, self.outsize, self.norm) for si in imutils.scale_images(img, self.scales)]
+        x = items[0][0] if len(items) == 1 else [it[0] for it in items]
+        orig = items[0][1] if len(items) == 1 else [it[1] for it in items]
         return {"name": name, "img": x, "orig_img": orig, "size": (img.shape[0], img.shape[1]),
                 "label": self.label_list[idx]}
 

@@ -16,6 +16,35 @@ def get_strided_up_size(orig_size, stride):
     return strided_size[0] * stride, strided_size[1] * stride
 
 
+def pil_resize(img, size, order):
+    """misc/imutils.py of the upstream IRN code base (the module is not vendored in the reference tree; its MSF datasets
+    call it at voc12/dataloader.py:236, adp/dataloader.py:228, deepglobe/dataloader.py:206): PIL resize of a uint8 HWC
+    image to size = (height, width), bicubic for order 3, nearest for order 0."""
+    from PIL import Image
+
+    if size[0] == img.shape[0] and size[1] == img.shape[1]:
+        return img
+    if order == 3:
+        resample = Image.BICUBIC
+    elif order == 0:
+        resample = Image.NEAREST
+    else:
+        raise ValueError("pil_resize: order %r (3 = bicubic, 0 = nearest)" % (order,))
+    return np.asarray(Image.fromarray(np.uint8(img)).resize(size[::-1], resample))
+
+
+def pil_rescale(img, scale, order):
+    """The multi-scale inference rescale (args.cam_scales): target = round(H * scale) x round(W * scale)."""
+    height, width = img.shape[:2]
+    target_size = (int(np.round(height * scale)), int(np.round(width * scale)))
+    return pil_resize(img, target_size, order)
+
+
+def scale_images(img_u8, scales):
+    """[img at every scale of `scales`] as the MSF datasets build them (s == 1: the image itself)."""
+    return [img_u8 if s == 1 else pil_rescale(img_u8, s, order=3) for s in scales]
+
+
 def HWC_to_CHW(img):
     return np.transpose(img, (2, 0, 1))
 

@@ -50,12 +50,20 @@ def _save(args, name, keys, strided, highres):
         np.save(path, {"keys": keys, "cam": strided, "high_res": highres})
 
 
+def _scales_of(v):
+    """The per-scale entries of an MSF dataset field: a list for several scales, the array itself for one."""
+    return list(v) if isinstance(v, (list, tuple)) else [v]
+
+
 def process_batch(model, packs, args, save=True):
     """One device batch: list of dataset items -> list of result dicts (and .npy files)."""
     ctx = model.ctx
     B = len(packs)
-    x = np.stack([np.asarray(p["img"], dtype=np.float32) for p in packs])  # (B,2,3,S,S)
-    if x.ndim != 5 or x.shape[1:3] != (2, 3) or x.shape[-2] != x.shape[-1]:
+    # multi-scale items carry a list of (2,3,S,S) pairs (one per args.cam_scales entry, all resized to the same S): the scales
+    # of an image run as consecutive "images" of one device batch and their CAMs are summed before the tail
+    n_sc = len(_scales_of(packs[0]["img"]))
+    x = np.stack([np.stack([np.asarray(v, dtype=np.float32) for v in _scales_of(p["img"])]) for p in packs])  # (B,n_sc,2,3,S,S)
+    if x.ndim != 6 or x.shape[2:4] != (2, 3) or x.shape[-2] != x.shape[-1]:
         # wsc_net_forward_cam takes square S x S inputs: the reference's outsize=None configuration (native, non-square
         # image sizes, func_sample.py:143-145) is not supported -- INTEGRATION.md, "limits"
         raise ValueError("make_cam: network inputs must be (B, 2, 3, S, S) with one square size per run "
@@ -65,20 +73,34 @@ def process_batch(model, packs, args, save=True):
     h = model.cam_size(S)
     has_cls = model.arch != _lib.ARCH_RESNET50_CAM
     x_dev = ctx.to_device(x)
-    cam_dev = ctx.alloc(B * C * h * h * 4)
-    score_dev = ctx.alloc(B * C * 4) if has_cls else None
-    model.forward_batch_device(x_dev, B, S, cam_dev, score_dev)
-    score = ctx.to_host(score_dev, (B, C), np.float32) if has_cls else None
+    cam_dev = ctx.alloc(B * n_sc * C * h * h * 4)
+    score_dev = ctx.alloc(B * n_sc * C * 4) if has_cls else None
+    model.forward_batch_device(x_dev, B * n_sc, S, cam_dev, score_dev)
+    # make_cam.py:52: `label = labels[0][args.use_cls]` -- the prediction of the FIRST scale decides the classes
+    score = ctx.to_host(score_dev, (B, n_sc, C), np.float32)[:, 0] if has_cls else None
     keys = [_valid_cat(args, p, None if score is None else score[b], model) for b, p in enumerate(packs)]
     sizes = [tuple(int(v) for v in p["size"]) for p in packs]
     if args.dataset in ("adp_morph", "adp_func"):
         # vgg16_cam.py:51-58 / common_cam.py:31-92: background (and 'other') channels are synthesised from the
-        # ORIGINAL image on the host (scipy Gaussian filter) and joined with the use_cls CAM channels before
-        # the tail; the modified maps go back to the device for the two resizes + normalisation.
-        cam = ctx.to_host(cam_dev, (B, C, h, h), np.float32)
-        mod = np.stack([model.adp_modify(cam[b], np.asarray(p["orig_img"])) for b, p in enumerate(packs)])
+        # ORIGINAL image (of that scale) on the host (scipy Gaussian filter) and joined with the use_cls CAM channels
+        # before the tail; the modified maps (summed over the scales) go back to the device for the two resizes +
+        # normalisation.
+        cam = ctx.to_host(cam_dev, (B, n_sc, C, h, h), np.float32)
+        mod = []
+        for b, p in enumerate(packs):
+            origs = _scales_of(p["orig_img"])
+            acc = None
+            for sidx in range(n_sc):
+                m = np.asarray(model.adp_modify(cam[b, sidx], np.asarray(origs[sidx])), dtype=np.float32)
+                acc = m if acc is None else acc + m
+            mod.append(acc)
+        mod = np.stack(mod)
         C = mod.shape[1]
         cam_dev = ctx.to_device(np.ascontiguousarray(mod, dtype=np.float32))
+    elif n_sc > 1:
+        sum_dev = ctx.alloc(B * C * h * h * 4)
+        _lib.cam_sum_scales(ctx, cam_dev, B, n_sc, C * h * h, sum_dev)
+        cam_dev = sum_dev
     s_dev, h_dev, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, B, C, h, h, sizes, keys)
     s_tot = sum(k * a * b for (k, a, b, _, _) in shapes)
     h_tot = sum(k * a * b for (k, _, _, a, b) in shapes)
@@ -120,11 +142,12 @@ def _work(process_id, model, dataset, args):
 
     first = databin[0]
     norm = None
+    n_sc = len(_scales_of(first["img"] if "img" in first else first["img_u8"]))
     if "img" in first:
-        S = int(np.asarray(first["img"]).shape[-1])
-        if np.asarray(first["img"]).shape != (2, 3, S, S):
-            raise ValueError("make_cam: network inputs must be (2, 3, S, S) with one square size per run; got %s"
-                             % (np.asarray(first["img"]).shape,))
+        f0 = np.asarray(_scales_of(first["img"])[0])
+        S = int(f0.shape[-1])
+        if f0.shape != (2, 3, S, S):
+            raise ValueError("make_cam: network inputs must be (2, 3, S, S) with one square size per run; got %s" % (f0.shape,))
     else:  # dataset built with device_transform=True: items carry the decoded image, the transform runs on the GPU
         S = int(args.outsize[0])
         base = getattr(databin, "dataset", databin)
@@ -140,7 +163,7 @@ def _work(process_id, model, dataset, args):
     pipe = CamPipeline(model, device, bs, S, keys_fn=lambda pack, score: _valid_cat(args, pack, score, model),
                        save_fn=lambda name, keys, sc, hc: _save(args, name, keys, sc, hc), needs_score=needs_score,
                        n_lanes=int(getattr(args, "cam_pipeline_lanes", 3)), n_loaders=int(getattr(args, "cam_loader_threads", 8)),
-                       n_writers=int(getattr(args, "cam_writer_threads", 8)), norm=norm)
+                       n_writers=int(getattr(args, "cam_writer_threads", 8)), norm=norm, n_scales=n_sc)
     try:
         pipe.run(databin)
     finally:

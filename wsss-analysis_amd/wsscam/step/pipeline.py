@@ -19,16 +19,17 @@ from .. import _lib
 
 
 class _Lane:
-    def __init__(self, device, B, S, C, h):
+    def __init__(self, device, B, S, C, h, n_sc=1):
         self.ctx = _lib.Context(device)
-        self.B, self.S, self.C, self.h = B, S, C, h
-        self.in_bytes = B * 2 * 3 * S * S * 4
+        self.B, self.S, self.C, self.h, self.n_sc = B, S, C, h, n_sc
+        self.in_bytes = B * n_sc * 2 * 3 * S * S * 4
         self.pin_in = self.ctx.host_alloc(self.in_bytes)
-        self.x_view = self.pin_in.view((B, 2, 3, S, S), np.float32)
+        self.x_view = self.pin_in.view((B, n_sc, 2, 3, S, S), np.float32)  # the scales of an image are consecutive samples
         self.x_dev = self.ctx.alloc(self.in_bytes)
-        self.cam_dev = self.ctx.alloc(B * C * h * h * 4)
-        self.score_dev = self.ctx.alloc(B * C * 4)
-        self.pin_score = self.ctx.host_alloc(B * C * 4)
+        self.cam_dev = self.ctx.alloc(B * n_sc * C * h * h * 4)
+        self.sum_dev = self.ctx.alloc(B * C * h * h * 4) if n_sc > 1 else None
+        self.score_dev = self.ctx.alloc(B * n_sc * C * 4)
+        self.pin_score = self.ctx.host_alloc(B * n_sc * C * 4)
         self.out_cap = 0
         self.pin_out = None
         self.s_dev = self.h_dev = None
@@ -61,7 +62,7 @@ class _Lane:
 
     def close(self):
         self.ctx.sync()
-        for b in (self.pin_in, self.pin_out, self.pin_score, self.x_dev, self.cam_dev, self.score_dev, self.s_dev, self.h_dev,
+        for b in (self.pin_in, self.pin_out, self.pin_score, self.x_dev, self.cam_dev, self.sum_dev, self.score_dev, self.s_dev, self.h_dev,
                   self.pin_u8, self.u8_dev):
             if b is not None:
                 b.free()
@@ -73,13 +74,14 @@ class CamPipeline:
     `save_fn(name, keys, strided, highres)` are the driver's own (make_cam._valid_cat / _save)."""
 
     def __init__(self, model, device, batch_images, S, keys_fn, save_fn, needs_score, n_lanes=3, n_loaders=8, n_writers=8,
-                 norm=None):
+                 norm=None, n_scales=1):
         self.model, self.device, self.B, self.S = model, device, batch_images, S
         self.norm = norm  # TorchvisionNormalize of the dataset (device transform of "img_u8" items)
         self.keys_fn, self.save_fn, self.needs_score = keys_fn, save_fn, needs_score
         self.C = model.num_classes
         self.h = model.cam_size(S)
-        self.lanes = [_Lane(device, batch_images, S, self.C, self.h) for _ in range(n_lanes)]
+        self.n_sc = int(n_scales)  # args.cam_scales: every image contributes n_sc network inputs, their CAMs are summed
+        self.lanes = [_Lane(device, batch_images, S, self.C, self.h, self.n_sc) for _ in range(n_lanes)]
         self.loaders = ThreadPoolExecutor(n_loaders, thread_name_prefix="wsc-load")
         self.writers = ThreadPoolExecutor(n_writers, thread_name_prefix="wsc-save")
         self.finishers = ThreadPoolExecutor(n_lanes, thread_name_prefix="wsc-finish")
@@ -91,10 +93,11 @@ class CamPipeline:
         pack = dataset[idx]
         if "img" not in pack:  # device transform: the decoded uint8 image travels, wsc_msf_input_u8 does the rest
             return dict(pack)
-        img = np.asarray(pack["img"], dtype=np.float32)
+        v = pack["img"]
+        img = np.stack([np.asarray(a, dtype=np.float32) for a in (v if isinstance(v, (list, tuple)) else [v])])
         if img.shape != lane.x_view.shape[1:]:
-            raise ValueError("make_cam: network inputs must be (2, 3, %d, %d) for every image of a run; %s has %s"
-                             % (self.S, self.S, pack.get("name"), img.shape))
+            raise ValueError("make_cam: network inputs must be %d x (2, 3, %d, %d) for every image of a run; %s has %s"
+                             % (self.n_sc, self.S, self.S, pack.get("name"), img.shape))
         lane.x_view[k] = img  # page-locked: the H2D below is a straight DMA
         return {key: v for key, v in pack.items() if key != "img"}
 
@@ -124,31 +127,39 @@ class CamPipeline:
         if "img_u8" in metas[0]:
             # decoded images: (sum H0 W0 3) bytes over PCIe instead of n x 2.47 MB of float32; resize + normalise + flip
             # pair on the device, bit-identical to the host transform (csrc/input.hip)
-            sizes_u8 = [tuple(int(v) for v in np.asarray(m["img_u8"]).shape[:2]) for m in metas]
+            imgs_u8 = []
+            for m in metas:  # (image, scale) order = sample order of the device batch
+                v = m.pop("img_u8")
+                imgs_u8.extend(v if isinstance(v, (list, tuple)) else [v])
+            sizes_u8 = [tuple(int(v) for v in np.asarray(a).shape[:2]) for a in imgs_u8]
             offs = np.concatenate(([0], np.cumsum([h * w * 3 for h, w in sizes_u8]))).astype(np.int64)
             lane.ensure_u8(int(offs[-1]))
             buf = lane.pin_u8.view((lane.u8_cap,), np.uint8)
-            for k, m in enumerate(metas):
-                buf[offs[k]:offs[k + 1]] = np.ascontiguousarray(m.pop("img_u8"), dtype=np.uint8).reshape(-1)
+            for k, a in enumerate(imgs_u8):
+                buf[offs[k]:offs[k + 1]] = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
             ctx.h2d_async(lane.u8_dev, lane.pin_u8, int(offs[-1]))
             norm = self.norm
             _lib.msf_input_u8(ctx, lane.u8_dev, sizes_u8, offs[:-1], self.S, norm.mean, norm.std, lane.x_dev,
                               pre_div255=norm.norm_mode == "float", pair=True)
         else:
-            ctx.h2d_async(lane.x_dev, lane.pin_in, n * 2 * 3 * self.S * self.S * 4)
-        self.model._ensure_net().forward_cam(lane.x_dev, n, self.S, lane.cam_dev, lane.score_dev if self.needs_score else None,
-                                             ctx=ctx)
+            ctx.h2d_async(lane.x_dev, lane.pin_in, n * self.n_sc * 2 * 3 * self.S * self.S * 4)
+        self.model._ensure_net().forward_cam(lane.x_dev, n * self.n_sc, self.S, lane.cam_dev,
+                                             lane.score_dev if self.needs_score else None, ctx=ctx)
+        cam_dev = lane.cam_dev
+        if self.n_sc > 1:  # make_cam.py:62-69: sum over the scales (all of one size: see wsc_cam_sum_scales)
+            _lib.cam_sum_scales(ctx, lane.cam_dev, n, self.n_sc, self.C * self.h * self.h, lane.sum_dev)
+            cam_dev = lane.sum_dev
         score = None
         if self.needs_score:  # predicted labels decide which maps are produced: one small read-back
-            ctx.d2h_async(lane.pin_score, lane.score_dev, n * self.C * 4)
+            ctx.d2h_async(lane.pin_score, lane.score_dev, n * self.n_sc * self.C * 4)
             ctx.sync()
-            score = lane.pin_score.view((n, self.C), np.float32).copy()
+            score = lane.pin_score.view((n, self.n_sc, self.C), np.float32)[:, 0].copy()  # labels[0]: the first scale's
         keys = [self.keys_fn(m, None if score is None else score[b]) for b, m in enumerate(metas)]
         sizes = [tuple(int(v) for v in m["size"]) for m in metas]
         s_tot = sum(len(k) * ((H - 1) // 4 + 1) * ((W - 1) // 4 + 1) for k, (H, W) in zip(keys, sizes))
         h_tot = sum(len(k) * H * W for k, (H, W) in zip(keys, sizes))
         lane.ensure_out(s_tot, h_tot)
-        _, _, s_off, h_off, shapes = _lib.cam_postprocess(ctx, lane.cam_dev, n, self.C, self.h, self.h, sizes, keys,
+        _, _, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, n, self.C, self.h, self.h, sizes, keys,
                                                           lane.s_dev, lane.h_dev)
         ctx.d2h_async(lane.pin_out, lane.s_dev, max(s_tot, 1) * 4)
         ctx.d2h_async(lane.pin_out, lane.h_dev, max(h_tot, 1) * 4, dst_offset=max(s_tot, 1) * 4)

@@ -82,7 +82,7 @@ class VOC12ClassificationDatasetMSF:
                  cls_labels_path=None, device_transform=False):
         assert norm_mode in ["float", "int"]
         assert outsize in [(321, 321), (224, 224), None]
-        assert tuple(scales) == (1.0,), "multi-scale inference (pil_rescale) is not implemented"
+        self.scales = tuple(scales)
         self.img_name_list = load_img_name_list(img_name_list_path)
         self.dev_root = dev_root
         self.outsize = outsize
@@ -104,9 +104,16 @@ class VOC12ClassificationDatasetMSF:
 
         name_str = decode_int_filename(self.img_name_list[idx])
         img = np.asarray(Image.open(get_img_path(name_str, self.dev_root)).convert("RGB"))
+        # voc12/dataloader.py:231-242: every scale is rescaled (PIL bicubic), then resized to `outsize` like the plain image;
+        # one scale -> the array itself, several -> a list (the reference's item format)
+        from ..misc import imutils
+
+        s_imgs = imutils.scale_images(img, self.scales)
         if self.device_transform:
-            return {"name": name_str, "img_u8": img, "size": (img.shape[0], img.shape[1]), "label": self.label_list[idx]}
-        return {"name": name_str, "img": msf_pack(img, self.outsize, self.norm), "size": (img.shape[0], img.shape[1]),
+            return {"name": name_str, "img_u8": s_imgs[0] if len(s_imgs) == 1 else s_imgs, "size": (img.shape[0], img.shape[1]),
+                    "label": self.label_list[idx]}
+        ms = [msf_pack(si, self.outsize, self.norm) for si in s_imgs]
+        return {"name": name_str, "img": ms[0] if len(ms) == 1 else ms, "size": (img.shape[0], img.shape[1]),
                 "label": self.label_list[idx]}
 
 
