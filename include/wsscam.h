@@ -245,6 +245,18 @@ int wsc_cam_eval_confusion(wsc_ctx *ctx, const float *highres_dev, int B, const 
 int wsc_unary_from_maps(wsc_ctx *ctx, const float *maps_dev, int B, int C, int N, float bg_value,
                         float *unary_dev);
 
+/* The ADP / DeepGlobe branch of eval_cam (03b_irn/step/eval_cam.py:53-63): no background padding, the keys are class ids,
+ *   pred = keys[np.argmax(maps, axis=0)];  pred = cv2.resize(pred, outsize, interpolation=cv2.INTER_NEAREST)
+ *   confusion[gt][pred] += 1 where gt != ignore_label
+ * maps_dev: image b's [K_b][h_b * w_b] block at float offset maps_off[b] (high_res for ADP, the strided cam for DeepGlobe);
+ * gt_dev / pred_dev: uint8 at the OUTPUT size (out_h * out_w per image, packed in batch order; 1088 x 1088 / 2448 x 2448 in
+ * the reference).  The nearest-neighbour source index follows cv2: min(floor(x * (1. / (out / src))), src - 1) in double.
+ * confusion_dev int64 [n_class][n_class] is accumulated into, as in wsc_cam_eval_confusion. */
+int wsc_cam_eval_confusion_nn(wsc_ctx *ctx, const float *maps_dev, int B, const int32_t *src_hw_host /*[B][2]*/,
+                              const int32_t *out_hw_host /*[B][2]*/, const int32_t *keys_host, const int32_t *key_off_host /*[B+1]*/,
+                              const int64_t *maps_off_host /*[B]*/, const uint8_t *gt_dev, int n_class, int ignore_label,
+                              uint8_t *pred_dev, int64_t *confusion_dev);
+
 /* wsc_cam_postprocess (all C classes, every image at H0 x W0) followed by wsc_unary_from_maps, fused: the
  * max-normalised high-resolution maps are never written to HBM, only the unaries are (bit-identical to the
  * two-step path).  Replaces, for a whole batch, make_cam.py:64-76 (upsample to the strided-up size, crop,

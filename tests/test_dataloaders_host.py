@@ -191,3 +191,33 @@ def test_resize_bilinear_f64_against_cv2_rule():
     src = (np.arange(32) + 0.5) / 2 - 0.5
     assert np.abs(r - np.maximum(0, 1 - np.abs(src - 5))).max() <= 1e-12
     assert np.all(voc_dl.resize_bilinear_f64(np.full((9, 7, 3), 4.25), (15, 3)) == 4.25)
+
+
+def test_eval_cam_colour_label_readers(tmp_path):
+    """Ground-truth readers of the ADP / DeepGlobe eval_cam branch (adp_semantic_segmentation_dataset.py:33-70,
+    deepglobe_semantic_segmentation_dataset.py:21-64): split -> id list, colour PNG -> class index (an unlisted colour
+    stays 0)."""
+    import os
+
+    from wsscam.step import eval_cam
+
+    rng = np.random.default_rng(3)
+    for htt, colours in eval_cam.ADP_CLS_COLOURS.items():
+        lab = rng.integers(0, len(colours), (9, 11))
+        rgb = np.asarray(colours, np.uint8)[lab]
+        rgb[0, 0] = (1, 2, 3)  # not a class colour
+        ref = lab.copy()
+        ref[0, 0] = 0
+        assert np.array_equal(eval_cam.label_from_colours(rgb, colours), ref)
+    assert len(eval_cam.ADP_CLS_COLOURS["morph"]) == 29 and len(eval_cam.DEEPGLOBE_CLS_COLOURS) == 6
+    os.makedirs(tmp_path / "ImageSets" / "Segmentation")
+    os.makedirs(tmp_path / "SegmentationClassAug" / "ADP-func")
+    (tmp_path / "ImageSets" / "Segmentation" / "segtest.txt").write_text("a\nb\n")
+    (tmp_path / "ImageSets" / "Segmentation" / "train37.5.txt").write_text("c\n")
+    lab = rng.integers(0, 5, (6, 7))
+    _write(str(tmp_path / "SegmentationClassAug" / "ADP-func" / "b.png"), np.asarray(eval_cam.ADP_CLS_COLOURS["func"], np.uint8)[lab])
+    ds = eval_cam.ADPSegLabels("evaluation", str(tmp_path), "func")
+    assert ds.ids == ["a", "b"] and np.array_equal(ds.label(1), lab) and ds.label(1).dtype == np.uint8
+    assert eval_cam.DeepGlobeSegLabels("train", str(tmp_path), is_balanced=True).ids == ["c"]
+    with pytest.raises(ValueError):
+        eval_cam.ADPSegLabels("val", str(tmp_path), "func")

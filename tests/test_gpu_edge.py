@@ -392,3 +392,69 @@ def test_full_config_batch_properties(ctx):
         assert np.array_equal(q1[0], q[b]) and np.array_equal(a1[0], a[b]) and vb1[0] == vb[b]
     q2, a2, _, _ = run(rgb, U)
     assert np.array_equal(q2, q) and np.array_equal(a2, a)
+
+
+def _cv2_nearest(a, out_hw):
+    """cv2.resize(a, (W, H), interpolation=cv2.INTER_NEAREST): source index min(floor(x * (1. / (dst / src))), src - 1)."""
+    H, W = out_hw
+    h, w = a.shape
+    sy = np.minimum(np.floor(np.arange(H) * (1.0 / (H / h))).astype(np.int64), h - 1)
+    sx = np.minimum(np.floor(np.arange(W) * (1.0 / (W / w))).astype(np.int64), w - 1)
+    return a[sy][:, sx]
+
+
+@pytest.mark.parametrize("dataset", ["adp_func", "deepglobe"])
+def test_eval_cam_adp_deepglobe_branch(tmp_path, dataset):
+    """eval_cam.run for the ADP / DeepGlobe branch (eval_cam.py:53-63, 89-115): keys[argmax(high_res | cam)] without a
+    background channel, nearest-neighbour resize to the ground truth's size, confusion matrix, CSV rows (DeepGlobe drops its
+    last class), colour PNGs -- against the numpy restatement; ground truth read from colour-coded PNGs as the dataset
+    classes do (adp_semantic_segmentation_dataset.py:55-62)."""
+    from PIL import Image
+
+    from wsscam.step import eval_cam
+
+    rng = np.random.default_rng(17)
+    if dataset == "adp_func":
+        names = {"bg": ["Background", "Other"], "fg": ["G.O", "G.N", "T"]}
+        colours, field, out_hw, src_hws = eval_cam.ADP_CLS_COLOURS["func"], "high_res", (88, 88), [(22, 22), (30, 41), (88, 88)]
+        label_dir = tmp_path / "SegmentationClassAug" / "ADP-func"
+        split_file, n_eval = "segtest", 5
+    else:
+        names = {"bg": [], "fg": ["urban", "agriculture", "rangeland", "forest", "water", "unknown"]}
+        colours, field, out_hw, src_hws = eval_cam.DEEPGLOBE_CLS_COLOURS, "cam", (96, 96), [(24, 24), (24, 24), (13, 31)]
+        label_dir = tmp_path / "SegmentationClassAug"
+        split_file, n_eval = "test", 5  # the 6th class never occurs: its row is dropped from the report
+    n_class = len(names["bg"]) + len(names["fg"])
+    os.makedirs(label_dir)
+    os.makedirs(tmp_path / "ImageSets" / "Segmentation")
+    os.makedirs(tmp_path / "cams")
+    ids = ["img_%d" % i for i in range(len(src_hws))]
+    (tmp_path / "ImageSets" / "Segmentation" / (split_file + ".txt")).write_text("\n".join(ids) + "\n")
+    conf_ref = np.zeros((n_class, n_class), np.int64)
+    preds_ref = []
+    for i, (name, shw) in enumerate(zip(ids, src_hws)):
+        gt = rng.integers(0, n_eval, out_hw)
+        Image.fromarray(np.asarray(colours, np.uint8)[gt]).save(str(label_dir / (name + ".png")))
+        keys = np.sort(rng.choice(n_eval, size=int(rng.integers(1, n_eval + 1)), replace=False)).astype(np.int64)
+        maps = rng.random((len(keys),) + shw).astype(np.float32)
+        maps[:, : shw[0] // 2] = np.round(maps[:, : shw[0] // 2], 1)  # ties: the first maximum wins
+        np.save(str(tmp_path / "cams" / (name + ".npy")), {"keys": keys, field: maps, "cam" if field != "cam" else "x": maps[:1]})
+        pred = _cv2_nearest(keys[np.argmax(maps, axis=0)], out_hw)
+        preds_ref.append(pred)
+        np.add.at(conf_ref, (gt.ravel(), pred.ravel()), 1)
+    args = types.SimpleNamespace(dataset=dataset, chainer_eval_set="evaluation" if dataset == "adp_func" else "test",
+                                 dev_root=str(tmp_path), cam_out_dir=str(tmp_path / "cams"), class_names=names,
+                                 class_colours={"bg": [tuple(c) for c in colours[:len(names["bg"])]],
+                                                "fg": [tuple(c) for c in colours[len(names["bg"]):]]},
+                                 cam_clr_out_dir=str(tmp_path / "clr"), eval_dir=str(tmp_path / "eval"), run_name="run",
+                                 split="evaluation", logfile=str(tmp_path / "log.txt"), overlay_r=0.75, cam_eval_thres=0.15)
+    conf, s = eval_cam.run(args, batch_images=2)
+    ref = conf_ref[:-1, :-1] if dataset == "deepglobe" else conf_ref
+    assert np.array_equal(conf, ref)
+    sr = eval_cam.scores_from_confusion(ref)
+    assert np.allclose(s["iou"], sr["iou"], equal_nan=True) and np.isclose(s["miou"], sr["miou"])
+    lines = open(os.path.join(args.eval_dir, "run_evaluation_cam_iou.csv")).read().splitlines()
+    assert lines[0] == ",iou,precision,recall" and len(lines) == 1 + ref.shape[0] + 1 and lines[-1].startswith("mean,")
+    for name, pred in zip(ids, preds_ref):
+        clr = np.asarray(Image.open(os.path.join(args.cam_clr_out_dir, name + ".png")))
+        assert np.array_equal(clr, np.asarray(colours, np.uint8)[pred])

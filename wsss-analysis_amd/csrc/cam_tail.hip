@@ -300,6 +300,54 @@ __global__ __launch_bounds__(256) void cam_eval_kernel(const float *__restrict__
         if (hist[i]) atomicAdd(&confusion[i], (unsigned long long)hist[i]);
 }
 
+// ADP / DeepGlobe branch of eval_cam (eval_cam.py:53-63): no background padding, pred = keys[argmax(maps)] taken at the
+// maps' own size, then cv2.resize(pred, outsize, INTER_NEAREST) -- evaluated per OUTPUT pixel: source pixel
+// (min(floor(Y * inv_y), h - 1), min(floor(X * inv_x), w - 1)) with inv = 1 / (out / src) in double, cv2's rule.
+struct EvalNNJob {
+    long long maps_off; // float offset of this image's [K][h*w] block
+    long long pix_off;  // offset of this image in the packed gt / pred arrays (out_h * out_w each)
+    int h, w, out_h, out_w, K, key_base;
+    double inv_y, inv_x;
+};
+
+__global__ __launch_bounds__(256) void cam_eval_nn_kernel(const float *__restrict__ maps, const EvalNNJob *__restrict__ jobs,
+                                                          const int32_t *__restrict__ keys, const uint8_t *__restrict__ gt,
+                                                          int n_class, int ignore_label, uint8_t *__restrict__ pred,
+                                                          unsigned long long *__restrict__ confusion,
+                                                          unsigned *__restrict__ n_bad) {
+    extern __shared__ unsigned hist[]; // n_class * n_class
+    const EvalNNJob job = jobs[blockIdx.y];
+    const int cells = n_class * n_class;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const long long n_out = (long long)job.out_h * job.out_w, n_src = (long long)job.h * job.w;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n_out; p += (long long)gridDim.x * blockDim.x) {
+        const int Y = (int)(p / job.out_w), X = (int)(p - (long long)Y * job.out_w);
+        const int sy = min((int)floor((double)Y * job.inv_y), job.h - 1);
+        const int sx = min((int)floor((double)X * job.inv_x), job.w - 1);
+        const long long sp = (long long)sy * job.w + sx;
+        float best = maps[job.maps_off + sp];
+        int idx = 0;
+        for (int k = 1; k < job.K; ++k) {
+            const float v = maps[job.maps_off + (long long)k * n_src + sp];
+            if (v > best) { // strict: np.argmax keeps the first maximum
+                best = v;
+                idx = k;
+            }
+        }
+        const int cls = keys[job.key_base + idx];
+        if (pred != nullptr) pred[job.pix_off + p] = (uint8_t)cls;
+        const int g = gt != nullptr ? (int)gt[job.pix_off + p] : ignore_label;
+        if (g != ignore_label) {
+            if (g < n_class && cls < n_class) atomicAdd(&hist[g * n_class + cls], 1u);
+            else atomicAdd(n_bad, 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells; i += blockDim.x)
+        if (hist[i]) atomicAdd(&confusion[i], (unsigned long long)hist[i]);
+}
+
 } // namespace
 
 extern "C" {
@@ -350,6 +398,59 @@ int wsc_cam_eval_confusion(wsc_ctx *ctx, const float *highres_dev, int B, const 
     wsc_ctx_cached_free(ctx, d);
     WSC_CHECK(n_bad == 0, WSC_ERR_INVALID,
               "wsc_cam_eval_confusion: %u pixels carry a ground-truth label outside [0, %d) (and != ignore_label %d)", n_bad,
+              n_class, ignore_label);
+    return WSC_OK;
+}
+
+int wsc_cam_eval_confusion_nn(wsc_ctx *ctx, const float *maps_dev, int B, const int32_t *src_hw_host,
+                              const int32_t *out_hw_host, const int32_t *keys_host, const int32_t *key_off_host,
+                              const int64_t *maps_off_host, const uint8_t *gt_dev, int n_class, int ignore_label,
+                              uint8_t *pred_dev, int64_t *confusion_dev) {
+    WSC_CHECK(ctx && maps_dev && src_hw_host && out_hw_host && keys_host && key_off_host && maps_off_host && confusion_dev,
+              WSC_ERR_INVALID, "wsc_cam_eval_confusion_nn: null argument");
+    WSC_CHECK(B > 0 && n_class > 0 && n_class <= 64, WSC_ERR_INVALID, "wsc_cam_eval_confusion_nn: B=%d n_class=%d", B, n_class);
+    WSC_HIP(hipSetDevice(ctx->device));
+    std::vector<EvalNNJob> jobs(B);
+    long long pix = 0, max_pix = 0;
+    for (int b = 0; b < B; ++b) {
+        EvalNNJob &j = jobs[b];
+        j.h = src_hw_host[2 * b]; j.w = src_hw_host[2 * b + 1];
+        j.out_h = out_hw_host[2 * b]; j.out_w = out_hw_host[2 * b + 1];
+        WSC_CHECK(j.h > 0 && j.w > 0 && j.out_h > 0 && j.out_w > 0, WSC_ERR_INVALID, "image %d: %dx%d -> %dx%d", b, j.h, j.w,
+                  j.out_h, j.out_w);
+        j.K = key_off_host[b + 1] - key_off_host[b];
+        WSC_CHECK(j.K >= 1, WSC_ERR_INVALID, "wsc_cam_eval_confusion_nn: image %d has no class map (np.argmax of an empty stack)", b);
+        j.key_base = key_off_host[b];
+        j.maps_off = maps_off_host[b];
+        j.pix_off = pix;
+        // cv2.resize: inv_scale = 1. / (dsize / ssize), both in double
+        j.inv_y = 1.0 / ((double)j.out_h / (double)j.h);
+        j.inv_x = 1.0 / ((double)j.out_w / (double)j.w);
+        pix += (long long)j.out_h * j.out_w;
+        max_pix = std::max(max_pix, (long long)j.out_h * j.out_w);
+    }
+    const int nkeys = key_off_host[B];
+    for (int i = 0; i < nkeys; ++i)
+        WSC_CHECK(keys_host[i] >= 0 && keys_host[i] < n_class, WSC_ERR_INVALID,
+                  "wsc_cam_eval_confusion_nn: key %d outside [0, %d)", keys_host[i], n_class);
+    const size_t jb = (jobs.size() * sizeof(EvalNNJob) + 15) / 16 * 16, kb = ((size_t)nkeys * sizeof(int32_t) + 15) / 16 * 16;
+    char *d = nullptr;
+    WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + kb + 16, (void **)&d));
+    std::vector<char> stage(jb + kb + 16, 0); // the last 16 bytes: out-of-range counter, zeroed
+    memcpy(stage.data(), jobs.data(), jobs.size() * sizeof(EvalNNJob));
+    memcpy(stage.data() + jb, keys_host, (size_t)nkeys * sizeof(int32_t));
+    WSC_TRY(wsc_ctx_upload_small(ctx, d, stage.data(), stage.size()));
+    const dim3 grid((unsigned)std::min<long long>((max_pix + 255) / 256, 1024), (unsigned)B);
+    hipLaunchKernelGGL(cam_eval_nn_kernel, grid, dim3(256), (size_t)n_class * n_class * sizeof(unsigned), ctx->stream, maps_dev,
+                       (const EvalNNJob *)d, (const int32_t *)(d + jb), gt_dev, n_class, ignore_label, pred_dev,
+                       (unsigned long long *)confusion_dev, (unsigned *)(d + jb + kb));
+    WSC_HIP(hipGetLastError());
+    unsigned n_bad = 0;
+    WSC_HIP(hipMemcpyAsync(&n_bad, d + jb + kb, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    wsc_ctx_cached_free(ctx, d);
+    WSC_CHECK(n_bad == 0, WSC_ERR_INVALID,
+              "wsc_cam_eval_confusion_nn: %u pixels carry a ground-truth label outside [0, %d) (and != ignore_label %d)", n_bad,
               n_class, ignore_label);
     return WSC_OK;
 }

@@ -97,6 +97,7 @@ _SIGNATURES = {
     "wsc_cam_unary": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wsc_cam_unary_pm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wsc_cam_sum_scales": (_i, [_vp, _vp, _i, _i, ctypes.c_longlong, _vp]),
+    "wsc_cam_eval_confusion_nn": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     "wsc_msf_input_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "wsc_label_unary_from_cam": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
@@ -477,6 +478,24 @@ def cam_eval_confusion(ctx, highres_dev, sizes, keys_per_image, highres_off, bg_
     check(ctx._lib.wsc_cam_eval_confusion(ctx.h, _ptr(highres_dev), B, size_hw.ctypes.data, keys.ctypes.data,
                                           key_off.ctypes.data, h_off.ctypes.data, float(bg_thres), _ptr(gt_dev),
                                           int(n_class), int(ignore_label), _ptr(pred_dev), _ptr(confusion_dev)))
+
+
+def cam_eval_confusion_nn(ctx, maps_dev, src_sizes, out_sizes, keys_per_image, maps_off, gt_dev, n_class, confusion_dev,
+                          pred_dev=None, ignore_label=255):
+    """ADP / DeepGlobe eval_cam branch: keys[argmax(maps)] at the maps' size, cv2 nearest resize to out_sizes, confusion."""
+    B = len(src_sizes)
+    src_hw = np.asarray(src_sizes, dtype=np.int32).reshape(B, 2)
+    out_hw = np.asarray(out_sizes, dtype=np.int32).reshape(B, 2)
+    key_off = np.zeros(B + 1, dtype=np.int32)
+    for b in range(B):
+        key_off[b + 1] = key_off[b] + len(keys_per_image[b])
+    keys = np.zeros(max(int(key_off[-1]), 1), dtype=np.int32)
+    for b in range(B):
+        keys[key_off[b]:key_off[b + 1]] = np.asarray(keys_per_image[b], dtype=np.int32)
+    m_off = np.ascontiguousarray(maps_off, dtype=np.int64)
+    check(ctx._lib.wsc_cam_eval_confusion_nn(ctx.h, _ptr(maps_dev), B, src_hw.ctypes.data, out_hw.ctypes.data, keys.ctypes.data,
+                                             key_off.ctypes.data, m_off.ctypes.data, _ptr(gt_dev), int(n_class),
+                                             int(ignore_label), _ptr(pred_dev), _ptr(confusion_dev)))
 
 
 def unary_from_maps(ctx, maps_dev, B, C, N, bg_value, unary_dev):
