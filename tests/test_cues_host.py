@@ -2,6 +2,7 @@
 import pickle
 
 import numpy as np
+import pytest
 
 from wsscam.cues import utilities as cues
 
@@ -169,3 +170,36 @@ def test_grad_cam_alpha_closed_forms_vs_autograd():
         h = S // (8 if root == "vgg16" else 4)
         raw = common.grad_cam_alpha(Model._sd[root + ".classifier.0.weight"], h, h, "max" if root == "m7" else "avg", False)
         assert np.allclose(raw, Model._sd[root + ".classifier.0.weight"].T / (h * h))
+
+
+def test_keras_store_settings_sessions_and_csv(tmp_path, monkeypatch):
+    """keras_store: settings.ini keys (02_cues/demo.py:16-21), the background session's directory rule (:139-150) and the
+    split CSV reader (02_cues/dataset.py:98-124)."""
+    import os
+
+    from wsscam import keras_store as ks
+
+    ini = tmp_path / "settings.ini"
+    ini.write_text("[Download Directory]\ndata_dir = ../database\n\n[Data Folders]\nmodel_cnn_dir = models_cnn\ncues_dir = cues\n")
+    work = tmp_path / "02_cues"
+    work.mkdir()
+    monkeypatch.chdir(work)
+    st = ks.read_settings()  # '../settings.ini' relative to the working directory, like the reference
+    assert st["DATA_ROOT"] == str(tmp_path / "database") and st["MODEL_ROOT"] == str(tmp_path / "database" / "models_cnn")
+    assert st["CUES_ROOT"] == str(tmp_path / "database" / "cues")
+    s = ks.fgbg_sessions("/m/VOC2012_VGG16", "VOC2012_VGG16", ["fg", "bg"])
+    assert s == {"fg": ("/m/VOC2012_VGG16", "VOC2012_VGG16"), "bg": ("/m/VOC2012_VGG16bg", "VOC2012_VGG16bg")}
+    assert ks.fgbg_sessions("/m/X_fg", "X_fg", ["bg"]) == {"bg": ("/m/X_bg", "X_bg")}
+    voc = tmp_path / "database" / "VOCdevkit" / "VOC2012"
+    os.makedirs(voc / "ImageSets" / "Segmentation")
+    head = "Patch Names," + ",".join(ks.VOC_CLASSES)
+    for split, n in (("trainaug", 3), ("val", 2)):
+        rows = ["%s_%d.jpg,%s" % (split, i, ",".join("1" if c == i else "0" for c in range(20))) for i in range(n)]
+        (voc / "ImageSets" / "Segmentation" / (split + ".csv")).write_text(head + "\n" + "\n".join(rows) + "\n")
+    ds = ks.Dataset("VOC2012", 321, 4)  # database_dir defaults to <parent of cwd>/database
+    assert ds.sets == ["trainaug", "val"] and ds.is_evals == [False, True] and len(ds.class_names) == 20
+    g = ds.set_gens["val"]
+    assert g.filenames == ["val_0.jpg", "val_1.jpg"] and g.directory == str(voc / "JPEGImages")
+    assert g.data.shape == (2, 20) and g.data[1, 1] == 1 and g.data.sum() == 2
+    with pytest.raises(FileNotFoundError):
+        ks.read_settings(str(tmp_path / "missing.ini"))

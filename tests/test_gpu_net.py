@@ -8,6 +8,8 @@ max over every pixel of every class of every image, vs the fp32 oracle:
                                                            moves by 3e-5 with its reduction order)
 and on the raw (un-normalised) CAM: f16 5e-3, bf16 3e-2, bf16x3 2e-4 (x max(cam)).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -572,3 +574,85 @@ def test_gen_cues_adp_driver(tmp_path):
         lb[b[1], b[2]] = b[0] + 1
         assert (la == lb).mean() >= 0.99
         assert out["func"]["%d_labels" % i][0] == 1 and out["func"]["%d_cues" % i].shape[0] == 3
+
+
+def _keras_list_from_state_dict(sd, root, batchnorm, use_bias):
+    """model.get_weights() order of the Keras CNN whose transplant is `sd` (inverse of net.common.state_dict_from_keras_weights)."""
+    from wsscam.net import common
+
+    out = []
+    for kind, key in common.plain_module_order(root, batchnorm):
+        if kind == "conv":
+            out += [np.transpose(np.asarray(sd[key + ".weight"]), (2, 3, 1, 0)), np.asarray(sd[key + ".bias"])]
+        elif kind == "bn":
+            out += [np.asarray(sd[key + "." + n]) for n in ("weight", "bias", "running_mean", "running_var")]
+        else:
+            out.append(np.transpose(np.asarray(sd[key + ".weight"])))
+            if use_bias:
+                out.append(np.asarray(sd[key + ".bias"]))
+    return out
+
+
+def test_gen_cues_reference_call_form(tmp_path, monkeypatch):
+    """gen_cues(dataset, model_type, thresh, batch_size) -- the reference's own call form (02_cues/demo.py:26): settings.ini,
+    the session's Keras weight / threshold files under MODEL_ROOT, the split's CSV and images under DATA_ROOT are read through
+    wsscam.keras_store, the pickle lands under the cues root.  Same cues as the call with the loaded objects handed in.
+    (h5py is not installed here: the .h5 reader is replaced by one that reads the same weight list from an .npz.)"""
+    import pickle
+
+    import scipy.io
+    from PIL import Image
+
+    from wsscam import keras_store, synth
+    from wsscam.cues import demo as cues_demo
+    from wsscam.cues import utilities as cues
+    from wsscam.net import common, m7_cam
+
+    C = 7
+    db = tmp_path / "database"
+    dg = db / "DGdevkit"
+    os.makedirs(dg / "JPEGImages")
+    os.makedirs(dg / "ImageSets" / "Segmentation")
+    os.makedirs(db / "models_cnn" / "DeepGlobe_M7")
+    ini = tmp_path / "settings.ini"
+    ini.write_text("[Download Directory]\ndata_dir = %s\n\n[Data Folders]\nmodel_cnn_dir = models_cnn\ncues_dir = cues\n" % db)
+    rng = np.random.default_rng(21)
+    names = ["t%d.png" % i for i in range(3)]
+    images = [cnn_ref.synth_image(rng, 224, 224) for _ in names]
+    labels = (rng.random((3, C)) < 0.4).astype(np.float32)
+    labels[:, 1] = 1
+    for n, im in zip(names, images):
+        Image.fromarray(im).save(str(dg / "JPEGImages" / n))
+    header = "Patch Names," + ",".join(keras_store.DEEPGLOBE_CLASSES)
+    rows = [n + "," + ",".join(str(int(v)) for v in lb) for n, lb in zip(names, labels)]
+    (dg / "ImageSets" / "Segmentation" / "train75.csv").write_text(header + "\n" + "\n".join(rows) + "\n")
+    (dg / "ImageSets" / "Segmentation" / "test.csv").write_text(header + "\n" + rows[0] + "\n")
+    sd = synth.plain_state_dict("m7", C, True, seed=5)
+    thr = np.full((1, C), 0.4)
+    mdir = db / "models_cnn" / "DeepGlobe_M7"
+    np.savez(str(mdir / "DeepGlobe_M7.npz"), *_keras_list_from_state_dict(sd, "m7", True, True))
+    (mdir / "DeepGlobe_M7.h5").write_bytes(b"placeholder")
+    scipy.io.savemat(str(mdir / "DeepGlobe_M7.mat"), {"optimalScoreThresh": thr})
+
+    def fake_h5(path):
+        z = np.load(path[:-3] + ".npz")
+        return [z["arr_%d" % i] for i in range(len(z.files))]
+
+    monkeypatch.setattr(common, "keras_h5_weight_list", fake_h5)
+    ds = keras_store.Dataset("DeepGlobe", 224, 2, database_dir=str(db))
+    assert ds.sets == ["train75", "test"] and ds.set_gens["train75"].filenames == names
+    assert np.array_equal(ds.set_gens["train75"].data, labels)
+    out = cues_demo.gen_cues("DeepGlobe", "M7", 0.2, 2, is_verbose=False, settings=str(ini))
+    saved = pickle.load(open(db / "cues" / "DeepGlobe_M7" / "localization_cues.pickle", "rb"))
+    assert sorted(saved) == sorted(out)
+    # the same through the explicit objects
+    model = m7_cam.CAM(None, "deepglobe", "M7", C, None)
+    model.load_state_dict(dict(sd))
+    model.cuda(0)
+    alpha = cues.get_grad_cam_weights(model, cues.find_final_layer(model), np.zeros((1, 224, 224, 3)))
+    ref = cues_demo.gen_cues("DeepGlobe", "M7", 0.2, 2, is_verbose=False, models={"fg": model}, alphas={"fg": alpha},
+                             thresholds={"fg": thr}, images=images, labels=labels, out_dir=str(tmp_path / "explicit"))
+    assert sorted(ref) == sorted(out)
+    for k in ref:
+        assert np.array_equal(np.asarray(ref[k]), np.asarray(out[k])), k
+    assert any(np.asarray(out["%d_cues" % i]).size for i in range(3))

@@ -1,8 +1,10 @@
 """gen_cues -- mirror of 02_cues/demo.py:26-222 (VOC2012 / DeepGlobe seed generation; the ADP redirect uses
 cues.utilities.update_cues_adp on hsn.utilities.modify_by_htt's output).
 
-Same positional signature.  What the reference loads from `MODEL_ROOT` (Keras `.json/.h5/.mat` files) and from
-its Keras `Dataset` generators cannot be read here, so the loaded objects are passed in keyword-only:
+Same signature: `gen_cues(dataset, model_type, thresh, batch_size, set_name, run_train, is_verbose)` alone reads what the
+reference reads -- settings.ini, the session's `.h5` weights + `.mat` thresholds under MODEL_ROOT (the fixed device
+architectures stand in for the `.json`), the split's CSV and images under DATA_ROOT -- through wsscam.keras_store and
+writes the pickle under the cues root.  Callers that hold the loaded objects pass them keyword-only instead:
   models     {'fg': CAM wrapper, 'bg': CAM wrapper}  (wsscam.net.vgg16_cam.CAM / m7_cam.CAM with weights loaded)
   alphas     {'fg': (F,C), 'bg': (F,C)} Grad-CAM weights (cues.utilities.get_grad_cam_weights or precomputed)
   thresholds {'fg': (1,C), 'bg': (1,C)}  optimalScoreThresh of the .mat files
@@ -23,6 +25,21 @@ from . import utilities as cu
 SEED_SIZE = 41
 
 
+class _LazyImages:
+    """The images of a keras_store.SetList, decoded per batch slice (len + slicing is all the batch loop needs)."""
+
+    def __init__(self, set_list):
+        self.set_list = set_list
+
+    def __len__(self):
+        return len(self.set_list.filenames)
+
+    def __getitem__(self, sl):
+        if isinstance(sl, slice):
+            return self.set_list.images(sl.start or 0, sl.stop)
+        return self.set_list.images(sl, sl + 1)[0]
+
+
 def read_batch(images, size, img_mean, img_std):
     """02_cues/utilities.py:146-181 on in-memory images: (normalised float (B,S,S,3), original (B,S,S,3))."""
     B = len(images)
@@ -35,13 +52,33 @@ def read_batch(images, size, img_mean, img_std):
     return norm, raw
 
 
-def gen_cues(dataset, model_type, thresh, batch_size, set_name=None, run_train=True, is_verbose=True, *, models,
-             alphas, thresholds, images, labels, out_dir, class_names=None):
+def gen_cues(dataset, model_type, thresh, batch_size, set_name=None, run_train=True, is_verbose=True, *, models=None,
+             alphas=None, thresholds=None, images=None, labels=None, out_dir=None, class_names=None, settings=None):
     assert dataset in ["VOC2012", "DeepGlobe", "DeepGlobe_balanced"], "ADP: use gen_cues_adp"
     assert model_type in ["X1.7", "M7", "VGG16"]
     assert batch_size > 0 and set_name in [None, "tuning", "segtest"]
     img_size = 321 if model_type in ["VGG16", "VGG16bg"] else 224
     fgbg_modes = ["fg", "bg"] if dataset == "VOC2012" else ["fg"]
+    if models is None or images is None or out_dir is None:
+        # the reference's own call form gen_cues(dataset, model_type, thresh, batch_size, ...): everything else comes from
+        # settings.ini and the files under it (02_cues/demo.py:16-24, 60-150), through keras_store
+        from .. import keras_store as ks
+
+        st = ks.read_settings(settings)
+        sess_id = dataset + "_" + model_type if set_name is None else dataset + "_" + set_name + "_" + model_type
+        if thresh != 0.2:
+            sess_id += "_" + str(thresh)
+        model_dir = os.path.join(st["MODEL_ROOT"], dataset + "_" + model_type)
+        if out_dir is None:
+            out_dir = os.path.join(st["CUES_ROOT"], sess_id) if run_train else os.path.join("./eval", sess_id)
+        if images is None:
+            ds = ks.Dataset(data_type=dataset, size=img_size, batch_size=batch_size, database_dir=st["DATA_ROOT"])
+            gen_curr = ds.set_gens[ds.sets[ds.is_evals.index(not run_train)]]
+            images, labels = _LazyImages(gen_curr), gen_curr.data
+        if models is None:
+            models, alphas, thresholds = {}, {}, {}
+            for m, (mdir, sid) in ks.fgbg_sessions(model_dir, sess_id, fgbg_modes).items():
+                models[m], alphas[m], _, thresholds[m] = ks.load_model(mdir, sid, model_type, dataset)
     labels = np.asarray(labels)
     n_cls = labels.shape[1]
     if dataset == "VOC2012":

@@ -1,10 +1,12 @@
 """segment -- mirror of the VOC2012 / DeepGlobe branch of 03c_hsn/demo.py:18-268 (HistoSegNet on natural images):
 per batch, scores -> thresholds collapsed to 1/3 (demo.py:83) -> HSN Grad-CAM upsampled to the input
 size -> foreground/background combination (VOC: bg channel 0.15 * expit(max_batch(X_bg) - X_bg), Q6) -> dense CRF
--> label maps.  The Keras model / dataset objects the reference builds from MODEL_ROOT / DATA_ROOT are passed in:
+-> label maps.  `segment(dataset, model_type, batch_size)` alone loads models and the evaluation image list from settings.ini's
+MODEL_ROOT / DATA_ROOT like the reference (wsscam.keras_store); callers that hold the objects pass them keyword-only:
   models {'fg': CAM wrapper[, 'bg': CAM wrapper]}, alphas {'fg': (F,C)[, 'bg']}, images: list of uint8 RGB.
 Returns the list of (S, S) int64 label maps (what the reference feeds its evaluation / image writers)."""
 import math
+import os
 
 import numpy as np
 import scipy.special
@@ -21,8 +23,8 @@ def dcrf_config_for(dataset, model_type):
     return np.array([3 / 2, 3, 80 / 2, 13, 10, 10])
 
 
-def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True, is_verbose=True, *, models, alphas,
-            images, n_seg_classes=None):
+def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True, is_verbose=True, *, models=None, alphas=None,
+            images=None, n_seg_classes=None, settings=None):
     """Device resident between the batch upload and the label maps, like segment_adp: both models' Grad-CAM stacks are
     written straight into one [B][1 + C][S*S] stack (wsc_hsn_gradcam_post with a channel offset), the VOC background
     channel comes from wsc_hsn_voc_background (max over the whole batch, Q6), class mass flags from wsc_hsn_class_mass,
@@ -32,6 +34,22 @@ def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True,
     assert dataset in ["VOC2012", "DeepGlobe", "DeepGlobe_balanced"], "ADP: segment_adp"
     assert model_type in ["VGG16", "M7"]
     img_size = 321 if model_type == "VGG16" else 224
+    if models is None or images is None:
+        # the reference's own call form segment(dataset, model_type, batch_size, ...): models, thresholds and the evaluation
+        # image list come from settings.ini and the files under it (03c_hsn/demo.py:46-90), through keras_store
+        from .. import keras_store as ks
+        from ..cues.demo import _LazyImages
+
+        st = ks.read_settings(settings)
+        sess_id = dataset + "_" + model_type
+        model_dir = os.path.join(st["MODEL_ROOT"], sess_id)
+        if images is None:
+            ds = ks.Dataset(data_type=dataset, size=img_size, batch_size=batch_size, database_dir=st["DATA_ROOT"])
+            images = _LazyImages(ds.set_gens[ds.sets[ds.is_evals.index(True)]])
+        if models is None:
+            models, alphas = {}, {}
+            for m in (["fg", "bg"] if dataset == "VOC2012" else ["fg"]):  # demo.py:80-85: one directory, both modes
+                models[m], alphas[m], _, _ = ks.load_model(model_dir, sess_id, model_type, dataset)
     voc = dataset == "VOC2012"
     mean, std = ([104, 117, 123], [255, 255, 255]) if voc else ([0, 0, 0], [255, 255, 255])
     cfg = dcrf_config_for(dataset, model_type)
