@@ -234,6 +234,30 @@ def test_crf_fused_gaussian_blur_is_bit_identical(ctx, case, monkeypatch):
     assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)
 
 
+@pytest.mark.parametrize("case", [(47, 61, 5, 2, (1.5, 3, 40, 13, 10, 3)), (96, 130, 21, 3, (3, 3, 50, 5, 10, 2)),
+                                  (33, 200, 4, 1, (5, 3, 40, 13, 10, 2)), (70, 64, 3, 2, (3, 3, 6, 1.5, 10, 2))])
+def test_crf_lattice_build_rank_paths_agree(ctx, case, monkeypatch):
+    """Lattice build, stable rank of a tile's entries inside their vertex group: the pixel-mask path (a group holds one entry
+    per pixel: rank = popcount of the lower pixels) against the ballot-matching walk (WSC_CRF_RANK_BALLOT=1, read per build).
+    Same lattice sizes, same Q bits.  The last case (bilateral sxy = 6, srgb = 1.5 on a noisy image) has tiles with more
+    distinct vertices than the masks hold, so the default build itself takes the ballot path there."""
+    H, W, M, B, cfg = case
+    rng = np.random.default_rng(H * 13 + W)
+    rgbs, Us = [], []
+    for _ in range(B):
+        rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
+        rgbs.append(rgb)
+        Us.append(U)
+    monkeypatch.setenv("WSC_CRF_RANK_BALLOT", "1")
+    q_ref, a_ref, vg, vb = _gpu_crf(ctx, rgbs, Us, cfg)
+    monkeypatch.setenv("WSC_CRF_RANK_BALLOT", "0")
+    q, a, vg2, vb2 = _gpu_crf(ctx, rgbs, Us, cfg)
+    assert list(vg) == list(vg2) and list(vb) == list(vb2)
+    assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)
+    if cfg[3] == 1.5:
+        assert max(vb) > 2.5 * H * W  # nearly every pixel owns its vertices: > 640 groups per 16 x 16 tile
+
+
 def test_crf_labels_only_call_matches_full_call(ctx):
     """q_dev = NULL (labels only) returns the labels of the full call (Q + arg max): first maximum in class order, also
     on exact ties.  (Writing the arg max from the last slice_update instead of a finish pass was measured: no gain.)"""

@@ -550,21 +550,34 @@ __device__ __forceinline__ void tile_slot_flags(const int *srow, int ne, int *au
 // order.  (The ORDER OF THE GROUPS within the tile is that of an LDS hash table and may differ from run to run: it only
 // decides where a slot's partial row lives, never a value.)
 //   A  keys -> slots of an LDS hash table (64-bit compare-and-swap), per slot the smallest global entry index
-//   B  stable rank of every entry inside its group: wave q walks the q-th quarter of the index range in order, 64
-//      entries at a time -- equal slots are matched with ballots, the running per-(wave, slot) count gives the rank
+//   B  stable rank of every entry inside its group.  A group holds at most ONE entry per pixel (the d+1 vertices of a simplex
+//      are distinct), so index order inside a group is pixel order and rank = number of lower pixels of the tile that touch
+//      the vertex: every group gets a TILE_PIX-bit pixel mask (LDS atomicOr: the result does not depend on arrival order),
+//      rank = popcount of the mask below the pixel.  ~120 instructions per wave instead of the ~1800 of the ballot-matching
+//      walk (wave q walks the q-th quarter of the index range, 64 entries at a time, equal slots matched with ballots),
+//      which stays as the path for tiles with more than RANK_GMAX distinct vertices (noise images) or WSC_CRF_RANK_BALLOT=1
 //   C  per occupied slot: group size; global insert + atomicMin of the first-touch index (vertex ids are assigned in
 //      first-touch raster order, the CPU reference's insertion order)
 //   D  scan -> group starts; position = start + entries of the group in earlier quarters + rank
 constexpr int GROUP_HT = SORT_MAX; // hash slots (load <= 0.75 even when every entry has its own vertex)
+constexpr int RANK_MW = (TILE_PIX + 31) / 32;            // mask words per group
+constexpr int RANK_GMAX = (4 * GROUP_HT * 2 + SORT_MAX * 2) / (RANK_MW * 4); // groups whose masks fit the wcnt + erank storage
 template <int D>
 __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom tg, uint2 *__restrict__ tent,
-                                                         int32_t *__restrict__ sslot_out, unsigned *__restrict__ tile_nslots) {
+                                                         int32_t *__restrict__ sslot_out, unsigned *__restrict__ tile_nslots,
+                                                         int force_ballot) {
     constexpr int dp1 = D + 1;
     __shared__ unsigned long long table[GROUP_HT]; // vertex key, later the vertex's global hash slot
     __shared__ int start[GROUP_HT];                // first-touch entry index, then group size, then group start
-    __shared__ unsigned short wcnt[4][GROUP_HT];
-    __shared__ unsigned short eslot[SORT_MAX], erank[SORT_MAX];
+    // ballot path: wcnt[4][GROUP_HT] + erank[SORT_MAX] (unsigned short); mask path: RANK_GMAX pixel masks in the same bytes
+    __shared__ __attribute__((aligned(16))) unsigned short rank_store[4 * GROUP_HT + SORT_MAX];
+    unsigned short(*wcnt)[GROUP_HT] = reinterpret_cast<unsigned short(*)[GROUP_HT]>(rank_store);
+    unsigned short *erank = rank_store + 4 * GROUP_HT;
+    unsigned *gmask = reinterpret_cast<unsigned *>(rank_store); // [group][RANK_MW]
+    __shared__ unsigned short eslot[SORT_MAX];
+    __shared__ unsigned short cid[GROUP_HT]; // compact group id of an occupied slot (mask path)
     __shared__ int wtot[4];
+    __shared__ int n_groups_s;
     const int tile = blockIdx.x;
     const int b = tile / tg.tpi, j = tile - b * tg.tpi;
     const TileBox tb = tile_box(tg, j);
@@ -573,8 +586,8 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
     for (int i = threadIdx.x; i < GROUP_HT; i += 256) {
         table[i] = EMPTY_KEY;
         start[i] = 0x7fffffff;
-        wcnt[0][i] = 0; wcnt[1][i] = 0; wcnt[2][i] = 0; wcnt[3][i] = 0;
     }
+    for (int i = threadIdx.x; i < (4 * GROUP_HT + SORT_MAX) / 2; i += 256) gmask[i] = 0u; // wcnt + erank / the pixel masks
     __syncthreads();
     // ---- A: this thread's pixel
     const int t = threadIdx.x;
@@ -600,31 +613,65 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
         }
     }
     __syncthreads();
-    // ---- B: stable ranks
+    // ---- compact ids of the occupied slots (thread i owns slots [8 i, 8 i + 8): count, block prefix, number)
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int Q = ((ne + 3) / 4 + 63) / 64 * 64; // entries per quarter, whole wave trips
-    for (int c = q * Q; c < min(ne, (q + 1) * Q); c += 64) {
-        const int e = c + lane;
-        const bool valid = e < ne;
-        const unsigned sl = valid ? eslot[e] : 0u;
-        unsigned long long remaining = __ballot(valid);
-        unsigned long long mine = 0;
-        while (remaining) {
-            const int leader = __ffsll((long long)remaining) - 1;
-            const bool same = valid && sl == (unsigned)__shfl((int)sl, leader, 64);
-            const unsigned long long m = __ballot(same);
-            if (same) mine = m;
-            remaining &= ~m;
+    {
+        constexpr int PER = GROUP_HT / 256;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) cnt += table[threadIdx.x * PER + k] != EMPTY_KEY ? 1 : 0;
+        int x = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
         }
-        if (valid) {
-            const int leader = __ffsll((long long)mine) - 1;
-            int base = 0;
-            if (lane == leader) {
-                base = wcnt[q][sl];
-                wcnt[q][sl] = (unsigned short)(base + __popcll(mine));
+        if (lane == 63) wtot[q] = x;
+        __syncthreads();
+        int base = x - cnt;
+        for (int i = 0; i < q; ++i) base += wtot[i];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int sl = threadIdx.x * PER + k;
+            const bool occ = table[sl] != EMPTY_KEY;
+            cid[sl] = (unsigned short)base;
+            base += occ ? 1 : 0;
+        }
+        if (threadIdx.x == 255) n_groups_s = base;
+        __syncthreads();
+    }
+    const bool use_mask = !force_ballot && n_groups_s <= RANK_GMAX;
+    const int Q = ((ne + 3) / 4 + 63) / 64 * 64; // ballot path: entries per quarter, whole wave trips
+    // ---- B: stable ranks
+    if (use_mask) {
+        if (have) {
+#pragma unroll
+            for (int r = 0; r < dp1; ++r)
+                atomicOr(&gmask[(unsigned)cid[eslot[t * dp1 + r]] * RANK_MW + (t >> 5)], 1u << (t & 31));
+        }
+    } else {
+        for (int c = q * Q; c < min(ne, (q + 1) * Q); c += 64) {
+            const int e = c + lane;
+            const bool valid = e < ne;
+            const unsigned sl = valid ? eslot[e] : 0u;
+            unsigned long long remaining = __ballot(valid);
+            unsigned long long mine = 0;
+            while (remaining) {
+                const int leader = __ffsll((long long)remaining) - 1;
+                const bool same = valid && sl == (unsigned)__shfl((int)sl, leader, 64);
+                const unsigned long long m = __ballot(same);
+                if (same) mine = m;
+                remaining &= ~m;
             }
-            base = __shfl(base, leader, 64);
-            erank[e] = (unsigned short)(base + __popcll(mine & ((1ull << lane) - 1ull)));
+            if (valid) {
+                const int leader = __ffsll((long long)mine) - 1;
+                int base = 0;
+                if (lane == leader) {
+                    base = wcnt[q][sl];
+                    wcnt[q][sl] = (unsigned short)(base + __popcll(mine));
+                }
+                base = __shfl(base, leader, 64);
+                erank[e] = (unsigned short)(base + __popcll(mine & ((1ull << lane) - 1ull)));
+            }
         }
     }
     __syncthreads();
@@ -633,8 +680,16 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
     int32_t *gfirst = a.first + (long long)b * a.cap;
     int my_slots = 0;
     for (int i = threadIdx.x; i < GROUP_HT; i += 256) {
-        const int c0 = wcnt[0][i], c1 = wcnt[1][i], c2 = wcnt[2][i], c3 = wcnt[3][i];
-        const int tot = c0 + c1 + c2 + c3;
+        int tot = 0, c0 = 0, c1 = 0, c2 = 0;
+        if (use_mask) {
+            if (table[i] != EMPTY_KEY) {
+#pragma unroll
+                for (int w = 0; w < RANK_MW; ++w) tot += __popc(gmask[(unsigned)cid[i] * RANK_MW + w]);
+            }
+        } else {
+            c0 = wcnt[0][i]; c1 = wcnt[1][i]; c2 = wcnt[2][i];
+            tot = c0 + c1 + c2 + wcnt[3][i];
+        }
         if (tot > 0) {
             int gs = hash_insert(gtable, a.cap_mask, table[i]);
             if (gs >= 0) atomicMin(&gfirst[gs], start[i]);
@@ -645,10 +700,12 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
             table[i] = (unsigned long long)(unsigned)gs;
         }
         start[i] = tot;
-        wcnt[0][i] = 0;
-        wcnt[1][i] = (unsigned short)c0;
-        wcnt[2][i] = (unsigned short)(c0 + c1);
-        wcnt[3][i] = (unsigned short)(c0 + c1 + c2);
+        if (!use_mask) {
+            wcnt[0][i] = 0;
+            wcnt[1][i] = (unsigned short)c0;
+            wcnt[2][i] = (unsigned short)(c0 + c1);
+            wcnt[3][i] = (unsigned short)(c0 + c1 + c2);
+        }
         my_slots += (tot + SLOT_ENT - 1) / SLOT_ENT;
     }
     for (int o = 32; o > 0; o >>= 1) my_slots += __shfl_down(my_slots, o, 64);
@@ -666,7 +723,16 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
             const int e = t * dp1 + r;
             const int sl = eslot[e];
             const int prev = sl > 0 ? start[sl - 1] : 0; // exclusive start of the group
-            const int pos = prev + (int)wcnt[e / Q][sl] + (int)erank[e];
+            int rank;
+            if (use_mask) {
+                // pixels of the tile below t that touch this vertex
+                const unsigned *m = gmask + (unsigned)cid[sl] * RANK_MW;
+                rank = __popc(m[t >> 5] & ((1u << (t & 31)) - 1u));
+                for (int w = 0; w < (t >> 5); ++w) rank += __popc(m[w]);
+            } else {
+                rank = (int)wcnt[e / Q][sl] + (int)erank[e];
+            }
+            const int pos = prev + rank;
             const int gs = (int)(unsigned)table[sl];
             tent[ebase + pos] = make_uint2((unsigned)t, __float_as_uint(bary[r]));
             sslot_out[ebase + pos] = gs;
@@ -1749,7 +1815,9 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(tmp.alloc(sizeof(int32_t) * total, (void **)&sslot));
     WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.n_tiles + 1), (void **)&tile_nslots));
     WSC_HIP(hipMemsetAsync(tile_nslots, 0, sizeof(unsigned) * (L.n_tiles + 1), ctx->stream));
-    hipLaunchKernelGGL(tile_embed_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent, sslot, tile_nslots);
+    const char *rbe = getenv("WSC_CRF_RANK_BALLOT"); // read per build: a test compares the two ranking paths
+    hipLaunchKernelGGL(tile_embed_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent, sslot, tile_nslots,
+                       (rbe && atoi(rbe) != 0) ? 1 : 0);
     const int per_img = N * dp1; // entries of one image (total < 2^31 checked above)
     const dim3 grid_img((unsigned)grid1d(per_img, 256, B >= 32 ? 256 : 8192 / (B > 0 ? B : 1)), (unsigned)B);
     hipLaunchKernelGGL(flag_first_kernel, grid_img, dim3(256), 0, ctx->stream, eslot, first, cap, per_img, flag);
