@@ -85,6 +85,40 @@ __global__ void maxpool_kernel(const bf16_t *__restrict__ x, const bf16_t *__res
     }
 }
 
+// The same pooling for IEEE-half activations with one precision plane (the default path): the maximum of halves is taken
+// on the halves themselves (v_pk_max_f16, two channels per instruction -- exact, no conversion), one block row per output
+// row (blockIdx.y = n * Ho + ho: no 64-bit index divisions).  8 channels = one 16-byte load per tap.
+__global__ __launch_bounds__(256) void maxpool_f16_kernel(const bf16_t *__restrict__ x, int H, int W, int C, int k, int stride,
+                                                          int pad, int Ho, int Wo, bf16_t *__restrict__ y) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const int C8 = C >> 3;
+    const int row = blockIdx.y; // n * Ho + ho
+    const int n = row / Ho, ho = row - n * Ho;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Wo * C8; i += gridDim.x * blockDim.x) {
+        const int wo = i / C8, c8 = i - wo * C8;
+        const h2_t lowest = {(_Float16)-65504.f, (_Float16)-65504.f};
+        h2_t best[4] = {lowest, lowest, lowest, lowest};
+        bool any = false;
+        for (int dy = 0; dy < k; ++dy) {
+            const int hi = ho * stride - pad + dy;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int wi = wo * stride - pad + dx;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const uint4 v = *reinterpret_cast<const uint4 *>(x + ((((long long)n * H + hi) * W + wi) * C + c8 * 8));
+                const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) best[j] = __builtin_elementwise_max(best[j], __builtin_bit_cast(h2_t, vw[j]));
+                any = true;
+            }
+        }
+        (void)any;
+        *reinterpret_cast<uint4 *>(y + (((long long)row * Wo + wo) * C + c8 * 8)) =
+            make_uint4(__builtin_bit_cast(uint32_t, best[0]), __builtin_bit_cast(uint32_t, best[1]),
+                       __builtin_bit_cast(uint32_t, best[2]), __builtin_bit_cast(uint32_t, best[3]));
+    }
+}
+
 // x = relu(head); cam = x[0] + x[1].flip(-1)   (resnet50_cam.py:66-68, vgg16_cam.py:49-50)
 // head: fp32 [2B][h][w][Cs] (NHWC, first C channels valid) -> cam fp32 [B][C][h][w]
 __global__ void flip_add_kernel(const float *__restrict__ head, int B, int h, int w, int C, int Cs,
@@ -202,6 +236,13 @@ int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int
     WSC_CHECK(C % 8 == 0, WSC_ERR_INVALID, "maxpool: C=%d not a multiple of 8", C);
     const long long total = (long long)N * Ho * Wo * (C / 8);
     WscKernelTimer timer(ctx, WSC_K_POOL_MISC, ((double)N * H * W * C + (double)N * Ho * Wo * C) * 2);
+    if (fmt == 1 && x_lo == nullptr && y_lo == nullptr && (long long)N * Ho <= 65535) {
+        const int per_row = Wo * (C / 8);
+        hipLaunchKernelGGL(maxpool_f16_kernel, dim3((unsigned)((per_row + 255) / 256), (unsigned)(N * Ho)), dim3(256), 0, ctx->stream,
+                           x, H, W, C, k, stride, pad, Ho, Wo, y);
+        WSC_HIP(hipGetLastError());
+        return WSC_OK;
+    }
     hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, x_lo, N, H, W, C, k,
                        stride, pad, Ho, Wo, y, y_lo, fmt);
     WSC_HIP(hipGetLastError());
