@@ -370,16 +370,50 @@ __device__ __forceinline__ bool embed_pixel(const EmbedArgs &a, long long gp, in
     return ok;
 }
 
-// flag[e] = 1 if entry e is the first (raster order) toucher of its vertex
-// (blockIdx.y = image: the per-entry image index used to be a 64-bit division, ~60 slow VALU instructions per entry)
-__global__ void flag_first_kernel(const int32_t *__restrict__ eslot, const int32_t *__restrict__ first, long long cap,
-                                  int per_img, unsigned *__restrict__ flag) {
+// Vertex ids in first-touch raster order (the CPU reference's insertion order): every occupied table slot knows the smallest
+// entry index that touches its vertex (`first`, an atomicMin of the embed pass).  One bit per ENTRY marks the first touchers
+// (set from the table side: 4 M slots instead of 19.8 M entries), a popcount scan over the 32-bit words ranks them, and a
+// second pass over the table hands every vertex its row = 1 + rank(first).  (Round 1 flagged, scanned and re-read all
+// entries: three 80 MB passes where these move ~70 MB in total.)
+__global__ void first_bits_kernel(const int32_t *__restrict__ first, long long cap, int per_img, unsigned *__restrict__ bitmap) {
     const int b = blockIdx.y;
-    const int32_t *es = eslot + (long long)b * per_img;
     const int32_t *fi = first + (long long)b * cap;
-    unsigned *fl = flag + (long long)b * per_img;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_img; i += gridDim.x * blockDim.x)
-        fl[i] = fi[es[i]] == i ? 1u : 0u;
+    for (long long sl = (long long)blockIdx.x * blockDim.x + threadIdx.x; sl < cap; sl += (long long)gridDim.x * blockDim.x) {
+        const int f = fi[sl];
+        if (f != 0x7fffffff) {
+            const long long g = (long long)b * per_img + f;
+            atomicOr(&bitmap[g >> 5], 1u << (unsigned)(g & 31));
+        }
+    }
+}
+__global__ void popc_words_kernel(const unsigned *__restrict__ bitmap, long long nw, unsigned *__restrict__ cnt) {
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += (long long)gridDim.x * blockDim.x)
+        cnt[w] = (unsigned)__popc(bitmap[w]);
+}
+__device__ __forceinline__ unsigned first_rank(const unsigned *bitmap, const unsigned *wprefix, long long g) {
+    return wprefix[g >> 5] + (unsigned)__popc(bitmap[g >> 5] & ((1u << (unsigned)(g & 31)) - 1u));
+}
+// vertices of the images before image b (bound[b]), one thread per image
+__global__ void image_bounds_kernel(const unsigned *__restrict__ bitmap, const unsigned *__restrict__ wprefix, int per_img, int B,
+                                    unsigned *__restrict__ bound) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) bound[b] = first_rank(bitmap, wprefix, (long long)b * per_img);
+}
+// occupied slots publish their row id, key and image
+__global__ void assign_rows_kernel(const int32_t *__restrict__ first, const unsigned long long *__restrict__ table, long long cap,
+                                   int per_img, const unsigned *__restrict__ bitmap, const unsigned *__restrict__ wprefix,
+                                   int32_t *__restrict__ slot2row, unsigned long long *__restrict__ rowkey,
+                                   int32_t *__restrict__ rowimg) {
+    const int b = blockIdx.y;
+    for (long long sl = (long long)blockIdx.x * blockDim.x + threadIdx.x; sl < cap; sl += (long long)gridDim.x * blockDim.x) {
+        const long long s_ = (long long)b * cap + sl;
+        const int f = first[s_];
+        if (f == 0x7fffffff) continue;
+        const int row = 1 + (int)first_rank(bitmap, wprefix, (long long)b * per_img + f);
+        slot2row[s_] = row;
+        rowkey[row] = table[s_];
+        rowimg[row] = b;
+    }
 }
 
 // ---- flat exclusive scan (3 kernels), unsigned 32-bit -------------------------------
@@ -462,23 +496,6 @@ int exclusive_scan(wsc_ctx *ctx, const unsigned *in, long long n, unsigned *out,
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(256), 0, ctx->stream, in, n, sums, out);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
-}
-
-// first-toucher entries publish the row id of their slot and the slot's key
-__global__ void assign_ids_kernel(const int32_t *__restrict__ eslot, const unsigned *__restrict__ flag,
-                                  const unsigned *__restrict__ prefix, const unsigned long long *__restrict__ table,
-                                  long long cap, int per_img, int32_t *__restrict__ slot2row,
-                                  unsigned long long *__restrict__ rowkey, int32_t *__restrict__ rowimg) {
-    const int b = blockIdx.y;
-    const long long e0 = (long long)b * per_img;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_img; i += gridDim.x * blockDim.x) {
-        if (!flag[e0 + i]) continue;
-        const long long s = (long long)b * cap + eslot[e0 + i];
-        const int row = 1 + (int)prefix[e0 + i];
-        slot2row[s] = row;
-        rowkey[row] = table[s];
-        rowimg[row] = b;
-    }
 }
 
 // offset[e] = row of entry e
@@ -1775,16 +1792,19 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     TempBuf tmp(ctx);
     unsigned long long *table;
     int32_t *first, *eslot, *slot2row, *rowimg;
-    unsigned *flag, *prefix, *sums;
+    unsigned *bitmap, *wcount, *wprefix, *sums, *bound_dev;
     unsigned long long *rowkey;
     int *err;
     WSC_TRY(tmp.alloc(sizeof(unsigned long long) * B * cap, (void **)&table));
     WSC_TRY(tmp.alloc(sizeof(int32_t) * B * cap, (void **)&first));
     WSC_TRY(tmp.alloc(sizeof(int32_t) * B * cap, (void **)&slot2row));
     WSC_TRY(tmp.alloc(sizeof(int32_t) * total, (void **)&eslot));
-    WSC_TRY(tmp.alloc(sizeof(unsigned) * total, (void **)&flag));
-    WSC_TRY(tmp.alloc(sizeof(unsigned) * (total + 1), (void **)&prefix));
-    const int nblk = (int)((total + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    const long long nw = (total + 31) / 32 + 1; // first-toucher bitmap over the entries
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * nw, (void **)&bitmap));
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * nw, (void **)&wcount));
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * (nw + 1), (void **)&wprefix));
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * (size_t)(B + 1), (void **)&bound_dev));
+    const int nblk = (int)((nw + SCAN_CHUNK - 1) / SCAN_CHUNK);
     WSC_TRY(tmp.alloc(sizeof(unsigned) * (nblk + 2), (void **)&sums));
     WSC_TRY(tmp.alloc(sizeof(int), (void **)&err));
     WSC_TRY(crf_alloc(crf, sizeof(int32_t) * total, (void **)&L.offset));
@@ -1820,17 +1840,20 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
                        (rbe && atoi(rbe) != 0) ? 1 : 0);
     const int per_img = N * dp1; // entries of one image (total < 2^31 checked above)
     const dim3 grid_img((unsigned)grid1d(per_img, 256, B >= 32 ? 256 : 8192 / (B > 0 ? B : 1)), (unsigned)B);
-    hipLaunchKernelGGL(flag_first_kernel, grid_img, dim3(256), 0, ctx->stream, eslot, first, cap, per_img, flag);
-    WSC_TRY(exclusive_scan(ctx, flag, total, prefix, sums));
+    const dim3 grid_tab((unsigned)grid1d(cap, 256, B >= 32 ? 256 : 8192 / (B > 0 ? B : 1)), (unsigned)B);
+    WSC_HIP(hipMemsetAsync(bitmap, 0, sizeof(unsigned) * nw, ctx->stream));
+    hipLaunchKernelGGL(first_bits_kernel, grid_tab, dim3(256), 0, ctx->stream, first, cap, per_img, bitmap);
+    hipLaunchKernelGGL(popc_words_kernel, dim3(grid1d(nw)), dim3(256), 0, ctx->stream, bitmap, nw, wcount);
+    WSC_TRY(exclusive_scan(ctx, wcount, nw, wprefix, sums));
+    hipLaunchKernelGGL(image_bounds_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, bitmap, wprefix, per_img, B,
+                       bound_dev);
     // vertex counts: grand total and per-image boundaries
     int herr = 0;
     unsigned vtot = 0;
     WSC_HIP(hipMemcpyAsync(&vtot, sums + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     WSC_HIP(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<unsigned> bound(B, 0);
-    for (int b = 1; b < B; ++b)
-        WSC_HIP(hipMemcpyAsync(&bound[b], prefix + (long long)b * N * dp1, sizeof(unsigned), hipMemcpyDeviceToHost,
-                               ctx->stream));
+    WSC_HIP(hipMemcpyAsync(bound.data(), bound_dev, sizeof(unsigned) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     WSC_HIP(hipStreamSynchronize(ctx->stream));
     WSC_CHECK((herr & 1) == 0, WSC_ERR_KEY_RANGE,
               "CRF lattice coordinate outside the packed-key range (sxy=%g srgb=%g too small for this image size)",
@@ -1850,8 +1873,8 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(tmp.alloc(sizeof(int32_t) * L.rows, (void **)&rowimg));
     WSC_TRY(crf_alloc(crf, sizeof(int2) * (size_t)dp1 * L.rows, (void **)&L.nbr));
 
-    hipLaunchKernelGGL(assign_ids_kernel, grid_img, dim3(256), 0, ctx->stream, eslot, flag, prefix, table, cap, per_img,
-                       slot2row, rowkey, rowimg);
+    hipLaunchKernelGGL(assign_rows_kernel, grid_tab, dim3(256), 0, ctx->stream, first, table, cap, per_img, bitmap, wprefix, slot2row,
+                       rowkey, rowimg);
     hipLaunchKernelGGL(remap_kernel, grid_img, dim3(256), 0, ctx->stream, eslot, slot2row, cap, per_img, L.offset);
     {   // splat tables: slots of the grouped tile entries, partial rows of each lattice row
         int32_t *slot_row;
