@@ -1126,6 +1126,9 @@ __global__ void gauss_tile_pstart_kernel(const int32_t *__restrict__ tile_rows, 
     }
 }
 
+#ifndef WSC_BLUR3_INPLACE
+#define WSC_BLUR3_INPLACE 1
+#endif
 template <int LH>
 __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__restrict__ in, const int32_t *__restrict__ tile_rows,
                                                          const int32_t *__restrict__ tile_list, int n_occ, int LP,
@@ -1138,7 +1141,12 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
     // plane stride P + 1: the row-wise load / store phases address (point, float4) with the float4 index fastest, and a
     // stride of exactly P float4s (4096 B) would put a row's LH float4s on one bank
     constexpr int PS = P + 1;
+#if WSC_BLUR3_INPLACE
+    __shared__ f32x4_t b0[LH * PS];
+    f32x4_t *const b1 = b0; // (unused by the in-place passes)
+#else
     __shared__ f32x4_t b0[LH * PS], b1[LH * PS];
+#endif
     // XCD-contiguous logical block id: neighbouring tiles of one replica (which share halo rows) on one L2
     const int nb = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qq = nb >> 3, rr = nb & 7;
@@ -1203,6 +1211,54 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
             }
         }
         __syncthreads();
+#if WSC_BLUR3_INPLACE
+        // ONE LDS plane set: a pass reads its three taps into registers, a barrier, then writes them back in place (two
+        // barriers per pass instead of one, but 24.7 KB of LDS per block instead of 49.3: six blocks per CU instead of three
+        // for the load phase's dependent gathers to hide behind)
+        f32x4_t o[LH];
+        // pass 0, axis 0: (i +- 1, j) = p +- GBJ
+#pragma unroll
+        for (int l = 0; l < LH; ++l) {
+            o[l] = zero;
+            if (r0) {
+                const f32x4_t c = b0[l * PS + p], a = b0[l * PS + p + GBJ], b = b0[l * PS + p - GBJ];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[l][q] = c[q] + 0.5f * (a[q] + b[q]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < LH; ++l) b0[l * PS + p] = o[l];
+        __syncthreads();
+        // pass 1, axis 1: (i, j +- 1) = p +- 1
+#pragma unroll
+        for (int l = 0; l < LH; ++l) {
+            o[l] = zero;
+            if (r1) {
+                const f32x4_t c = b0[l * PS + p], a = b0[l * PS + p - 1], b = b0[l * PS + p + 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[l][q] = c[q] + 0.5f * (a[q] + b[q]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < LH; ++l) b0[l * PS + p] = o[l];
+        __syncthreads();
+        // pass 2, axis 2: (i -+ 1, j -+ 1) = p -+ (GBJ + 1); interior only
+        if (r2) {
+#pragma unroll
+            for (int l = 0; l < LH; ++l) {
+                const f32x4_t c = b0[l * PS + p], a = b0[l * PS + p - GBJ - 1], b = b0[l * PS + p + GBJ + 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[l][q] = c[q] + 0.5f * (a[q] + b[q]);
+            }
+        }
+        __syncthreads();
+        if (r2) {
+#pragma unroll
+            for (int l = 0; l < LH; ++l) b0[l * PS + p] = o[l];
+        }
+#else
         // pass 0, axis 0: (i +- 1, j) = p +- GBJ
 #pragma unroll
         for (int l = 0; l < LH; ++l) {
@@ -1238,11 +1294,12 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
                 b1[l * PS + p] = o;
             }
         }
+#endif
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < LH; ++i) {
             const int idx = i * P + p, pp = idx / LH, ll = idx - pp * LH;
-            if (prow[i] > 0 && lbase + ll < LP) out[(unsigned)prow[i] * (unsigned)LP + lbase + ll] = b1[ll * PS + pp];
+            if (prow[i] > 0 && lbase + ll < LP) out[(unsigned)prow[i] * (unsigned)LP + lbase + ll] = (WSC_BLUR3_INPLACE ? b0 : b1)[ll * PS + pp];
         }
     }
 }
