@@ -152,10 +152,12 @@ def dcrf_process_device(ctx, cs_dev, mass, rgb_host, Cv, H, W, config):
         a_dev = ctx.alloc(Bg * N * 4, pooled=True)
         d = _lib.Crf(ctx, rgb_dev, Bg, H, W, gauss_sxy, bilat_sxy, bilat_srgb)
         d.inference(u_dev, M, gauss_compat, bilat_compat, int(n_infer), None, a_dev)
-        lab = ctx.to_host(a_dev, (Bg, H, W), np.int32)
+        # arg-max -> class index through each image's list of passing classes, on the device (a lookup table per image;
+        # the host loop of 103 k-element fancy indexings cost 0.15 ms per image); one uint8 read-back per group
+        conf_dev = ctx.alloc(Bg * N, pooled=True)
+        _lib.ir_label_combine(ctx, a_dev, None, np.stack([pass_inds[i] for i in idxs]), N, conf_dev)
+        out[idxs] = ctx.to_host(conf_dev, (Bg, H, W), np.uint8)
         d.close()
-        for j, i in enumerate(idxs):
-            out[i] = pass_inds[i][lab[j]]
     return out
 
 
