@@ -373,12 +373,11 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
             cur = cur == 2 ? 0 : cur + 1;
         }
     } else if (GLDS && MODE == 0) {
-        // Two LDS buffers.  The 4 + NB LDS-DMA pieces of K-step kt+1 are issued BETWEEN the MFMA groups of
-        // K-step kt (one A and one B piece after each k-slice): a DMA piece costs ~100 issue cycles (address
-        // math, M0, the VMEM slot) and a front-loaded batch of 8 left the matrix pipe idle for longer than
-        // the 16 MFMAs of the step take.  The (segment, tap, channel-chunk) decode of the next K-step is
-        // carried incrementally in SGPRs (no per-step integer divisions).  The barrier at the end of a step
-        // carries the vmcnt(0) for the pieces in flight.
+        // Two LDS buffers.  The 4 + NB LDS-DMA pieces of K-step kt+1 are issued at the top of K-step kt, before its
+        // fragment reads and MFMAs (interleaving one piece after every 1 ... 4 MFMAs was measured: no layer gained,
+        // profiles/README.md).  The (segment, tap, channel-chunk) decode of the next K-step is carried incrementally in
+        // SGPRs (no per-step integer divisions).  The barrier at the end of a step carries the vmcnt(0) for the pieces
+        // in flight.
         int n_seg = 0, n_khi = 0, n_kwi = 0, n_cc = 0, n_ktl = 0; // decode of the next K-step to issue
         const bf16_t *n_src = p.x;
         long long n_tap = 0;
