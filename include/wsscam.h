@@ -257,6 +257,18 @@ int wsc_cam_eval_confusion_nn(wsc_ctx *ctx, const float *maps_dev, int B, const 
                               const int64_t *maps_off_host /*[B]*/, const uint8_t *gt_dev, int n_class, int ignore_label,
                               uint8_t *pred_dev, int64_t *confusion_dev);
 
+/* The tail of make_sem_seg_labels for a batch of images (03b_irn/step/make_sem_seg_labels.py:74-79 voc12, :91-96 ADP,
+ * :113-118 DeepGlobe), straight from the random-walk maps wsc_rw_propagate_batch left in HBM:
+ *   rw_up = F.interpolate(rw, size=up_hw, mode='bilinear', align_corners=False)[..., 0, :H0, :W0]
+ *   rw_up = rw_up / torch.max(rw_up)                      (one maximum over all of the image's maps and pixels)
+ *   has_bg: rw_up = F.pad(rw_up, (0,0,0,0,1,0), value=bg_thres)          (voc12; keys then hold K + 1 entries)
+ *   label = keys[torch.argmax(rw_up, dim=0)]              (first maximum; an all-zero image gives NaN maps: the first of them)
+ * rw_dev: image b's [K_b][h_b * w_b] maps at float offset rw_off[b]; khw = (K, h, w); label_dev uint8, H0 * W0 per image,
+ * packed in batch order.  Keys must fit a uint8 label. */
+int wsc_sem_seg_finish(wsc_ctx *ctx, const float *rw_dev, int B, const int64_t *rw_off_host /*[B]*/, const int32_t *khw_host /*[B][3]*/,
+                       const int32_t *up_hw_host /*[B][2]*/, const int32_t *out_hw_host /*[B][2]*/, const int32_t *keys_host,
+                       const int32_t *key_off_host /*[B+1]*/, int has_bg, float bg_thres, uint8_t *label_dev);
+
 /* wsc_cam_postprocess (all C classes, every image at H0 x W0) followed by wsc_unary_from_maps, fused: the
  * max-normalised high-resolution maps are never written to HBM, only the unaries are (bit-identical to the
  * two-step path).  Replaces, for a whole batch, make_cam.py:64-76 (upsample to the strided-up size, crop,

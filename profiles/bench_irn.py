@@ -69,6 +69,32 @@ def main():
     t_up = timed(lambda: _lib.bilinear_resize(ctx, rw_dev, K, h, w, up_dev, 375, 500), args.steps)
     per_img = t_net / B + t_rw + t_up
     hw = h * w
+    # the driver itself: make_sem_seg_labels.sem_seg_batch on 16 VOC-sized images (host arrays in, label maps out; no file I/O)
+    import types
+
+    from wsscam.step import make_sem_seg_labels as mssl
+
+    if args.arch == "vgg16":
+        from wsscam.net import vgg16_irn as irn_mod
+
+        model = irn_mod.EdgeDisplacement(None, "voc12", "", 20, None, precision=prec)
+    else:
+        from wsscam.net import resnet50_irn as irn_mod
+
+        model = irn_mod.EdgeDisplacement(None, 20, precision=prec)
+    model.load_state_dict({k: v.numpy() for k, v in sd.items()}, strict=False)
+    model.cuda(0)
+    DB = 16
+    packs = [{"name": "i%d" % i, "img": rng.normal(0, 1, (2, 3, 375, 500)).astype(np.float32), "size": (375, 500)} for i in range(DB)]
+    cam_dicts = [{"keys": np.array([3, 11]), "cam": rng.random((K, h, w)).astype(np.float32)} for _ in range(DB)]
+    dargs = types.SimpleNamespace(dataset="voc12", beta=10, exp_times=8, sem_seg_bg_thres=0.25)
+    mssl.sem_seg_batch(model, packs, cam_dicts, dargs)
+    model.ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        mssl.sem_seg_batch(model, packs, cam_dicts, dargs)
+    model.ctx.sync()
+    t_drv = (time.perf_counter() - t0) / 3 / DB * 1e3
     print(json.dumps({
         "workload": "IRNet inference (BASELINE config 4): %s EdgeDisplacement @512 pad + random walk K=%d %dx%d 2^8 steps"
                     % (args.arch, K, h, w),
@@ -76,6 +102,7 @@ def main():
         "edge_net_ms_per_image": round(t_net / B, 3), "random_walk_ms_per_image": round(t_rw, 3),
         "random_walk_batch_images": RB, "random_walk_ms_single_image_call": round(t_rw1, 3),
         "upsample_ms_per_image": round(t_up, 3), "images_per_s": round(1e3 / per_img, 1),
+        "driver_ms_per_image": round(t_drv, 3), "driver_images_per_s": round(1e3 / t_drv, 1), "driver_batch_images": DB,
         "stencil_GFLOP_per_image": round(256 * K * hw * 69 * 2 / 1e9, 2),
         "reference_dense_TFLOP_per_image": round(8 * 2 * hw ** 3 / 1e12, 1)}))
 

@@ -359,6 +359,68 @@ __global__ __launch_bounds__(256) void cam_eval_nn_kernel(const float *__restric
         if (hist[i]) atomicAdd(&confusion[i], (unsigned long long)hist[i]);
 }
 
+// make_sem_seg_labels tail (03b_irn/step/make_sem_seg_labels.py:74-79, :91-96, :113-118): the random-walk maps of an image
+//   rw_up = F.interpolate(rw, size, 'bilinear', align_corners=False)[..., :H0, :W0];  rw_up /= rw_up.max()
+//   [voc12: rw_up = pad(rw_up, bg channel = sem_seg_bg_thres)];  pred = keys[argmax(rw_up, 0)]
+// WRITE = false: the image's maximum over all maps and pixels (ordered-uint atomicMax, one per block);
+// WRITE = true: the label map.  A zero maximum gives NaN maps in the reference: argmax then picks the first of them.
+struct SemSegJob {
+    long long rw_off;  // float offset of the image's [K][h*w] maps
+    long long pix_off; // offset of the image's labels in the packed output (H0 * W0 each)
+    int K, h, w, Hu, Wu, H0, W0, key_base;
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void sem_seg_finish_kernel(const float *__restrict__ rw, const SemSegJob *__restrict__ jobs,
+                                                             const int32_t *__restrict__ keys, int has_bg, float bg_thres,
+                                                             unsigned int *__restrict__ mx, uint8_t *__restrict__ label) {
+    const SemSegJob job = jobs[blockIdx.y];
+    const int n = job.H0 * job.W0, hw = job.h * job.w;
+    const float sh = (float)job.h / (float)job.Hu, sw = (float)job.w / (float)job.Wu;
+    const float *src = rw + job.rw_off;
+    float m = -3.0e38f, d = 1.f;
+    bool degenerate = false;
+    if (WRITE) {
+        d = ord_dec(mx[blockIdx.y]);
+        degenerate = d == 0.f; // 0 / 0 everywhere: NaN maps
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int yy = i / job.W0, xx = i - yy * job.W0;
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index(yy, sh, job.h, y0, y1, ly0, ly1);
+        src_index(xx, sw, job.w, x0, x1, lx0, lx1);
+        if (!WRITE) {
+            for (int k = 0; k < job.K; ++k) m = fmaxf(m, bilerp(src + (long long)k * hw, job.w, y0, y1, ly0, ly1, x0, x1, lx0, lx1));
+        } else {
+            int idx = has_bg ? 0 : -1;
+            float best = has_bg ? bg_thres : -3.0e38f;
+            if (degenerate) {
+                idx = has_bg ? 1 : 0; // torch.argmax / np.argmax return the first NaN
+            } else {
+                for (int k = 0; k < job.K; ++k) {
+                    const float v = bilerp(src + (long long)k * hw, job.w, y0, y1, ly0, ly1, x0, x1, lx0, lx1) / d;
+                    if (idx < 0 || v > best) { // strict: the first maximum wins (the background channel comes first)
+                        best = v;
+                        idx = k + (has_bg ? 1 : 0);
+                    }
+                }
+            }
+            label[job.pix_off + i] = (uint8_t)keys[job.key_base + idx];
+        }
+    }
+    if (!WRITE) {
+        __shared__ float wmax[4];
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (m > -3.0e38f) atomicMax(&mx[blockIdx.y], ord_enc(m));
+        }
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -463,6 +525,54 @@ int wsc_cam_eval_confusion_nn(wsc_ctx *ctx, const float *maps_dev, int B, const 
     WSC_CHECK(n_bad == 0, WSC_ERR_INVALID,
               "wsc_cam_eval_confusion_nn: %u pixels carry a ground-truth label outside [0, %d) (and != ignore_label %d)", n_bad,
               n_class, ignore_label);
+    return WSC_OK;
+}
+
+int wsc_sem_seg_finish(wsc_ctx *ctx, const float *rw_dev, int B, const int64_t *rw_off_host, const int32_t *khw_host,
+                       const int32_t *up_hw_host, const int32_t *out_hw_host, const int32_t *keys_host, const int32_t *key_off_host,
+                       int has_bg, float bg_thres, uint8_t *label_dev) {
+    WSC_CHECK(ctx && rw_dev && rw_off_host && khw_host && up_hw_host && out_hw_host && keys_host && key_off_host && label_dev,
+              WSC_ERR_INVALID, "wsc_sem_seg_finish: null argument");
+    WSC_CHECK(B > 0 && B <= 65535, WSC_ERR_INVALID, "wsc_sem_seg_finish: B=%d", B);
+    WSC_HIP(hipSetDevice(ctx->device));
+    std::vector<SemSegJob> jobs(B);
+    long long pix = 0;
+    int max_pix = 0;
+    for (int b = 0; b < B; ++b) {
+        SemSegJob &j = jobs[b];
+        j.K = khw_host[3 * b]; j.h = khw_host[3 * b + 1]; j.w = khw_host[3 * b + 2];
+        j.Hu = up_hw_host[2 * b]; j.Wu = up_hw_host[2 * b + 1];
+        j.H0 = out_hw_host[2 * b]; j.W0 = out_hw_host[2 * b + 1];
+        WSC_CHECK(j.K >= 1 && j.h > 0 && j.w > 0 && j.Hu >= j.H0 && j.Wu >= j.W0 && j.H0 > 0 && j.W0 > 0, WSC_ERR_INVALID,
+                  "wsc_sem_seg_finish: image %d: K=%d %dx%d -> %dx%d crop %dx%d", b, j.K, j.h, j.w, j.Hu, j.Wu, j.H0, j.W0);
+        WSC_CHECK(key_off_host[b + 1] - key_off_host[b] == j.K + (has_bg ? 1 : 0), WSC_ERR_INVALID,
+                  "wsc_sem_seg_finish: image %d has %d keys for %d maps%s", b, key_off_host[b + 1] - key_off_host[b], j.K,
+                  has_bg ? " + background" : "");
+        j.key_base = key_off_host[b];
+        j.rw_off = rw_off_host[b];
+        j.pix_off = pix;
+        pix += (long long)j.H0 * j.W0;
+        max_pix = std::max(max_pix, j.H0 * j.W0);
+    }
+    const int nkeys = key_off_host[B];
+    for (int i = 0; i < nkeys; ++i)
+        WSC_CHECK(keys_host[i] >= 0 && keys_host[i] <= 255, WSC_ERR_INVALID, "wsc_sem_seg_finish: key %d does not fit a uint8 label", keys_host[i]);
+    const size_t jb = (jobs.size() * sizeof(SemSegJob) + 15) / 16 * 16, kb = ((size_t)nkeys * sizeof(int32_t) + 15) / 16 * 16,
+                 mb = ((size_t)B * sizeof(unsigned) + 15) / 16 * 16;
+    char *d = nullptr;
+    WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + kb + mb, (void **)&d));
+    std::vector<char> stage(jb + kb + mb, 0); // the maxima start at code 0 = "below every real number"
+    memcpy(stage.data(), jobs.data(), jobs.size() * sizeof(SemSegJob));
+    memcpy(stage.data() + jb, keys_host, (size_t)nkeys * sizeof(int32_t));
+    WSC_TRY(wsc_ctx_upload_small(ctx, d, stage.data(), stage.size()));
+    const dim3 grid((unsigned)std::min((max_pix + 255) / 256, 256), (unsigned)B);
+    WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, (double)pix * 4);
+    hipLaunchKernelGGL(sem_seg_finish_kernel<false>, grid, dim3(256), 0, ctx->stream, rw_dev, (const SemSegJob *)d,
+                       (const int32_t *)(d + jb), has_bg, bg_thres, (unsigned int *)(d + jb + kb), label_dev);
+    hipLaunchKernelGGL(sem_seg_finish_kernel<true>, grid, dim3(256), 0, ctx->stream, rw_dev, (const SemSegJob *)d,
+                       (const int32_t *)(d + jb), has_bg, bg_thres, (unsigned int *)(d + jb + kb), label_dev);
+    WSC_HIP(hipGetLastError());
+    wsc_ctx_cached_free(ctx, d); // stream-ordered reuse
     return WSC_OK;
 }
 

@@ -98,6 +98,7 @@ _SIGNATURES = {
     "wsc_cam_unary_pm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wsc_cam_sum_scales": (_i, [_vp, _vp, _i, _i, ctypes.c_longlong, _vp]),
     "wsc_cam_eval_confusion_nn": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "wsc_sem_seg_finish": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     "wsc_msf_input_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "wsc_label_unary_from_cam": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
@@ -496,6 +497,21 @@ def cam_eval_confusion_nn(ctx, maps_dev, src_sizes, out_sizes, keys_per_image, m
     check(ctx._lib.wsc_cam_eval_confusion_nn(ctx.h, _ptr(maps_dev), B, src_hw.ctypes.data, out_hw.ctypes.data, keys.ctypes.data,
                                              key_off.ctypes.data, m_off.ctypes.data, _ptr(gt_dev), int(n_class),
                                              int(ignore_label), _ptr(pred_dev), _ptr(confusion_dev)))
+
+
+def sem_seg_finish(ctx, rw_dev, rw_off, khw, up_hw, out_hw, keys_per_image, has_bg, bg_thres, label_dev):
+    """make_sem_seg_labels tail on the device: upsample + crop + / max + [bg pad] + argmax + keys -> packed uint8 labels."""
+    B = len(khw)
+    key_off = np.zeros(B + 1, dtype=np.int32)
+    for b in range(B):
+        key_off[b + 1] = key_off[b] + len(keys_per_image[b])
+    keys = np.zeros(max(int(key_off[-1]), 1), dtype=np.int32)
+    for b in range(B):
+        keys[key_off[b]:key_off[b + 1]] = np.asarray(keys_per_image[b], dtype=np.int32)
+    off = np.ascontiguousarray(rw_off, dtype=np.int64)
+    a, u, o = (np.ascontiguousarray(v, dtype=np.int32).reshape(B, -1) for v in (khw, up_hw, out_hw))
+    check(ctx._lib.wsc_sem_seg_finish(ctx.h, _ptr(rw_dev), B, off.ctypes.data, a.ctypes.data, u.ctypes.data, o.ctypes.data,
+                                      keys.ctypes.data, key_off.ctypes.data, int(bool(has_bg)), float(bg_thres), _ptr(label_dev)))
 
 
 def unary_from_maps(ctx, maps_dev, B, C, N, bg_value, unary_dev):

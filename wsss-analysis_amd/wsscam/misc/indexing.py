@@ -109,6 +109,13 @@ def propagate_to_edge(x, edge, radius=5, beta=10, exp_times=8, ctx=None):
     return rw
 
 
+def device_path_tables(radius=5):
+    """(dirs, path_start, path_yx) of PathIndex(radius) as wsc_rw_propagate_batch takes them (cached)."""
+    if radius not in _PATH_CACHE:
+        _PATH_CACHE[radius] = PathIndex(radius=radius).device_tables()
+    return _PATH_CACHE[radius]
+
+
 def propagate_to_edge_batch(xs, edges, radius=5, beta=10, exp_times=8, ctx=None):
     """propagate_to_edge for a list of images of different sizes in one device pass (every stencil step is one
     launch over all of them): xs[b] (K_b,h_b,w_b), edges[b] (1,h_b,w_b) or (h_b,w_b) -> list of (K_b,1,h_b,w_b)."""

@@ -18,25 +18,48 @@ class EdgeDisplacementBase(DeviceCAMBase):
 
     def forward_batch(self, x):
         """x: numpy/torch float32 (B,2,3,h,w) -> (edge (B,1,fh,fw), dp (B,2,fh,fw)) numpy."""
+        edge_dev, dp_dev, (B, fh, fw) = self.forward_batch_device(x)
+        ctx = self._ctx
+        return ctx.to_host(edge_dev, (B, 1, fh, fw), np.float32), ctx.to_host(dp_dev, (B, 2, fh, fw), np.float32)
+
+    def forward_batch_device(self, x):
+        """forward_batch with the outputs left in HBM: (edge_dev float32 [B][fh][fw], dp_dev [B][2][fh][fw], (B, fh, fw)).
+        x: (B,2,3,h,w) array / tensor, or a list of B (2,3,h,w) arrays of one size (copied straight into the page-locked,
+        zero-padded staging batch: no stacked temporary, no pageable upload)."""
         net = self._ensure_net()
-        xn = x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
-        xn = np.ascontiguousarray(xn, dtype=np.float32)
-        assert xn.ndim == 5 and xn.shape[1] == 2 and xn.shape[2] == 3, xn.shape
-        B, h, w = xn.shape[0], xn.shape[3], xn.shape[4]
+        if isinstance(x, (list, tuple)):
+            items = [np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32) for v in x]
+        else:
+            xn = x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+            assert xn.ndim == 5, xn.shape
+            items = list(np.asarray(xn, dtype=np.float32))
+        B = len(items)
+        assert B > 0 and all(v.shape == items[0].shape and v.ndim == 4 and v.shape[:2] == (2, 3) for v in items), \
+            [v.shape for v in items][:4]
+        h, w = items[0].shape[2], items[0].shape[3]
         S = self.crop_size
         if h > S or w > S:
             raise ValueError("input %dx%d is larger than crop_size %d" % (h, w, S))
         fh, fw = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
-        xp = np.zeros((B, 2, 3, S, S), np.float32)  # F.pad(x, [0, S - w, 0, S - h])
-        xp[..., :h, :w] = xn
         ctx = self._ctx
-        x_dev = ctx.to_device(xp)
+        st = self.__dict__.setdefault("_stage", {})
+        if st.get("key") != (B, S):  # page-locked (B,2,3,S,S) staging batch + its device twin, kept across calls
+            for k in ("pin", "dev"):
+                if st.get(k) is not None:
+                    st[k].free()
+            st.update(key=(B, S), pin=ctx.host_alloc(B * 2 * 3 * S * S * 4), dev=ctx.alloc(B * 2 * 3 * S * S * 4), hw=None)
+        xp = st["pin"].view((B, 2, 3, S, S), np.float32)
+        ctx.sync()  # the previous batch's upload has left the staging buffer
+        if st["hw"] != (h, w):
+            xp[...] = 0.0  # F.pad(x, [0, S - w, 0, S - h]): the margins stay zero while the image size does not change
+            st["hw"] = (h, w)
+        for i, v in enumerate(items):
+            xp[i, :, :, :h, :w] = v
+        ctx.h2d_async(st["dev"], st["pin"], B * 2 * 3 * S * S * 4)
         edge_dev = ctx.alloc(B * fh * fw * 4)
         dp_dev = ctx.alloc(B * 2 * fh * fw * 4)
-        net.forward_edge(x_dev, B, S, fh, fw, edge_dev, dp_dev)
-        edge = ctx.to_host(edge_dev, (B, 1, fh, fw), np.float32)
-        dp = ctx.to_host(dp_dev, (B, 2, fh, fw), np.float32)
-        return edge, dp
+        net.forward_edge(st["dev"], B, S, fh, fw, edge_dev, dp_dev)
+        return edge_dev, dp_dev, (B, fh, fw)
 
     def forward(self, x):
         is_torch = hasattr(x, "detach")

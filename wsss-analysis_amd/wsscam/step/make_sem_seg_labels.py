@@ -34,73 +34,66 @@ def _build_model(args):
         return cls(args.model_dir, args.num_classes, **kw)
 
 
-def _upsample_norm(ctx, rw, size, crop):
-    """F.interpolate(rw, size, bilinear, align_corners=False)[..., 0, :crop[0], :crop[1]] / max -- on the device."""
-    K, _, h, w = rw.shape
-    src = ctx.to_device(np.ascontiguousarray(rw.reshape(K, h, w)))
-    dst = ctx.alloc(K * size[0] * size[1] * 4)
-    _lib.bilinear_resize(ctx, src, K, h, w, dst, int(size[0]), int(size[1]))
-    up = ctx.to_host(dst, (K, int(size[0]), int(size[1])), np.float32)[:, :crop[0], :crop[1]]
-    src.free()
-    dst.free()
-    with np.errstate(invalid="ignore", divide="ignore"):  # an all-zero map gives NaN, as rw_up / torch.max(rw_up) does
-        return up / np.max(up)
-
-
-def _resize(ctx, maps, hw):
-    """F.interpolate(maps[None], size=hw, mode='bilinear', align_corners=False)[0] on the device."""
-    maps = np.ascontiguousarray(maps, dtype=np.float32)
-    if maps.shape[1:] == tuple(hw):
-        return maps
-    src = ctx.to_device(maps)
-    dst = ctx.alloc(maps.shape[0] * int(hw[0]) * int(hw[1]) * 4)
-    _lib.bilinear_resize(ctx, src, maps.shape[0], maps.shape[1], maps.shape[2], dst, int(hw[0]), int(hw[1]))
-    out = ctx.to_host(dst, (maps.shape[0], int(hw[0]), int(hw[1])), np.float32)
-    src.free()
-    dst.free()
-    return out
-
-
-def _prepare(ctx, edge, pack, cam_dict, args):
-    """Per-image inputs of the random walk (make_sem_seg_labels.py:50-93): (cams, edge at the cam size, keys,
-    output size) or a finished label map when there is nothing to propagate."""
-    size = np.asarray(pack["size"]).reshape(-1)
-    cams = np.asarray(cam_dict["cam"], dtype=np.float32)
-    keys_in = np.asarray(cam_dict["keys"])
-    if args.dataset == "voc12":
-        if len(keys_in) == 0:
-            return np.zeros(tuple(size), dtype="uint8")
-        return cams, _resize(ctx, edge, cams.shape[1:]), np.pad(keys_in + 1, (1, 0), mode="constant"), size
-    if args.dataset in ("adp_morph", "adp_func"):
-        return cams, _resize(ctx, edge, cams.shape[1:]), keys_in, size
-    if args.dataset in ("deepglobe", "deepglobe_balanced"):
-        if len(keys_in) == 0:
-            return 5 * np.ones(tuple(size // 4))
-        small = [v // 6 for v in cams.shape[1:]]  # down_fac = 6
-        return _resize(ctx, cams, small), _resize(ctx, edge, small), keys_in, size // 4
-    raise KeyError("Dataset %s not yet implemented" % args.dataset)
-
-
-def _finish(ctx, rw, keys, size, args):
-    rw_up = _upsample_norm(ctx, rw, size, size)
-    if args.dataset == "voc12":
-        rw_up = np.concatenate((np.full((1,) + rw_up.shape[1:], float(args.sem_seg_bg_thres), np.float32), rw_up))
-    return keys[np.argmax(rw_up, axis=0)]
-
-
 def sem_seg_batch(model, packs, cam_dicts, args):
-    """A list of images -> list of label maps: one EdgeDisplacement pass and ONE random-walk pass for all of them
-    (every stencil step is a single launch over the whole list), then the per-image upsample / argmax."""
+    """A list of images -> list of label maps, device resident between the batch upload and the label maps: one
+    EdgeDisplacement pass, the boundary maps resized to each image's CAM size on the device, ONE random-walk pass for all
+    images (every stencil step is a single launch over the whole list) and one tail pass (upsample, / max, background
+    channel, arg-max, keys: wsc_sem_seg_finish); the host sees the uint8 label maps.  (Round 1 / mid round 2: edges, walk
+    results and upsampled maps each went to the host and back, the arg-max ran in numpy.)"""
     ctx = model.ctx
-    edges, _dp = model.forward_batch(np.stack([np.asarray(p["img"], dtype=np.float32) for p in packs]))
-    prepared = [_prepare(ctx, edges[i], p, c, args) for i, (p, c) in enumerate(zip(packs, cam_dicts))]
-    todo = [i for i, v in enumerate(prepared) if isinstance(v, tuple)]
-    out = [None if isinstance(v, tuple) else v for v in prepared]
-    if todo:
-        rws = indexing.propagate_to_edge_batch([prepared[i][0] for i in todo], [prepared[i][1] for i in todo], radius=5,
-                                               beta=args.beta, exp_times=args.exp_times, ctx=ctx)
-        for i, rw in zip(todo, rws):
-            out[i] = _finish(ctx, rw, prepared[i][2], prepared[i][3], args)
+    edge_dev, _dp_dev, (B, fh, fw) = model.forward_batch_device([p["img"] for p in packs])
+    voc = args.dataset == "voc12"
+    dg = args.dataset in ("deepglobe", "deepglobe_balanced")
+    if not (voc or dg or args.dataset in ("adp_morph", "adp_func")):
+        raise KeyError("Dataset %s not yet implemented" % args.dataset)
+    out = [None] * len(packs)
+    todo, cams, keys, sizes = [], [], [], []
+    for i, (p, c) in enumerate(zip(packs, cam_dicts)):
+        size = np.asarray(p["size"]).reshape(-1)
+        k_in = np.asarray(c["keys"])
+        if voc and len(k_in) == 0:      # make_sem_seg_labels.py:81-82
+            out[i] = np.zeros(tuple(size), dtype="uint8")
+            continue
+        if dg and len(k_in) == 0:       # :120-121
+            out[i] = 5 * np.ones(tuple(size // 4))
+            continue
+        todo.append(i)
+        cams.append(np.ascontiguousarray(c["cam"], dtype=np.float32))
+        keys.append(np.pad(k_in + 1, (1, 0), mode="constant") if voc else k_in)
+        sizes.append(size // 4 if dg else size)
+    if not todo:
+        return out
+    n = len(todo)
+    Ks = [c.shape[0] for c in cams]
+    # the maps the walk runs on: the strided CAMs, for DeepGlobe resized by 1/6 on the device (:108-112)
+    if dg:
+        hs, ws = [c.shape[1] // 6 for c in cams], [c.shape[2] // 6 for c in cams]
+    else:
+        hs, ws = [c.shape[1] for c in cams], [c.shape[2] for c in cams]
+    x_off = np.concatenate(([0], np.cumsum([k * h * w for k, h, w in zip(Ks, hs, ws)]))).astype(np.int64)
+    e_off = np.concatenate(([0], np.cumsum([h * w for h, w in zip(hs, ws)]))).astype(np.int64)
+    if dg:
+        src = ctx.to_device(np.concatenate([c.ravel() for c in cams]), pooled=True)
+        x_dev = ctx.alloc(int(x_off[-1]) * 4, pooled=True)
+        so = 0
+        for j, c in enumerate(cams):
+            _lib.bilinear_resize(ctx, src.ptr + so * 4, Ks[j], c.shape[1], c.shape[2], x_dev.ptr + int(x_off[j]) * 4, hs[j], ws[j])
+            so += c.size
+    else:
+        x_dev = ctx.to_device(np.concatenate([c.ravel() for c in cams]), pooled=True)
+    e_dev = ctx.alloc(int(e_off[-1]) * 4, pooled=True)
+    for j, i in enumerate(todo):  # F.interpolate(edge, size = the maps' size) -- also when the sizes agree (an exact copy)
+        _lib.bilinear_resize(ctx, edge_dev.ptr + i * fh * fw * 4, 1, fh, fw, e_dev.ptr + int(e_off[j]) * 4, hs[j], ws[j])
+    dirs, start, yx = indexing.device_path_tables(5)
+    rw_dev = _lib.rw_propagate_batch(ctx, x_dev, e_dev, Ks, hs, ws, dirs, start, yx, float(args.beta), 2 ** int(args.exp_times))
+    lab_off = np.concatenate(([0], np.cumsum([int(s[0]) * int(s[1]) for s in sizes]))).astype(np.int64)
+    lab_dev = ctx.alloc(int(lab_off[-1]), pooled=True)
+    _lib.sem_seg_finish(ctx, rw_dev, x_off[:-1], list(zip(Ks, hs, ws)), [tuple(int(v) for v in s) for s in sizes],
+                        [tuple(int(v) for v in s) for s in sizes], keys, voc, float(getattr(args, "sem_seg_bg_thres", 0.0)), lab_dev)
+    flat = ctx.to_host(lab_dev, (int(lab_off[-1]),), np.uint8)
+    for j, i in enumerate(todo):
+        out[i] = flat[lab_off[j]:lab_off[j + 1]].reshape(int(sizes[j][0]), int(sizes[j][1])).astype(np.int64)
+    rw_dev.free()
     return out
 
 
