@@ -512,15 +512,15 @@ __global__ __launch_bounds__(256) void remap_kernel(const int32_t *__restrict__ 
 // ---- splat tables of a pixel tile (lattice build) -------------------------------------------------------
 // Block-wide inclusive scan of an int array in LDS (n <= SORT_MAX, 256 threads, 8 consecutive elements per
 // thread).  MAXOP: running maximum instead of running sum.
-template <bool MAXOP>
-__device__ __forceinline__ void block_scan_lds(int *v, int n, int *wtot /* [4] */) {
+template <bool MAXOP, class T = int>
+__device__ __forceinline__ void block_scan_lds(T *v, int n, int *wtot /* [4] */) {
     constexpr int PER = SORT_MAX / 256;
     const int t0 = threadIdx.x * PER;
     int loc[PER];
     int run = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int x = t0 + i < n ? v[t0 + i] : 0;
+        const int x = t0 + i < n ? (int)v[t0 + i] : 0;
         run = MAXOP ? max(run, x) : run + x;
         loc[i] = run;
     }
@@ -539,19 +539,20 @@ __device__ __forceinline__ void block_scan_lds(int *v, int n, int *wtot /* [4] *
     const int carry = MAXOP ? max(base, prev) : base + prev;
 #pragma unroll
     for (int i = 0; i < PER; ++i)
-        if (t0 + i < n) v[t0 + i] = MAXOP ? max(carry, loc[i]) : carry + loc[i];
+        if (t0 + i < n) v[t0 + i] = (T)(MAXOP ? max(carry, loc[i]) : carry + loc[i]);
     __syncthreads();
 }
 
 // Grouped rows of a tile in LDS -> flag[i] = 1 where a slot starts (a new row, or SLOT_ENT entries into a row's
 // run); on return aux[i] holds the inclusive count of slot starts (aux[ne-1] = slots of the tile) and seg[i] the
 // first entry of i's run of equal rows.
-__device__ __forceinline__ void tile_slot_flags(const int *srow, int ne, int *aux, int *flag, int *seg, int *wtot) {
-    for (int i = threadIdx.x; i < ne; i += 256) seg[i] = (i == 0 || srow[i] != srow[i - 1]) ? i : 0;
+__device__ __forceinline__ void tile_slot_flags(const int *srow, int ne, unsigned short *aux, unsigned short *flag, unsigned short *seg,
+                                                int *wtot) {
+    for (int i = threadIdx.x; i < ne; i += 256) seg[i] = (unsigned short)((i == 0 || srow[i] != srow[i - 1]) ? i : 0);
     __syncthreads();
     block_scan_lds<true>(seg, ne, wtot); // seg[i] = start of the run of equal rows containing i
     for (int i = threadIdx.x; i < ne; i += 256) {
-        flag[i] = ((i - seg[i]) % SLOT_ENT == 0) ? 1 : 0;
+        flag[i] = ((i - (int)seg[i]) % SLOT_ENT == 0) ? 1 : 0;
         aux[i] = flag[i];
     }
     __syncthreads();
@@ -765,11 +766,12 @@ __global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ tslot_start, int2 *__restrict__ slot_desc,
                                                          int32_t *__restrict__ slot_row, unsigned *__restrict__ slot_key,
                                                          unsigned *__restrict__ row_nslots) {
+    // entry indices and counts of a tile fit 16 bits (SORT_MAX = 2048): 24 KB of LDS per block instead of 41 (6 blocks per CU)
     __shared__ int rows_s[SORT_MAX];
-    __shared__ int aux[SORT_MAX];
-    __shared__ int flag[SORT_MAX];
-    __shared__ int seg[SORT_MAX];
-    __shared__ int pos[SORT_MAX + 1];
+    __shared__ unsigned short aux[SORT_MAX];
+    __shared__ unsigned short flag[SORT_MAX];
+    __shared__ unsigned short seg[SORT_MAX];
+    __shared__ unsigned short pos[SORT_MAX + 2];
     __shared__ int wtot[4];
     const int tile = blockIdx.x;
     const int b = tile / tg.tpi, j = tile - b * tg.tpi;
@@ -782,8 +784,8 @@ __global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restri
     tile_slot_flags(rows_s, ne, aux, flag, seg, wtot);
     const int ns = aux[ne - 1];
     for (int i = threadIdx.x; i < ne; i += 256)
-        if (flag[i]) pos[aux[i] - 1] = i;
-    if (threadIdx.x == 0) pos[ns] = ne;
+        if (flag[i]) pos[aux[i] - 1] = (unsigned short)i;
+    if (threadIdx.x == 0) pos[ns] = (unsigned short)ne;
     __syncthreads();
     // The tile's slots are stored longest first: the lane groups of a wave of the update kernel take consecutive
     // slots and wait for the longest of them (the order of a tile's slots is free -- it only decides which
