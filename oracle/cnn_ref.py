@@ -135,8 +135,27 @@ def resnet50_cam_forward(x, sd):
 # ---------------------------------------------------------------------------------------------
 # VGG16 / M7 (common_cnn.make_layers)
 # ---------------------------------------------------------------------------------------------
-def plain_features(x, sd, root, cfg):
-    """make_layers stacks, 03b_irn/net/common_cnn.py:128-141: conv(bias) -> ReLU -> BatchNorm(eps=1e-3)."""
+def last_bn_key(sd, root, cfg):
+    """Key prefix of the BatchNorm that follows the LAST conv of a make_layers stack, or None (ADP VGG16: no BN)."""
+    key = None
+    for lname, layer in cfg:
+        idx = 0
+        for v in layer:
+            if v in ("M", "D"):
+                idx += 1
+                continue
+            bn = "%s.%s.%d" % (root, lname, idx + 2)
+            key = bn if bn + ".running_mean" in sd else None
+            idx += 3 if key else 2
+    return key
+
+
+def plain_features(x, sd, root, cfg, return_pre_bn=False):
+    """make_layers stacks, 03b_irn/net/common_cnn.py:128-141: conv(bias) -> ReLU -> BatchNorm(eps=1e-3).
+    return_pre_bn: also return the last conv's post-ReLU, PRE-BatchNorm activation -- the output of the Keras layer
+    `find_final_layer` names (the layer after the last Conv2D = its Activation, 02_cues/utilities.py:42-58, "activation_7"),
+    which is what the Keras-side drivers contract with alpha (02_cues/utilities.py:129-133, 03c_hsn/utilities.py:259-262)."""
+    pre = None
     for lname, layer in cfg:
         idx = 0
         for v in layer:
@@ -148,13 +167,21 @@ def plain_features(x, sd, root, cfg):
             else:
                 key = "%s.%s.%d" % (root, lname, idx)
                 x = F.relu(F.conv2d(x, sd[key + ".weight"], sd[key + ".bias"], padding=1))
+                pre = x
                 bn = "%s.%s.%d" % (root, lname, idx + 2)
                 if bn + ".running_mean" in sd:
                     x = _fixed_bn(x, sd, bn, eps=1e-3)
                     idx += 3
                 else:
                     idx += 2
-    return x
+    return (x, pre) if return_pre_bn else x
+
+
+def keras_conv_val(x, sd, root, cfg):
+    """`conv_func([images])[0]` of the Keras drivers: the final Activation's output, NHWC (02_cues/utilities.py:129-132)."""
+    with torch.no_grad():
+        _, pre = plain_features(x, sd, root, cfg, return_pre_bn=True)
+    return pre.permute(0, 2, 3, 1).contiguous()
 
 
 def vgg16_cam_forward(x, sd, num_classes):
@@ -183,17 +210,23 @@ def m7_cam_forward(x, sd, gradcam_weights, num_classes):
 
 def grad_cam_weights(sd, root, cfg, S, num_classes):
     """get_grad_cam_weights (02_cues/utilities.py:60-99; 03b_irn/net/common_cnn.py:84-121) on the
-    restated torch net: alpha[:, c] = mean_hw normalize(d logit_c / d A) on a zeros image."""
+    restated torch net: alpha[:, c] = mean_hw normalize(d logit_c / d A) on a zeros image, where A is the output of the
+    layer AFTER the last Conv2D (find_final_layer) -- its ReLU Activation, i.e. the PRE-BatchNorm tensor of the
+    conv -> ReLU -> BatchNorm order (common_cnn.py:138): the gradient passes through the inference-mode BatchNorm."""
     x = torch.zeros(1, 3, S, S)
-    feat = plain_features(x, sd, root, cfg).detach().requires_grad_(True)
+    with torch.no_grad():
+        _, pre = plain_features(x, sd, root, cfg, return_pre_bn=True)
+    A = pre.detach().requires_grad_(True)
+    bn = last_bn_key(sd, root, cfg)
+    feat = _fixed_bn(A, sd, bn, eps=1e-3) if bn else A
     if root == "m7":
         pooled = torch.flatten(F.adaptive_max_pool2d(F.max_pool2d(feat, 2, 2), (1, 1)), 1)
     else:
         pooled = torch.flatten(F.adaptive_avg_pool2d(feat, (1, 1)), 1)
     logits = F.linear(pooled, sd[root + ".classifier.0.weight"], sd.get(root + ".classifier.0.bias"))[0]
-    alpha = np.zeros((feat.shape[1], num_classes))
+    alpha = np.zeros((A.shape[1], num_classes))
     for c in range(num_classes):
-        (g,) = torch.autograd.grad(logits[c], feat, retain_graph=True)
+        (g,) = torch.autograd.grad(logits[c], A, retain_graph=True)
         g = g / (torch.sqrt(torch.mean(g * g)) + 1e-5)
         alpha[:, c] = g[0].mean(dim=(1, 2)).numpy()
     return alpha

@@ -149,27 +149,64 @@ def test_eval_sem_seg_report(tmp_path):
 
 def test_grad_cam_alpha_closed_forms_vs_autograd():
     """get_grad_cam_weights (02_cues/utilities.py:60-99, common_cnn.py:84-121) for BOTH classifier heads against
-    torch.autograd on the restated nets (oracle/cnn_ref.grad_cam_weights): GAP + Linear (VGG16) and
-    MaxPool + global max + Linear (M7 -- the all-zeros image ties every position; alpha does not depend on the winner),
-    incl. an odd feature-map size where MaxPool2d(2, 2) drops the last row / column."""
+    torch.autograd on the restated nets (oracle/cnn_ref.grad_cam_weights, which differentiates with respect to the final
+    Activation's output = the PRE-BatchNorm tensor, so the gradient carries gamma / sqrt(var + eps) per channel):
+    GAP + Linear (VGG16) and MaxPool + global max + Linear (M7 -- the all-zeros image ties every position; alpha does not
+    depend on the winner), incl. an odd feature-map size where MaxPool2d(2, 2) drops the last row / column, negative
+    BatchNorm scales (the pooled maximum then sits on the activation's minimum) and a stack without BatchNorm."""
     from oracle import cnn_ref
     from wsscam.net import common
 
     C = 7
-    for root, cfg, S in (("vgg16", cnn_ref.VGG16_CFG, 64), ("m7", cnn_ref.M7_CFG, 32), ("m7", cnn_ref.M7_CFG, 28)):
-        sd = cnn_ref.make_plain_state_dict(root, cfg, C, True, seed=11)
-        ref = cnn_ref.grad_cam_weights(sd, root, cfg, S, C)
+    cases = (("vgg16", cnn_ref.VGG16_CFG, 64, True), ("m7", cnn_ref.M7_CFG, 32, True), ("m7", cnn_ref.M7_CFG, 28, True),
+             ("vgg16", cnn_ref.VGG16_CFG, 32, False))
+    for root, cfg, S, batchnorm in cases:
+        sd = cnn_ref.make_plain_state_dict(root, cfg, C, batchnorm, seed=11)
+        bn = cnn_ref.last_bn_key(sd, root, cfg)
+        assert (bn is not None) == batchnorm
+        if bn:
+            sd[bn + ".weight"][::3] *= -1.0
 
         class Model:  # what cues.get_grad_cam_weights reads from a wsscam CAM wrapper
             _sd = {k: v.numpy() for k, v in sd.items()}
 
         Model.root = root
+        ref = cnn_ref.grad_cam_weights(sd, root, cfg, S, C)
         alpha = cues.get_grad_cam_weights(Model, cues.find_final_layer(Model), np.zeros((1, S, S, 3), np.float32))
         assert alpha.shape == ref.shape
         assert np.abs(alpha - ref).max() <= 2e-5 * np.abs(ref).max(), (root, S, np.abs(alpha - ref).max())
         h = S // (8 if root == "vgg16" else 4)
-        raw = common.grad_cam_alpha(Model._sd[root + ".classifier.0.weight"], h, h, "max" if root == "m7" else "avg", False)
-        assert np.allclose(raw, Model._sd[root + ".classifier.0.weight"].T / (h * h))
+        W = Model._sd[root + ".classifier.0.weight"]
+        raw = common.grad_cam_alpha(W, h, h, "max" if root == "m7" else "avg", False)
+        assert np.allclose(raw, W.T / (h * h))
+        affine = common.last_bn_affine(Model._sd, root)
+        if batchnorm:
+            g, v = Model._sd[bn + ".weight"].astype(np.float64), Model._sd[bn + ".running_var"].astype(np.float64)
+            assert np.allclose(affine[0], g / np.sqrt(v + 1e-3)) and (affine[0] < 0).any()
+            # without the BatchNorm fold the closed form is NOT the reference's alpha (the round-2 behaviour)
+            plain = common.grad_cam_alpha(W, h, h, "max" if root == "m7" else "avg", True)
+            assert np.abs(plain - ref).max() > 0.05 * np.abs(ref).max()
+        else:
+            assert affine is None
+
+
+def test_pre_bn_head_algebra():
+    """net.common.pre_bn_head: a head on the post-BatchNorm map that equals einsum(pre-BN activation, alpha)."""
+    from wsscam.net import common
+
+    rng = np.random.default_rng(5)
+    F, C = 12, 4
+    pre = rng.random((3, 5, 5, F))
+    s, t = rng.uniform(-2, 2, F), rng.normal(size=F)
+    alpha = rng.normal(size=(F, C))
+    w, b = common.pre_bn_head(alpha, (s, t))
+    post = pre * s + t
+    assert np.allclose(np.einsum("ijkl,lm->ijkm", post, w) + b, np.einsum("ijkl,lm->ijkm", pre, alpha))
+    w0, b0 = common.pre_bn_head(alpha, None)
+    assert np.array_equal(w0, alpha) and not b0.any()
+    s[3] = 0
+    with pytest.raises(ValueError):
+        common.pre_bn_head(alpha, (s, t))
 
 
 def test_keras_store_settings_sessions_and_csv(tmp_path, monkeypatch):
@@ -203,3 +240,14 @@ def test_keras_store_settings_sessions_and_csv(tmp_path, monkeypatch):
     assert g.data.shape == (2, 20) and g.data[1, 1] == 1 and g.data.sum() == 2
     with pytest.raises(FileNotFoundError):
         ks.read_settings(str(tmp_path / "missing.ini"))
+    # 03c_hsn/dataset.py:57-59: VOC2012 lives under VOC_trainaug_val, evaluation split only, database_dir = DATA_ROOT argument
+    voc_h = tmp_path / "database" / "VOCdevkit" / "VOC_trainaug_val" / "VOC2012"
+    os.makedirs(voc_h / "ImageSets" / "Segmentation")
+    (voc_h / "ImageSets" / "Segmentation" / "val.csv").write_text(head + "\nv0.jpg," + ",".join(["0"] * 19 + ["1"]) + "\n")
+    dh = ks.Dataset("VOC2012", 321, 4, database_dir=st["DATA_ROOT"], layout="hsn")
+    assert dh.sets == ["val"] and dh.is_evals == [True] and dh.set_gens["val"].filenames == ["v0.jpg"]
+    assert dh.set_gens["val"].directory == str(voc_h / "JPEGImages") and dh.set_gens["val"].data[0, 19] == 1
+    with pytest.raises(ValueError):
+        ks.Dataset("VOC2012", 321, 4, layout="hsn")  # no default directory in the HSN class
+    with pytest.raises(ValueError):
+        ks.Dataset("DeepGlobe_train75", 224, 4, database_dir=st["DATA_ROOT"], layout="hsn")  # a 02_cues name

@@ -240,10 +240,9 @@ def test_cues_grad_cam_and_resize_stack():
     keep = np.array([0, 2, 5, 19])
     is_pass = rng.random((3, len(keep))) > 0.3
     out = cues.grad_cam(model, alpha, imgs, is_pass, "x", keep)
-    with torch.no_grad():
-        feat = cnn_ref.plain_features(torch.from_numpy(np.transpose(imgs, (0, 3, 1, 2)).copy()), sd, "vgg16",
-                                      cnn_ref.VGG16_CFG).numpy()
-    conv_val = np.transpose(feat, (0, 2, 3, 1)).astype(np.float64)
+    # conv_val = output of the final Activation (pre-BatchNorm): 02_cues/utilities.py:129-132
+    conv_val = cnn_ref.keras_conv_val(torch.from_numpy(np.transpose(imgs, (0, 3, 1, 2)).copy()), sd, "vgg16",
+                                      cnn_ref.VGG16_CFG).numpy().astype(np.float64)
     ref = np.maximum(np.einsum("ijkl,lm->ijkm", conv_val, alpha), 0)[:, :, :, keep] * is_pass[:, None, None, :]
     assert out.shape == ref.shape == (3, 8, 8, 4)
     assert np.abs(out - ref).max() <= 2e-4 * ref.max()
@@ -267,10 +266,9 @@ def test_hsn_grad_cam_and_postprocessing():
     scores = rng.random((2, C))
     is_pass = scores > 0.4
     out = hsn.grad_cam(model, alpha, imgs, is_pass, "x", scores, orig_sz=[65, 65], should_upsample=True)
-    with torch.no_grad():
-        feat = cnn_ref.plain_features(torch.from_numpy(np.transpose(imgs, (0, 3, 1, 2)).copy()), sd, "vgg16",
-                                      cnn_ref.VGG16_CFG).numpy()
-    cams = np.einsum("ijkl,lm->ijkm", np.transpose(feat, (0, 2, 3, 1)).astype(np.float64), alpha)
+    conv_val = cnn_ref.keras_conv_val(torch.from_numpy(np.transpose(imgs, (0, 3, 1, 2)).copy()), sd, "vgg16",
+                                      cnn_ref.VGG16_CFG).numpy().astype(np.float64)  # final Activation, pre-BatchNorm
+    cams = np.einsum("ijkl,lm->ijkm", conv_val, alpha)
     up = torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cams, (0, 3, 1, 2))), (65, 65), mode="bilinear",
                                          align_corners=False).numpy()
     up = np.maximum(np.transpose(up, (0, 2, 3, 1)), 0)
@@ -387,11 +385,11 @@ def test_gen_cues_driver(tmp_path):
         for m, sd, a in (("fg", sd_fg, alphas["fg"]), ("bg", sd_bg, alphas["bg"])):
             xt = torch.from_numpy(np.transpose(x[lo:hi], (0, 3, 1, 2)).astype(np.float32).copy())
             with torch.no_grad():
-                feat = cnn_ref.plain_features(xt, sd, "vgg16", cnn_ref.VGG16_CFG)
+                feat, pre = cnn_ref.plain_features(xt, sd, "vgg16", cnn_ref.VGG16_CFG, return_pre_bn=True)
                 sc = torch.sigmoid(torch.nn.functional.linear(feat.mean((2, 3)), sd["vgg16.classifier.0.weight"],
                                                               sd["vgg16.classifier.0.bias"])).numpy()
             ip[m] = (sc >= 0.45) * labels[lo:hi]
-            cam = np.maximum(np.einsum("ijkl,lm->ijkm", np.transpose(feat.numpy(), (0, 2, 3, 1)).astype(np.float64), a), 0)
+            cam = np.maximum(np.einsum("ijkl,lm->ijkm", np.transpose(pre.numpy(), (0, 2, 3, 1)).astype(np.float64), a), 0)
             cam = cam * ip[m][:, None, None, :]
             Hm[m] = torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cam, (0, 3, 1, 2))), (41, 41),
                                                     mode="bilinear", align_corners=False).numpy()
@@ -406,10 +404,12 @@ def test_gen_cues_driver(tmp_path):
         assert (la == lb).mean() >= 0.995  # thresholded maps: a pixel on the 0.2 x max contour may flip
 
 
-def test_hsn_segment_driver():
+@pytest.mark.parametrize("quirk", [False, True])
+def test_hsn_segment_driver(quirk):
     """03c_hsn/demo.py:18-268 (VOC2012 branch) end to end at the real 321 x 321 size: scores -> 1/3 threshold ->
     HSN Grad-CAM -> batch-max background channel -> dense CRF; labels vs the oracle chain (torch net, numpy
-    post-processing, C CRF)."""
+    post-processing, C CRF).  quirk: the reference's actual VOC normalisation (utilities.py:142-146: uint8 wrap-around on
+    image columns 0..2, in place, so the CRF sees the modified image too) instead of the intended per-channel one."""
     import scipy.special
 
     from wsscam.hsn import demo as hsn_demo
@@ -423,18 +423,26 @@ def test_hsn_segment_driver():
     images = [cnn_ref.synth_image(rng, 321, 321) for _ in range(2)]
     alphas = {"fg": cnn_ref.grad_cam_weights(sd_fg, "vgg16", cnn_ref.VGG16_CFG, 33, C),
               "bg": cnn_ref.grad_cam_weights(sd_bg, "vgg16", cnn_ref.VGG16_CFG, 33, C)}
-    out = hsn_demo.segment("VOC2012", "VGG16", 2, models={"fg": fg, "bg": bg}, alphas=alphas, images=images,
-                           is_verbose=False)
+    out = hsn_demo.segment("VOC2012", "VGG16", 2, models={"fg": fg, "bg": bg}, alphas=alphas, images=[im.copy() for im in images],
+                           is_verbose=False, reference_normalize_quirk=quirk)
     assert len(out) == 2 and out[0].shape == (321, 321)
-    x = np.stack([cnn_ref.normalize_int(im.astype(np.float64)) for im in images])
+    if quirk:
+        batch = np.stack(images)          # normalize('VOC2012', img_batch) of the reference, verbatim
+        batch[:, :, 0] -= 104
+        batch[:, :, 1] -= 117
+        batch[:, :, 2] -= 123
+        x = batch / 255
+        images = list(batch)              # in place: dcrf_process gets the modified batch (demo.py:111,167)
+    else:
+        x = np.stack([cnn_ref.normalize_int(im.astype(np.float64)) for im in images])
     xt = torch.from_numpy(np.transpose(x, (0, 3, 1, 2)).astype(np.float32).copy())
     H = {}
     for m, sd in (("fg", sd_fg), ("bg", sd_bg)):
         with torch.no_grad():
-            feat = cnn_ref.plain_features(xt, sd, "vgg16", cnn_ref.VGG16_CFG)
+            feat, pre = cnn_ref.plain_features(xt, sd, "vgg16", cnn_ref.VGG16_CFG, return_pre_bn=True)
             sc = torch.sigmoid(torch.nn.functional.linear(feat.mean((2, 3)), sd["vgg16.classifier.0.weight"],
                                                           sd["vgg16.classifier.0.bias"])).numpy().astype(np.float64)
-        cams = np.einsum("ijkl,lm->ijkm", np.transpose(feat.numpy(), (0, 2, 3, 1)).astype(np.float64), alphas[m])
+        cams = np.einsum("ijkl,lm->ijkm", np.transpose(pre.numpy(), (0, 2, 3, 1)).astype(np.float64), alphas[m])
         up = torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cams, (0, 3, 1, 2))), (321, 321),
                                              mode="bilinear", align_corners=False).numpy()
         up = np.maximum(up, 0)

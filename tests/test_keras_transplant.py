@@ -60,7 +60,7 @@ def _keras_list(net, rng, use_bias, extra_classes=0):
 
 
 @pytest.mark.parametrize("root,batchnorm,tag", [("vgg16", True, "VOC2012_VGG16"), ("vgg16", False, "ADP_VGG16"),
-                                                ("m7", True, "VOC2012_M7"), ("m7", False, "ADP_X1.7")])
+                                                ("m7", True, "VOC2012_M7"), ("m7", True, "ADP_X1.7")])
 def test_state_dict_from_keras_weights(root, batchnorm, tag):
     rng = np.random.default_rng(3)
     C = 20
@@ -100,3 +100,21 @@ def test_keras_h5_reader_needs_h5py(tmp_path):
     except ImportError:
         with pytest.raises(RuntimeError, match="h5py"):
             common.keras_h5_weight_list(str(tmp_path / "x.h5"))
+
+
+def test_cam_wrappers_batchnorm_and_class_count():
+    """Which CAM wrapper expects BatchNorm weights, and the X1.7 class count: vgg16_cam.py:16-19 drops BatchNorm for the ADP
+    datasets only; m7_cam.py:16-18 ALWAYS builds m7.m7(..., batchnorm=True) and scores 51 classes for ADP X1.7 sessions
+    (filtered to the 31 of common_cam.py:26-29 afterwards)."""
+    from wsscam.net import m7_cam, vgg16_cam
+
+    assert vgg16_cam.CAM(None, "voc12", "VOC2012_VGG16", 20, None).batchnorm is True
+    assert vgg16_cam.CAM(None, "adp_morph", "ADP_VGG16", 31, None).batchnorm is False
+    assert vgg16_cam.CAM(None, "adp_func", "ADP_VGG16", 31, None).batchnorm is False
+    for ds in ("voc12", "deepglobe", "adp_morph", "adp_func"):
+        assert m7_cam.CAM(None, ds, "X_M7", 20, None).batchnorm is True
+    m = m7_cam.CAM(None, "adp_morph", "ADP_X1.7", 31, None)
+    assert m.batchnorm is True and m.num_classes == 51 and len(m.thresholds) == 51
+    assert m7_cam.CAM(None, "voc12", "VOC2012_X1.7", 20, None).num_classes == 20
+    y = m.predict_labels(np.linspace(0, 1, 51).astype(np.float32))
+    assert y.shape == (31,) and y[-1] and not y[0]

@@ -1766,14 +1766,14 @@ void splat_ones(wsc_ctx *ctx, const LatticeDev &L, const TileGeom &tg, float *va
 }
 
 // rows of a lattice from the slot partials of the splat
-void combine4(wsc_ctx *ctx, const LatticeDev &L, const float *part, int LP, float *val) {
+void combine4(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, const float *part, int LP, float *val) {
     WscKernelTimer timer(ctx, WSC_K_BLUR, ((double)L.n_slots + L.rows) * L.rep * L.M_cur * 4);
     if (L.sorted_dest)
         hipLaunchKernelGGL(combine4_kernel<true>, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
-                           ctx->stream, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
+                           st, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
     else
         hipLaunchKernelGGL(combine4_kernel<false>, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
-                           ctx->stream, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
+                           st, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
 }
 
 // d+1 blur passes of the one-value-per-row normalisation lattice, ping-pong between a and b
@@ -1787,8 +1787,10 @@ float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
 }
 
 // Rows from the splat's slot partials (`part`), then the d+1 blur passes; a / b: two row buffers.  Returns the
-// buffer holding the result.
-float *combine_blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, const float *part, float *a, float *b) {
+// buffer holding the result.  The launches go to `st` (the ctx's main or side stream): the shared ctx is never
+// re-pointed, so an error return or another thread's wsc_sync always sees ctx->stream = the main stream.  The timers are
+// live only while profiling, which runs without the fork (st == ctx->stream then).
+float *combine_blur_all4(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int LP, const float *part, float *a, float *b) {
     // WSC_CRF_NO_FUSED_BLUR=1 (read per call, so a test can flip it) keeps the three separate passes
     const char *fe = getenv("WSC_CRF_NO_FUSED_BLUR");
     const bool fused_off = fe && atoi(fe) != 0;
@@ -1799,24 +1801,24 @@ float *combine_blur_all4(wsc_ctx *ctx, const LatticeDev &L, int LP, const float 
         const char *ge = getenv("WSC_CRF_GLH");
         const int glh = ge ? atoi(ge) : WSC_GLH;
         if (glh == 3)
-            hipLaunchKernelGGL(blur3_tile_kernel<3>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, ctx->stream,
+            hipLaunchKernelGGL(blur3_tile_kernel<3>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, st,
                                (const f32x4_t *)nullptr, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b,
                                (const f32x4_t *)part, L.tile_pstart, L.n_slots);
         else if (glh == 2)
-            hipLaunchKernelGGL(blur3_tile_kernel<2>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, ctx->stream,
+            hipLaunchKernelGGL(blur3_tile_kernel<2>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, st,
                                (const f32x4_t *)nullptr, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b,
                                (const f32x4_t *)part, L.tile_pstart, L.n_slots);
         else
-        hipLaunchKernelGGL(blur3_tile_kernel<WSC_GLH>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, ctx->stream,
+        hipLaunchKernelGGL(blur3_tile_kernel<WSC_GLH>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, st,
                            (const f32x4_t *)nullptr, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b,
                            (const f32x4_t *)part, L.tile_pstart, L.n_slots);
         return b;
     }
-    combine4(ctx, L, part, LP, a);
+    combine4(ctx, st, L, part, LP, a);
     for (int j = 0; j <= L.d; ++j) {
         WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.rep * L.M_cur * 4); // read + write every row once
         hipLaunchKernelGGL(blur4_kernel, dim3(grid_rep((long long)L.rows * L.rep, (256 / LP) * 4, L.rep)), dim3(256),
-                           0, ctx->stream, (const f32x4_t *)a, L.nbr + (long long)j * L.rows, LP, L.rows, L.rep,
+                           0, st, (const f32x4_t *)a, L.nbr + (long long)j * L.rows, LP, L.rows, L.rep,
                            (f32x4_t *)b);
         float *t = a; a = b; b = t;
     }
@@ -2241,14 +2243,10 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
         if (fork) {
             WSC_HIP(hipEventRecord(ctx->fork_ev, main_stream));
             WSC_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->fork_ev, 0));
-            ctx->stream = ctx->aux_stream; // launches and timers of the bilateral path go to the side stream
         }
-        a.val_b = combine_blur_all4(ctx, Bl, LP, partb, vb0, vb1);
-        if (fork) {
-            WSC_HIP(hipEventRecord(ctx->aux_done_ev, ctx->aux_stream));
-            ctx->stream = main_stream;
-        }
-        a.val_g = combine_blur_all4(ctx, G, LP, partg, vg0, vg1);
+        a.val_b = combine_blur_all4(ctx, fork ? ctx->aux_stream : main_stream, Bl, LP, partb, vb0, vb1);
+        if (fork) WSC_HIP(hipEventRecord(ctx->aux_done_ev, ctx->aux_stream));
+        a.val_g = combine_blur_all4(ctx, main_stream, G, LP, partg, vg0, vg1);
         if (fork) WSC_HIP(hipStreamWaitEvent(main_stream, ctx->aux_done_ev, 0));
     }
     {

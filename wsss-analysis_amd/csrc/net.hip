@@ -306,6 +306,19 @@ int build_plain_stack(wsc_net *net, const Dict &d, const std::string &root,
     return WSC_OK;
 }
 
+// optional per-class bias of a Grad-CAM head (`gradcam_bias`, C values): the Keras drivers contract alpha with the
+// PRE-BatchNorm activation; on the post-BN feature map that is a head with weights alpha / s and this bias
+// (wsscam/net/common.py::pre_bn_head).
+int gradcam_bias(const Dict &d, int C, std::vector<float> &bias) {
+    bias.assign(C, 0.f);
+    if (!has(d, "gradcam_bias")) return WSC_OK;
+    const HostTensor *gb;
+    WSC_TRY(get(d, "gradcam_bias", 1, &gb));
+    WSC_CHECK(gb->shape[0] == C, WSC_ERR_SHAPE, "gradcam_bias must be [%d]", C);
+    for (int c = 0; c < C; ++c) bias[c] = gb->data[c];
+    return WSC_OK;
+}
+
 int build_vgg16(wsc_net *net, const Dict &d) {
     const std::vector<std::pair<std::string, std::vector<int>>> cfg = {
         {"layer1", {64, 64, -1}},
@@ -335,6 +348,7 @@ int build_vgg16(wsc_net *net, const Dict &d) {
         for (int f = 0; f < net->F; ++f)
             for (int c = 0; c < net->C; ++c) wt[(size_t)c * net->F + f] = gw->data[(size_t)f * net->C + c];
         hw.data = wt.data();
+        WSC_TRY(gradcam_bias(d, net->C, zero));
     }
     WSC_TRY(make_conv(net, &hw, 1, 0, 0, 0, one, zero, nullptr, nullptr, &net->head));
     net->Ccls = net->C;
@@ -365,6 +379,7 @@ int build_m7(wsc_net *net, const Dict &d) {
     HostTensor hw;
     hw.data = wt.data(); hw.ndim = 4; hw.shape[0] = net->C; hw.shape[1] = net->F; hw.shape[2] = 1; hw.shape[3] = 1;
     std::vector<float> one(net->C, 1.f), zero(net->C, 0.f);
+    WSC_TRY(gradcam_bias(d, net->C, zero));
     WSC_TRY(make_conv(net, &hw, 1, 0, 0, 0, one, zero, nullptr, nullptr, &net->head));
     // classifier branch: layer3_p2 (MaxPool 2x2 + Dropout) -> AdaptiveMaxPool2d(1) -> Linear + Sigmoid
     // (m7_cam.py:32-35).  max over 2x2-pooled map == global max when h, w are even.

@@ -72,7 +72,10 @@ def gen_cues(dataset, model_type, thresh, batch_size, set_name=None, run_train=T
         if out_dir is None:
             out_dir = os.path.join(st["CUES_ROOT"], sess_id) if run_train else os.path.join("./eval", sess_id)
         if images is None:
-            ds = ks.Dataset(data_type=dataset, size=img_size, batch_size=batch_size, database_dir=st["DATA_ROOT"])
+            # 02_cues/dataset.py:12 ignores settings.ini: <parent of cwd>/database.  An explicitly passed settings file is a
+            # caller with its own tree, whose data_dir is honoured.
+            ds = ks.Dataset(data_type=dataset, size=img_size, batch_size=batch_size,
+                            database_dir=st["DATA_ROOT"] if settings is not None else None)
             gen_curr = ds.set_gens[ds.sets[ds.is_evals.index(not run_train)]]
             images, labels = _LazyImages(gen_curr), gen_curr.data
         if models is None:

@@ -17,15 +17,20 @@ def find_final_layer(model):
 
 def get_grad_cam_weights(input_model, final_layer, dummy_image, should_normalize=True):
     """02_cues/utilities.py:60-99 (twin: 03b_irn/net/common_cnn.py:84-121): alpha[:, c] = mean_{h,w} normalize(d y_c / d A)
-    on `dummy_image`, A = the final conv feature map (h x w x F), y_c the pre-sigmoid logit.
+    on `dummy_image`, y_c the pre-sigmoid logit, A = the output of `final_layer` -- the layer after the last Conv2D, its ReLU
+    Activation, which sits BEFORE the last BatchNorm in the reference's Conv2D -> Activation -> BatchNormalization order
+    (common_cnn.py:138 "# reversed"), so K.gradients passes through the inference-mode BatchNorm:
+    d y_c / d A = W[c, f] * gamma_f / sqrt(var_f + 1e-3) * (d pool / d feature).
 
     Both classifier heads of the reference's networks give a closed form (net.common.grad_cam_alpha):
-      * GAP + Linear (modified VGG16 / X1.7, net/vgg16.py:17-22): d y_c / d A = W[c, f] / (h w) at every position;
-      * MaxPool + global max + Linear (M7, net/m7.py:15-21): the gradient is W[c, f] at the ONE position the pooling
-        selected in channel f and zero elsewhere -- which position wins the ties of the all-zeros image does not
-        matter, because alpha is the spatial MEAN of the normalised gradient.
-    Identical to K.gradients / torch.autograd up to round-off (tests/test_cues_host.py)."""
-    from ..net.common import PLAIN_CFG, grad_cam_alpha
+      * GAP + Linear (modified VGG16 / X1.7, net/vgg16.py:17-22): d pool = 1 / (h w) at every position;
+      * MaxPool + global max + Linear (M7, net/m7.py:15-21): d pool = 1 at the ONE position the pooling selected in
+        channel f and zero elsewhere -- which position wins the ties of the all-zeros image does not matter, because
+        alpha is the spatial MEAN of the normalised gradient.  (A framework that splits the gradient of a tied maximum
+        evenly over the ties, as TF's reduce_max does, keeps the mean but changes the RMS normaliser; the Keras
+        architecture files are not in the tree, so this is the torch port's reading, m7.py:17 AdaptiveMaxPool2d.)
+    Equal to torch.autograd on the restated nets up to round-off (tests/test_cues_host.py)."""
+    from ..net.common import PLAIN_CFG, grad_cam_alpha, last_bn_affine
 
     sd = input_model._sd
     root = input_model.root
@@ -34,7 +39,9 @@ def get_grad_cam_weights(input_model, final_layer, dummy_image, should_normalize
     h = S
     for _, layer in PLAIN_CFG[root]:
         h //= 2 ** sum(1 for v in layer if v == "M")
-    return grad_cam_alpha(W, h, h, "max" if root == "m7" else "avg", should_normalize)
+    affine = last_bn_affine(sd, root)
+    return grad_cam_alpha(W, h, h, "max" if root == "m7" else "avg", should_normalize,
+                          bn_scale=None if affine is None else affine[0])
 
 
 def _to_nchw(images):
@@ -44,7 +51,8 @@ def _to_nchw(images):
 
 
 def conv_and_cams(input_model, weights, images, relu, want_scores=False):
-    """One device pass: (cams (B,h,w,C) float32 = [relu] einsum(conv_val, weights), scores (B,C) or None)."""
+    """One device pass: (cams (B,h,w,C) float32 = [relu] einsum(conv_val, weights), scores (B,C) or None); conv_val is the
+    final Activation's output (pre-BatchNorm, `gradcam_net(pre_bn=True)`), as K.function([input], [conv_output]) gives it."""
     net, ctx = input_model.gradcam_net(weights)
     x = _to_nchw(images)
     B, S = x.shape[0], x.shape[2]

@@ -24,8 +24,15 @@ def dcrf_config_for(dataset, model_type):
 
 
 def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True, is_verbose=True, *, models=None, alphas=None,
-            images=None, n_seg_classes=None, settings=None):
-    """Device resident between the batch upload and the label maps, like segment_adp: both models' Grad-CAM stacks are
+            images=None, n_seg_classes=None, settings=None, reference_normalize_quirk=False):
+    """`reference_normalize_quirk`: the reference's VOC2012 normalisation (03c_hsn/utilities.py:142-146) runs
+    `x[:, :, 0] -= 104; x[:, :, 1] -= 117; x[:, :, 2] -= 123` on the 4-D uint8 BATCH -- that indexes image COLUMNS 0..2 of
+    every row and channel, wraps around in uint8, and works in place, so the array later handed to the CRF is modified
+    too; the result is divided by 255.  The default here is the intended per-channel (x - [104, 117, 123]) / 255 on an
+    untouched image (what the 02_cues twin does, 02_cues/demo.py:163-164); True reproduces the reference's actual
+    arithmetic for parity runs against it (deviations).
+
+    Device resident between the batch upload and the label maps, like segment_adp: both models' Grad-CAM stacks are
     written straight into one [B][1 + C][S*S] stack (wsc_hsn_gradcam_post with a channel offset), the VOC background
     channel comes from wsc_hsn_voc_background (max over the whole batch, Q6), class mass flags from wsc_hsn_class_mass,
     unaries from wsc_hsn_gather_unary; the host sees scores, flags and labels."""
@@ -44,7 +51,7 @@ def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True,
         sess_id = dataset + "_" + model_type
         model_dir = os.path.join(st["MODEL_ROOT"], sess_id)
         if images is None:
-            ds = ks.Dataset(data_type=dataset, size=img_size, batch_size=batch_size, database_dir=st["DATA_ROOT"])
+            ds = ks.Dataset(data_type=dataset, size=img_size, batch_size=batch_size, database_dir=st["DATA_ROOT"], layout="hsn")
             images = _LazyImages(ds.set_gens[ds.sets[ds.is_evals.index(True)]])
         if models is None:
             models, alphas = {}, {}
@@ -67,6 +74,12 @@ def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True,
         else:  # the resize of read_batch stays on the host (float64, kept un-rounded like the reference's batch)
             norm, raw = read_batch(chunk, (img_size, img_size), mean, std)
             raw_u8 = raw.astype(np.uint8)
+        if voc and reference_normalize_quirk:
+            raw_u8 = np.ascontiguousarray(raw_u8)
+            raw_u8[:, :, 0] -= 104  # (B, H, 3): image column 0 of every row and channel, uint8 wrap-around, in place
+            raw_u8[:, :, 1] -= 117
+            raw_u8[:, :, 2] -= 123
+            norm, mean = None, [0, 0, 0]
         C = np.asarray(alphas["fg"]).shape[1]
         if voc:
             Cv = n_seg_classes or C + 1

@@ -46,23 +46,44 @@ class SetList:
 
 
 class Dataset:
-    """02_cues/dataset.py:5-124 without the Keras generators: per split the image directory, the file names ('Patch Names'
-    column) and the label matrix (the class-name columns) of <devkit>/ImageSets/Segmentation/<split>.csv, in file order
-    (the evaluation generators are not shuffled; the drivers only read `.filenames` / `.data` of the training one)."""
+    """02_cues/dataset.py:5-124 / 03c_hsn/dataset.py:5-124 without the Keras generators: per split the image directory, the
+    file names ('Patch Names' column) and the label matrix (the class-name columns) of
+    <devkit>/ImageSets/Segmentation/<split>.csv, in file order (the evaluation generators are not shuffled; the drivers only
+    read `.filenames` / `.data` of the training one).
 
-    def __init__(self, data_type="ADP", size=321, batch_size=16, database_dir=None):
-        self.data_type, self.size, self.batch_size = data_type, size, batch_size
+    The two reference classes differ, selected by `layout`:
+      * "cues" (02_cues/dataset.py): `database_dir` is ALWAYS <parent of the working directory>/database (:12 -- the class
+        takes no directory argument; an explicit `database_dir` here is an override for callers with another tree);
+        VOC2012 = VOCdevkit/VOC2012 with ['trainaug', 'val']; DeepGlobe names 'DeepGlobe_train75' / 'DeepGlobe_train37.5'
+        (the drivers' 'DeepGlobe' / 'DeepGlobe_balanced' are accepted as aliases of the two);
+      * "hsn" (03c_hsn/dataset.py): `database_dir` is the DATA_ROOT argument (:8, demo.py:88); VOC2012 =
+        VOCdevkit/VOC_trainaug_val/VOC2012 with the 'val' split only (:57-59); DeepGlobe names 'DeepGlobe' (train75) /
+        'DeepGlobe_balanced' (train37.5) (:84-89)."""
+
+    def __init__(self, data_type="ADP", size=321, batch_size=16, database_dir=None, layout="cues"):
+        if layout not in ("cues", "hsn"):
+            raise ValueError("layout must be 'cues' or 'hsn'")
+        if layout == "hsn" and database_dir is None:
+            raise ValueError("the 03c_hsn Dataset takes its database_dir argument (DATA_ROOT), there is no default")
+        self.data_type, self.size, self.batch_size, self.layout = data_type, size, batch_size, layout
         self.database_dir = database_dir or os.path.join(os.path.dirname(os.getcwd()), "database")
         if data_type == "ADP":
             self.devkit_dir = os.path.join(self.database_dir, "ADPdevkit", "ADPRelease1")
             self.sets, self.is_evals, self.class_names = ["valid", "test"], [True, True], list(ADP_CLASSES)
         elif data_type == "VOC2012":
-            self.devkit_dir = os.path.join(self.database_dir, "VOCdevkit", "VOC2012")
-            self.sets, self.is_evals, self.class_names = ["trainaug", "val"], [False, True], list(VOC_CLASSES)
+            if layout == "hsn":
+                self.devkit_dir = os.path.join(self.database_dir, "VOCdevkit", "VOC_trainaug_val", "VOC2012")
+                self.sets, self.is_evals = ["val"], [True]
+            else:
+                self.devkit_dir = os.path.join(self.database_dir, "VOCdevkit", "VOC2012")
+                self.sets, self.is_evals = ["trainaug", "val"], [False, True]
+            self.class_names = list(VOC_CLASSES)
         elif "DeepGlobe" in data_type:
             self.devkit_dir = os.path.join(self.database_dir, "DGdevkit")
-            train = {"DeepGlobe_train75": "train75", "DeepGlobe_train37.5": "train37.5", "DeepGlobe": "train75",
-                     "DeepGlobe_balanced": "train37.5"}.get(data_type)
+            names = {"DeepGlobe": "train75", "DeepGlobe_balanced": "train37.5"}
+            if layout == "cues":
+                names.update({"DeepGlobe_train75": "train75", "DeepGlobe_train37.5": "train37.5"})
+            train = names.get(data_type)
             if train is None:
                 raise ValueError("unknown DeepGlobe data_type %r" % data_type)
             self.sets, self.is_evals, self.class_names = [train, "test"], [False, True], list(DEEPGLOBE_CLASSES)

@@ -74,17 +74,24 @@ class DeviceCAMBase:
     def cam_size(self, S):
         return self._ensure_net().cam_size(S)
 
-    def gradcam_net(self, weights, ctx=None):
+    def gradcam_net(self, weights, ctx=None, pre_bn=True):
         """(wsc_net with `weights` (F x C Grad-CAM alpha) as its 1x1 head, ctx); cached per alpha.  `ctx`: run on
-        this context instead of the model's own (two models of one driver share a stream and its buffers)."""
+        this context instead of the model's own (two models of one driver share a stream and its buffers).
+        pre_bn=True (the Keras drivers, 02_cues/utilities.py:129-133 and 03c_hsn/utilities.py:259-262): alpha is
+        contracted with the final Activation's output, i.e. the tensor BEFORE the last BatchNorm -- realised as an
+        equivalent head on the post-BN feature map (`pre_bn_head`).  pre_bn=False contracts with the post-BN map as
+        the torch port's m7_cam.py:45-46 does."""
         w = np.ascontiguousarray(weights, dtype=np.float32)
-        key = (w.shape, hash(w.tobytes()))
+        key = (w.shape, hash(w.tobytes()), bool(pre_bn))
         cache = self.__dict__.setdefault("_gradcam_nets", {})
         if key not in cache:
             if self._ctx is None:
                 self._ctx = _lib.Context(self._device)
             sd = dict(self._sd)
-            sd["gradcam_weights"] = w
+            affine = last_bn_affine(sd, self.root) if pre_bn and getattr(self, "root", None) in PLAIN_CFG else None
+            hw, hb = pre_bn_head(w, affine)
+            sd["gradcam_weights"] = np.ascontiguousarray(hw, dtype=np.float32)
+            sd["gradcam_bias"] = np.ascontiguousarray(hb, dtype=np.float32)
             cache[key] = _lib.Net(self._ctx, self.arch, sd, w.shape[1], self.precision)
         return cache[key], (ctx or self._ctx)
 
@@ -225,11 +232,41 @@ def load_pretrained(model_dir, tag, root="vgg16", batchnorm=True):
     return state_dict_from_keras_weights(weights, tag, root, batchnorm, mat)
 
 
-def grad_cam_alpha(W, h, w, pool, should_normalize=True):
-    """Grad-CAM weights alpha (F, C) of a `pool` + Linear classifier head on an h x w x F feature map
-    (02_cues/utilities.py:60-99): g = d y_c / d A, g <- g / (sqrt(mean(g^2)) + 1e-5), alpha[:, c] = mean_{h,w} g.
-    pool = "avg": g = W[c, f] / (h w) everywhere; "max": g = W[c, f] at one position per channel, else 0."""
+def last_bn_affine(sd, root):
+    """(scale, shift) of the BatchNorm that follows the LAST conv of a make_layers stack as the per-channel map
+    post = scale * pre + shift (inference mode, eps = 1e-3: common_cnn.py:138), or None when the stack has no
+    BatchNorm there (the ADP VGG16 models, vgg16_cam.py:16-17).  `pre` is the tensor the Keras drivers call the final
+    layer's output: find_final_layer returns the layer AFTER the last Conv2D, its ReLU Activation ("activation_7",
+    02_cues/utilities.py:42-58) -- and the reference's layer order is Conv2D -> Activation -> BatchNormalization
+    (make_layers' "# reversed", the get_weights() pop order of load_weights_from_file)."""
+    key = None
+    for lname, layer in PLAIN_CFG[root]:
+        idx = 0
+        for v in layer:
+            if v in ("M", "D"):
+                idx += 1
+                continue
+            bn = "%s.%s.%d" % (root, lname, idx + 2)
+            key = bn if bn + ".running_mean" in sd else None
+            idx += 3 if key else 2
+    if key is None:
+        return None
+    eps = float(np.asarray(sd[key + ".eps"]).reshape(-1)[0]) if key + ".eps" in sd else 1e-3
+    scale = np.asarray(sd[key + ".weight"], np.float64) / np.sqrt(np.asarray(sd[key + ".running_var"], np.float64) + eps)
+    shift = np.asarray(sd[key + ".bias"], np.float64) - np.asarray(sd[key + ".running_mean"], np.float64) * scale
+    return scale, shift
+
+
+def grad_cam_alpha(W, h, w, pool, should_normalize=True, bn_scale=None):
+    """Grad-CAM weights alpha (F, C) of a [BatchNorm ->] `pool` -> Linear classifier head on an h x w x F activation A
+    (02_cues/utilities.py:60-99, common_cnn.py:84-121): g = d y_c / d A, g <- g / (sqrt(mean(g^2)) + 1e-5),
+    alpha[:, c] = mean_{h,w} g.  A is the final conv's ReLU output; when the stack carries a BatchNorm between A and the
+    pooling (`bn_scale` = gamma / sqrt(running_var + eps), see last_bn_affine) the gradient passes through it:
+    g = W[c, f] * bn_scale[f] * (d pool / d feature).  pool = "avg": 1 / (h w) everywhere; "max": 1 at the one position
+    the pooling selected in channel f, else 0 (which position wins does not matter to the mean or to the RMS)."""
     W = np.asarray(W, dtype=np.float64)  # (C, F)
+    if bn_scale is not None:
+        W = W * np.asarray(bn_scale, dtype=np.float64)[None, :]
     F = W.shape[1]
     hw = float(h * w)
     if pool == "avg":
@@ -242,3 +279,18 @@ def grad_cam_alpha(W, h, w, pool, should_normalize=True):
         raise ValueError("pool must be 'avg' or 'max'")
     g = mean_g / (rms + 1e-5) if should_normalize else mean_g
     return np.ascontiguousarray(g.T)
+
+
+def pre_bn_head(alpha, affine):
+    """Head (weights (F, C), bias (C,)) that contracts alpha with the PRE-BatchNorm activation while the device stack
+    hands the head its post-BatchNorm feature map: post = s * pre + t  =>  sum_f pre_f alpha_fc =
+    sum_f post_f (alpha_fc / s_f) - sum_f t_f alpha_fc / s_f.  Exact in real arithmetic; a zero BatchNorm scale makes
+    the pre-BN activation unrecoverable and is an error."""
+    alpha = np.asarray(alpha, dtype=np.float64)
+    if affine is None:
+        return alpha, np.zeros(alpha.shape[1])
+    s, t = affine
+    if np.any(s == 0):
+        raise ValueError("BatchNorm scale of the final layer has zeros: the pre-BN activation cannot be recovered")
+    w = alpha / s[:, None]
+    return w, -(t[:, None] * w).sum(axis=0)

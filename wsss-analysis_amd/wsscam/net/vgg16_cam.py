@@ -23,9 +23,12 @@ class CAM(DeviceCAMBase):
         self.tag = tag
         self.use_cls = use_cls
         self.thresholds = 0.5 * np.ones(num_classes, dtype=np.float32)  # common_cnn.py:22
-        self.batchnorm = dataset not in ("adp_morph", "adp_func")       # vgg16_cam.py:16-19 / m7_cam.py:15-18
+        self.batchnorm = self._has_batchnorm()
         if model_dir is not None and tag:
             self._load_pretrained(model_dir, tag)
+
+    def _has_batchnorm(self):
+        return self.dataset not in ("adp_morph", "adp_func")  # vgg16_cam.py:16-19: the ADP VGG16 models carry no BatchNorm
 
     def _load_pretrained(self, model_dir, tag):
         """CommonCNN._load_pretrained (common_cnn.py:25-41): Keras <tag>.h5 + <tag>.mat under <model_dir>/<tag>/.
