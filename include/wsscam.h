@@ -384,6 +384,11 @@ void wsc_crf_destroy(wsc_crf *crf);
 /* number of occupied lattice vertices per image: v_gauss/v_bilat int32[B] host arrays (may be NULL) */
 int wsc_crf_lattice_sizes(wsc_ctx *ctx, const wsc_crf *crf, int32_t *v_gauss_host,
                           int32_t *v_bilat_host);
+/* 1 when wsc_crf_inference with M classes sums, blurs and slices the Gaussian (addPairwiseGaussian) lattice inside its
+ * update kernel -- per pixel tile, in LDS, no value rows in HBM -- and 0 when the separate blur kernel runs (vertex sets of
+ * a pixel tile too large for the kernel's LDS at this M: very narrow g_sxy; or WSC_CRF_NO_GFUSE=1).  Same Q bits either
+ * way; a diagnostic for tests and benchmarks (03c_hsn/utilities.py:435 is the call this concerns). */
+int wsc_crf_gaussian_on_chip(const wsc_crf *crf, int M);
 
 /* d.setUnaryEnergy(U); Q = d.inference(n_iters) with Potts compatibilities
  * g_compat / bi_compat (03c_hsn/utilities.py:431-442):

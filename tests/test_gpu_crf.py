@@ -26,6 +26,7 @@ def _gpu_crf(ctx, rgbs, Us, cfg):
     a_dev = ctx.alloc(B * H * W * 4)
     crf = _lib.Crf(ctx, rgb_dev, B, H, W, cfg[0], cfg[2], cfg[3])
     vg, vb = crf.lattice_sizes()
+    _gpu_crf.on_chip = crf.gaussian_on_chip(M)
     crf.inference(u_dev, M, cfg[1], cfg[4], int(cfg[5]), q_dev, a_dev)
     q = ctx.to_host(q_dev, (B, M, H * W), np.float32)
     a = ctx.to_host(a_dev, (B, H * W), np.int32)
@@ -226,11 +227,41 @@ def test_crf_fused_gaussian_blur_is_bit_identical(ctx, case, monkeypatch):
         rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
         rgbs.append(rgb)
         Us.append(U)
+    monkeypatch.setenv("WSC_CRF_NO_GFUSE", "1")  # the blur kernels under test only run when the update kernel leaves the blur to them
     monkeypatch.setenv("WSC_CRF_NO_FUSED_BLUR", "1")
     q_ref, a_ref, vg, _ = _gpu_crf(ctx, rgbs, Us, cfg)
     monkeypatch.setenv("WSC_CRF_NO_FUSED_BLUR", "0")
     q, a, vg2, _ = _gpu_crf(ctx, rgbs, Us, cfg)
     assert list(vg) == list(vg2)
+    assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)
+
+
+@pytest.mark.parametrize("case", [(47, 61, 5, 2, (1.5, 3, 40, 13, 10, 5)), (96, 130, 21, 3, (3, 3, 50, 5, 10, 4)),
+                                  (9, 7, 2, 1, (3 / 12, 3, 80 / 12, 13, 10, 3)), (33, 200, 29, 1, (5, 3, 40, 13, 10, 2)),
+                                  (321, 321, 21, 2, (1.5, 3, 40, 13, 10, 3)), (41, 41, 21, 4, (3 / 12, 3, 80 / 12, 13, 10, 5)),
+                                  (64, 80, 1, 2, (1.5, 3, 40, 13, 10, 2)), (100, 75, 12, 1, (0.7, 3, 30, 10, 10, 3))])
+def test_crf_gaussian_blur_inside_update_is_bit_identical(ctx, case, monkeypatch):
+    """update_splat_kernel<.., GF>: the Gaussian lattice summed from its slot partials, blurred and sliced inside the update
+    kernel (per-tile closed vertex sets, LDS) against the separate blur kernel + value-row gathers (WSC_CRF_NO_GFUSE=1, read
+    per call): identical Q bits and labels -- one image and several, ragged edge tiles, wide / narrow kernels (the narrow ones
+    have vertex sets too large for the LDS at M = 21 and silently take the unfused path), LP = 1 ... 8, and the labels-only
+    call whose last update writes the arg-max."""
+    H, W, M, B, cfg = case
+    rng = np.random.default_rng(H * 11 + W)
+    rgbs, Us = [], []
+    for _ in range(B):
+        rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
+        rgbs.append(rgb)
+        Us.append(U)
+    monkeypatch.setenv("WSC_CRF_NO_GFUSE", "1")
+    q_ref, a_ref, vg, vb = _gpu_crf(ctx, rgbs, Us, cfg)
+    assert not _gpu_crf.on_chip
+    monkeypatch.setenv("WSC_CRF_NO_GFUSE", "0")
+    q, a, vg2, vb2 = _gpu_crf(ctx, rgbs, Us, cfg)
+    if cfg[0] >= 1.0:  # (narrow kernels: on chip only while a tile's vertex set fits the LDS -- the 9 x 7 image does)
+        assert _gpu_crf.on_chip, cfg
+    print("gaussian on chip:", case, _gpu_crf.on_chip)
+    assert list(vg) == list(vg2) and list(vb) == list(vb2)
     assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)
 
 

@@ -66,6 +66,13 @@ struct LatticeDev {
     int2 *tile_pstart = nullptr;  // [n_tiles][GBI * GBJ] {first partial row, count} of that row
     int32_t *tile_list = nullptr; // [n_tiles_occ] tiles with at least one interior vertex
     int n_tiles_occ = 0;
+    // Gaussian lattice only: per PIXEL tile, the closed vertex set the update kernel blurs on chip (gauss_fuse_tables):
+    // the tile's own vertices first, then the neighbours the three blur passes reach (axis 2, then 1, then 0)
+    int4 *gt_cnt = nullptr;      // [tpi] sizes of the nested sets: T, T + nbr_2, T + nbr_2 + nbr_1, all (passes 2 / 1 / 0 / load)
+    int2 *gt_rows = nullptr;     // [tpi][gt_stride] {first partial row, partial rows} of local vertex v (padding: {0, 0})
+    uint4 *gt_nbr = nullptr;     // [tpi][gt_stride] local ids of the blur neighbours: x / y / z = axis 0 / 1 / 2 as n1 | n2 << 16
+    uint4 *gt_pix = nullptr;     // [N] per pixel {local ids of its 3 vertices (10 bits each), bary[r] * norm (3 floats)}
+    int gt_stride = 0;           // max vertices of a tile's set + 1; local id gt_stride - 1 is every set's zero row
     std::vector<int32_t> v_per_image;
 };
 
@@ -123,6 +130,9 @@ struct wsc_crf {
     LatticeDev lat[2]; // 0: Gaussian (d=2), 1: bilateral (d=5)
     // per pixel, 20 dwords = five 16-byte loads: offG[3] offB[6] baryG[3] baryB[6] normG normB
     uint4 *pix_rec = nullptr;
+    // per pixel, 13 dwords (52 bytes): the bilateral part alone -- offB[6] baryB[6] normB -- for the updates that start from
+    // the Gaussian message kernel's E (GF variants); built when the Gaussian lattice has its tile vertex sets
+    uint32_t *pix_rec_b = nullptr;
     std::vector<void *> allocs;
     std::vector<void *> persist_allocs; // blocks of a cached Gaussian lattice under construction (freed if the build fails)
     bool persist = false; // allocations made while set belong to the ctx (cached Gaussian lattice)
@@ -1346,6 +1356,16 @@ __global__ void pack_pixels_kernel(const int32_t *__restrict__ off_g, const floa
     }
 }
 
+// the bilateral part of the record alone: 13 dwords per pixel (one thread per dword: coalesced)
+__global__ void pack_pixels_b_kernel(const int32_t *__restrict__ off_b, const float *__restrict__ bary_b,
+                                     const float *__restrict__ norm_b, long long npix, uint32_t *__restrict__ rec) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix * 13; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / 13;
+        const int k = (int)(i - p * 13);
+        rec[i] = k < 6 ? (uint32_t)off_b[p * 6 + k] : (k < 12 ? __float_as_uint(bary_b[p * 6 + (k - 6)]) : __float_as_uint(norm_b[p]));
+    }
+}
+
 struct SplatTab { // splat tables of one lattice as the update kernel sees them
     const int32_t *tslot_start;
     const int2 *slot_desc;
@@ -1358,6 +1378,7 @@ struct SplatTab { // splat tables of one lattice as the update kernel sees them
 
 struct UpdateArgs {
     const uint4 *pix_rec; // [pixel][5]
+    const uint32_t *pix_rec_b; // [pixel][13] bilateral part alone (GF variants)
     const float *val_g, *val_b;
     const float *u; // [pixel][Mp]
     float *q;       // [pixel][Mp] or null (only the last iteration's Q leaves the chip)
@@ -1457,7 +1478,13 @@ __device__ __forceinline__ void tile_gather(const SplatTab &T, int tile, long lo
 // LP lanes per pixel (4 classes each, 16-byte gathers), floor(64/LP) pixels per wave; the max / sum over a
 // pixel's classes are reduced inside the lane, then across the pixel's LP lanes by shuffle-down with a segment
 // bound and a broadcast from the segment's first lane.  Between iterations Q exists only as the tile's LDS copy.
-template <bool SLICE, bool SPLAT>
+// GF (with SLICE): the Gaussian lattice's message is not gathered here.  gauss_msg_kernel (below) has already summed the
+// Gaussian slot partials of every pixel tile's closed vertex set, blurred them in LDS and left E = -U + (Gaussian message)
+// in a pixel-major buffer of U's layout -- with the very FMAs, in the very order, this kernel would have used -- so a.u
+// points at E, the energy starts from +E instead of -U, and only the six bilateral rows are gathered.  Bit-identical to
+// the unfused path; the Gaussian lattice's value rows never exist, and the message kernel runs beside the bilateral
+// lattice's combine + blur chain between two updates.
+template <bool SLICE, bool SPLAT, bool GF = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void update_splat_kernel(UpdateArgs a) {
     extern __shared__ f32x4_t stage[]; // [TILE_PIX][LP]
     const int LP = a.LP;
@@ -1483,7 +1510,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
     const unsigned cw_magic = tile_div_magic(tb.cw);
     const size_t pix0 = (size_t)k * (size_t)N + (size_t)tb.y0 * (size_t)a.tg.W + (size_t)tb.x0;
     const unsigned LP16 = (unsigned)LP * 16u, l16 = (unsigned)l * 16u;
-    const char *rec_b = reinterpret_cast<const char *>(a.pix_rec) + pix0 * 80;
+    constexpr unsigned REC_BYTES = GF ? 52u : 80u; // GF: the 13-dword bilateral record (ids 0..5, bary 6..11, norm 12)
+    constexpr int REC_ID = GF ? 0 : 3, REC_BARY = GF ? 6 : 12, REC_NORM = GF ? 12 : 19;
+    const char *rec_b = (GF ? reinterpret_cast<const char *>(a.pix_rec_b) : reinterpret_cast<const char *>(a.pix_rec)) + pix0 * REC_BYTES;
     const char *u_b = reinterpret_cast<const char *>(a.u) + pix0 * LP16;
     char *q_b = reinterpret_cast<char *>(a.q) + pix0 * LP16;
     const char *vg_b = reinterpret_cast<const char *>(a.val_g) + (a.g_rows ? (size_t)k * a.g_rows * LP16 : (size_t)0);
@@ -1506,8 +1535,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
     f32x2_t e01, e23;     // energy of the current trip
     const float cag = a.compat_g * a.alpha_g, cab = a.compat_b * a.alpha_b;
     auto load_rec = [&](unsigned p, uint4(&r)[5]) {
+        if (GF) { // 3 x 16 bytes + 4 (dword-aligned 16-byte loads)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) r[i] = ld_off<uint4>(rec_b, __umul24(p, 80u) + 16u * i);
+            for (int i = 0; i < 3; ++i) r[i] = ld_off<uint4>(rec_b, __umul24(p, REC_BYTES) + 16u * i);
+            r[3] = make_uint4(ld_off<uint32_t>(rec_b, __umul24(p, REC_BYTES) + 48u), 0u, 0u, 0u);
+            r[4] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) r[i] = ld_off<uint4>(rec_b, __umul24(p, REC_BYTES) + 16u * i);
+        }
     };
     // the pixel's record: 5 x 16 bytes, identical for the LP lanes of the pixel (broadcast loads)
     auto issue_rows = [&](const uint4(&r)[5], f32x4_t(&g3)[3], f32x4_t(&b6)[6], float(&w9)[9]) {
@@ -1516,28 +1552,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
         for (int i = 0; i < 5; ++i) {
             rc[4 * i] = r[i].x; rc[4 * i + 1] = r[i].y; rc[4 * i + 2] = r[i].z; rc[4 * i + 3] = r[i].w;
         }
+        if (!GF) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) g3[i] = ld_off<f32x4_t>(vg_b, __umul24(rc[i], LP16) + l16);
+            for (int i = 0; i < 3; ++i) g3[i] = ld_off<f32x4_t>(vg_b, __umul24(rc[i], LP16) + l16);
+        }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) b6[i] = ld_off<f32x4_t>(vb_b, __umul24(rc[3 + i], LP16) + l16);
-        const float wg = cag * __uint_as_float(rc[18]);
-        const float wb = cab * __uint_as_float(rc[19]);
+        for (int i = 0; i < 6; ++i) b6[i] = ld_off<f32x4_t>(vb_b, __umul24(rc[REC_ID + i], LP16) + l16);
+        const float wb = cab * __uint_as_float(rc[REC_NORM]);
+        if (!GF) { // (bary * norm) * (compat * alpha): the product the GF path reads precomputed from gt_pix
 #pragma unroll
-        for (int i = 0; i < 3; ++i) w9[i] = __uint_as_float(rc[9 + i]) * wg;
+            for (int i = 0; i < 3; ++i) w9[i] = (__uint_as_float(rc[9 + i]) * __uint_as_float(rc[18])) * cag;
+        }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) w9[3 + i] = __uint_as_float(rc[12 + i]) * wb;
+        for (int i = 0; i < 6; ++i) w9[3 + i] = __uint_as_float(rc[REC_BARY + i]) * wb;
     };
     // E = -U + sum_r (compat * alpha * norm * bary_r) * row_r : nine packed FMAs per class pair (the weights are formed
     // once per pixel, the row sums run as v_pk_fma_f32)
     auto fold = [&](const f32x4_t &u, const f32x4_t(&g3)[3], const f32x4_t(&b6)[6], const float(&w9)[9], f32x2_t &o01, f32x2_t &o23) {
-        o01 = f32x2_t{-u[0], -u[1]};
-        o23 = f32x2_t{-u[2], -u[3]};
+        if (SLICE && GF) { // `u` is E = -U + Gaussian message
+            o01 = f32x2_t{u[0], u[1]};
+            o23 = f32x2_t{u[2], u[3]};
+        } else {
+            o01 = f32x2_t{-u[0], -u[1]};
+            o23 = f32x2_t{-u[2], -u[3]};
+        }
         if (SLICE) {
+            if (!GF) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const f32x2_t w2 = {w9[r], w9[r]}, lo = {g3[r][0], g3[r][1]}, hi = {g3[r][2], g3[r][3]};
-                o01 = __builtin_elementwise_fma(w2, lo, o01);
-                o23 = __builtin_elementwise_fma(w2, hi, o23);
+                for (int r = 0; r < 3; ++r) {
+                    const f32x2_t w2 = {w9[r], w9[r]}, lo = {g3[r][0], g3[r][1]}, hi = {g3[r][2], g3[r][3]};
+                    o01 = __builtin_elementwise_fma(w2, lo, o01);
+                    o23 = __builtin_elementwise_fma(w2, hi, o23);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
@@ -1642,6 +1688,179 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
                     LP, l, g, gpw, act);
         tile_gather(a.sb, a.sb.shared ? j : lb, (a.sb.shared ? 0ll : (long long)k * N) + tb.ebase, np, k, stage, lent, ldesc,
                     LP, l, g, gpw, act);
+    }
+}
+
+// ---- Gaussian message of a pixel tile, on chip ------------------------------------------------------------------------
+// E[pixel] = -U[pixel] + (compat * alpha * norm) * slice(blur(splat values)) for the pixels of one tile, from the Gaussian
+// lattice's slot partials: the block sums the partial rows of the tile's closed vertex set (gauss_fuse_tables) into LDS,
+// runs the three blur passes there in place (taps -> registers, barrier, write back: the arithmetic of blur4_kernel /
+// blur3_tile_kernel, value for value) and folds the three vertex rows of every pixel into -U with the FMAs, in the order,
+// update_splat_kernel uses -- which then starts from E (its GF variants) and gathers the bilateral rows only.  One read of
+// the partial rows, no value rows in HBM, and the launch runs beside the bilateral lattice's combine + blur chain.
+#ifndef WSC_GF_ABL
+#define WSC_GF_ABL 0 // timing-only ablations (wrong results): 1 no blur passes, 2 no partial-row loads, 4 no slice
+#endif
+struct GaussMsgArgs {
+    const int4 *gt_cnt;
+    const int2 *gt_rows;
+    const uint4 *gt_nbr;
+    const uint4 *gt_pix;
+    const float *part; // [rep][n_slots][Mp] slot partials of the last splat
+    const float *u;    // [pixel][Mp]
+    float *e;          // [pixel][Mp] out
+    int gt_stride, n_slots, shared, LP, B;
+    float cag;         // compat * alpha
+    TileGeom tg;
+};
+constexpr int GM_THREADS = 512;
+// NIT: (vertex, float4) items per thread in a blur pass; NPI: (pixel, float4) items per thread in the slice
+template <int NIT, int NPI>
+__global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void gauss_msg_kernel(GaussMsgArgs a) {
+    extern __shared__ f32x4_t gl[]; // [stride][LP] splat values, blurred in place; then [stride][4] neighbour words
+    const int LP = a.LP, stride = a.gt_stride, tid = (int)threadIdx.x;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nb >> 3, rr = nb & 7;
+    const int lb = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int k = lb / a.tg.tpi, j = lb - k * a.tg.tpi; // image, tile of the image
+    const TileBox tb = tile_box(a.tg, j);
+    const int np = tb.cw * tb.ch;
+    const int N = a.tg.H * a.tg.W;
+    unsigned *lnb = reinterpret_cast<unsigned *>(gl + (size_t)stride * (size_t)LP);
+    const f32x4_t *partg = reinterpret_cast<const f32x4_t *>(a.part) + (a.shared ? (size_t)k * a.n_slots * LP : (size_t)0);
+    // items = (vertex, float4) over the PADDED set: padding vertices have no partial rows (value 0) and the last one is the
+    // zero row absent neighbours point at, so nothing waits for a per-tile count
+    const int nitems = stride * LP;
+    const unsigned lp_magic = (65536u + (unsigned)LP - 1u) / (unsigned)LP; // i / LP for i < 8192, LP <= 8
+    const unsigned cw_magic = tile_div_magic(tb.cw);
+    const int2 *trow = a.gt_rows + (size_t)j * stride;
+    const uint4 *tn = a.gt_nbr + (size_t)j * stride;
+    const unsigned gpix0 = (unsigned)tb.y0 * (unsigned)a.tg.W + (unsigned)tb.x0;
+    const size_t pix0 = (size_t)k * (size_t)N + gpix0;
+    const f32x4_t *u4 = reinterpret_cast<const f32x4_t *>(a.u) + pix0 * LP;
+    f32x4_t *e4 = reinterpret_cast<f32x4_t *>(a.e) + pix0 * LP;
+    // every load that depends on nothing first: the set sizes, row descriptors, the pixels' records and unaries, the
+    // neighbour words
+    const int4 cnt = a.gt_cnt[j];
+    int2 ps[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * GM_THREADS;
+        ps[it] = make_int2(0, 0);
+        if (i < nitems) ps[it] = trow[((unsigned)i * lp_magic) >> 16];
+    }
+    // the pixels' records and unaries: requested up front when the registers allow it (the small variant), else after the blur
+    constexpr bool EARLY = false; // (up front they cost 30 registers: two blocks per CU instead of four, 186 -> 241 us)
+    uint4 gpx[NPI];
+    f32x4_t uu[NPI];
+    unsigned poff[NPI];
+    auto load_pixels = [&]() {
+    #pragma unroll
+        for (int it = 0; it < NPI; ++it) {
+            const int i = tid + it * GM_THREADS;
+            gpx[it] = make_uint4(0, 0, 0, 0);
+            uu[it] = zero;
+            poff[it] = 0;
+            if (i < np * LP) {
+                const unsigned t = ((unsigned)i * lp_magic) >> 16, ll = (unsigned)i - t * (unsigned)LP;
+                const unsigned ty = (t * cw_magic) >> 16, tx = t - ty * (unsigned)tb.cw;
+                const unsigned po = ty * (unsigned)a.tg.W + tx;
+                poff[it] = po * (unsigned)LP + ll;
+                gpx[it] = a.gt_pix[gpix0 + po];
+                uu[it] = u4[poff[it]];
+            }
+        }
+    };
+    if (EARLY) load_pixels();
+#pragma unroll 2
+    for (int v = tid; v < stride; v += GM_THREADS) reinterpret_cast<uint4 *>(lnb)[v] = tn[v];
+    {
+        // all first partials (independent loads: one round trip for the whole set), then the rows with several partials
+        // (tile-border vertices, ~20 %), summed in index order as combine_slots4 does everywhere
+        f32x4_t val[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * GM_THREADS;
+            const unsigned v = ((unsigned)i * lp_magic) >> 16, ll = (unsigned)i - v * (unsigned)LP;
+            val[it] = zero;
+            if (!(WSC_GF_ABL & 2) && ps[it].y > 0) val[it] = partg[(unsigned)ps[it].x * (unsigned)LP + ll];
+        }
+        // further partials of the rows that have them, all items of the thread per step (static register indices;
+        // every row still adds its partials in index order: first + second + ...)
+        int maxc = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) maxc = max(maxc, ps[it].y);
+        if (WSC_GF_ABL & 2) maxc = 0;
+        for (int c = 1; c < maxc; ++c) {
+            f32x4_t more[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * GM_THREADS;
+                const unsigned v = ((unsigned)i * lp_magic) >> 16, ll = (unsigned)i - v * (unsigned)LP;
+                more[it] = zero;
+                if (c < ps[it].y) more[it] = partg[(unsigned)(ps[it].x + c) * (unsigned)LP + ll];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (c < ps[it].y) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) val[it][q] += more[it][q];
+                }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * GM_THREADS;
+            if (i < nitems) gl[i] = val[it];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int axis = 0; axis < ((WSC_GF_ABL & 1) ? 0 : 3); ++axis) {
+        // pass `axis` only has to be right on the vertices the later passes and the slice read: the nested prefixes of the
+        // set (gauss_fuse_tables); the rest keeps its old value, which nothing reads any more
+        const int nitems = (axis == 0 ? cnt.z : (axis == 1 ? cnt.y : cnt.x)) * LP;
+        f32x4_t o[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * GM_THREADS;
+            o[it] = zero;
+            if (i < nitems) {
+                const unsigned v = ((unsigned)i * lp_magic) >> 16, ll = (unsigned)i - v * (unsigned)LP;
+                const unsigned w = lnb[v * 4 + axis];
+                const f32x4_t c = gl[i], x1 = gl[(w & 0xffffu) * (unsigned)LP + ll], x2 = gl[(w >> 16) * (unsigned)LP + ll];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[it][q] = c[q] + 0.5f * (x1[q] + x2[q]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * GM_THREADS;
+            if (i < nitems) gl[i] = o[it];
+        }
+        __syncthreads();
+    }
+    // slice into the energy: E = -U, then the three FMAs of update_splat_kernel, same order, same weights
+    // ((bary * norm) * (compat * alpha))
+    if (!EARLY) load_pixels();
+#pragma unroll
+    for (int it = 0; it < NPI; ++it) {
+        const int i = tid + it * GM_THREADS;
+        if (i < np * LP) {
+            const unsigned t = ((unsigned)i * lp_magic) >> 16, ll = (unsigned)i - t * (unsigned)LP;
+            const uint4 gp = gpx[it];
+            f32x2_t o01 = {-uu[it][0], -uu[it][1]}, o23 = {-uu[it][2], -uu[it][3]};
+            const float wr[3] = {__uint_as_float(gp.y) * a.cag, __uint_as_float(gp.z) * a.cag, __uint_as_float(gp.w) * a.cag};
+#pragma unroll
+            for (int r = 0; r < ((WSC_GF_ABL & 4) ? 0 : 3); ++r) {
+                const f32x4_t row = gl[((gp.x >> (10 * r)) & 1023u) * (unsigned)LP + ll];
+                const f32x2_t w2 = {wr[r], wr[r]}, lo = {row[0], row[1]}, hi = {row[2], row[3]};
+                o01 = __builtin_elementwise_fma(w2, lo, o01);
+                o23 = __builtin_elementwise_fma(w2, hi, o23);
+            }
+            e4[poff[it]] = f32x4_t{o01[0], o01[1], o23[0], o23[1]};
+        }
     }
 }
 
@@ -1823,6 +2042,115 @@ float *combine_blur_all4(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int 
         float *t = a; a = b; b = t;
     }
     return a;
+}
+
+// ---- Gaussian blur on chip: per-pixel-tile vertex sets ------------------------------------------------------------
+// The update kernel can run the three blur passes of the Gaussian lattice itself: a pixel tile's slice reads only the
+// ~120-160 vertices its pixels touch, and their blurred values depend on the splat values of the vertices within one step
+// along axis 2, then axis 1, then axis 0 of them (the passes run 0, 1, 2: Permutohedral::compute).  This host pass (one-off
+// per cached Gaussian lattice, i.e. per image size and sxy) lists, for every pixel tile, that closed set: the tile's own
+// vertices T first, then nbr_2(T), then nbr_1 of all so far, then nbr_0 of all so far -- pass 0 is then exact on T + nbr_2 +
+// nbr_1, pass 1 on T + nbr_2, pass 2 on T, whatever the values outside the set are taken to be (zero).  A neighbour that
+// does not exist in the lattice or lies outside the set points at the set's zero row (the last, padding, local index).
+// Tables: see LatticeDev::gt_*.  Sets of more than GT_MAX_LOCAL vertices (tiny sxy: every pixel its own simplex) switch
+// the fusion off for the lattice (gt_rows stays null) and the separate blur kernel runs.
+constexpr int GT_MAX_LOCAL = 1022; // local ids are packed in 10 bits; the set's zero row takes one more id
+int gauss_fuse_tables(wsc_crf *crf, LatticeDev &L, const TileGeom &tg) {
+    wsc_ctx *ctx = crf->ctx;
+    const int N = crf->N, rows = L.rows, W = crf->W;
+    std::vector<int32_t> off((size_t)N * 3), rss((size_t)rows + 1);
+    std::vector<float> bary((size_t)N * 3), norm((size_t)N);
+    std::vector<int2> nbr((size_t)3 * rows);
+    WSC_HIP(hipMemcpyAsync(off.data(), L.offset, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, ctx->stream));
+    WSC_HIP(hipMemcpyAsync(bary.data(), L.bary, sizeof(float) * bary.size(), hipMemcpyDeviceToHost, ctx->stream));
+    WSC_HIP(hipMemcpyAsync(norm.data(), L.norm, sizeof(float) * norm.size(), hipMemcpyDeviceToHost, ctx->stream));
+    WSC_HIP(hipMemcpyAsync(rss.data(), L.row_slot_start, sizeof(int32_t) * rss.size(), hipMemcpyDeviceToHost, ctx->stream));
+    WSC_HIP(hipMemcpyAsync(nbr.data(), L.nbr, sizeof(int2) * nbr.size(), hipMemcpyDeviceToHost, ctx->stream));
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int> loc((size_t)rows, -1);
+    // pass 1: the sets (row ids in local order) and their sizes
+    std::vector<std::vector<int>> sets((size_t)tg.tpi);
+    std::vector<int4> cnt((size_t)tg.tpi);
+    int nvmax = 0;
+    for (int j = 0; j < tg.tpi; ++j) {
+        const TileBox tb = tile_box(tg, j);
+        std::vector<int> &list = sets[j];
+        auto add = [&](int R) {
+            if (R > 0 && R < rows && loc[R] < 0) {
+                loc[R] = (int)list.size();
+                list.push_back(R);
+            }
+        };
+        for (int ty = 0; ty < tb.ch; ++ty)
+            for (int tx = 0; tx < tb.cw; ++tx) {
+                const size_t n = (size_t)(tb.y0 + ty) * W + tb.x0 + tx;
+                for (int r = 0; r < 3; ++r) add(off[n * 3 + r]);
+            }
+        int4 &c = cnt[j];
+        c.x = (int)list.size(); // T: the tile's own vertices -- where pass 2 has to be right
+        for (int axis = 2; axis >= 0; --axis) {
+            const size_t cur = list.size();
+            for (size_t i = 0; i < cur; ++i) {
+                const int2 nb = nbr[(size_t)axis * rows + list[i]];
+                add(nb.x);
+                add(nb.y);
+            }
+            if (axis == 2) c.y = (int)list.size(); // T + nbr_2: where pass 1 has to be right
+            if (axis == 1) c.z = (int)list.size(); // ... + nbr_1: where pass 0 has to be right
+        }
+        c.w = (int)list.size();
+        for (int R : list) loc[R] = -1;
+        if ((int)list.size() > nvmax) nvmax = (int)list.size();
+    }
+    if (nvmax > GT_MAX_LOCAL || nvmax == 0) return WSC_OK; // no fusion for this lattice
+    // pass 2: the tables, padded to `stride` entries per tile; local id stride - 1 is every tile's zero row (a padding
+    // entry: no partial rows), so the kernel needs no per-tile count
+    const int stride = nvmax + 1, zr = stride - 1;
+    std::vector<int2> trows((size_t)tg.tpi * stride, make_int2(0, 0));
+    std::vector<uint4> tnbr((size_t)tg.tpi * stride, make_uint4((unsigned)zr | ((unsigned)zr << 16), (unsigned)zr | ((unsigned)zr << 16),
+                                                                (unsigned)zr | ((unsigned)zr << 16), 0u));
+    std::vector<uint4> pix((size_t)N);
+    for (int j = 0; j < tg.tpi; ++j) {
+        const TileBox tb = tile_box(tg, j);
+        const std::vector<int> &list = sets[j];
+        const int nv = (int)list.size();
+        for (int v = 0; v < nv; ++v) loc[list[v]] = v;
+        auto lid = [&](int R) { return (R > 0 && R < rows && loc[R] >= 0) ? loc[R] : zr; };
+        for (int v = 0; v < nv; ++v) {
+            const int R = list[v];
+            trows[(size_t)j * stride + v] = make_int2(rss[R], rss[R + 1] - rss[R]);
+            unsigned w[3];
+            for (int axis = 0; axis < 3; ++axis) {
+                const int2 nb = nbr[(size_t)axis * rows + R];
+                w[axis] = (unsigned)lid(nb.x) | ((unsigned)lid(nb.y) << 16);
+            }
+            tnbr[(size_t)j * stride + v] = make_uint4(w[0], w[1], w[2], 0u);
+        }
+        for (int ty = 0; ty < tb.ch; ++ty)
+            for (int tx = 0; tx < tb.cw; ++tx) {
+                const size_t n = (size_t)(tb.y0 + ty) * W + tb.x0 + tx;
+                unsigned ids = 0;
+                uint32_t bw[3];
+                for (int r = 0; r < 3; ++r) {
+                    ids |= (unsigned)lid(off[n * 3 + r]) << (10 * r);
+                    const float bn = bary[n * 3 + r] * norm[n]; // the slice weight up to compat * alpha: (bary * norm) * (compat * alpha)
+                    memcpy(&bw[r], &bn, sizeof(float));
+                }
+                pix[n] = make_uint4(ids, bw[0], bw[1], bw[2]);
+            }
+        for (int R : list) loc[R] = -1;
+    }
+    WSC_TRY(crf_alloc(crf, sizeof(int4) * cnt.size(), (void **)&L.gt_cnt));
+    WSC_HIP(hipMemcpyAsync(L.gt_cnt, cnt.data(), sizeof(int4) * cnt.size(), hipMemcpyHostToDevice, ctx->stream));
+    WSC_TRY(crf_alloc(crf, sizeof(int2) * trows.size(), (void **)&L.gt_rows));
+    WSC_TRY(crf_alloc(crf, sizeof(uint4) * tnbr.size(), (void **)&L.gt_nbr));
+    WSC_TRY(crf_alloc(crf, sizeof(uint4) * pix.size(), (void **)&L.gt_pix));
+    WSC_HIP(hipMemcpyAsync(L.gt_rows, trows.data(), sizeof(int2) * trows.size(), hipMemcpyHostToDevice, ctx->stream));
+    WSC_HIP(hipMemcpyAsync(L.gt_nbr, tnbr.data(), sizeof(uint4) * tnbr.size(), hipMemcpyHostToDevice, ctx->stream));
+    WSC_HIP(hipMemcpyAsync(L.gt_pix, pix.data(), sizeof(uint4) * pix.size(), hipMemcpyHostToDevice, ctx->stream));
+    WSC_HIP(hipStreamSynchronize(ctx->stream)); // the sources are pageable host vectors
+    L.gt_stride = stride;
+    return WSC_OK;
 }
 
 constexpr int WSC_RETRY_FULL_TABLE = 1; // internal status of build_lattice: the right-sized hash table overflowed
@@ -2030,6 +2358,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     hipLaunchKernelGGL(tile_scale_entries_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.norm, dp1,
                        make_geom(crf->H, crf->W), L.tent);
     WSC_HIP(hipGetLastError());
+    if (D == 2 && shared) WSC_TRY(gauss_fuse_tables(crf, L, tg));
     return WSC_OK;
 }
 
@@ -2043,17 +2372,51 @@ void gauss_cache_delete(void *p) { delete static_cast<GaussCache *>(p); }
 
 // slice: messages of both lattices are read (false before the first iteration); splat: the result is splatted
 // (false in the last iteration, whose Q is written to a.q instead)
-int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat) {
+// block size of the update kernel (WSC_CRF_UPD_THREADS: A/B runs)
+int update_threads() {
+    const char *te = getenv("WSC_CRF_UPD_THREADS");
+    const int nthr = te ? atoi(te) : 256;
+    return nthr == 512 ? 512 : (nthr == 128 ? 128 : 256);
+}
+size_t update_splat_lds(int LP) { return sizeof(f32x4_t) * TILE_PIX * LP + sizeof(uint2) * GATHER_ENT + sizeof(int2) * GATHER_SB; }
+size_t gauss_msg_lds(int LP, int gt_stride) { return ((size_t)LP * sizeof(f32x4_t) + sizeof(uint4)) * (size_t)gt_stride; }
+// can the Gaussian message be formed on chip (gauss_msg_kernel) for this call?  The tile vertex sets must exist (sets within
+// the local-id range) and fit the kernel's LDS and its per-thread item bound.
+bool update_gf_ok(const LatticeDev &G, int LP) {
+    const char *e = getenv("WSC_CRF_NO_GFUSE"); // read per call: a test compares the two paths
+    if (e && atoi(e) != 0) return false;
+    if (!G.gt_rows || G.rep < 1 || G.gt_stride <= 0) return false;
+    if ((long long)G.gt_stride * LP > 6ll * GM_THREADS || (long long)G.gt_stride * LP >= 8192) return false;
+    return gauss_msg_lds(LP, G.gt_stride) <= 64 * 1024;
+}
+
+int launch_gauss_msg(wsc_ctx *ctx, hipStream_t st, const GaussMsgArgs &g, double bytes) {
+    WscKernelTimer timer(ctx, WSC_K_BLUR, bytes);
+    const dim3 grid((unsigned)(g.B * g.tg.tpi)), block(GM_THREADS);
+    size_t lds = gauss_msg_lds(g.LP, g.gt_stride);
+    const char *le = getenv("WSC_CRF_GM_LDS"); // A/B: pad the LDS request (bytes) to cap the blocks per CU
+    if (le && (size_t)atoi(le) > lds && atoi(le) <= 64 * 1024) lds = (size_t)atoi(le);
+    if ((long long)g.gt_stride * g.LP <= 4ll * GM_THREADS && g.LP <= 6)
+        hipLaunchKernelGGL((gauss_msg_kernel<4, 3>), grid, block, lds, st, g);
+    else
+        hipLaunchKernelGGL((gauss_msg_kernel<6, 4>), grid, block, lds, st, g);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+// gf: the energy starts from the E buffer of gauss_msg_kernel (a.u points at it), no Gaussian rows are gathered
+int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat, bool gf) {
     const double npix = (double)a.B * a.tg.H * a.tg.W;
     // algorithmic bytes: read U, write Q; slice: index+weight of both lattices (9 entries of 8 bytes) and the
     // two messages the reference materialises (N*M*4 each); splat: read Q for both lattices + index+weight
     const double by = npix * (2.0 * a.M * 4 + (slice ? 9 * 8 + 2.0 * a.M * 4 : 0.0) + (splat ? 9 * 8 + 2.0 * a.M * 4 : 0.0));
     WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, by);
-    const char *te = getenv("WSC_CRF_UPD_THREADS");
-    const int nthr = te ? atoi(te) : 256;
-    const dim3 grid((unsigned)(a.B * a.tg.tpi)), block(nthr == 512 ? 512 : (nthr == 128 ? 128 : 256));
-    const size_t lds = splat ? sizeof(f32x4_t) * TILE_PIX * a.LP + sizeof(uint2) * GATHER_ENT + sizeof(int2) * GATHER_SB : 0;
-    if (slice && splat) hipLaunchKernelGGL((update_splat_kernel<true, true>), grid, block, lds, ctx->stream, a);
+    const dim3 grid((unsigned)(a.B * a.tg.tpi)), block(update_threads());
+    const size_t lds = splat ? update_splat_lds(a.LP) : 0;
+    if (slice && gf) {
+        if (splat) hipLaunchKernelGGL((update_splat_kernel<true, true, true>), grid, block, lds, ctx->stream, a);
+        else hipLaunchKernelGGL((update_splat_kernel<true, false, true>), grid, block, lds, ctx->stream, a);
+    } else if (slice && splat) hipLaunchKernelGGL((update_splat_kernel<true, true>), grid, block, lds, ctx->stream, a);
     else if (slice) hipLaunchKernelGGL((update_splat_kernel<true, false>), grid, block, lds, ctx->stream, a);
     else if (splat) hipLaunchKernelGGL((update_splat_kernel<false, true>), grid, block, lds, ctx->stream, a);
     else hipLaunchKernelGGL((update_splat_kernel<false, false>), grid, block, lds, ctx->stream, a);
@@ -2121,6 +2484,11 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
                            ctx->stream, crf->lat[0].offset, crf->lat[0].bary, crf->lat[0].norm, crf->lat[1].offset,
                            crf->lat[1].bary, crf->lat[1].norm, crf->N, crf->lat[0].rep > 1 ? 1 : 0, crf->pix_rec);
     }
+    if (st == WSC_OK && crf->lat[0].gt_rows)
+        st = crf_alloc(crf, sizeof(uint32_t) * 13 * (size_t)B * crf->N, (void **)&crf->pix_rec_b);
+    if (st == WSC_OK && crf->pix_rec_b)
+        hipLaunchKernelGGL(pack_pixels_b_kernel, dim3((unsigned)grid1d((long long)B * crf->N * 13, 256, 8192)), dim3(256), 0, ctx->stream,
+                           crf->lat[1].offset, crf->lat[1].bary, crf->lat[1].norm, (long long)B * crf->N, crf->pix_rec_b);
     if (st != WSC_OK) {
         wsc_crf_destroy(crf);
         return st;
@@ -2146,6 +2514,11 @@ int wsc_crf_lattice_sizes(wsc_ctx *ctx, const wsc_crf *crf, int32_t *v_gauss_hos
         if (v_bilat_host) v_bilat_host[b] = crf->lat[1].v_per_image[b];
     }
     return WSC_OK;
+}
+
+int wsc_crf_gaussian_on_chip(const wsc_crf *crf, int M) {
+    if (!crf || M < 1 || M > 32) return 0;
+    return update_gf_ok(crf->lat[0], (M + 3) / 4) && crf->pix_rec_b ? 1 : 0;
 }
 
 static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, bool pixel_major, int M, float g_compat,
@@ -2181,8 +2554,8 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
               "CRF image / lattice too large for 24-bit row arithmetic (N = %d, rows = %d / %d)", N, G.rows, Bl.rows);
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t qb = al(sizeof(float) * npix * Mp);
-    const size_t vg = al(sizeof(float) * (size_t)g_rows * Mp), vb = al(sizeof(float) * (size_t)Bl.rows * Mp);
     const size_t pg = al(sizeof(float) * (size_t)g_slots * Mp), pb = al(sizeof(float) * (size_t)Bl.n_slots * Mp);
+    const size_t vg = al(sizeof(float) * (size_t)g_rows * Mp), vb = al(sizeof(float) * (size_t)Bl.rows * Mp);
     void *ws;
     WSC_TRY(wsc_ctx_workspace(ctx, 2 * qb + 2 * vg + 2 * vb + pg + pb, &ws));
     char *p = (char *)ws;
@@ -2208,12 +2581,14 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     const char *nf = getenv("WSC_CRF_NO_FORK");
     const bool no_fork = (nf && atoi(nf) != 0) || ctx->profiling; // per-kernel timing wants the launches one after the other
     if (!no_fork && !ctx->aux_stream) {
+        // (default priority: a high-priority side stream, or any other priority split between the stages of a pipelined
+        // caller, was measured and lost 3-20 %: profiles/README.md)
         WSC_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
         WSC_HIP(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
         WSC_HIP(hipEventCreateWithFlags(&ctx->aux_done_ev, hipEventDisableTiming));
     }
     UpdateArgs a;
-    a.pix_rec = crf->pix_rec; a.val_g = nullptr; a.val_b = nullptr;
+    a.pix_rec = crf->pix_rec; a.pix_rec_b = crf->pix_rec_b; a.val_g = nullptr; a.val_b = nullptr;
     a.u = u; a.q = nullptr; a.argmax = nullptr;
     a.alpha_g = G.alpha; a.alpha_b = Bl.alpha; a.compat_g = g_compat; a.compat_b = bi_compat;
     a.M = M; a.LP = LP; a.B = B;
@@ -2223,18 +2598,28 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     a.sg.n_slots = G.n_slots; a.sg.shared = G.rep > 1 ? 1 : 0; a.sg.dp1 = 3;
     a.sb.tslot_start = Bl.tslot_start; a.sb.slot_desc = Bl.slot_desc; a.sb.tent = Bl.tent; a.sb.part = partb;
     a.sb.n_slots = Bl.n_slots; a.sb.shared = 0; a.sb.dp1 = 6;
+    // Gaussian message on chip (tile vertex sets that fit the LDS): no Gaussian value rows, no Gaussian blur launch --
+    // gauss_msg_kernel turns the Gaussian slot partials into E = -U + message (in the Q buffer: an update reads its slot of
+    // E before it writes Q there) beside the bilateral lattice's combine + six passes, and the update starts from E
+    const bool gf = update_gf_ok(G, LP) && crf->pix_rec_b != nullptr;
+    GaussMsgArgs gm;
+    gm.gt_cnt = G.gt_cnt; gm.gt_rows = G.gt_rows; gm.gt_nbr = G.gt_nbr; gm.gt_pix = G.gt_pix; gm.part = partg; gm.u = u; gm.e = q;
+    gm.gt_stride = G.gt_stride; gm.n_slots = G.n_slots; gm.shared = G.rep > 1 ? 1 : 0; gm.LP = LP; gm.B = B;
+    gm.cag = g_compat * G.alpha; gm.tg = a.tg;
+    const double gf_bytes = 2.0 * 3.0 * (double)(G.rows - 1) * G.rep * M * 4; // the blur's share of the SURVEY 8d bytes
     // Q(0) = softmax(-U) is splatted straight from the kernel that computes it; iteration t slices the blurred
     // lattices, forms Q(t) and splats it for iteration t+1; the last iteration writes Q(T) instead.
     if (n_iters == 0 && pixel_major) { // Q = softmax(-U): the update kernel without messages and without the splat
         a.q = q;
-        WSC_TRY(launch_update(ctx, a, false, false));
+        WSC_TRY(launch_update(ctx, a, false, false, false));
     }
     for (int it = 0; it <= n_iters && n_iters > 0; ++it) {
         const bool last = it == n_iters;
         const bool labels_only = last && q_dev == nullptr && argmax_dev != nullptr;
         a.q = last && !labels_only ? q : nullptr;
         a.argmax = labels_only ? argmax_dev : nullptr;
-        WSC_TRY(launch_update(ctx, a, it > 0, !last));
+        a.u = (gf && it > 0) ? q : u;
+        WSC_TRY(launch_update(ctx, a, it > 0, !last, gf));
         if (last) break;
         // The two lattices are independent until the next update: the bilateral one (seven short launches on ~1 MB per
         // image) runs on the ctx's side stream beside the Gaussian lattice's fused blur.
@@ -2246,7 +2631,8 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
         }
         a.val_b = combine_blur_all4(ctx, fork ? ctx->aux_stream : main_stream, Bl, LP, partb, vb0, vb1);
         if (fork) WSC_HIP(hipEventRecord(ctx->aux_done_ev, ctx->aux_stream));
-        a.val_g = combine_blur_all4(ctx, main_stream, G, LP, partg, vg0, vg1);
+        if (gf) WSC_TRY(launch_gauss_msg(ctx, main_stream, gm, gf_bytes));
+        else a.val_g = combine_blur_all4(ctx, main_stream, G, LP, partg, vg0, vg1);
         if (fork) WSC_HIP(hipStreamWaitEvent(main_stream, ctx->aux_done_ev, 0));
     }
     {

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "wsc_crf_create": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _f, ctypes.POINTER(_vp)]),
     "wsc_crf_destroy": (None, [_vp]),
     "wsc_crf_lattice_sizes": (_i, [_vp, _vp, _vp, _vp]),
+    "wsc_crf_gaussian_on_chip": (_i, [_vp, _i]),
     "wsc_crf_inference": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
     "wsc_crf_inference_pm": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
 }
@@ -561,6 +562,10 @@ class Crf:
         vb = np.zeros(self.B, dtype=np.int32)
         check(self.ctx._lib.wsc_crf_lattice_sizes(self.ctx.h, self.h, vg.ctypes.data, vb.ctypes.data))
         return vg, vb
+
+    def gaussian_on_chip(self, M):
+        """True when the update kernel blurs the Gaussian lattice itself for an M-class inference (wsc_crf_gaussian_on_chip)."""
+        return bool(self.ctx._lib.wsc_crf_gaussian_on_chip(self.h, int(M)))
 
     def inference(self, unary_dev, M, g_compat, bi_compat, n_iters, q_dev=None, argmax_dev=None, ctx=None, pixel_major=False):
         """ctx: the context (stream, workspace) to run the mean-field loop on; defaults to the one the
