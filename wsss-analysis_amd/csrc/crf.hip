@@ -1403,28 +1403,64 @@ constexpr int GATHER_ENT = TILE_PIX * 6;
 // partial[slot] = sum over the slot's entries of w * stage[pixel] in the entries' order, one slot per lane group per
 // trip.  The tile's entries (contiguous in memory) and slot descriptors are copied into LDS first: the per-slot chains
 // (descriptor -> entries -> Q rows) then run on LDS latency, not on three dependent trips to L2 / HBM per slot.
-__device__ __forceinline__ void tile_gather(const SplatTab &T, int tile, long long ebase_pix, int np, int rep_k,
+#ifndef WSC_SPLAT_ABL
+#define WSC_SPLAT_ABL 0 // timing-only ablations of the splat phase (wrong results): 1 no partial-row stores, 2 no gather, 4 no entry copy
+#endif
+// The splat tables of one (tile, lattice) held in registers between their request and their use: the tile's entries
+// (TILE_PIX * (d+1) of them: EN per thread), the thread's slot descriptor of the first batch and the tile's slot range.
+// Requested early (the Gaussian lattice's before the trips, the bilateral one's before the Gaussian gather), they arrive
+// under other work; the loop form (load -> LDS per entry, one after the other) had every block wait ~6 dependent HBM
+// round trips per update.
+template <int EN>
+struct SplatRegs {
+    uint2 en[EN];
+    int2 desc;
+    int s_beg, s_end;
+};
+template <int EN>
+__device__ __forceinline__ void splat_fetch(const SplatTab &T, int tile, long long ebase_pix, int np, SplatRegs<EN> &r) {
+    r.s_beg = T.tslot_start[tile];
+    r.s_end = T.tslot_start[tile + 1];
+    const int ne = (WSC_SPLAT_ABL & 4) ? 0 : np * T.dp1;
+    const uint2 *src = T.tent + ebase_pix * T.dp1;
+#pragma unroll
+    for (int i = 0; i < EN; ++i) {
+        const int e = (int)threadIdx.x + i * (int)blockDim.x;
+        r.en[i] = make_uint2(0u, 0u);
+        if (e < ne) r.en[i] = src[e];
+    }
+    r.desc = make_int2(0, 0);
+    if ((int)threadIdx.x < r.s_end - r.s_beg && threadIdx.x < GATHER_SB) r.desc = T.slot_desc[r.s_beg + threadIdx.x];
+}
+template <int EN>
+__device__ __forceinline__ void splat_commit(const SplatTab &T, int np, const SplatRegs<EN> &r, uint2 *lent, int2 *ldesc, int LP) {
+    const int ne = (WSC_SPLAT_ABL & 4) ? 0 : np * T.dp1;
+#pragma unroll
+    for (int i = 0; i < EN; ++i) {
+        const int e = (int)threadIdx.x + i * (int)blockDim.x;
+        uint2 en = r.en[i];
+        en.x *= (unsigned)LP; // float4 index of the pixel's row in `stage`
+        if (e < ne) lent[e] = en;
+    }
+    if (threadIdx.x < GATHER_SB) ldesc[threadIdx.x] = r.desc;
+}
+// gather of the committed tables (first batch of slot descriptors already in LDS; a barrier separates commit and gather)
+__device__ __forceinline__ void tile_gather(const SplatTab &T, int s_beg, int s_end, int rep_k,
                                             const f32x4_t *stage, uint2 *lent, int2 *ldesc, int LP, int l, int g, int gpw,
                                             bool act) {
-    const int s_beg = T.tslot_start[tile], s_end = T.tslot_start[tile + 1];
     f32x4_t *part = reinterpret_cast<f32x4_t *>(T.part) + (T.shared ? (size_t)rep_k * T.n_slots * LP : (size_t)0);
     const int nw = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6);
-    const int ne = np * T.dp1;
-    const uint2 *src = T.tent + ebase_pix * T.dp1;
-    for (int i = threadIdx.x; i < ne; i += blockDim.x) {
-        uint2 en = src[i];
-        en.x *= (unsigned)LP; // float4 index of the pixel's row in `stage`
-        lent[i] = en;
-    }
     for (int sb0 = s_beg; sb0 < s_end; sb0 += GATHER_SB) {
         const int nsb = min(GATHER_SB, s_end - sb0);
-        if ((int)threadIdx.x < nsb) ldesc[threadIdx.x] = T.slot_desc[sb0 + threadIdx.x];
-        __syncthreads();
+        if (sb0 > s_beg) { // further batches (tiles with more than GATHER_SB slots: noise images)
+            if ((int)threadIdx.x < nsb) ldesc[threadIdx.x] = T.slot_desc[sb0 + threadIdx.x];
+            __syncthreads();
+        }
         for (int s0 = wv * gpw; s0 < nsb; s0 += nw * gpw) {
             const int s = s0 + g;
             const bool ok = act && s < nsb;
             const int2 d = ok ? ldesc[s] : make_int2(0, 0);
-            const int i0 = d.x & 0xffff, n = d.x >> 16;
+            const int i0 = d.x & 0xffff, n = (WSC_SPLAT_ABL & 2) ? 0 : d.x >> 16;
             // explicit packed FMAs (this file is compiled with -ffp-contract=off for the simplex search): the gather
             // is VALU/LDS-issue bound, 8 v_pk_fma_f32 per 4 entries instead of 16 mul + 16 add
             f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
@@ -1464,7 +1500,7 @@ __device__ __forceinline__ void tile_gather(const SplatTab &T, int tile, long lo
                 }
             }
             const f32x4_t acc = {a01[0], a01[1], a23[0], a23[1]};
-            if (ok) part[(unsigned)d.y * (unsigned)LP + l] = acc;
+            if (ok && !(WSC_SPLAT_ABL & 1)) part[(unsigned)d.y * (unsigned)LP + l] = acc;
         }
         __syncthreads();
     }
@@ -1484,8 +1520,16 @@ __device__ __forceinline__ void tile_gather(const SplatTab &T, int tile, long lo
 // points at E, the energy starts from +E instead of -U, and only the six bilateral rows are gathered.  Bit-identical to
 // the unfused path; the Gaussian lattice's value rows never exist, and the message kernel runs beside the bilateral
 // lattice's combine + blur chain between two updates.
-template <bool SLICE, bool SPLAT, bool GF = false>
+// DMA (GF variants): the tile's E rows and 52-byte records are streamed into LDS by LDS-DMA loads (global_load_lds: no
+// registers, every byte of the tile in flight at once) before the trips start -- E straight into the Q-stage slots its lanes
+// overwrite later, the records (padded to 56 bytes) into the region the splat tables use afterwards.  The trips then read
+// both from LDS and only the six bilateral row gathers (L2) remain in a trip's dependent chain; without it a trip waits
+// for its record from HBM before it can request its rows, and the kernel is bound by that latency at 4 waves per SIMD.
+constexpr int REC_LDS_BYTES = 56; // 13 dwords + 1 pad: 8-byte aligned records, TILE_PIX of them fit the splat-table region
+static_assert(TILE_PIX * REC_LDS_BYTES <= (int)(sizeof(uint2) * GATHER_ENT + sizeof(int2) * GATHER_SB), "record stage");
+template <bool SLICE, bool SPLAT, bool GF = false, bool DMA = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void update_splat_kernel(UpdateArgs a) {
+    static_assert(!DMA || (SLICE && GF), "the LDS-DMA staging belongs to the GF updates");
     extern __shared__ f32x4_t stage[]; // [TILE_PIX][LP]
     const int LP = a.LP;
     const int gpw = 64 / LP;
@@ -1534,7 +1578,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
     f32x4_t unn;          // unary of the trip after the next one to be folded
     f32x2_t e01, e23;     // energy of the current trip
     const float cag = a.compat_g * a.alpha_g, cab = a.compat_b * a.alpha_b;
-    auto load_rec = [&](unsigned p, uint4(&r)[5]) {
+    const char *lrec = reinterpret_cast<const char *>(stage + TILE_PIX * LP); // DMA: the tile's records in LDS
+    auto tile_idx = [&](int t0) -> unsigned { // the lane group's pixel of trip t0 inside the tile (clamped like pixel_of)
+        const int t = t0 + g;
+        return (act && t < np) ? (unsigned)t : 0u;
+    };
+    auto load_u = [&](int t0) -> f32x4_t {
+        if (DMA) return stage[tile_idx(t0) * (unsigned)LP + (unsigned)l];
+        return ld_off<f32x4_t>(u_b, __umul24(pixel_of(t0), LP16) + l16);
+    };
+    auto load_rec = [&](int t0, uint4(&r)[5]) {
+        if (DMA) { // 6 x 8 bytes + 4 from the LDS copy
+            const char *q = lrec + tile_idx(t0) * (unsigned)REC_LDS_BYTES;
+            uint2 w[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i] = *reinterpret_cast<const uint2 *>(q + 8 * i);
+            r[0] = make_uint4(w[0].x, w[0].y, w[1].x, w[1].y);
+            r[1] = make_uint4(w[2].x, w[2].y, w[3].x, w[3].y);
+            r[2] = make_uint4(w[4].x, w[4].y, w[5].x, w[5].y);
+            r[3] = make_uint4(*reinterpret_cast<const uint32_t *>(q + 48), 0u, 0u, 0u);
+            r[4] = make_uint4(0u, 0u, 0u, 0u);
+            return;
+        }
+        const unsigned p = pixel_of(t0);
         if (GF) { // 3 x 16 bytes + 4 (dword-aligned 16-byte loads)
 #pragma unroll
             for (int i = 0; i < 3; ++i) r[i] = ld_off<uint4>(rec_b, __umul24(p, REC_BYTES) + 16u * i);
@@ -1594,20 +1660,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
         }
     };
     const int t_first = (int)(threadIdx.x >> 6) * gpw;
+    // splat tables of the Gaussian lattice: requested now, used after the trips (8 registers across the loop)
+    constexpr int EN_G = (TILE_PIX * 3 + 255) / 256, EN_B = (TILE_PIX * 6 + 255) / 256; // blocks of >= 256 threads (update_threads)
+    SplatRegs<EN_G> rg;
+    if (SPLAT) splat_fetch<EN_G>(a.sg, a.sg.shared ? j : lb, (a.sg.shared ? 0ll : (long long)k * N) + tb.ebase, np, rg);
+    if (DMA) {
+        // E rows -> stage[t][l] (16-byte units u = t * LP + l), records -> lrec[t][14 dwords] (dword units d = t * 14 + k);
+        // a wave instruction fills 64 consecutive units from per-lane source addresses (units past the tile re-read its
+        // last one: the destination is lane-linear and has room for whole wave instructions)
+        const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwv = (int)(blockDim.x >> 6);
+        const unsigned lp_magic = (65536u + (unsigned)LP - 1u) / (unsigned)LP; // u / LP for u < 8192, LP <= 8
+        const int nE = np * LP;
+        for (int u0 = wvu * 64; u0 < nE; u0 += nwv * 64) {
+            const unsigned u = min((unsigned)(u0 + lane), (unsigned)(nE - 1));
+            const unsigned t = (u * lp_magic) >> 16, ll = u - t * (unsigned)LP;
+            const unsigned ty = (t * cw_magic) >> 16, tx = t - __umul24(ty, (unsigned)tb.cw);
+            const char *src = u_b + (__umul24(__umul24(ty, (unsigned)a.tg.W) + tx, LP16) + ll * 16u);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(stage) + u0 * 16), 16, 0, 0);
+        }
+        const int nR = np * 14;
+        for (int d0 = wvu * 64; d0 < nR; d0 += nwv * 64) {
+            const unsigned d = min((unsigned)(d0 + lane), (unsigned)(nR - 1));
+            const unsigned t = (d * 4682u) >> 16; // d / 14 for d < 4096
+            const unsigned kk = min(d - t * 14u, 12u); // the pad dword re-reads the norm
+            const unsigned ty = (t * cw_magic) >> 16, tx = t - __umul24(ty, (unsigned)tb.cw);
+            const char *src = rec_b + (__umul24(__umul24(ty, (unsigned)a.tg.W) + tx, REC_BYTES) + kk * 4u);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(const_cast<char *>(lrec) + d0 * 4), 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     {
-        const unsigned p = pixel_of(t_first);
-        const f32x4_t u0 = ld_off<f32x4_t>(u_b, __umul24(p, LP16) + l16);
+        const f32x4_t u0 = load_u(t_first);
         f32x4_t g3[3], b6[6];
         float w9[9];
         if (SLICE) {
-            load_rec(p, rq);
+            load_rec(t_first, rq);
             issue_rows(rq, g3, b6, w9);
         }
         unn = u0;
         if (t_first + ppt < np) {
-            const unsigned pn = pixel_of(t_first + ppt);
-            if (SLICE) load_rec(pn, rq);
-            unn = ld_off<f32x4_t>(u_b, __umul24(pn, LP16) + l16);
+            if (SLICE) load_rec(t_first + ppt, rq);
+            unn = load_u(t_first + ppt);
         }
         fold(u0, g3, b6, w9, e01, e23);
     }
@@ -1622,9 +1718,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
         const f32x4_t un1 = unn;
         if (SLICE && has_next) issue_rows(rq, vgn, vbn, wrn);
         if (t0 + 2 * ppt < np) {
-            const unsigned p2 = pixel_of(t0 + 2 * ppt);
-            if (SLICE) load_rec(p2, rq);
-            unn = ld_off<f32x4_t>(u_b, __umul24(p2, LP16) + l16);
+            if (SLICE) load_rec(t0 + 2 * ppt, rq);
+            unn = load_u(t0 + 2 * ppt);
         }
         float e[4] = {e01[0], e01[1], e23[0], e23[1]};
         float mx = -3.0e38f;
@@ -1682,12 +1777,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
     if (SPLAT) {
         uint2 *lent = reinterpret_cast<uint2 *>(stage + TILE_PIX * LP);
         int2 *ldesc = reinterpret_cast<int2 *>(lent + GATHER_ENT);
-        // (the entry copy of the first lattice needs no barrier of its own: the one inside tile_gather covers it and
-        // the stage writes above)
-        tile_gather(a.sg, a.sg.shared ? j : lb, (a.sg.shared ? 0ll : (long long)k * N) + tb.ebase, np, k, stage, lent, ldesc,
-                    LP, l, g, gpw, act);
-        tile_gather(a.sb, a.sb.shared ? j : lb, (a.sb.shared ? 0ll : (long long)k * N) + tb.ebase, np, k, stage, lent, ldesc,
-                    LP, l, g, gpw, act);
+        if (DMA) __syncthreads(); // every wave is done with the records: their region becomes the splat tables
+        splat_commit<EN_G>(a.sg, np, rg, lent, ldesc, LP);
+        // the bilateral lattice's tables travel while the Gaussian lattice's slots are gathered
+        SplatRegs<EN_B> rb;
+        splat_fetch<EN_B>(a.sb, a.sb.shared ? j : lb, (a.sb.shared ? 0ll : (long long)k * N) + tb.ebase, np, rb);
+        __syncthreads(); // Q stage + Gaussian tables complete
+        tile_gather(a.sg, rg.s_beg, rg.s_end, k, stage, lent, ldesc, LP, l, g, gpw, act); // (ends with a barrier)
+        splat_commit<EN_B>(a.sb, np, rb, lent, ldesc, LP);
+        __syncthreads();
+        tile_gather(a.sb, rb.s_beg, rb.s_end, k, stage, lent, ldesc, LP, l, g, gpw, act);
     }
 }
 
@@ -2376,7 +2475,7 @@ void gauss_cache_delete(void *p) { delete static_cast<GaussCache *>(p); }
 int update_threads() {
     const char *te = getenv("WSC_CRF_UPD_THREADS");
     const int nthr = te ? atoi(te) : 256;
-    return nthr == 512 ? 512 : (nthr == 128 ? 128 : 256);
+    return nthr == 512 ? 512 : 256; // (the kernel's per-thread table registers cover a tile with >= 256 threads)
 }
 size_t update_splat_lds(int LP) { return sizeof(f32x4_t) * TILE_PIX * LP + sizeof(uint2) * GATHER_ENT + sizeof(int2) * GATHER_SB; }
 size_t gauss_msg_lds(int LP, int gt_stride) { return ((size_t)LP * sizeof(f32x4_t) + sizeof(uint4)) * (size_t)gt_stride; }
@@ -2412,8 +2511,14 @@ int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat, boo
     const double by = npix * (2.0 * a.M * 4 + (slice ? 9 * 8 + 2.0 * a.M * 4 : 0.0) + (splat ? 9 * 8 + 2.0 * a.M * 4 : 0.0));
     WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, by);
     const dim3 grid((unsigned)(a.B * a.tg.tpi)), block(update_threads());
-    const size_t lds = splat ? update_splat_lds(a.LP) : 0;
-    if (slice && gf) {
+    size_t lds = splat ? update_splat_lds(a.LP) : 0;
+    const char *de = getenv("WSC_CRF_UPD_DMA"); // A/B: 0 keeps the register loads of E and the records
+    const bool dma = slice && gf && !(de && atoi(de) == 0);
+    if (dma) lds = update_splat_lds(a.LP); // the last update stages E + records too
+    if (dma) {
+        if (splat) hipLaunchKernelGGL((update_splat_kernel<true, true, true, true>), grid, block, lds, ctx->stream, a);
+        else hipLaunchKernelGGL((update_splat_kernel<true, false, true, true>), grid, block, lds, ctx->stream, a);
+    } else if (slice && gf) {
         if (splat) hipLaunchKernelGGL((update_splat_kernel<true, true, true>), grid, block, lds, ctx->stream, a);
         else hipLaunchKernelGGL((update_splat_kernel<true, false, true>), grid, block, lds, ctx->stream, a);
     } else if (slice && splat) hipLaunchKernelGGL((update_splat_kernel<true, true>), grid, block, lds, ctx->stream, a);
