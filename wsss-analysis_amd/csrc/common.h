@@ -111,8 +111,8 @@ enum WscKernelClass {
     WSC_K_POOL_MISC,     // maxpool, layout changes, flip-add, classifier branch
     WSC_K_CAM_TAIL,      // cam_tail_kernel (both passes) + unary_from_maps
     WSC_K_CRF_BUILD,     // every kernel of wsc_crf_create
-    WSC_K_SPLAT,         // (unused since the splat moved into update_splat_kernel)
-    WSC_K_BLUR,          // combine4_kernel + blur4_kernel (bilateral) + blur3_tile_kernel (Gaussian: combine + three passes)
+    WSC_K_GAUSS_MSG,     // gauss_msg_kernel: Gaussian lattice combine + three blur passes + slice into E, per pixel tile, in LDS
+    WSC_K_BLUR,          // combine4_kernel + blur4_kernel (bilateral) + blur3_tile_kernel (Gaussian, when its message is not formed on chip)
     WSC_K_SLICE_UPDATE,  // update_splat_kernel: slice + mean-field update + splat of the result
     WSC_K_CRF_MISC,      // init_q / finish
     WSC_K_COUNT

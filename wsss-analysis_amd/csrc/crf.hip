@@ -2490,7 +2490,7 @@ bool update_gf_ok(const LatticeDev &G, int LP) {
 }
 
 int launch_gauss_msg(wsc_ctx *ctx, hipStream_t st, const GaussMsgArgs &g, double bytes) {
-    WscKernelTimer timer(ctx, WSC_K_BLUR, bytes);
+    WscKernelTimer timer(ctx, WSC_K_GAUSS_MSG, bytes);
     const dim3 grid((unsigned)(g.B * g.tg.tpi)), block(GM_THREADS);
     size_t lds = gauss_msg_lds(g.LP, g.gt_stride);
     const char *le = getenv("WSC_CRF_GM_LDS"); // A/B: pad the LDS request (bytes) to cap the blocks per CU
