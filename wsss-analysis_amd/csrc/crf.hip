@@ -2508,7 +2508,10 @@ int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat, boo
     const double npix = (double)a.B * a.tg.H * a.tg.W;
     // algorithmic bytes: read U, write Q; slice: index+weight of both lattices (9 entries of 8 bytes) and the
     // two messages the reference materialises (N*M*4 each); splat: read Q for both lattices + index+weight
-    const double by = npix * (2.0 * a.M * 4 + (slice ? 9 * 8 + 2.0 * a.M * 4 : 0.0) + (splat ? 9 * 8 + 2.0 * a.M * 4 : 0.0));
+    // (gf: the Gaussian lattice's slice -- 3 of the 9 entries and one of the two messages -- is gauss_msg_kernel's work and
+    // is accounted there)
+    const double by = npix * (2.0 * a.M * 4 + (slice ? (gf ? 6 * 8 + 1.0 * a.M * 4 : 9 * 8 + 2.0 * a.M * 4) : 0.0) +
+                              (splat ? 9 * 8 + 2.0 * a.M * 4 : 0.0));
     WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, by);
     const dim3 grid((unsigned)(a.B * a.tg.tpi)), block(update_threads());
     size_t lds = splat ? update_splat_lds(a.LP) : 0;
@@ -2525,6 +2528,24 @@ int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat, boo
     else if (slice) hipLaunchKernelGGL((update_splat_kernel<true, false>), grid, block, lds, ctx->stream, a);
     else if (splat) hipLaunchKernelGGL((update_splat_kernel<false, true>), grid, block, lds, ctx->stream, a);
     else hipLaunchKernelGGL((update_splat_kernel<false, false>), grid, block, lds, ctx->stream, a);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+// the 80-byte per-pixel records (pack_pixels_kernel) of a crf, built on `st`.  The block comes from the BUILD ctx's
+// stream-ordered cache: when `st` is another stream, it first waits for everything enqueued on the build stream so far
+// (the block's previous user), and the build stream waits for this launch before it can hand the block on (crf->use_ev).
+int crf_full_records(wsc_crf *crf, hipStream_t st) {
+    if (crf->pix_rec) return WSC_OK;
+    wsc_ctx *bctx = crf->ctx;
+    WSC_TRY(crf_alloc(crf, sizeof(uint4) * 5 * (size_t)crf->B * crf->N, (void **)&crf->pix_rec));
+    if (st != bctx->stream) {
+        WSC_HIP(hipEventRecord(bctx->join_ev, bctx->stream));
+        WSC_HIP(hipStreamWaitEvent(st, bctx->join_ev, 0));
+    }
+    hipLaunchKernelGGL(pack_pixels_kernel, dim3((unsigned)grid1d((long long)crf->N * 5, 256, 2048), (unsigned)crf->B), dim3(256), 0, st,
+                       crf->lat[0].offset, crf->lat[0].bary, crf->lat[0].norm, crf->lat[1].offset, crf->lat[1].bary,
+                       crf->lat[1].norm, crf->N, crf->lat[0].rep > 1 ? 1 : 0, crf->pix_rec);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
@@ -2581,14 +2602,10 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
             st = build_lattice<5>(crf, crf->lat[1], rgb_dev, bi_sxy, bi_srgb, false, true);
         }
     }
-    if (st == WSC_OK) st = crf_alloc(crf, sizeof(uint4) * 5 * (size_t)B * crf->N, (void **)&crf->pix_rec);
-    if (st == WSC_OK) {
-        const long long npix = (long long)B * crf->N;
-        (void)npix;
-        hipLaunchKernelGGL(pack_pixels_kernel, dim3((unsigned)grid1d((long long)crf->N * 5, 256, 2048), (unsigned)B), dim3(256), 0,
-                           ctx->stream, crf->lat[0].offset, crf->lat[0].bary, crf->lat[0].norm, crf->lat[1].offset,
-                           crf->lat[1].bary, crf->lat[1].norm, crf->N, crf->lat[0].rep > 1 ? 1 : 0, crf->pix_rec);
-    }
+    // The 80-byte record (both lattices) serves the updates that gather the Gaussian rows themselves.  When the Gaussian
+    // message can be formed on chip for every class count (the tile vertex sets fit at LP = 8), it is not built here: a
+    // call that still wants it (WSC_CRF_NO_GFUSE=1) builds it on first use (crf_full_records).
+    if (st == WSC_OK && !(crf->lat[0].gt_rows && update_gf_ok(crf->lat[0], 8))) st = crf_full_records(crf, ctx->stream);
     if (st == WSC_OK && crf->lat[0].gt_rows)
         st = crf_alloc(crf, sizeof(uint32_t) * 13 * (size_t)B * crf->N, (void **)&crf->pix_rec_b);
     if (st == WSC_OK && crf->pix_rec_b)
@@ -2707,11 +2724,17 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     // gauss_msg_kernel turns the Gaussian slot partials into E = -U + message (in the Q buffer: an update reads its slot of
     // E before it writes Q there) beside the bilateral lattice's combine + six passes, and the update starts from E
     const bool gf = update_gf_ok(G, LP) && crf->pix_rec_b != nullptr;
+    if (!gf && n_iters > 0) {
+        WSC_TRY(crf_full_records(crf, ctx->stream));
+        a.pix_rec = crf->pix_rec;
+    }
     GaussMsgArgs gm;
     gm.gt_cnt = G.gt_cnt; gm.gt_rows = G.gt_rows; gm.gt_nbr = G.gt_nbr; gm.gt_pix = G.gt_pix; gm.part = partg; gm.u = u; gm.e = q;
     gm.gt_stride = G.gt_stride; gm.n_slots = G.n_slots; gm.shared = G.rep > 1 ? 1 : 0; gm.LP = LP; gm.B = B;
     gm.cag = g_compat * G.alpha; gm.tg = a.tg;
-    const double gf_bytes = 2.0 * 3.0 * (double)(G.rows - 1) * G.rep * M * 4; // the blur's share of the SURVEY 8d bytes
+    // SURVEY 8d terms of the Gaussian kernel this launch covers: the blur (2 (d+1) V M 4) and the slice (index + weight of the
+    // 3 vertices per pixel, the message N M 4)
+    const double gf_bytes = 2.0 * 3.0 * (double)(G.rows - 1) * G.rep * M * 4 + (double)npix * (3 * 8 + 1.0 * M * 4);
     // Q(0) = softmax(-U) is splatted straight from the kernel that computes it; iteration t slices the blurred
     // lattices, forms Q(t) and splats it for iteration t+1; the last iteration writes Q(T) instead.
     if (n_iters == 0 && pixel_major) { // Q = softmax(-U): the update kernel without messages and without the splat
