@@ -15,8 +15,9 @@ CLASSES = {  # bench.py kernel-class label -> (kernel-name substrings, substring
     "update_splat_kernel": (("update_splat_kernel",), "update_splat_kernel"),
     "combine4+blur4+blur3_tile": (("combine4_kernel", "blur4_kernel", "blur3_tile_kernel"),
                                   ("combine4_kernel", "blur4_kernel", "blur3_tile_kernel")),
+    "gauss_msg_kernel": (("gauss_msg_kernel",), "gauss_msg_kernel"),
     "blur3_tile_kernel": (("blur3_tile_kernel",), "blur3_tile_kernel"),
-    "update_splat_kernel<true, true>": (("update_splat_kernel<true, true>",), "update_splat_kernel<true, true>"),
+    "update_splat_kernel<true, true, true, true>": (("update_splat_kernel<true, true, true, true>",), "update_splat_kernel<true, true, true, true>"),
 }
 
 
@@ -31,7 +32,7 @@ def per_kernel(db, counter):
     return tot, {k: len(v) for k, v in disp.items()}
 
 
-ROUND = "r02"
+ROUND = "r03"
 
 
 def main(fetch_db, write_db):

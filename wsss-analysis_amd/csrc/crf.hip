@@ -1023,6 +1023,71 @@ __global__ __launch_bounds__(256) void combine4_kernel(const f32x4_t *__restrict
     }
 }
 
+// The same rows from the same partials, balanced over the PARTIALS instead of the rows (bilateral lattice: ~5 partials per
+// row on average, 1 ... 30+ per row -- with a lane group per row a wave waits for its longest row).  A block owns CB_ROWS
+// consecutive rows, i.e. one contiguous run of partial rows; its lane groups walk that run in stride (four independent
+// 96-byte loads in flight each), find a partial's row by bisection in the block's slice of row_slot_start, and add it into
+// the row's 64-bit fixed-point accumulators in LDS (integer atomics: order-independent, so the result is the one of
+// combine_slots4<false>, bit for bit; a row's single partial is passed through unconverted as there).
+constexpr int CB_ROWS = 64;
+__global__ __launch_bounds__(256) void combine4_balanced_kernel(const f32x4_t *__restrict__ part, const int32_t *__restrict__ row_slot_start,
+                                                                int LP, int rows, f32x4_t *__restrict__ val) {
+    __shared__ int rss_l[CB_ROWS + 1];
+    __shared__ unsigned long long acc[CB_ROWS * 32];
+    const int r0 = blockIdx.x * CB_ROWS;
+    const int nr = min(CB_ROWS, rows - r0);
+    for (int i = threadIdx.x; i <= nr; i += 256) rss_l[i] = row_slot_start[r0 + i];
+    for (int i = threadIdx.x; i < CB_ROWS * 32; i += 256) acc[i] = 0ull;
+    __syncthreads();
+    const int P0 = rss_l[0], P1 = rss_l[nr];
+    const int gpb = 256 / LP;
+    const int tr = threadIdx.x / LP, l = threadIdx.x - tr * LP;
+    constexpr int U = 4;
+    if (tr < gpb) {
+        for (int p = P0 + tr; p < P1; p += U * gpb) {
+            f32x4_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pp = p + u * gpb;
+                v[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (pp < P1) v[u] = part[(unsigned)pp * (unsigned)LP + l];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pp = p + u * gpb;
+                if (pp < P1) {
+                    int lo = 0, hi = nr; // largest row with rss_l[row] <= pp (rows without partials are skipped by the <=)
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (rss_l[mid] <= pp) lo = mid;
+                        else hi = mid;
+                    }
+                    if (rss_l[lo + 1] - rss_l[lo] == 1) {
+                        val[(unsigned)(r0 + lo) * (unsigned)LP + l] = v[u];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            atomicAdd(&acc[lo * 32 + 4 * l + k], (unsigned long long)(long long)__float2int_rn(v[u][k] * PFIX_SCALE));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tr < gpb) {
+        for (int row = tr; row < nr; row += gpb) {
+            const int n = rss_l[row + 1] - rss_l[row];
+            if (n == 1) continue; // written above
+            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+            if (n > 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (float)(long long)acc[row * 32 + 4 * l + k] * PFIX_INV;
+            }
+            val[(unsigned)(r0 + row) * (unsigned)LP + l] = o;
+        }
+    }
+}
+
 // One blur pass along one lattice axis: out[row] = in[row] + 0.5*(in[n1] + in[n2]).
 // Scalar form for the normalisation pass (one value per row).
 __global__ __launch_bounds__(256) void blur1_kernel(const float *__restrict__ in, const int2 *__restrict__ nbr,
@@ -2086,9 +2151,13 @@ void splat_ones(wsc_ctx *ctx, const LatticeDev &L, const TileGeom &tg, float *va
 // rows of a lattice from the slot partials of the splat
 void combine4(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, const float *part, int LP, float *val) {
     WscKernelTimer timer(ctx, WSC_K_BLUR, ((double)L.n_slots + L.rows) * L.rep * L.M_cur * 4);
+    const char *be = getenv("WSC_CRF_COMBINE_BALANCED"); // A/B: 0 keeps the lane-group-per-row kernel
     if (L.sorted_dest)
         hipLaunchKernelGGL(combine4_kernel<true>, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
                            st, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
+    else if (L.rep == 1 && !(be && atoi(be) == 0))
+        hipLaunchKernelGGL(combine4_balanced_kernel, dim3((unsigned)((L.rows + CB_ROWS - 1) / CB_ROWS)), dim3(256), 0, st,
+                           (const f32x4_t *)part, L.row_slot_start, LP, L.rows, (f32x4_t *)val);
     else
         hipLaunchKernelGGL(combine4_kernel<false>, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
                            st, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
