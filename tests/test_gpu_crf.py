@@ -343,3 +343,24 @@ def test_pixel_major_unary_path_is_bit_identical(ctx):
         else:
             assert np.array_equal(Q1, Q2) and np.array_equal(A1, A2) and np.array_equal(A1, A3)
         assert np.array_equal(ctx.to_host(u_pm, (B, N, Mp), np.float32), Upm)  # read in place, never written
+
+
+def test_crf_gaussian_cache_overflow_takes_the_unfused_path():
+    """A ctx keeps the Gaussian lattices of 64 image sizes (with the host-built tile vertex sets of the on-chip message
+    path).  Later sizes are rebuilt per call WITHOUT those tables and run the separate blur kernel: same bits as the cached,
+    on-chip form of the same size on a fresh ctx."""
+    ctx_a = _lib.Context(0)
+    rng = np.random.default_rng(77)
+    cfg = (1.5, 3, 20, 10, 10, 2)
+    M = 3
+    last = None
+    for i in range(66):
+        H, W = 18 + i, 20
+        rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
+        q, a, _, _ = _gpu_crf(ctx_a, [rgb], [U], cfg)
+        assert _gpu_crf.on_chip == (i < 64), (i, _gpu_crf.on_chip)
+        last = (rgb, U, q, a)
+    ctx_b = _lib.Context(0)
+    q2, a2, _, _ = _gpu_crf(ctx_b, [last[0]], [last[1]], cfg)
+    assert _gpu_crf.on_chip
+    assert np.array_equal(q2, last[2]) and np.array_equal(a2, last[3])

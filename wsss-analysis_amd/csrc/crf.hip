@@ -2526,7 +2526,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     hipLaunchKernelGGL(tile_scale_entries_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.norm, dp1,
                        make_geom(crf->H, crf->W), L.tent);
     WSC_HIP(hipGetLastError());
-    if (D == 2 && shared) WSC_TRY(gauss_fuse_tables(crf, L, tg));
+    if (D == 2 && shared && crf->persist) WSC_TRY(gauss_fuse_tables(crf, L, tg));
     return WSC_OK;
 }
 
@@ -2535,7 +2535,9 @@ struct GaussCache {
     float sxy;
     LatticeDev L;
 };
-constexpr int GAUSS_CACHE_MAX = 16; // distinct image sizes kept per ctx; later sizes are rebuilt per call
+// distinct image sizes kept per ctx (~25 MB each at 375 x 500); later sizes are rebuilt per call, without the host-built
+// tile vertex sets of the on-chip message path (a rebuild per call must stay cheap: cam_to_ir_label walks hundreds of sizes)
+constexpr int GAUSS_CACHE_MAX = 64;
 void gauss_cache_delete(void *p) { delete static_cast<GaussCache *>(p); }
 
 // slice: messages of both lattices are read (false before the first iteration); splat: the result is splatted
