@@ -1443,9 +1443,7 @@ struct SplatTab { // splat tables of one lattice as the update kernel sees them
 
 struct UpdateArgs {
     const uint4 *pix_rec; // [pixel][5]
-    const uint32_t *pix_rec_b; // [pixel][13] bilateral part alone (GF variants without the LDS-DMA staging)
-    const int32_t *off_b;      // the same fields where the lattice build leaves them: row ids [pixel][6], barycentric weights
-    const float *bary_b, *norm_b; // [pixel][6], norm [pixel] -- the DMA variants stage their records straight from these
+    const uint32_t *pix_rec_b; // [pixel][13] bilateral part alone (GF variants)
     const float *val_g, *val_b;
     const float *u; // [pixel][Mp]
     float *q;       // [pixel][Mp] or null (only the last iteration's Q leaves the chip)
@@ -1624,8 +1622,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
     constexpr unsigned REC_BYTES = GF ? 52u : 80u; // GF: the 13-dword bilateral record (ids 0..5, bary 6..11, norm 12)
     constexpr int REC_ID = GF ? 0 : 3, REC_BARY = GF ? 6 : 12, REC_NORM = GF ? 12 : 19;
     const char *rec_b = (GF ? reinterpret_cast<const char *>(a.pix_rec_b) : reinterpret_cast<const char *>(a.pix_rec)) + pix0 * REC_BYTES;
-    const char *offb_b = reinterpret_cast<const char *>(a.off_b) + pix0 * 24, *baryb_b = reinterpret_cast<const char *>(a.bary_b) + pix0 * 24;
-    const char *normb_b = reinterpret_cast<const char *>(a.norm_b) + pix0 * 4;
     const char *u_b = reinterpret_cast<const char *>(a.u) + pix0 * LP16;
     char *q_b = reinterpret_cast<char *>(a.q) + pix0 * LP16;
     const char *vg_b = reinterpret_cast<const char *>(a.val_g) + (a.g_rows ? (size_t)k * a.g_rows * LP16 : (size_t)0);
@@ -1754,12 +1750,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
             const unsigned t = (d * 4682u) >> 16; // d / 14 for d < 4096
             const unsigned kk = min(d - t * 14u, 12u); // the pad dword re-reads the norm
             const unsigned ty = (t * cw_magic) >> 16, tx = t - __umul24(ty, (unsigned)tb.cw);
-            // no packed record in HBM: row ids, weights and norm come from the lattice's own arrays (24 + 24 + 4 contiguous
-            // bytes per pixel), dword by dword
-            const unsigned po = __umul24(ty, (unsigned)a.tg.W) + tx;
-            const char *src = kk < 6 ? offb_b + (__umul24(po, 24u) + kk * 4u)
-                                     : (kk < 12 ? baryb_b + (__umul24(po, 24u) + (kk - 6u) * 4u) : normb_b + po * 4u);
-            if (a.pix_rec_b) src = rec_b + (__umul24(po, REC_BYTES) + kk * 4u); // (A/B: the packed 52-byte record)
+            // (staging straight from the lattice's row-id / weight / norm arrays instead of the packed record was measured:
+            // 322 vs 311 us per launch -- three source streams per pixel -- for the ~90 us of pack_pixels_b_kernel per build)
+            const char *src = rec_b + (__umul24(__umul24(ty, (unsigned)a.tg.W) + tx, REC_BYTES) + kk * 4u);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(const_cast<char *>(lrec) + d0 * 4), 4, 0, 0);
         }
@@ -2630,8 +2623,7 @@ int crf_full_records(wsc_crf *crf, hipStream_t st) {
     return WSC_OK;
 }
 
-// the 52-byte bilateral records (pack_pixels_b_kernel), for GF updates that load them through registers
-// (WSC_CRF_UPD_DMA=0); same stream rules as crf_full_records
+// the 52-byte bilateral records (pack_pixels_b_kernel) of the GF updates; same stream rules as crf_full_records
 int crf_bilateral_records(wsc_crf *crf, hipStream_t st) {
     if (crf->pix_rec_b) return WSC_OK;
     wsc_ctx *bctx = crf->ctx;
@@ -2702,6 +2694,7 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
     // message can be formed on chip for every class count (the tile vertex sets fit at LP = 8), it is not built here: a
     // call that still wants it (WSC_CRF_NO_GFUSE=1) builds it on first use (crf_full_records).
     if (st == WSC_OK && !(crf->lat[0].gt_rows && update_gf_ok(crf->lat[0], 8))) st = crf_full_records(crf, ctx->stream);
+    if (st == WSC_OK && crf->lat[0].gt_rows) st = crf_bilateral_records(crf, ctx->stream);
     if (st != WSC_OK) {
         wsc_crf_destroy(crf);
         return st;
@@ -2802,7 +2795,6 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     }
     UpdateArgs a;
     a.pix_rec = crf->pix_rec; a.pix_rec_b = crf->pix_rec_b; a.val_g = nullptr; a.val_b = nullptr;
-    a.off_b = Bl.offset; a.bary_b = Bl.bary; a.norm_b = Bl.norm;
     a.u = u; a.q = nullptr; a.argmax = nullptr;
     a.alpha_g = G.alpha; a.alpha_b = Bl.alpha; a.compat_g = g_compat; a.compat_b = bi_compat;
     a.M = M; a.LP = LP; a.B = B;
@@ -2816,13 +2808,9 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     // gauss_msg_kernel turns the Gaussian slot partials into E = -U + message (in the Q buffer: an update reads its slot of
     // E before it writes Q there) beside the bilateral lattice's combine + six passes, and the update starts from E
     const bool gf = update_gf_ok(G, LP);
-    {
-        const char *de = getenv("WSC_CRF_UPD_DMA");
-        const char *pe = getenv("WSC_CRF_REC_PACKED"); // A/B: 1 stages the DMA variants' records from the packed form too
-        if (gf && n_iters > 0 && ((de && atoi(de) == 0) || (pe && atoi(pe) != 0))) { // the packed form, built on first use
-            WSC_TRY(crf_bilateral_records(crf, ctx->stream));
-            a.pix_rec_b = crf->pix_rec_b;
-        }
+    if (gf && n_iters > 0) { // (built by wsc_crf_create whenever the lattice has its tile vertex sets; here for completeness)
+        WSC_TRY(crf_bilateral_records(crf, ctx->stream));
+        a.pix_rec_b = crf->pix_rec_b;
     }
     if (!gf && n_iters > 0) {
         WSC_TRY(crf_full_records(crf, ctx->stream));
