@@ -265,6 +265,32 @@ def test_crf_gaussian_blur_inside_update_is_bit_identical(ctx, case, monkeypatch
     assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)
 
 
+@pytest.mark.parametrize("case", [(321, 321, 21, 8, (1.5, 3, 40, 13, 10, 4)), (47, 61, 5, 1, (1.5, 3, 40, 13, 10, 3)),
+                                  (96, 130, 21, 3, (3, 3, 50, 5, 10, 5)), (18, 23, 2, 37, (1.5, 3, 20, 10, 10, 2)),
+                                  (70, 64, 3, 2, (3, 3, 6, 1.5, 10, 2)), (5, 4, 3, 300, (1.5, 3, 20, 10, 10, 2)),
+                                  (300, 400, 4, 2, (3, 3, 10, 3, 10, 2)), (321, 321, 29, 2, (1.5, 3, 20, 6, 10, 2))])
+def test_crf_bilateral_blur_on_chip_is_bit_identical(ctx, case, monkeypatch):
+    """blur_lds_kernel: the six passes of the bilateral lattice in one launch, one image x GW classes per workgroup as float
+    planes in LDS, against one blur4_kernel launch per pass (WSC_CRF_BLUR_LDS=0, read per call): identical Q bits and labels.
+    Cases: the VOC size (3 classes per workgroup, 13 rows per thread), small images (4 classes, 4 rows), images of unequal
+    vertex counts, more workgroups than CUs (several rounds), noisy / narrow-kernel images whose ~20-60 k vertices leave
+    room for 1-2 classes per workgroup (40 rows per thread), M = 29."""
+    H, W, M, B, cfg = case
+    rng = np.random.default_rng(H * 17 + W)
+    rgbs, Us = [], []
+    for _ in range(B):
+        rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
+        rgbs.append(rgb)
+        Us.append(U)
+    monkeypatch.setenv("WSC_CRF_BLUR_LDS", "0")
+    q_ref, a_ref, vg, vb = _gpu_crf(ctx, rgbs, Us, cfg)
+    monkeypatch.setenv("WSC_CRF_BLUR_LDS", "1")
+    q, a, vg2, vb2 = _gpu_crf(ctx, rgbs, Us, cfg)
+    print("bilateral vertices per image:", list(vb)[:4])
+    assert list(vg) == list(vg2) and list(vb) == list(vb2)
+    assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)
+
+
 @pytest.mark.parametrize("case", [(47, 61, 5, 2, (1.5, 3, 40, 13, 10, 3)), (96, 130, 21, 3, (3, 3, 50, 5, 10, 2)),
                                   (33, 200, 4, 1, (5, 3, 40, 13, 10, 2)), (70, 64, 3, 2, (3, 3, 6, 1.5, 10, 2))])
 def test_crf_lattice_build_rank_paths_agree(ctx, case, monkeypatch):

@@ -155,6 +155,32 @@ def test_cam_unary_fused_equals_two_step_and_oracle(ctx, size):
         assert np.abs(u1[b] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("case", [(20, 21, 321, 321), (20, 21, 97, 130), (20, 21, 16, 33), (7, 5, 1, 1), (3, 4, 1, 63),
+                                  (30, 21, 70, 65), (32, 9, 33, 64)])
+def test_cam_unary_pixel_major_rows_equal_class_major(ctx, case):
+    """wsc_cam_unary_pm writes the rows of a wave through an LDS slab as contiguous kilobytes (or, when the slabs do not fit
+    beside the class maps -- the 30 x 21 x 21 case -- with strided stores): same bits as the class-major kernel, padding
+    columns zero, nothing written past the last pixel (sizes that are not multiples of a wave of 64 pixels)."""
+    C, h, H0, W0 = case
+    B = 2
+    rng = np.random.default_rng(C * 100 + H0 + W0)
+    cam = np.maximum(rng.normal(0.3, 1.0, (B, C, h, h)), 0).astype(np.float32)
+    cam_dev = ctx.to_device(cam)
+    n, M = H0 * W0, C + 1
+    Mp = (M + 3) // 4 * 4
+    u_cm = ctx.alloc(B * M * n * 4)
+    guard = 64 * Mp
+    sentinel = np.full(B * n * Mp + guard, -7.5, np.float32)
+    u_pm = ctx.to_device(sentinel)
+    _lib.cam_unary(ctx, cam_dev, B, C, h, h, H0, W0, 0.15, u_cm)
+    _lib.cam_unary(ctx, cam_dev, B, C, h, h, H0, W0, 0.15, u_pm, pixel_major=True)
+    U = ctx.to_host(u_cm, (B, M, n), np.float32)
+    raw = ctx.to_host(u_pm, (B * n * Mp + guard,), np.float32)
+    Upm = raw[: B * n * Mp].reshape(B, n, Mp)
+    assert np.array_equal(np.transpose(Upm[:, :, :M], (0, 2, 1)), U) and np.all(Upm[:, :, M:] == 0)
+    assert np.all(raw[B * n * Mp:] == -7.5)
+
+
 def _gpu_crf(ctx, rgb, U, cfg):
     H, W, _ = rgb.shape
     M = U.shape[0]

@@ -74,6 +74,17 @@ struct LatticeDev {
     uint4 *gt_pix = nullptr;     // [N] per pixel {local ids of its 3 vertices (10 bits each), bary[r] * norm (3 floats)}
     int gt_stride = 0;           // max vertices of a tile's set + 1; local id gt_stride - 1 is every set's zero row
     std::vector<int32_t> v_per_image;
+    // per-image lattices (rep == 1): rows [img_row[b], img_row[b + 1]) are image b's (row 0, the zero row, is nobody's)
+    int32_t *img_row = nullptr; // [B + 1]
+    int max_img_rows = 0;
+    // blur_lds_kernel: the images grouped by the kernel variant their vertex count admits (BL_VAR); images of variant v are
+    // bl_list[bl_off[v] .. bl_off[v + 1])
+    bool bl_ok = false;           // every image fits a variant
+    int2 *bl_blk = nullptr;                      // device [bl_cap] workgroup table {image | variant << 24, class group} (-1: idle),
+    int bl_cap = 0;                              // written per class count by blur_lds()
+    mutable std::vector<int2> bl_blk_host;       // (kept alive for the asynchronous upload)
+    mutable int bl_M = -1, bl_nblk = 0;          // class count the table was built for, its length
+    mutable size_t bl_lds = 0;
 };
 
 // ---- pixel tiles ------------------------------------------------------------------------------------
@@ -408,6 +419,12 @@ __global__ void image_bounds_kernel(const unsigned *__restrict__ bitmap, const u
                                     unsigned *__restrict__ bound) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) bound[b] = first_rank(bitmap, wprefix, (long long)b * per_img);
+}
+// row ranges of the images: rows [1 + bound[b], 1 + bound[b + 1]) (row 0 is the zero row), the last one ends at `rows`
+__global__ void image_rows_kernel(const unsigned *__restrict__ bound, int B, int rows, int32_t *__restrict__ img_row) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) img_row[b] = 1 + (int)bound[b];
+    if (b == B) img_row[b] = rows;
 }
 // occupied slots publish their row id, key and image
 __global__ void assign_rows_kernel(const int32_t *__restrict__ first, const unsigned long long *__restrict__ table, long long cap,
@@ -1138,6 +1155,154 @@ __global__ __launch_bounds__(256) void blur4_kernel(const f32x4_t *__restrict__ 
                 out[(unsigned)row * (unsigned)LP + l] = o;
             }
         }
+    }
+}
+
+// All d+1 passes of a per-image lattice (the bilateral one) in ONE launch, on chip.  The passes of an image depend on each
+// other through the whole image but never on another image or another class, so a workgroup takes ONE image and GW
+// classes: the image's rows of those classes as GW float planes in LDS (10.8 k vertices x 3 classes = 130 KB at 321 x 321,
+// M = 21: 7 workgroups per image, 224 for a batch of 32 -- one round of the chip), every pass gathers the two neighbours
+// of a row from the planes (4-byte LDS reads), the new values wait in registers across a barrier and overwrite the planes.
+// The arithmetic per value is blur4_kernel's (c + 0.5 (x1 + x2), same operand order): bit-identical.  HBM sees one read
+// and one write of the rows instead of six of each plus twelve neighbour gathers (~27 us a pass at the fabric's rate).
+// The workgroups of an image sit on one XCD (they read the same row lines and the same neighbour tables: L2 hits).
+constexpr int BL_THREADS = 1024;
+// variants {classes per workgroup GW, rows per thread RPT}: an image of `rows` vertices takes the first one with
+// rows <= RPT * 1024 and (rows + 1) * GW * 4 bytes <= 160 KB of LDS -- the most classes its rows leave room for (the new
+// values of a pass wait in RPT * GW registers next to RPT packed neighbour pairs: no spills at 128 registers)
+constexpr int BL_NVAR = 5;
+constexpr int BL_VAR[BL_NVAR][2] = {{4, 4}, {4, 10}, {3, 13}, {2, 20}, {1, 26}};
+inline int blur_lds_variant(int rows) {
+    for (int v = 0; v < BL_NVAR; ++v)
+        if (rows <= BL_VAR[v][1] * BL_THREADS && (size_t)(rows + 1) * BL_VAR[v][0] * 4 <= 160 * 1024 && rows < 65535) return v;
+    return -1;
+}
+struct BlurLdsArgs {
+    const int2 *nbr;        // [(d+1)][rows] global row ids (0 = absent)
+    const int32_t *img_row; // [B + 1]
+    const int2 *blk;        // [gridDim.x] {image | variant << 24, class group}; x < 0: nothing to do
+    float *val;             // [rows][Mp], blurred in place
+    int Mp, M, rows, npass;
+};
+// GW consecutive floats at a 4-byte-aligned address as ONE access (a wave's 64 rows are 64 different cache lines: one
+// request per row instead of GW)
+template <int GW> struct FloatRun { float v[GW]; };
+typedef float f32x3u_t __attribute__((ext_vector_type(3), aligned(4))); // three floats at a 4-byte-aligned address
+template <int GW>
+__device__ __forceinline__ FloatRun<GW> load_run(const float *q) { // q: 4 GW-byte aligned for GW = 1, 2, 4; 4-byte aligned for GW = 3
+    FloatRun<GW> r;
+    if constexpr (GW == 4) {
+        const f32x4_t x = *reinterpret_cast<const f32x4_t *>(q);
+        r.v[0] = x[0]; r.v[1] = x[1]; r.v[2] = x[2]; r.v[3] = x[3];
+    } else if constexpr (GW == 3) {
+        const f32x3u_t x = *reinterpret_cast<const f32x3u_t *>(q);
+        r.v[0] = x[0]; r.v[1] = x[1]; r.v[2] = x[2];
+    } else if constexpr (GW == 2) {
+        const f32x2_t x = *reinterpret_cast<const f32x2_t *>(q);
+        r.v[0] = x[0]; r.v[1] = x[1];
+    } else {
+        r.v[0] = q[0];
+    }
+    return r;
+}
+template <int GW>
+__device__ __forceinline__ void store_run(float *q, const FloatRun<GW> &r) {
+    if constexpr (GW == 4) *reinterpret_cast<f32x4_t *>(q) = f32x4_t{r.v[0], r.v[1], r.v[2], r.v[3]};
+    else if constexpr (GW == 3) {
+        f32x3u_t x;
+        x[0] = r.v[0]; x[1] = r.v[1]; x[2] = r.v[2];
+        *reinterpret_cast<f32x3u_t *>(q) = x;
+    } else if constexpr (GW == 2) *reinterpret_cast<f32x2_t *>(q) = f32x2_t{r.v[0], r.v[1]};
+    else q[0] = r.v[0];
+}
+template <int GW, int RPT>
+__device__ __forceinline__ void blur_lds_body(const BlurLdsArgs &p, float *pl, int img, int grp) {
+    const int r0 = p.img_row[img], nr = p.img_row[img + 1] - r0;
+    const int stride = nr + 1; // plane g, local row r: pl[g * stride + r]; index nr of every plane is the zero row
+    const int c0 = grp * GW;
+    const int tid = (int)threadIdx.x;
+    float *vb = p.val + (size_t)r0 * p.Mp + c0;
+    unsigned nb[RPT]; // the two neighbours as local row ids (16 bits each; absent -> the zero row nr)
+    auto load_idx = [&](int pass) {
+        const int2 *q = p.nbr + (size_t)pass * p.rows + r0;
+        constexpr int CH = RPT < 10 ? RPT : 10; // raw pairs in flight (registers)
+#pragma unroll
+        for (int i0 = 0; i0 < RPT; i0 += CH) {
+            int2 raw[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int r = tid + (i0 + i) * BL_THREADS;
+                raw[i] = (i0 + i < RPT && r < nr) ? q[r] : make_int2(0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if (i0 + i < RPT)
+                    nb[i0 + i] = (unsigned)(raw[i].x ? raw[i].x - r0 : nr) | ((unsigned)(raw[i].y ? raw[i].y - r0 : nr) << 16);
+        }
+    };
+    load_idx(0);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = tid + i * BL_THREADS;
+        if (r < nr) { // (the rows are Mp >= c0 + GW floats long: classes past M are padding, read and dropped)
+            const FloatRun<GW> run = load_run<GW>(vb + (size_t)r * p.Mp);
+#pragma unroll
+            for (int g = 0; g < GW; ++g) pl[g * stride + r] = c0 + g < p.M ? run.v[g] : 0.f;
+        }
+    }
+    if (tid < GW) pl[tid * stride + nr] = 0.f;
+    __syncthreads();
+    float o[RPT][GW];
+    for (int pass = 0; pass < p.npass; ++pass) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = tid + i * BL_THREADS;
+            const int rc = r < nr ? r : nr;
+            const int l1 = (int)(nb[i] & 0xffffu), l2 = (int)(nb[i] >> 16);
+#pragma unroll
+            for (int g = 0; g < GW; ++g) o[i][g] = pl[g * stride + rc] + 0.5f * (pl[g * stride + l1] + pl[g * stride + l2]);
+        }
+        if (pass + 1 < p.npass) load_idx(pass + 1); // travels across the barriers
+        else break;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = tid + i * BL_THREADS;
+            if (r < nr) {
+#pragma unroll
+                for (int g = 0; g < GW; ++g) pl[g * stride + r] = o[i][g];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = tid + i * BL_THREADS;
+        if (r < nr) {
+            if (c0 + GW <= p.M) {
+                FloatRun<GW> run;
+#pragma unroll
+                for (int g = 0; g < GW; ++g) run.v[g] = o[i][g];
+                store_run<GW>(vb + (size_t)r * p.Mp, run);
+            } else {
+#pragma unroll
+                for (int g = 0; g < GW; ++g)
+                    if (c0 + g < p.M) vb[(size_t)r * p.Mp + g] = o[i][g];
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(BL_THREADS) void blur_lds_kernel(BlurLdsArgs p) {
+    extern __shared__ float pl[];
+    const int2 w = p.blk[blockIdx.x];
+    if (w.x < 0) return;
+    const int img = w.x & 0xffffff;
+    switch (w.x >> 24) { // (uniform over the workgroup)
+    case 0: blur_lds_body<BL_VAR[0][0], BL_VAR[0][1]>(p, pl, img, w.y); break;
+    case 1: blur_lds_body<BL_VAR[1][0], BL_VAR[1][1]>(p, pl, img, w.y); break;
+    case 2: blur_lds_body<BL_VAR[2][0], BL_VAR[2][1]>(p, pl, img, w.y); break;
+    case 3: blur_lds_body<BL_VAR[3][0], BL_VAR[3][1]>(p, pl, img, w.y); break;
+    default: blur_lds_body<BL_VAR[4][0], BL_VAR[4][1]>(p, pl, img, w.y); break;
     }
 }
 
@@ -2175,6 +2340,52 @@ float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
     return a;
 }
 
+// blur_lds_kernel on the rows in `val` when the lattice is per image and an image's rows of GW classes fit a workgroup's
+// LDS (and its registers: RPT rows per thread); returns false when the per-pass launches have to run.  GW: the fewest
+// rounds of the chip, then the widest.  WSC_CRF_BLUR_LDS=0 (read per call: a test compares the two paths) switches it off.
+bool blur_lds(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int LP, float *val) {
+    const char *e = getenv("WSC_CRF_BLUR_LDS");
+    if ((e && atoi(e) == 0) || L.rep != 1 || !L.img_row || !L.bl_ok) return false;
+    const int M = L.M_cur, B = (int)L.v_per_image.size();
+    if (L.bl_M != M) {
+        // workgroup table for this class count: the images are dealt to the 8 XCDs (workgroup b runs on XCD b % 8), an
+        // image's class groups follow each other on its XCD (they read the same row lines and neighbour tables: L2 hits)
+        std::vector<std::vector<int2>> q(8);
+        size_t lds = 0;
+        for (int b = 0; b < B; ++b) {
+            const int v = blur_lds_variant(L.v_per_image[b]), gw = BL_VAR[v][0];
+            lds = std::max(lds, (size_t)(L.v_per_image[b] + 1) * gw * 4);
+            for (int g = 0; g * gw < M; ++g) q[b & 7].push_back(make_int2(b | (v << 24), g));
+        }
+        size_t len = 0;
+        for (int x = 0; x < 8; ++x) len = std::max(len, q[x].size());
+        std::vector<int2> &h = L.bl_blk_host;
+        h.assign(len * 8, make_int2(-1, 0));
+        for (int x = 0; x < 8; ++x)
+            for (size_t i = 0; i < q[x].size(); ++i) h[i * 8 + x] = q[x][i];
+        if ((int)h.size() > L.bl_cap) return false; // (the table was sized for M <= 32 at one class per workgroup)
+        if (hipMemcpyAsync(L.bl_blk, h.data(), sizeof(int2) * h.size(), hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        L.bl_nblk = (int)h.size();
+        L.bl_lds = lds;
+        L.bl_M = M;
+    }
+    if (L.bl_nblk == 0) return true;
+    static bool attr_set[64] = {};
+    const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(blur_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return false;
+        attr_set[dev] = true;
+    }
+    BlurLdsArgs ba;
+    ba.nbr = L.nbr; ba.img_row = L.img_row; ba.blk = L.bl_blk; ba.val = val; ba.Mp = 4 * LP; ba.M = M; ba.rows = L.rows;
+    ba.npass = L.d + 1;
+    WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * (L.d + 1) * L.rows * M * 4);
+    hipLaunchKernelGGL(blur_lds_kernel, dim3((unsigned)L.bl_nblk), dim3(BL_THREADS), L.bl_lds, st, ba);
+    return true;
+}
+
 // Rows from the splat's slot partials (`part`), then the d+1 blur passes; a / b: two row buffers.  Returns the
 // buffer holding the result.  The launches go to `st` (the ctx's main or side stream): the shared ctx is never
 // re-pointed, so an error return or another thread's wsc_sync always sees ctx->stream = the main stream.  The timers are
@@ -2204,6 +2415,7 @@ float *combine_blur_all4(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int 
         return b;
     }
     combine4(ctx, st, L, part, LP, a);
+    if (blur_lds(ctx, st, L, LP, a)) return a;
     for (int j = 0; j <= L.d; ++j) {
         WscKernelTimer timer(ctx, WSC_K_BLUR, 2.0 * L.rows * L.rep * L.M_cur * 4); // read + write every row once
         hipLaunchKernelGGL(blur4_kernel, dim3(grid_rep((long long)L.rows * L.rep, (256 / LP) * 4, L.rep)), dim3(256),
@@ -2427,6 +2639,20 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
         for (int b = 0; b < crf->B; ++b) L.v_per_image[b] = (int)vtot;
     else
         for (int b = 0; b < B; ++b) L.v_per_image[b] = (int)((b + 1 < B ? bound[b + 1] : vtot) - bound[b]);
+    if (!shared) { // row range of every image (blur_lds_kernel takes one image's rows into a workgroup's LDS)
+        WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (size_t)(B + 1), (void **)&L.img_row));
+        hipLaunchKernelGGL(image_rows_kernel, dim3((unsigned)(B / 64 + 1)), dim3(64), 0, ctx->stream, bound_dev, B, (int)vtot + 1,
+                           L.img_row);
+        L.max_img_rows = 0;
+        for (int b = 0; b < B; ++b) L.max_img_rows = std::max(L.max_img_rows, (int)L.v_per_image[b]);
+        L.bl_ok = B < (1 << 24);
+        for (int b = 0; b < B; ++b)
+            if (blur_lds_variant(L.v_per_image[b]) < 0) L.bl_ok = false; // an image with too many vertices for any variant
+        if (L.bl_ok) { // the workgroup table: at most 32 class groups per image, the images dealt to 8 XCD queues
+            L.bl_cap = 8 * ((B + 7) / 8) * 32;
+            WSC_TRY(crf_alloc(crf, sizeof(int2) * (size_t)L.bl_cap, (void **)&L.bl_blk));
+        }
+    }
 
     WSC_TRY(tmp.alloc(sizeof(unsigned long long) * L.rows, (void **)&rowkey));
     WSC_TRY(tmp.alloc(sizeof(int32_t) * L.rows, (void **)&rowimg));
