@@ -1046,7 +1046,13 @@ __global__ __launch_bounds__(256) void combine4_kernel(const f32x4_t *__restrict
 // 96-byte loads in flight each), find a partial's row by bisection in the block's slice of row_slot_start, and add it into
 // the row's 64-bit fixed-point accumulators in LDS (integer atomics: order-independent, so the result is the one of
 // combine_slots4<false>, bit for bit; a row's single partial is passed through unconverted as there).
-constexpr int CB_ROWS = 64;
+#ifndef WSC_CB_ROWS
+#define WSC_CB_ROWS 32 // (A/B on the VOC batch: 128 / 64 / 32 / 16 / 8 rows per block -> 85 / 75 / 67 / 67 / 77 us per launch)
+#endif
+#ifndef WSC_CB_U
+#define WSC_CB_U 4
+#endif
+constexpr int CB_ROWS = WSC_CB_ROWS;
 __global__ __launch_bounds__(256) void combine4_balanced_kernel(const f32x4_t *__restrict__ part, const int32_t *__restrict__ row_slot_start,
                                                                 int LP, int rows, f32x4_t *__restrict__ val) {
     __shared__ int rss_l[CB_ROWS + 1];
@@ -1059,7 +1065,7 @@ __global__ __launch_bounds__(256) void combine4_balanced_kernel(const f32x4_t *_
     const int P0 = rss_l[0], P1 = rss_l[nr];
     const int gpb = 256 / LP;
     const int tr = threadIdx.x / LP, l = threadIdx.x - tr * LP;
-    constexpr int U = 4;
+    constexpr int U = WSC_CB_U;
     if (tr < gpb) {
         for (int p = P0 + tr; p < P1; p += U * gpb) {
             f32x4_t v[U];
