@@ -16,7 +16,7 @@ rm -rf $out/prof_stats $out/pmc_f $out/pmc_w
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --quick > $out/${tag}_prof_stats.log 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --quick"; python profiles/summarize_rocpd.py $out/prof_stats/*/*_results.db; } > $out/${tag}_kernel_stats_bench.txt 2>&1
 { echo "# one ResNet50-CAM forward (64 samples @321^2, f16) out of the same trace"; python profiles/conv_layer_table.py $out/prof_stats/*/*_results.db; } > $out/${tag}_conv_layers.txt 2>&1
-RX='update_splat_kernel|gauss_msg_kernel|combine4_kernel|blur4_kernel|blur3_tile_kernel|conv_igemm'
+RX='update_splat_kernel|gauss_msg_kernel|combine4_kernel|combine4_balanced_kernel|blur_lds_kernel|blur4_kernel|blur3_tile_kernel|conv_igemm'
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$RX" -d $out/pmc_f -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --quick > $out/${tag}_pmc_f.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$RX" -d $out/pmc_w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --quick > $out/${tag}_pmc_w.log 2>&1
 { echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-include-regex '$RX' -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --quick"
@@ -33,7 +33,7 @@ for i in 1 2; do
   [ $i = 1 ] && C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU"
   [ $i = 2 ] && C="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM"
   rm -rf $out/pmcq_$i
-  timeout 200 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'update_splat_kernel|gauss_msg_kernel|blur3_tile_kernel|combine4_kernel|blur4_kernel' -d $out/pmcq_$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --quick > $out/${tag}_pmcq_$i.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'update_splat_kernel|gauss_msg_kernel|blur3_tile_kernel|combine4_kernel|combine4_balanced_kernel|blur_lds_kernel|blur4_kernel' -d $out/pmcq_$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --quick > $out/${tag}_pmcq_$i.log 2>&1
 done
 { echo "# rocprofv3 --kernel-trace --pmc <SQ set 1 | SQ set 2> --kernel-include-regex 'update_splat_kernel|gauss_msg_kernel|blur3_tile_kernel|combine4_kernel|blur4_kernel' -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --quick"; python profiles/summarize_pmc.py $out/pmcq_1/*/*_results.db $out/pmcq_2/*/*_results.db; } > $out/${tag}_pmc_crf.txt 2>&1
 python profiles/make_traffic_json.py $out/pmc_f/*/*_results.db $out/pmc_w/*/*_results.db > $out/${tag}_hbm_traffic.json 2>> $out/${tag}_bench.err

@@ -3016,8 +3016,13 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     } else {
         u = const_cast<float *>(unary_dev); // already [pixel][Mp] (wsc_cam_unary_pm): read in place, never written
     }
+    // The side stream pays off only for the per-pass bilateral launches (seven short kernels beside the Gaussian message);
+    // with the on-chip blur (two launches whose workgroups fill the CUs' LDS) one stream and two are the same to +-0.5 %
+    // (profiles/README.md), so that path stays on one stream.  WSC_CRF_NO_FORK=1 / 0 forces either.
     const char *nf = getenv("WSC_CRF_NO_FORK");
-    const bool no_fork = (nf && atoi(nf) != 0) || ctx->profiling; // per-kernel timing wants the launches one after the other
+    const char *ble_ = getenv("WSC_CRF_BLUR_LDS");
+    const bool lds_blur = Bl.bl_ok && Bl.img_row && !(ble_ && atoi(ble_) == 0);
+    const bool no_fork = (nf ? atoi(nf) != 0 : lds_blur) || ctx->profiling; // per-kernel timing wants the launches one after the other
     if (!no_fork && !ctx->aux_stream) {
         // (default priority: a high-priority side stream, or any other priority split between the stages of a pipelined
         // caller, was measured and lost 3-20 %: profiles/README.md)
