@@ -53,7 +53,10 @@ struct LatticeDev {
     // value is the (order-independent, fixed-point) sum of its slots' partials.
     int32_t *tslot_start = nullptr;  // [n_tiles + 1] first slot of each tile
     int2 *slot_desc = nullptr;       // [n_slots] {first entry (relative to the tile) | entry count << 16, index of its partial row}
-    uint2 *tent = nullptr;           // [B*N*(d+1)] {pixel index inside the tile, bits(w * norm[pixel])}, tile-major, grouped by row
+    // entries, tile-major, grouped by row: weight w * norm[pixel] and the pixel's index inside its tile (TILE_PIX <= 256: one
+    // byte) as two arrays -- 5 bytes per entry instead of a uint2's 8 (the update re-reads them every iteration)
+    float *tent_w = nullptr;         // [B*N*(d+1)]
+    uint8_t *tent_p = nullptr;       // [B*N*(d+1)]
     // partial rows are laid out ROW-major: the slots of row r write partial rows [row_slot_start[r], row_slot_start[r+1])
     int32_t *row_slot_start = nullptr; // [rows + 1]
     int n_tiles = 0, n_slots = 0;
@@ -99,6 +102,7 @@ struct LatticeDev {
 #define WSC_TILE_H 16
 #endif
 constexpr int TILE_W = WSC_TILE_W, TILE_H = WSC_TILE_H, TILE_PIX = TILE_W * TILE_H;
+static_assert(TILE_PIX <= 256, "an entry's pixel index is stored in one byte");
 constexpr int SLOT_ENT = 32;       // entries per slot (bounds the serial chain of one lane group)
 constexpr int SORT_MAX = 2048;     // >= TILE_PIX * 6 entries of a bilateral tile, power of two
 static_assert(TILE_PIX * 6 <= SORT_MAX && SORT_MAX <= 65535, "tile too large for the in-LDS grouping");
@@ -608,7 +612,7 @@ constexpr int GROUP_HT = SORT_MAX; // hash slots (load <= 0.75 even when every e
 constexpr int RANK_MW = (TILE_PIX + 31) / 32;            // mask words per group
 constexpr int RANK_GMAX = (4 * GROUP_HT * 2 + SORT_MAX * 2) / (RANK_MW * 4); // groups whose masks fit the wcnt + erank storage
 template <int D>
-__global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom tg, uint2 *__restrict__ tent,
+__global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom tg, float *__restrict__ tent_w, uint8_t *__restrict__ tent_p,
                                                          int32_t *__restrict__ sslot_out, unsigned *__restrict__ tile_nslots,
                                                          int force_ballot) {
     constexpr int dp1 = D + 1;
@@ -779,7 +783,8 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
             }
             const int pos = prev + rank;
             const int gs = (int)(unsigned)table[sl];
-            tent[ebase + pos] = make_uint2((unsigned)t, __float_as_uint(bary[r]));
+            tent_w[ebase + pos] = bary[r];
+            tent_p[ebase + pos] = (uint8_t)t;
             sslot_out[ebase + pos] = gs;
             a.eslot[gp * dp1 + r] = gs;
             a.bary[gp * dp1 + r] = bary[r];
@@ -878,7 +883,7 @@ __global__ void row_sort_dest_kernel(const unsigned *__restrict__ slot_key, int3
 
 // entry weights: barycentric weight -> weight * norm[pixel]  (the splat input is norm * Q)
 __global__ __launch_bounds__(256) void tile_scale_entries_kernel(const float *__restrict__ norm, int dp1, TileGeom tg,
-                                                                 uint2 *__restrict__ tent) {
+                                                                 float *__restrict__ tent_w, const uint8_t *__restrict__ tent_p) {
     const int tile = blockIdx.x;
     const int b = tile / tg.tpi, j = tile - b * tg.tpi;
     const TileBox tb = tile_box(tg, j);
@@ -887,12 +892,10 @@ __global__ __launch_bounds__(256) void tile_scale_entries_kernel(const float *__
     const long long ebase = ((long long)b * N + tb.ebase) * dp1;
     const unsigned cw_magic = tile_div_magic(tb.cw);
     for (int i = threadIdx.x; i < ne; i += 256) {
-        uint2 en = tent[ebase + i];
-        const int t = (int)en.x;
+        const int t = (int)tent_p[ebase + i];
         const int ty = (int)(((unsigned)t * cw_magic) >> 16), tx = t - ty * tb.cw;
         const long long p = (long long)b * N + (long long)(tb.y0 + ty) * tg.W + tb.x0 + tx;
-        en.y = __float_as_uint(__uint_as_float(en.y) * norm[p]);
-        tent[ebase + i] = en;
+        tent_w[ebase + i] = tent_w[ebase + i] * norm[p];
     }
 }
 
@@ -988,7 +991,7 @@ __device__ __forceinline__ f32x4_t combine_slots4(const f32x4_t *__restrict__ pa
 
 // Normalisation pass (splat of the all-ones vector, one value per row): slot partials, then rows.
 __global__ __launch_bounds__(256) void slot_ones_kernel(const int32_t *__restrict__ tslot_start, const int2 *__restrict__ slot_desc,
-                                                        const uint2 *__restrict__ tent, int dp1, TileGeom tg,
+                                                        const float *__restrict__ tent_w, int dp1, TileGeom tg,
                                                         float *__restrict__ part) {
     const int tile = blockIdx.x;
     const int b = tile / tg.tpi, j = tile - b * tg.tpi;
@@ -998,7 +1001,7 @@ __global__ __launch_bounds__(256) void slot_ones_kernel(const int32_t *__restric
     // instead of <= 32 dependent trips to L2 (a tile has ~120 slots: half the block's threads each own a chain)
     __shared__ float w[TILE_PIX * 6];
     const int ne = tb.cw * tb.ch * dp1;
-    for (int i = threadIdx.x; i < ne; i += 256) w[i] = __uint_as_float(tent[ebase + i].y);
+    for (int i = threadIdx.x; i < ne; i += 256) w[i] = tent_w[ebase + i];
     __syncthreads();
     for (int s = tslot_start[tile] + threadIdx.x; s < tslot_start[tile + 1]; s += 256) {
         const int2 d = slot_desc[s];
@@ -1605,7 +1608,8 @@ __global__ void pack_pixels_b_kernel(const int32_t *__restrict__ off_b, const fl
 struct SplatTab { // splat tables of one lattice as the update kernel sees them
     const int32_t *tslot_start;
     const int2 *slot_desc;
-    const uint2 *tent;
+    const float *tent_w;
+    const uint8_t *tent_p;
     float *part;        // [slots][Mp] partial rows out
     int n_slots;        // per replica
     int shared;         // 1: tables describe one image (tile index j), replica k writes part + k*n_slots*Mp
@@ -1649,7 +1653,8 @@ constexpr int GATHER_ENT = TILE_PIX * 6;
 // round trips per update.
 template <int EN>
 struct SplatRegs {
-    uint2 en[EN];
+    float w[EN];
+    unsigned px[EN];
     int2 desc;
     int s_beg, s_end;
 };
@@ -1658,12 +1663,17 @@ __device__ __forceinline__ void splat_fetch(const SplatTab &T, int tile, long lo
     r.s_beg = T.tslot_start[tile];
     r.s_end = T.tslot_start[tile + 1];
     const int ne = (WSC_SPLAT_ABL & 4) ? 0 : np * T.dp1;
-    const uint2 *src = T.tent + ebase_pix * T.dp1;
+    const float *sw = T.tent_w + ebase_pix * T.dp1;
+    const uint8_t *sp = T.tent_p + ebase_pix * T.dp1;
 #pragma unroll
     for (int i = 0; i < EN; ++i) {
         const int e = (int)threadIdx.x + i * (int)blockDim.x;
-        r.en[i] = make_uint2(0u, 0u);
-        if (e < ne) r.en[i] = src[e];
+        r.w[i] = 0.f;
+        r.px[i] = 0u;
+        if (e < ne) {
+            r.w[i] = sw[e];
+            r.px[i] = sp[e];
+        }
     }
     r.desc = make_int2(0, 0);
     if ((int)threadIdx.x < r.s_end - r.s_beg && threadIdx.x < GATHER_SB) r.desc = T.slot_desc[r.s_beg + threadIdx.x];
@@ -1674,9 +1684,8 @@ __device__ __forceinline__ void splat_commit(const SplatTab &T, int np, const Sp
 #pragma unroll
     for (int i = 0; i < EN; ++i) {
         const int e = (int)threadIdx.x + i * (int)blockDim.x;
-        uint2 en = r.en[i];
-        en.x *= (unsigned)LP; // float4 index of the pixel's row in `stage`
-        if (e < ne) lent[e] = en;
+        // {float4 index of the pixel's row in `stage`, weight bits}
+        if (e < ne) lent[e] = make_uint2(r.px[i] * (unsigned)LP, __float_as_uint(r.w[i]));
     }
     if (threadIdx.x < GATHER_SB) ldesc[threadIdx.x] = r.desc;
 }
@@ -2317,7 +2326,7 @@ struct TempBuf { // build-time scratch handed back to the ctx cache at the end o
 // the normalisation pass: val = Lattice-splat of the all-ones vector (one value per row)
 void splat_ones(wsc_ctx *ctx, const LatticeDev &L, const TileGeom &tg, float *val, float *part) {
     hipLaunchKernelGGL(slot_ones_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.tslot_start, L.slot_desc,
-                       L.tent, L.d + 1, tg, part);
+                       L.tent_w, L.d + 1, tg, part);
     hipLaunchKernelGGL(combine1_kernel, dim3(grid1d(L.rows)), dim3(256), 0, ctx->stream, part, L.row_slot_start, L.rows, val);
 }
 
@@ -2587,7 +2596,8 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(crf_alloc(crf, sizeof(int32_t) * total, (void **)&L.offset));
     WSC_TRY(crf_alloc(crf, sizeof(float) * total, (void **)&L.bary));
     WSC_TRY(crf_alloc(crf, sizeof(float) * npix, (void **)&L.norm));
-    WSC_TRY(crf_alloc(crf, sizeof(uint2) * total, (void **)&L.tent));
+    WSC_TRY(crf_alloc(crf, sizeof(float) * total, (void **)&L.tent_w));
+    WSC_TRY(crf_alloc(crf, sizeof(uint8_t) * total, (void **)&L.tent_p));
 
     hipLaunchKernelGGL(fill_u64_kernel, dim3(grid1d(B * cap)), dim3(256), 0, ctx->stream, table, EMPTY_KEY,
                        (long long)B * cap);
@@ -2613,7 +2623,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.n_tiles + 1), (void **)&tile_nslots));
     WSC_HIP(hipMemsetAsync(tile_nslots, 0, sizeof(unsigned) * (L.n_tiles + 1), ctx->stream));
     const char *rbe = getenv("WSC_CRF_RANK_BALLOT"); // read per build: a test compares the two ranking paths
-    hipLaunchKernelGGL(tile_embed_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent, sslot, tile_nslots,
+    hipLaunchKernelGGL(tile_embed_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent_w, L.tent_p, sslot, tile_nslots,
                        (rbe && atoi(rbe) != 0) ? 1 : 0);
     const int per_img = N * dp1; // entries of one image (total < 2^31 checked above)
     const dim3 grid_img((unsigned)grid1d(per_img, 256, B >= 32 ? 256 : 8192 / (B > 0 ? B : 1)), (unsigned)B);
@@ -2758,7 +2768,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     hipLaunchKernelGGL(slice_norm_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1,
                        L.alpha, res, npix, L.norm);
     hipLaunchKernelGGL(tile_scale_entries_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.norm, dp1,
-                       make_geom(crf->H, crf->W), L.tent);
+                       make_geom(crf->H, crf->W), L.tent_w, L.tent_p);
     WSC_HIP(hipGetLastError());
     if (D == 2 && shared && crf->persist) WSC_TRY(gauss_fuse_tables(crf, L, tg));
     return WSC_OK;
@@ -3037,9 +3047,9 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     a.M = M; a.LP = LP; a.B = B;
     a.tg = make_geom(crf->H, crf->W);
     a.g_pix = (unsigned)G.n_pix; a.g_rows = G.rep > 1 ? (unsigned)G.rows : 0u;
-    a.sg.tslot_start = G.tslot_start; a.sg.slot_desc = G.slot_desc; a.sg.tent = G.tent; a.sg.part = partg;
+    a.sg.tslot_start = G.tslot_start; a.sg.slot_desc = G.slot_desc; a.sg.tent_w = G.tent_w; a.sg.tent_p = G.tent_p; a.sg.part = partg;
     a.sg.n_slots = G.n_slots; a.sg.shared = G.rep > 1 ? 1 : 0; a.sg.dp1 = 3;
-    a.sb.tslot_start = Bl.tslot_start; a.sb.slot_desc = Bl.slot_desc; a.sb.tent = Bl.tent; a.sb.part = partb;
+    a.sb.tslot_start = Bl.tslot_start; a.sb.slot_desc = Bl.slot_desc; a.sb.tent_w = Bl.tent_w; a.sb.tent_p = Bl.tent_p; a.sb.part = partb;
     a.sb.n_slots = Bl.n_slots; a.sb.shared = 0; a.sb.dp1 = 6;
     // Gaussian message on chip (tile vertex sets that fit the LDS): no Gaussian value rows, no Gaussian blur launch --
     // gauss_msg_kernel turns the Gaussian slot partials into E = -U + message (in the Q buffer: an update reads its slot of
