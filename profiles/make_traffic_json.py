@@ -13,8 +13,8 @@ from collections import defaultdict
 
 CLASSES = {  # bench.py kernel-class label -> (kernel-name substrings, substring whose dispatches count as launches)
     "update_splat_kernel": (("update_splat_kernel",), "update_splat_kernel"),
-    "combine4+blur4+blur3_tile": (("combine4_kernel", "blur4_kernel", "blur3_tile_kernel"),
-                                  ("combine4_kernel", "blur4_kernel", "blur3_tile_kernel")),
+    "combine4+blur_lds+blur4+blur3_tile": (("combine4_kernel", "combine4_balanced_kernel", "blur_lds_kernel", "blur4_kernel", "blur3_tile_kernel"),
+                                  ("combine4_kernel", "combine4_balanced_kernel", "blur_lds_kernel", "blur4_kernel", "blur3_tile_kernel")),
     "gauss_msg_kernel": (("gauss_msg_kernel",), "gauss_msg_kernel"),
     "blur3_tile_kernel": (("blur3_tile_kernel",), "blur3_tile_kernel"),
     "update_splat_kernel<true, true, true, true>": (("update_splat_kernel<true, true, true, true>",), "update_splat_kernel<true, true, true, true>"),
