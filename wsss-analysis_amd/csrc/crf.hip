@@ -1556,14 +1556,36 @@ __global__ __launch_bounds__(GBI * GBJ) void blur3_tile_kernel(const f32x4_t *__
 }
 
 // Slice of the ones-filter and norm = 1/sqrt(x + 1e-20)   (DenseKernel::initLattice)
-__global__ void slice_norm_kernel(const int32_t *__restrict__ offset, const float *__restrict__ bary, int dp1,
-                                  float alpha, const float *__restrict__ val, long long npix,
-                                  float *__restrict__ norm) {
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
-         p += (long long)gridDim.x * blockDim.x) {
-        float acc = 0.f;
-        for (int r = 0; r < dp1; ++r) acc += bary[p * dp1 + r] * val[offset[p * dp1 + r]] * alpha;
-        norm[p] = (float)(1.0 / sqrt((double)acc + 1e-20));
+// rec != null (bilateral lattice, dp1 = 6): the pixel's 13-dword record of the GF updates {6 row ids, 6 barycentric weights,
+// norm} is written here as well -- the values are in registers, the block's 256 records go through LDS so that the stores are
+// coalesced -- instead of by a second kernel that reads the three arrays back (pack_pixels_b_kernel: ~90-130 us per build).
+__global__ __launch_bounds__(256) void slice_norm_kernel(const int32_t *__restrict__ offset, const float *__restrict__ bary,
+                                                          int dp1, float alpha, const float *__restrict__ val, long long npix,
+                                                          float *__restrict__ norm, uint32_t *__restrict__ rec) {
+    __shared__ uint32_t lrec[256 * 13];
+    for (long long p0 = (long long)blockIdx.x * 256; p0 < npix; p0 += (long long)gridDim.x * 256) {
+        const long long p = p0 + threadIdx.x;
+        if (p < npix) {
+            float acc = 0.f;
+            for (int r = 0; r < dp1; ++r) {
+                const int o = offset[p * dp1 + r];
+                const float w = bary[p * dp1 + r];
+                acc += w * val[o] * alpha;
+                if (rec) {
+                    lrec[threadIdx.x * 13 + r] = (uint32_t)o;
+                    lrec[threadIdx.x * 13 + 6 + r] = __float_as_uint(w);
+                }
+            }
+            const float nv = (float)(1.0 / sqrt((double)acc + 1e-20));
+            norm[p] = nv;
+            if (rec) lrec[threadIdx.x * 13 + 12] = __float_as_uint(nv);
+        }
+        if (rec) {
+            __syncthreads();
+            const int n13 = (int)min(256ll, npix - p0) * 13;
+            for (int i = threadIdx.x; i < n13; i += 256) rec[p0 * 13 + i] = lrec[i];
+            __syncthreads();
+        }
     }
 }
 
@@ -2765,8 +2787,15 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(tmp.alloc(sizeof(float) * (size_t)(L.n_slots + 1), (void **)&vp));
     splat_ones(ctx, L, make_geom(crf->H, crf->W), va, vp);
     float *res = blur_all1(ctx, L, va, vb);
+    // the bilateral lattice of a crf whose updates start from the on-chip Gaussian message: their 52-byte record is
+    // written by the same pass (crf_bilateral_records finds it done)
+    uint32_t *rec_b = nullptr;
+    if (D == 5 && !shared && crf->lat[0].gt_rows && !crf->pix_rec_b) {
+        WSC_TRY(crf_alloc(crf, sizeof(uint32_t) * 13 * (size_t)npix, (void **)&crf->pix_rec_b));
+        rec_b = crf->pix_rec_b;
+    }
     hipLaunchKernelGGL(slice_norm_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1,
-                       L.alpha, res, npix, L.norm);
+                       L.alpha, res, npix, L.norm, rec_b);
     hipLaunchKernelGGL(tile_scale_entries_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.norm, dp1,
                        make_geom(crf->H, crf->W), L.tent_w, L.tent_p);
     WSC_HIP(hipGetLastError());
@@ -2928,6 +2957,7 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
         if (st == WSC_RETRY_FULL_TABLE) { // noise-like image: more vertices than the right-sized table holds
             for (size_t i = mark; i < crf->allocs.size(); ++i) wsc_ctx_cached_free(ctx, crf->allocs[i]);
             crf->allocs.resize(mark);
+            crf->pix_rec_b = nullptr; // (allocated by the failed attempt: handed back with its other blocks)
             crf->lat[1] = LatticeDev();
             st = build_lattice<5>(crf, crf->lat[1], rgb_dev, bi_sxy, bi_srgb, false, true);
         }
