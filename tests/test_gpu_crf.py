@@ -313,6 +313,13 @@ def test_crf_lattice_build_rank_paths_agree(ctx, case, monkeypatch):
     assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)
     if cfg[3] == 1.5:
         assert max(vb) > 2.5 * H * W  # nearly every pixel owns its vertices: > 640 groups per 16 x 16 tile
+    # the tile pass on the 2048-slot LDS table for every tile (one launch) against the default: 512 slots first, the tiles
+    # with more than 384 distinct vertices (all of them in the noisy case) redone by the full-table launch
+    monkeypatch.setenv("WSC_CRF_EMBED_FULL", "1")
+    q3, a3, vg3, vb3 = _gpu_crf(ctx, rgbs, Us, cfg)
+    monkeypatch.setenv("WSC_CRF_EMBED_FULL", "0")
+    assert list(vg) == list(vg3) and list(vb) == list(vb3)
+    assert np.array_equal(q, q3) and np.array_equal(a, a3)
 
 
 def test_crf_labels_only_call_matches_full_call(ctx):

@@ -608,13 +608,23 @@ __device__ __forceinline__ void tile_slot_flags(const int *srow, int ne, unsigne
 //   C  per occupied slot: group size; global insert + atomicMin of the first-touch index (vertex ids are assigned in
 //      first-touch raster order, the CPU reference's insertion order)
 //   D  scan -> group starts; position = start + entries of the group in earlier quarters + rank
-constexpr int GROUP_HT = SORT_MAX; // hash slots (load <= 0.75 even when every entry has its own vertex)
+// The LDS hash table has GROUP_HT slots in two sizes.  Everything a block does besides its pixels is a pass over the table
+// (clear, compact ids, group sizes, scan), and a 16 x 16 tile of a natural image touches ~120 distinct vertices: the
+// first launch runs every tile on a 512-slot table (19 KB of LDS instead of 53: eight blocks per CU instead of three) and
+// a tile with more than 0.75 * 512 distinct vertices -- noise -- quits before it has written anything and puts itself on a
+// list that a second launch works off with the full 2048-slot table (load <= 0.75 even when every entry has its own vertex).
+#ifndef WSC_EMBED_HT
+#define WSC_EMBED_HT 512
+#endif
+constexpr int GROUP_HT_SMALL = WSC_EMBED_HT, GROUP_HT_FULL = SORT_MAX;
 constexpr int RANK_MW = (TILE_PIX + 31) / 32;            // mask words per group
-constexpr int RANK_GMAX = (4 * GROUP_HT * 2 + SORT_MAX * 2) / (RANK_MW * 4); // groups whose masks fit the wcnt + erank storage
-template <int D>
-__global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom tg, float *__restrict__ tent_w, uint8_t *__restrict__ tent_p,
-                                                         int32_t *__restrict__ sslot_out, unsigned *__restrict__ tile_nslots,
-                                                         int force_ballot) {
+template <int D, int GROUP_HT>
+__device__ __forceinline__ void tile_embed_body(const EmbedArgs &a, const TileGeom &tg, float *__restrict__ tent_w,
+                                                uint8_t *__restrict__ tent_p, int32_t *__restrict__ sslot_out,
+                                                unsigned *__restrict__ tile_nslots, int force_ballot, int tile,
+                                                int32_t *__restrict__ redo_list, unsigned *__restrict__ redo_count) {
+    constexpr int RANK_GMAX = (4 * GROUP_HT * 2 + SORT_MAX * 2) / (RANK_MW * 4); // groups whose masks fit the wcnt + erank storage
+    constexpr bool SMALL = GROUP_HT < GROUP_HT_FULL;
     constexpr int dp1 = D + 1;
     __shared__ unsigned long long table[GROUP_HT]; // vertex key, later the vertex's global hash slot
     __shared__ int start[GROUP_HT];                // first-touch entry index, then group size, then group start
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
     __shared__ unsigned short cid[GROUP_HT]; // compact group id of an occupied slot (mask path)
     __shared__ int wtot[4];
     __shared__ int n_groups_s;
-    const int tile = blockIdx.x;
+    __shared__ int full_s; // SMALL: a probe walked the whole table
     const int b = tile / tg.tpi, j = tile - b * tg.tpi;
     const TileBox tb = tile_box(tg, j);
     const int N = tg.H * tg.W;
@@ -637,6 +647,7 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
         start[i] = 0x7fffffff;
     }
     for (int i = threadIdx.x; i < (4 * GROUP_HT + SORT_MAX) / 2; i += 256) gmask[i] = 0u; // wcnt + erank / the pixel masks
+    if (threadIdx.x == 0) full_s = 0;
     __syncthreads();
     // ---- A: this thread's pixel
     const int t = threadIdx.x;
@@ -652,9 +663,13 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
 #pragma unroll
         for (int r = 0; r < dp1; ++r) {
             unsigned sl = (unsigned)(mix64(pk[r]) >> 40) & (GROUP_HT - 1);
-            for (;;) {
+            for (int probes = 0;; ++probes) {
                 const unsigned long long old = atomicCAS(&table[sl], EMPTY_KEY, pk[r]);
                 if (old == EMPTY_KEY || old == pk[r]) break;
+                if (SMALL && probes >= GROUP_HT) { // (the full table always has a free slot: 1536 entries at most)
+                    full_s = 1;
+                    break;
+                }
                 sl = (sl + 1) & (GROUP_HT - 1);
             }
             eslot[t * dp1 + r] = (unsigned short)sl;
@@ -687,6 +702,10 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
         }
         if (threadIdx.x == 255) n_groups_s = base;
         __syncthreads();
+    }
+    if (SMALL && (full_s || n_groups_s > GROUP_HT * 3 / 4)) { // nothing written yet: the tile goes to the full-table launch
+        if (threadIdx.x == 0) redo_list[atomicAdd(redo_count, 1u)] = tile;
+        return;
     }
     const bool use_mask = !force_ballot && n_groups_s <= RANK_GMAX;
     const int Q = ((ne + 3) / 4 + 63) / 64 * 64; // ballot path: entries per quarter, whole wave trips
@@ -789,6 +808,28 @@ __global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom t
             a.eslot[gp * dp1 + r] = gs;
             a.bary[gp * dp1 + r] = bary[r];
         }
+    }
+}
+template <int D>
+__global__ __launch_bounds__(256) void tile_embed_kernel(EmbedArgs a, TileGeom tg, float *__restrict__ tent_w, uint8_t *__restrict__ tent_p,
+                                                         int32_t *__restrict__ sslot_out, unsigned *__restrict__ tile_nslots,
+                                                         int force_ballot, int32_t *__restrict__ redo_list,
+                                                         unsigned *__restrict__ redo_count) {
+    tile_embed_body<D, GROUP_HT_SMALL>(a, tg, tent_w, tent_p, sslot_out, tile_nslots, force_ballot, (int)blockIdx.x, redo_list,
+                                       redo_count);
+}
+// the tiles the first launch gave up on (usually none: the blocks leave at once), or every tile when the list is null
+template <int D>
+__global__ __launch_bounds__(256) void tile_embed_full_kernel(EmbedArgs a, TileGeom tg, float *__restrict__ tent_w,
+                                                              uint8_t *__restrict__ tent_p, int32_t *__restrict__ sslot_out,
+                                                              unsigned *__restrict__ tile_nslots, int force_ballot,
+                                                              const int32_t *__restrict__ redo_list,
+                                                              const unsigned *__restrict__ redo_count, int n_tiles) {
+    const int count = redo_list ? (int)*redo_count : n_tiles;
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        tile_embed_body<D, GROUP_HT_FULL>(a, tg, tent_w, tent_p, sslot_out, tile_nslots, force_ballot,
+                                          redo_list ? redo_list[i] : i, nullptr, nullptr);
+        __syncthreads(); // (the body's LDS arrays are reused by the next tile)
     }
 }
 
@@ -2645,8 +2686,27 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.n_tiles + 1), (void **)&tile_nslots));
     WSC_HIP(hipMemsetAsync(tile_nslots, 0, sizeof(unsigned) * (L.n_tiles + 1), ctx->stream));
     const char *rbe = getenv("WSC_CRF_RANK_BALLOT"); // read per build: a test compares the two ranking paths
-    hipLaunchKernelGGL(tile_embed_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent_w, L.tent_p, sslot, tile_nslots,
-                       (rbe && atoi(rbe) != 0) ? 1 : 0);
+    {
+        // small-table launch for every tile, full-table launch for the ones that gave up (WSC_CRF_EMBED_FULL=1: full table
+        // for every tile, the single-launch form; read per build so that a test can compare)
+        const char *efe = getenv("WSC_CRF_EMBED_FULL");
+        const int fb = (rbe && atoi(rbe) != 0) ? 1 : 0;
+        if (efe && atoi(efe) != 0) {
+            hipLaunchKernelGGL(tile_embed_full_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent_w,
+                               L.tent_p, sslot, tile_nslots, fb, (const int32_t *)nullptr, (const unsigned *)nullptr, L.n_tiles);
+        } else {
+            int32_t *redo_list;
+            unsigned *redo_count;
+            WSC_TRY(tmp.alloc(sizeof(int32_t) * (size_t)L.n_tiles, (void **)&redo_list));
+            WSC_TRY(tmp.alloc(sizeof(unsigned), (void **)&redo_count));
+            WSC_HIP(hipMemsetAsync(redo_count, 0, sizeof(unsigned), ctx->stream));
+            hipLaunchKernelGGL(tile_embed_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent_w, L.tent_p,
+                               sslot, tile_nslots, fb, redo_list, redo_count);
+            hipLaunchKernelGGL(tile_embed_full_kernel<D>, dim3((unsigned)std::min(L.n_tiles, 2048)), dim3(256), 0, ctx->stream, ea,
+                               tg, L.tent_w, L.tent_p, sslot, tile_nslots, fb, (const int32_t *)redo_list,
+                               (const unsigned *)redo_count, L.n_tiles);
+        }
+    }
     const int per_img = N * dp1; // entries of one image (total < 2^31 checked above)
     const dim3 grid_img((unsigned)grid1d(per_img, 256, B >= 32 ? 256 : 8192 / (B > 0 ? B : 1)), (unsigned)B);
     const dim3 grid_tab((unsigned)grid1d(cap, 256, B >= 32 ? 256 : 8192 / (B > 0 ? B : 1)), (unsigned)B);
