@@ -296,7 +296,6 @@ struct EmbedArgs {
     unsigned long long *table; // [B][cap]
     unsigned cap_mask;
     long long cap;
-    int32_t *eslot;  // [B*N*(d+1)] table slot of each entry
     float *bary;     // [B*N*(d+1)]
     int32_t *first;  // [B*cap] smallest entry index touching the slot
     int *err;        // key range error flag
@@ -527,17 +526,6 @@ int exclusive_scan(wsc_ctx *ctx, const unsigned *in, long long n, unsigned *out,
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(256), 0, ctx->stream, in, n, sums, out);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
-}
-
-// offset[e] = row of entry e
-__global__ __launch_bounds__(256) void remap_kernel(const int32_t *__restrict__ eslot,
-                                                    const int32_t *__restrict__ slot2row, long long cap,
-                                                    int per_img, int32_t *__restrict__ offset) {
-    const int b = blockIdx.y;
-    const int32_t *es = eslot + (long long)b * per_img;
-    const int32_t *s2r = slot2row + (long long)b * cap;
-    int32_t *of = offset + (long long)b * per_img;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_img; i += gridDim.x * blockDim.x) of[i] = s2r[es[i]];
 }
 
 // ---- splat tables of a pixel tile (lattice build) -------------------------------------------------------
@@ -804,8 +792,9 @@ __device__ __forceinline__ void tile_embed_body(const EmbedArgs &a, const TileGe
             const int gs = (int)(unsigned)table[sl];
             tent_w[ebase + pos] = bary[r];
             tent_p[ebase + pos] = (uint8_t)t;
-            sslot_out[ebase + pos] = gs;
-            a.eslot[gp * dp1 + r] = gs;
+            // global hash slot (< 2^28, checked by the host) | the entry's index r among its pixel's d+1 vertices: the slot pass
+            // turns both into offset[pixel][r] = row (no pixel-major copy of the slots, no separate remap pass)
+            sslot_out[ebase + pos] = gs | (r << 28);
             a.bary[gp * dp1 + r] = bary[r];
         }
     }
@@ -834,7 +823,8 @@ __global__ __launch_bounds__(256) void tile_embed_full_kernel(EmbedArgs a, TileG
 }
 
 // Pass 2, one block per tile: slot descriptors at their final (compact) index; slots per row counted.
-__global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restrict__ sslot_in, const int32_t *__restrict__ slot2row,
+__global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restrict__ sslot_in, const uint8_t *__restrict__ tent_p,
+                                                         int32_t *__restrict__ offset, const int32_t *__restrict__ slot2row,
                                                          long long cap, int dp1, TileGeom tg,
                                                          const int32_t *__restrict__ tslot_start, int2 *__restrict__ slot_desc,
                                                          int32_t *__restrict__ slot_row, unsigned *__restrict__ slot_key,
@@ -852,7 +842,17 @@ __global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restri
     const int N = tg.H * tg.W;
     const int ne = tb.cw * tb.ch * dp1;
     const long long ebase = ((long long)b * N + tb.ebase) * dp1;
-    for (int i = threadIdx.x; i < ne; i += 256) rows_s[i] = slot2row[(long long)b * cap + sslot_in[ebase + i]];
+    const unsigned cw_magic = tile_div_magic(tb.cw);
+    for (int i = threadIdx.x; i < ne; i += 256) {
+        const int ss = sslot_in[ebase + i];
+        const int row = slot2row[(long long)b * cap + (ss & 0x0fffffff)];
+        rows_s[i] = row;
+        // offset[pixel][r] = row of the pixel's r-th vertex (Permutohedral::init's offset_ array, pixel-major)
+        const unsigned t = tent_p[ebase + i];
+        const unsigned ty = (t * cw_magic) >> 16, tx = t - ty * (unsigned)tb.cw;
+        const long long p = (long long)b * N + (long long)(tb.y0 + (int)ty) * tg.W + tb.x0 + (int)tx;
+        offset[p * dp1 + (ss >> 28)] = row;
+    }
     __syncthreads();
     tile_slot_flags(rows_s, ne, aux, flag, seg, wtot);
     const int ns = aux[ne - 1];
@@ -2637,17 +2637,17 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     const long long want = full_table ? 2ll * N * dp1 : (long long)N * dp1 / 8;
     while (cap < want || cap < 1024) cap <<= 1;
     WSC_CHECK(B * cap < (1ll << 31), WSC_ERR_CAPACITY, "CRF batch too large for the hash tables");
+    WSC_CHECK(cap <= (1ll << 28), WSC_ERR_CAPACITY, "CRF image too large: hash slots do not fit 28 bits"); // (tile pass: slot | r << 28)
 
     TempBuf tmp(ctx);
     unsigned long long *table;
-    int32_t *first, *eslot, *slot2row, *rowimg;
+    int32_t *first, *slot2row, *rowimg;
     unsigned *bitmap, *wcount, *wprefix, *sums, *bound_dev;
     unsigned long long *rowkey;
     int *err;
     WSC_TRY(tmp.alloc(sizeof(unsigned long long) * B * cap, (void **)&table));
     WSC_TRY(tmp.alloc(sizeof(int32_t) * B * cap, (void **)&first));
     WSC_TRY(tmp.alloc(sizeof(int32_t) * B * cap, (void **)&slot2row));
-    WSC_TRY(tmp.alloc(sizeof(int32_t) * total, (void **)&eslot));
     const long long nw = (total + 31) / 32 + 1; // first-toucher bitmap over the entries
     WSC_TRY(tmp.alloc(sizeof(unsigned) * nw, (void **)&bitmap));
     WSC_TRY(tmp.alloc(sizeof(unsigned) * nw, (void **)&wcount));
@@ -2677,7 +2677,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
             ea.scale[i] = i < D ? (float)(1.0 / std::sqrt((double)((i + 2) * (i + 1))) * inv_std_dev) : 0.f;
     }
     ea.table = table; ea.cap_mask = (unsigned)(cap - 1); ea.cap = cap;
-    ea.eslot = eslot; ea.bary = L.bary; ea.first = first; ea.err = err;
+    ea.bary = L.bary; ea.first = first; ea.err = err;
     const TileGeom tg = make_geom(crf->H, crf->W);
     L.n_tiles = B * tg.tpi;
     int32_t *sslot;
@@ -2708,7 +2708,6 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
         }
     }
     const int per_img = N * dp1; // entries of one image (total < 2^31 checked above)
-    const dim3 grid_img((unsigned)grid1d(per_img, 256, B >= 32 ? 256 : 8192 / (B > 0 ? B : 1)), (unsigned)B);
     const dim3 grid_tab((unsigned)grid1d(cap, 256, B >= 32 ? 256 : 8192 / (B > 0 ? B : 1)), (unsigned)B);
     WSC_HIP(hipMemsetAsync(bitmap, 0, sizeof(unsigned) * nw, ctx->stream));
     hipLaunchKernelGGL(first_bits_kernel, grid_tab, dim3(256), 0, ctx->stream, first, cap, per_img, bitmap);
@@ -2758,7 +2757,6 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
 
     hipLaunchKernelGGL(assign_rows_kernel, grid_tab, dim3(256), 0, ctx->stream, first, table, cap, per_img, bitmap, wprefix, slot2row,
                        rowkey, rowimg);
-    hipLaunchKernelGGL(remap_kernel, grid_img, dim3(256), 0, ctx->stream, eslot, slot2row, cap, per_img, L.offset);
     {   // splat tables: slots of the grouped tile entries, partial rows of each lattice row
         int32_t *slot_row;
         unsigned *sums2, *row_nslots, *cursor, *sums3;
@@ -2784,7 +2782,8 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
             WSC_TRY(tmp.alloc(sizeof(unsigned) * (size_t)(L.n_slots + 1), (void **)&slot_key));
             WSC_TRY(tmp.alloc(sizeof(int32_t) * (size_t)(L.n_slots + 1), (void **)&dest_slot));
         }
-        hipLaunchKernelGGL(tile_slots_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, sslot, slot2row, cap, dp1, tg,
+        hipLaunchKernelGGL(tile_slots_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, sslot, L.tent_p, L.offset, slot2row,
+                           cap, dp1, tg,
                            L.tslot_start, L.slot_desc, slot_row, slot_key, row_nslots);
         WSC_TRY(exclusive_scan(ctx, row_nslots, L.rows + 1, (unsigned *)L.row_slot_start, sums3));
         hipLaunchKernelGGL(slot_dest_kernel, dim3(grid1d(L.n_slots)), dim3(256), 0, ctx->stream, slot_row, L.n_slots,
