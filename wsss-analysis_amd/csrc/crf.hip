@@ -940,7 +940,10 @@ __global__ __launch_bounds__(256) void tile_scale_entries_kernel(const float *__
     }
 }
 
-// blur neighbours of every row along every axis (Permutohedral::init, second half)
+// blur neighbours of every row along every axis (Permutohedral::init, second half).  The two neighbours of a vertex along an
+// axis sit at key + delta and key - delta, so n1(r) = r' implies n2(r') = r: every row looks up ONE key (a probe of the
+// image's hash table + the slot's row: two dependent random reads) and writes its own n1 and the other row's n2; rows
+// whose n2 does not exist keep the zero the array was cleared to.
 template <int D>
 __global__ void neighbors_kernel(const unsigned long long *__restrict__ rowkey, const int32_t *__restrict__ rowimg,
                                  const unsigned long long *__restrict__ table, const int32_t *__restrict__ slot2row,
@@ -948,40 +951,32 @@ __global__ void neighbors_kernel(const unsigned long long *__restrict__ rowkey, 
     const int j = blockIdx.y; // blur axis
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
         const long long i = (long long)j * rows + row;
+        int *nb = reinterpret_cast<int *>(nbr);
         if (row == 0) {
-            nbr[i] = make_int2(0, 0);
+            nb[2 * i] = 0; // (row 0 is nobody's neighbour: its n2 stays cleared)
             continue;
         }
-        int key[D], k1[D], k2[D];
+        int key[D], k1[D];
         unpack_key<D>(rowkey[row], key);
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            k1[k] = key[k] - 1;
-            k2[k] = key[k] + 1;
-        }
+        for (int k = 0; k < D; ++k) k1[k] = key[k] - 1;
         if (j < D) {
             // static indexing
 #pragma unroll
             for (int k = 0; k < D; ++k)
-                if (k == j) {
-                    k1[k] = key[k] + D;
-                    k2[k] = key[k] - D;
-                }
+                if (k == j) k1[k] = key[k] + D;
         }
         const int b = rowimg[row];
         const unsigned long long *tb = table + (long long)b * cap;
         const int32_t *s2r = slot2row + (long long)b * cap;
-        unsigned long long p1, p2;
-        int r1 = 0, r2 = 0;
+        unsigned long long p1;
+        int r1 = 0;
         if (pack_key<D>(k1, p1)) {
             const int s = hash_lookup(tb, cap_mask, p1);
             if (s >= 0) r1 = s2r[s];
         }
-        if (pack_key<D>(k2, p2)) {
-            const int s = hash_lookup(tb, cap_mask, p2);
-            if (s >= 0) r2 = s2r[s];
-        }
-        nbr[i] = make_int2(r1, r2);
+        nb[2 * i] = r1;
+        if (r1 > 0) nb[2 * ((long long)j * rows + r1) + 1] = row; // this row is r1's neighbour on the other side
     }
 }
 
@@ -2796,6 +2791,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
             L.sorted_dest = true;
         }
     }
+    WSC_HIP(hipMemsetAsync(L.nbr, 0, sizeof(int2) * (size_t)dp1 * L.rows, ctx->stream));
     hipLaunchKernelGGL(neighbors_kernel<D>, dim3((unsigned)grid1d(L.rows, 256, 4096), (unsigned)dp1), dim3(256), 0, ctx->stream, rowkey,
                        rowimg, table, slot2row, cap, (unsigned)(cap - 1), L.rows, L.nbr);
     WSC_HIP(hipGetLastError());
