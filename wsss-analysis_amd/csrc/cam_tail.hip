@@ -186,13 +186,22 @@ __global__ __launch_bounds__(1024) void cam_max_kernel(const float *__restrict__
         int x0, x1;
         float lx0, lx1;
         src_index(xx, sw, w, x0, x1, lx0, lx1);
+        // the two source rows of an output row change every Hu / h (= 16) output rows: the column's horizontal taps
+        // `top` / `bot` are recomputed only then (same values as per row: the maximum is unchanged, a sixteenth of the LDS reads)
+        int o0 = -1, o1 = -1;
+        float top = 0.f, bot = 0.f;
 #pragma unroll 4
         for (int yy = 0; yy < H0; ++yy) {
             const float4 r = rows[yy]; // uniform over the block
             // bilerp(src, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1) with the row offsets taken from the table
-            const float *r0 = src + __float_as_int(r.x), *r1 = src + __float_as_int(r.y);
-            const float top = __builtin_fmaf(lx0, r0[x0], lx1 * r0[x1]);
-            const float bot = __builtin_fmaf(lx0, r1[x0], lx1 * r1[x1]);
+            const int n0 = __float_as_int(r.x), n1 = __float_as_int(r.y);
+            if (n0 != o0 || n1 != o1) {
+                const float *r0 = src + n0, *r1 = src + n1;
+                top = __builtin_fmaf(lx0, r0[x0], lx1 * r0[x1]);
+                bot = __builtin_fmaf(lx0, r1[x0], lx1 * r1[x1]);
+                o0 = n0;
+                o1 = n1;
+            }
             m = fmaxf(m, __builtin_fmaf(r.z, top, r.w * bot));
         }
     }
