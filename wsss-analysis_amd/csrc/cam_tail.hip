@@ -120,6 +120,65 @@ __global__ __launch_bounds__(256) void cam_tail_kernel(const float *__restrict__
     }
 }
 
+// The maxima of cam_tail_kernel<false> in the column form of cam_max_kernel: gridDim.y blocks per job (each a band of output
+// rows), a thread per output column, the row taps of the band's output rows in an LDS table, a column's horizontal taps recomputed only when the source rows change.
+// Same bilerp operands per sample as the per-pixel form: the same maxima, without a division and two src_index calls per sample.
+__global__ __launch_bounds__(512) void cam_tail_max_kernel(const float *__restrict__ cam, const TailJob *__restrict__ jobs, int h,
+                                                           int w, unsigned int *__restrict__ mx) {
+    extern __shared__ float src[]; // h*w, then 16 wave maxima, then row taps {y0*w, y1*w, ly0, ly1} of max(H0, h4) output rows
+    const TailJob job = jobs[blockIdx.x];
+    float4 *rows = reinterpret_cast<float4 *>(src + ((h * w + 16 + 3) & ~3));
+    for (int i = threadIdx.x; i < h * w; i += blockDim.x) src[i] = cam[job.cam_off + i];
+    float result[2];
+    for (int part = 0; part < 2; ++part) { // 0: high_res (H0 x W0 of the Hu x Wu upsampling), 1: strided (h4 x w4)
+        const int Hall = part == 0 ? job.H0 : job.h4, Wo = part == 0 ? job.W0 : job.w4;
+        const int band = (Hall + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int yb = (int)blockIdx.y * band, Ho = max(0, min(band, Hall - yb)); // this block's rows [yb, yb + Ho)
+        const float sh = (float)h / (float)(part == 0 ? job.Hu : job.h4), sw = (float)w / (float)(part == 0 ? job.Wu : job.w4);
+        __syncthreads(); // (the source map is staged / the previous part is done with the table)
+        for (int yy = threadIdx.x; yy < Ho; yy += blockDim.x) {
+            int y0, y1;
+            float ly0, ly1;
+            src_index(yb + yy, sh, h, y0, y1, ly0, ly1);
+            rows[yy] = make_float4(__int_as_float(y0 * w), __int_as_float(y1 * w), ly0, ly1);
+        }
+        __syncthreads();
+        float m = -3.0e38f;
+        for (int xx = threadIdx.x; xx < Wo && Ho > 0; xx += blockDim.x) {
+            int x0, x1;
+            float lx0, lx1;
+            src_index(xx, sw, w, x0, x1, lx0, lx1);
+            int o0 = -1, o1 = -1;
+            float top = 0.f, bot = 0.f;
+            for (int yy = 0; yy < Ho; ++yy) {
+                const float4 r = rows[yy];
+                const int n0 = __float_as_int(r.x), n1 = __float_as_int(r.y);
+                if (n0 != o0 || n1 != o1) {
+                    const float *r0 = src + n0, *r1 = src + n1;
+                    top = __builtin_fmaf(lx0, r0[x0], lx1 * r0[x1]);
+                    bot = __builtin_fmaf(lx0, r1[x0], lx1 * r1[x1]);
+                    o0 = n0;
+                    o1 = n1;
+                }
+                m = fmaxf(m, __builtin_fmaf(r.z, top, r.w * bot));
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+        float *wm = src + h * w;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, wm[i]);
+            result[part] = m;
+        }
+    }
+    if (threadIdx.x == 0) { // (mx is cleared by the launch function; 0 = no value)
+        if (result[0] > -3.0e38f) atomicMax(&mx[2 * blockIdx.x], ord_enc(result[0]));
+        if (result[1] > -3.0e38f) atomicMax(&mx[2 * blockIdx.x + 1], ord_enc(result[1]));
+    }
+}
+
 // plain F.interpolate(bilinear, align_corners=False): [C][h][w] -> [C][H][W]
 __global__ void bilinear_kernel(const float *__restrict__ src, int C, int h, int w, float *__restrict__ dst, int H,
                                 int W) {
@@ -723,8 +782,18 @@ int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h,
     double out_bytes = 0;
     for (const TailJob &t : jobs) out_bytes += ((double)t.H0 * t.W0 + (double)t.h4 * t.w4) * 4;
     WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, out_bytes);
-    hipLaunchKernelGGL(cam_tail_kernel<false>, grid, dim3(256), lds, ctx->stream, cam_dev, (const TailJob *)d, h, w,
-                       (unsigned int *)(d + jb), strided_dev, highres_dev);
+    // pass 1, the maxima: column form (one block per job) while its row-tap table fits the LDS, else the per-pixel form
+    int max_rows = 1;
+    for (const TailJob &t : jobs) max_rows = std::max(max_rows, std::max(t.H0, t.h4));
+    const int bands = 8; // row bands per job: a few hundred blocks for the ~50 jobs of a 32-image batch
+    const size_t lds_max = (((size_t)h * w + 16 + 3) & ~(size_t)3) * sizeof(float) +
+                           (size_t)((max_rows + bands - 1) / bands) * sizeof(float4);
+    if (lds_max <= 64 * 1024)
+        hipLaunchKernelGGL(cam_tail_max_kernel, dim3((unsigned)jobs.size(), (unsigned)bands), dim3(512), lds_max, ctx->stream,
+                           cam_dev, (const TailJob *)d, h, w, (unsigned int *)(d + jb));
+    else
+        hipLaunchKernelGGL(cam_tail_kernel<false>, grid, dim3(256), lds, ctx->stream, cam_dev, (const TailJob *)d, h, w,
+                           (unsigned int *)(d + jb), strided_dev, highres_dev);
     hipLaunchKernelGGL(cam_tail_kernel<true>, grid, dim3(256), lds, ctx->stream, cam_dev, (const TailJob *)d, h, w,
                        (unsigned int *)(d + jb), strided_dev, highres_dev);
     WSC_HIP(hipGetLastError());
