@@ -140,39 +140,53 @@ __global__ void flip_add_kernel(const float *__restrict__ head, int B, int h, in
 
 // Classifier branch of vgg16_cam.py:34-36 on sample 0 of each image:
 // score[b][c] = sigmoid(bias[c] + sum_f Wc[c][f] * mean_hw feat[sample_stride*b][.][f])
-// Global pooling + Linear + Sigmoid of the classifier branch, in two kernels: (1) one THREAD per (image, channel) walks the
-// positions in order (the same sequential fp32 sum as before, eight independent loads in flight), 64 channels per block so
-// that a 16-image batch spreads over 256 blocks -- as one block per image it took 1.9 ms for 16 images; (2) one block per
-// image for the C dot products.  feat NHWC half / bf16 (+ lo plane).  hw < 0 selects the global max of m7
-// (m7_cam.py:32-35: MaxPool 2x2 then AdaptiveMaxPool2d((1,1))).
-__global__ __launch_bounds__(64) void gap_kernel(const bf16_t *__restrict__ feat, const bf16_t *__restrict__ feat_lo, int hw, int F,
-                                                 float *__restrict__ gap, int fmt, int sample_stride) {
+// Global pooling + Linear + Sigmoid of the classifier branch, in two kernels: (1) a block per (image, 64 channels), lane =
+// channel, the positions dealt to the block's GAP_WAVES waves in contiguous runs: every wave sums its run in order (fp32, eight
+// independent loads in flight) and wave 0 adds the GAP_WAVES partial sums in run order -- a fixed summation order, whatever
+// the batch.  (One wave per (image, 64 channels) walked all 1600 positions of a 40 x 40 map alone: 200 dependent round
+// trips, 450 us for 16 images; one block per image before that: 1.9 ms.)  (2) one block per image for the C dot products.
+// feat NHWC half / bf16 (+ lo plane).  hw < 0 selects the global max of m7 (m7_cam.py:32-35: MaxPool 2x2 then
+// AdaptiveMaxPool2d((1,1))).
+constexpr int GAP_WAVES = 16;
+__global__ __launch_bounds__(64 * GAP_WAVES) void gap_kernel(const bf16_t *__restrict__ feat, const bf16_t *__restrict__ feat_lo,
+                                                             int hw, int F, float *__restrict__ gap, int fmt, int sample_stride) {
+    __shared__ float part[GAP_WAVES][64];
     const int b = blockIdx.y;
-    const int f = blockIdx.x * 64 + threadIdx.x;
-    if (f >= F) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + lane;
     const bool use_max = hw < 0; // m7: AdaptiveMaxPool2d((1,1)) instead of the average
     const int npix = use_max ? -hw : hw;
-    const long long img = (long long)(sample_stride * b) * npix * F;
-    const bf16_t *f0 = feat + img + f;
-    const bf16_t *l0 = feat_lo ? feat_lo + img + f : nullptr;
+    const int run = (npix + GAP_WAVES - 1) / GAP_WAVES;
+    const int pb = wv * run, pe = min(npix, pb + run);
     float s = use_max ? -3.0e38f : 0.f;
-    int p = 0;
-    for (; p + 8 <= npix; p += 8) {
-        float v[8];
+    if (f < F) {
+        const long long img = (long long)(sample_stride * b) * npix * F;
+        const bf16_t *f0 = feat + img + f;
+        const bf16_t *l0 = feat_lo ? feat_lo + img + f : nullptr;
+        int p = pb;
+        for (; p + 8 <= pe; p += 8) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            v[u] = h16_to_f32(f0[(long long)(p + u) * F], fmt);
-            if (l0) v[u] += bf16_to_f32(l0[(long long)(p + u) * F]);
+            for (int u = 0; u < 8; ++u) {
+                v[u] = h16_to_f32(f0[(long long)(p + u) * F], fmt);
+                if (l0) v[u] += bf16_to_f32(l0[(long long)(p + u) * F]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = use_max ? fmaxf(s, v[u]) : s + v[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s = use_max ? fmaxf(s, v[u]) : s + v[u];
+        for (; p < pe; ++p) {
+            float v = h16_to_f32(f0[(long long)p * F], fmt);
+            if (l0) v += bf16_to_f32(l0[(long long)p * F]);
+            s = use_max ? fmaxf(s, v) : s + v;
+        }
     }
-    for (; p < npix; ++p) {
-        float v = h16_to_f32(f0[(long long)p * F], fmt);
-        if (l0) v += bf16_to_f32(l0[(long long)p * F]);
-        s = use_max ? fmaxf(s, v) : s + v;
+    part[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && f < F) {
+        float t = part[0][lane];
+        for (int k = 1; k < GAP_WAVES; ++k) t = use_max ? fmaxf(t, part[k][lane]) : t + part[k][lane];
+        gap[(long long)b * F + f] = use_max ? t : t / (float)npix;
     }
-    gap[(long long)b * F + f] = use_max ? s : s / (float)npix;
 }
 
 __global__ void linear_sigmoid_kernel(const float *__restrict__ gapbuf, int F, const float *__restrict__ Wc,
@@ -280,7 +294,7 @@ int launch_gap_linear_sigmoid(wsc_ctx *ctx, const bf16_t *feat, const bf16_t *fe
                               const float *Wc, const float *bias, int C, float *score, int fmt, int sample_stride) {
     float *gapbuf = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(float) * (size_t)B * F, (void **)&gapbuf));
-    hipLaunchKernelGGL(gap_kernel, dim3((unsigned)((F + 63) / 64), (unsigned)B), dim3(64), 0, ctx->stream, feat, feat_lo, hw, F, gapbuf,
+    hipLaunchKernelGGL(gap_kernel, dim3((unsigned)((F + 63) / 64), (unsigned)B), dim3(64 * GAP_WAVES), 0, ctx->stream, feat, feat_lo, hw, F, gapbuf,
                        fmt, sample_stride);
     hipLaunchKernelGGL(linear_sigmoid_kernel, dim3(B), dim3(256), F * sizeof(float), ctx->stream, (const float *)gapbuf, F, Wc, bias, C,
                        score);
