@@ -82,6 +82,7 @@ struct LatticeDev {
     int max_img_rows = 0;
     // blur_lds_kernel: the images grouped by the kernel variant their vertex count admits (BL_VAR); images of variant v are
     // bl_list[bl_off[v] .. bl_off[v + 1])
+    uint32_t *part_row = nullptr; // [n_slots] per partial row: its lattice row | min(partial rows of that row, 255) << 24
     bool bl_ok = false;           // every image fits a variant
     int2 *bl_blk = nullptr;                      // device [bl_cap] workgroup table {image | variant << 24, class group} (-1: idle),
     int bl_cap = 0;                              // written per class count by blur_lds()
@@ -892,10 +893,13 @@ __global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restri
 
 // every slot gets a partial row inside its row's range (any order: the combine adds fixed-point integers)
 __global__ void slot_dest_kernel(const int32_t *__restrict__ slot_row, int n_slots, const int32_t *__restrict__ row_slot_start,
-                                 unsigned *__restrict__ cursor, int2 *__restrict__ slot_desc) {
+                                 unsigned *__restrict__ cursor, int2 *__restrict__ slot_desc, uint32_t *__restrict__ part_row) {
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += gridDim.x * blockDim.x) {
         const int row = slot_row[s];
-        slot_desc[s].y = row_slot_start[row] + (int)atomicAdd(&cursor[row], 1u);
+        const int sb = row_slot_start[row];
+        const int dst = sb + (int)atomicAdd(&cursor[row], 1u);
+        slot_desc[s].y = dst;
+        if (part_row) part_row[dst] = (uint32_t)row | ((uint32_t)min(row_slot_start[row + 1] - sb, 255) << 24);
     }
 }
 
@@ -1092,39 +1096,62 @@ __global__ __launch_bounds__(256) void combine4_kernel(const f32x4_t *__restrict
 #define WSC_CB_U 4
 #endif
 constexpr int CB_ROWS = WSC_CB_ROWS;
+// part_row != null: a partial row's lattice row (and whether it is the row's only partial) comes from a table written at
+// build time -- one coalesced 4-byte load issued together with the partial row itself -- instead of a bisection in the
+// block's slice of row_slot_start, and the partial loads no longer wait for that slice to be staged in LDS.
 __global__ __launch_bounds__(256) void combine4_balanced_kernel(const f32x4_t *__restrict__ part, const int32_t *__restrict__ row_slot_start,
-                                                                int LP, int rows, f32x4_t *__restrict__ val) {
+                                                                const uint32_t *__restrict__ part_row, int LP, int rows,
+                                                                f32x4_t *__restrict__ val) {
     __shared__ int rss_l[CB_ROWS + 1];
     __shared__ unsigned long long acc[CB_ROWS * 32];
     const int r0 = blockIdx.x * CB_ROWS;
     const int nr = min(CB_ROWS, rows - r0);
+    const int P0 = row_slot_start[r0], P1 = row_slot_start[r0 + nr]; // (uniform: scalar loads)
     for (int i = threadIdx.x; i <= nr; i += 256) rss_l[i] = row_slot_start[r0 + i];
     for (int i = threadIdx.x; i < CB_ROWS * 32; i += 256) acc[i] = 0ull;
-    __syncthreads();
-    const int P0 = rss_l[0], P1 = rss_l[nr];
     const int gpb = 256 / LP;
     const int tr = threadIdx.x / LP, l = threadIdx.x - tr * LP;
     constexpr int U = WSC_CB_U;
+    // the first batch of partial rows travels while the accumulators are cleared
+    f32x4_t v[U];
+    uint32_t pr[U];
+    auto fetch = [&](int p) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pp = p + u * gpb;
+            v[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            pr[u] = 0u;
+            if (tr < gpb && pp < P1) {
+                v[u] = part[(unsigned)pp * (unsigned)LP + l];
+                if (part_row) pr[u] = part_row[pp];
+            }
+        }
+    };
+    fetch(P0 + tr);
+    __syncthreads();
     if (tr < gpb) {
         for (int p = P0 + tr; p < P1; p += U * gpb) {
-            f32x4_t v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int pp = p + u * gpb;
-                v[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (pp < P1) v[u] = part[(unsigned)pp * (unsigned)LP + l];
-            }
+            if (p != P0 + tr) fetch(p);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int pp = p + u * gpb;
                 if (pp < P1) {
-                    int lo = 0, hi = nr; // largest row with rss_l[row] <= pp (rows without partials are skipped by the <=)
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (rss_l[mid] <= pp) lo = mid;
-                        else hi = mid;
+                    int lo;
+                    bool single;
+                    if (part_row) {
+                        lo = (int)(pr[u] & 0xffffffu) - r0;
+                        single = (pr[u] >> 24) == 1u;
+                    } else {
+                        lo = 0;
+                        int hi = nr; // largest row with rss_l[row] <= pp (rows without partials are skipped by the <=)
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (rss_l[mid] <= pp) lo = mid;
+                            else hi = mid;
+                        }
+                        single = rss_l[lo + 1] - rss_l[lo] == 1;
                     }
-                    if (rss_l[lo + 1] - rss_l[lo] == 1) {
+                    if (single) {
                         val[(unsigned)(r0 + lo) * (unsigned)LP + l] = v[u];
                     } else {
 #pragma unroll
@@ -2397,7 +2424,7 @@ void combine4(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, const float *pa
                            st, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
     else if (L.rep == 1 && !(be && atoi(be) == 0))
         hipLaunchKernelGGL(combine4_balanced_kernel, dim3((unsigned)((L.rows + CB_ROWS - 1) / CB_ROWS)), dim3(256), 0, st,
-                           (const f32x4_t *)part, L.row_slot_start, LP, L.rows, (f32x4_t *)val);
+                           (const f32x4_t *)part, L.row_slot_start, (const uint32_t *)L.part_row, LP, L.rows, (f32x4_t *)val);
     else
         hipLaunchKernelGGL(combine4_kernel<false>, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
                            st, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
@@ -2781,8 +2808,9 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
                            cap, dp1, tg,
                            L.tslot_start, L.slot_desc, slot_row, slot_key, row_nslots);
         WSC_TRY(exclusive_scan(ctx, row_nslots, L.rows + 1, (unsigned *)L.row_slot_start, sums3));
+        if (!shared) WSC_TRY(crf_alloc(crf, sizeof(uint32_t) * (size_t)(L.n_slots + 1), (void **)&L.part_row));
         hipLaunchKernelGGL(slot_dest_kernel, dim3(grid1d(L.n_slots)), dim3(256), 0, ctx->stream, slot_row, L.n_slots,
-                           L.row_slot_start, cursor, L.slot_desc);
+                           L.row_slot_start, cursor, L.slot_desc, L.part_row);
         if (D == 2) { // Gaussian lattice (built once per image size): deterministic partial-row order, plain fp32 combine
             hipLaunchKernelGGL(dest_inverse_kernel, dim3(grid1d(L.n_slots)), dim3(256), 0, ctx->stream, L.slot_desc, L.n_slots,
                                dest_slot);
