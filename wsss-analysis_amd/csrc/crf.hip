@@ -80,9 +80,9 @@ struct LatticeDev {
     // per-image lattices (rep == 1): rows [img_row[b], img_row[b + 1]) are image b's (row 0, the zero row, is nobody's)
     int32_t *img_row = nullptr; // [B + 1]
     int max_img_rows = 0;
-    // blur_lds_kernel: the images grouped by the kernel variant their vertex count admits (BL_VAR); images of variant v are
-    // bl_list[bl_off[v] .. bl_off[v + 1])
     uint32_t *part_row = nullptr; // [n_slots] per partial row: its lattice row | min(partial rows of that row, 255) << 24
+    // blur_lds_kernel: every image takes the kernel variant its vertex count admits (BL_VAR); the workgroup table lists
+    // {image, variant, class group} for the class count of the call
     bool bl_ok = false;           // every image fits a variant
     int2 *bl_blk = nullptr;                      // device [bl_cap] workgroup table {image | variant << 24, class group} (-1: idle),
     int bl_cap = 0;                              // written per class count by blur_lds()
@@ -2440,9 +2440,9 @@ float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
     return a;
 }
 
-// blur_lds_kernel on the rows in `val` when the lattice is per image and an image's rows of GW classes fit a workgroup's
-// LDS (and its registers: RPT rows per thread); returns false when the per-pass launches have to run.  GW: the fewest
-// rounds of the chip, then the widest.  WSC_CRF_BLUR_LDS=0 (read per call: a test compares the two paths) switches it off.
+// blur_lds_kernel on the rows in `val` when the lattice is per image and every image's vertex count admits a variant
+// (BL_VAR: GW classes of its rows in a workgroup's LDS, RPT rows per thread); returns false when the per-pass launches have
+// to run.  WSC_CRF_BLUR_LDS=0 (read per call: a test compares the two paths) switches it off.
 bool blur_lds(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int LP, float *val) {
     const char *e = getenv("WSC_CRF_BLUR_LDS");
     if ((e && atoi(e) == 0) || L.rep != 1 || !L.img_row || !L.bl_ok) return false;
