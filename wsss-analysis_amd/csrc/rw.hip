@@ -115,6 +115,79 @@ __global__ __launch_bounds__(256) void rw_step_kernel(const RwImg *__restrict__ 
     }
 }
 
+// The same step on 16 x 16 pixel tiles: the tile's values with a halo of RW_R pixels are staged in LDS (float64, RW_KC
+// maps at a time), a thread owns one pixel and walks the directions once per group of maps -- the two weights of a direction
+// are loaded once for the group, the neighbour values come from LDS at offsets that are uniform over the block, and nothing
+// is divided per value.  Per (map, pixel) the additions run in the order of rw_step_kernel (direction by direction, +d then
+// -d, the same predicates): bit-identical.  Directions reach at most RW_R pixels (the host checks; IRNet's radius is 5).
+// RW_KC: maps per group -- 2, 4 or 8 by the largest map count of the batch (a group costs one walk over the directions
+// whatever it holds; 5.4 KB of LDS per map).
+constexpr int RW_T = 16, RW_R = 5, RW_W = RW_T + 2 * RW_R;
+template <int RW_KC>
+__global__ __launch_bounds__(RW_T * RW_T) void rw_step_tile_kernel(const RwImg *__restrict__ imgs, const double *__restrict__ in_all,
+                                                                    const float *__restrict__ S_all,
+                                                                    const double *__restrict__ inv_col_all,
+                                                                    const int32_t *__restrict__ dirs, int D,
+                                                                    double *__restrict__ out_all, float *__restrict__ out_f32_all) {
+    __shared__ double vt[RW_KC][RW_W * RW_W];
+    const RwImg im = imgs[blockIdx.y];
+    const int h = im.h, w = im.w, hw = im.hw;
+    const int ntx = (w + RW_T - 1) / RW_T, nty = (h + RW_T - 1) / RW_T;
+    if ((int)blockIdx.x >= ntx * nty) return;
+    const int ty0 = ((int)blockIdx.x / ntx) * RW_T, tx0 = ((int)blockIdx.x % ntx) * RW_T;
+    const int ty = (int)threadIdx.x / RW_T, tx = (int)threadIdx.x % RW_T;
+    const int y = ty0 + ty, x = tx0 + tx;
+    const bool ok = y < h && x < w;
+    const int j = y * w + x;
+    const float *S = S_all + im.s_off;
+    const double ic = ok ? inv_col_all[im.e_off + j] : 0.0;
+    const int lc = (ty + RW_R) * RW_W + tx + RW_R; // the pixel's slot in the staged tile
+    for (int k0 = 0; k0 < im.K; k0 += RW_KC) {
+        const int kc = min(RW_KC, im.K - k0);
+        __syncthreads(); // (the previous group's reads are done)
+        for (int i = threadIdx.x; i < kc * RW_W * RW_W; i += RW_T * RW_T) {
+            const int k = i / (RW_W * RW_W), r = i - k * (RW_W * RW_W);
+            const int yy = ty0 - RW_R + r / RW_W, xx = tx0 - RW_R + r % RW_W;
+            double v = 0.0;
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = in_all[im.x_off + (long long)(k0 + k) * hw + yy * w + xx];
+            vt[k][r] = v;
+        }
+        __syncthreads();
+        if (ok) {
+            double acc[RW_KC];
+#pragma unroll
+            for (int k = 0; k < RW_KC; ++k) acc[k] = vt[k][lc];
+            for (int d = 0; d < D; ++d) {
+                const int dy = dirs[2 * d], dx = dirs[2 * d + 1]; // (uniform)
+                const int qy = y + dy, qx = x + dx;
+                if (qy < h && qx >= 0 && qx < w) {
+                    const double s1 = (double)S[(long long)d * hw + j];
+                    const int o = lc + dy * RW_W + dx;
+#pragma unroll
+                    for (int k = 0; k < RW_KC; ++k)
+                        if (k < kc) acc[k] += s1 * vt[k][o];
+                }
+                const int py = y - dy, px = x - dx;
+                if (py >= 0 && px >= 0 && px < w) {
+                    const double s2 = (double)S[(long long)d * hw + py * w + px];
+                    const int o = lc - dy * RW_W - dx;
+#pragma unroll
+                    for (int k = 0; k < RW_KC; ++k)
+                        if (k < kc) acc[k] += s2 * vt[k][o];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RW_KC; ++k)
+                if (k < kc) {
+                    const double r = acc[k] * ic;
+                    const long long o = im.x_off + (long long)(k0 + k) * hw + j;
+                    if (out_f32_all) out_f32_all[o] = (float)r; // the last step writes the result
+                    else out_all[o] = r;
+                }
+        }
+    }
+}
+
 __global__ void rw_mask_kernel(const RwImg *__restrict__ imgs, const float *__restrict__ x_all,
                                const float *__restrict__ edge_all, double *__restrict__ v_all,
                                float *__restrict__ v_f32_all) {
@@ -198,7 +271,33 @@ extern "C" int wsc_rw_propagate_batch(wsc_ctx *ctx, int n_img, const int32_t *K_
     hipLaunchKernelGGL(rw_mask_kernel, g_khw, dim3(256), 0, ctx->stream, imgs_dev, x_dev, edge_dev, va,
                        n_steps == 0 ? rw_dev : (float *)nullptr);
     double *cur = va, *nxt = vbuf;
+    // tiled step (values through LDS) when every direction stays inside its halo; WSC_RW_TILED=0 keeps the flat kernel
+    bool tiled = !(getenv("WSC_RW_TILED") && atoi(getenv("WSC_RW_TILED")) == 0);
+    for (int d = 0; d < D; ++d) tiled = tiled && dirs_host[2 * d] <= RW_R && std::abs(dirs_host[2 * d + 1]) <= RW_R;
+    int max_tiles = 1, max_K = 1;
+    long long all_tiles = 0;
+    for (int b = 0; b < n_img; ++b) {
+        max_K = std::max(max_K, imgs[b].K);
+        const int t = ((imgs[b].h + RW_T - 1) / RW_T) * ((imgs[b].w + RW_T - 1) / RW_T);
+        max_tiles = std::max(max_tiles, t);
+        all_tiles += t;
+    }
+    // a thread of the tiled kernel owns ALL maps of a pixel: it needs a batch that fills the chip with tiles several times
+    // over (32 images of 94 x 125 = 1536 tiles: 0.48 -> 0.31 ms per image; 16 images, 768 tiles: 2 % slower than the flat
+    // kernel; a single image, 48 tiles: 4.0 -> 5.3 ms): smaller calls keep the flat kernel
+    if (!getenv("WSC_RW_TILED")) tiled = tiled && all_tiles >= 5ll * ctx->num_cus;
     for (int s = 0; s < n_steps; ++s) {
+        if (tiled) {
+            const dim3 tg((unsigned)max_tiles, (unsigned)n_img);
+            float *of = s == n_steps - 1 ? rw_dev : (float *)nullptr;
+            if (max_K <= 2)
+                hipLaunchKernelGGL(rw_step_tile_kernel<2>, tg, dim3(RW_T * RW_T), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt, of);
+            else if (max_K <= 4)
+                hipLaunchKernelGGL(rw_step_tile_kernel<4>, tg, dim3(RW_T * RW_T), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt, of);
+            else
+                hipLaunchKernelGGL(rw_step_tile_kernel<8>, tg, dim3(RW_T * RW_T), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt, of);
+        }
+        else
         hipLaunchKernelGGL(rw_step_kernel, g_khw, dim3(256), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt,
                            s == n_steps - 1 ? rw_dev : (float *)nullptr);
         double *t = cur; cur = nxt; nxt = t;
