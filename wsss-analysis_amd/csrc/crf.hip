@@ -2443,10 +2443,12 @@ float *blur_all1(wsc_ctx *ctx, const LatticeDev &L, float *a, float *b) {
 // blur_lds_kernel on the rows in `val` when the lattice is per image and every image's vertex count admits a variant
 // (BL_VAR: GW classes of its rows in a workgroup's LDS, RPT rows per thread); returns false when the per-pass launches have
 // to run.  WSC_CRF_BLUR_LDS=0 (read per call: a test compares the two paths) switches it off.
-bool blur_lds(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int LP, float *val) {
-    const char *e = getenv("WSC_CRF_BLUR_LDS");
-    if ((e && atoi(e) == 0) || L.rep != 1 || !L.img_row || !L.bl_ok) return false;
-    const int M = L.M_cur, B = (int)L.v_per_image.size();
+// The workgroup table of blur_lds_kernel for a class count, written on the ctx's MAIN stream at the start of an inference
+// call (through the ctx's page-locked staging buffer: the host vector may be rebuilt by the next call at once), so that
+// whichever stream runs the blur later in the call is ordered behind it.
+int blur_lds_prepare(wsc_ctx *ctx, const LatticeDev &L, int M) {
+    if (L.rep != 1 || !L.img_row || !L.bl_ok) return WSC_OK;
+    const int B = (int)L.v_per_image.size();
     if (L.bl_M != M) {
         // workgroup table for this class count: the images are dealt to the 8 XCDs (workgroup b runs on XCD b % 8), an
         // image's class groups follow each other on its XCD (they read the same row lines and neighbour tables: L2 hits)
@@ -2463,12 +2465,19 @@ bool blur_lds(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int LP, float *
         h.assign(len * 8, make_int2(-1, 0));
         for (int x = 0; x < 8; ++x)
             for (size_t i = 0; i < q[x].size(); ++i) h[i * 8 + x] = q[x][i];
-        if ((int)h.size() > L.bl_cap) return false; // (the table was sized for M <= 32 at one class per workgroup)
-        if (hipMemcpyAsync(L.bl_blk, h.data(), sizeof(int2) * h.size(), hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        L.bl_M = -1;
+        if ((int)h.size() > L.bl_cap) return WSC_OK; // (sized for M <= 32 at one class per workgroup: the per-pass launches run)
+        WSC_TRY(wsc_ctx_upload_small(ctx, L.bl_blk, h.data(), sizeof(int2) * h.size()));
         L.bl_nblk = (int)h.size();
         L.bl_lds = lds;
         L.bl_M = M;
     }
+    return WSC_OK;
+}
+bool blur_lds(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int LP, float *val) {
+    const char *e = getenv("WSC_CRF_BLUR_LDS");
+    const int M = L.M_cur;
+    if ((e && atoi(e) == 0) || L.rep != 1 || !L.img_row || !L.bl_ok || L.bl_M != M) return false;
     if (L.bl_nblk == 0) return true;
     static bool attr_set[64] = {};
     const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
@@ -3131,6 +3140,7 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
 
     crf->lat[0].M_cur = M;
     crf->lat[1].M_cur = M;
+    if (n_iters > 0) WSC_TRY(blur_lds_prepare(ctx, crf->lat[1], M));
     const dim3 tgrid((N + TP - 1) / TP, B);
     if (!pixel_major) {
         WscKernelTimer timer(ctx, WSC_K_CRF_MISC, (double)npix * M * 12);
