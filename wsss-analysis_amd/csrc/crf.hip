@@ -1859,7 +1859,7 @@ constexpr int REC_LDS_BYTES = 56; // 13 dwords + 1 pad: 8-byte aligned records, 
 static_assert(TILE_PIX * REC_LDS_BYTES <= (int)(sizeof(uint2) * GATHER_ENT + sizeof(int2) * GATHER_SB), "record stage");
 template <bool SLICE, bool SPLAT, bool GF = false, bool DMA = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void update_splat_kernel(UpdateArgs a) {
-    static_assert(!DMA || (SLICE && GF), "the LDS-DMA staging belongs to the GF updates");
+    static_assert(!DMA || (SLICE && GF) || (!SLICE && SPLAT), "the LDS-DMA staging belongs to the GF updates and the first update");
     extern __shared__ f32x4_t stage[]; // [TILE_PIX][LP]
     const int LP = a.LP;
     const int gpw = 64 / LP;
@@ -2009,7 +2009,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(stage) + u0 * 16), 16, 0, 0);
         }
-        const int nR = np * 14;
+        const int nR = SLICE ? np * 14 : 0; // (the first update has no records: U rows only)
         for (int d0 = wvu * 64; d0 < nR; d0 += nwv * 64) {
             const unsigned d = min((unsigned)(d0 + lane), (unsigned)(nR - 1));
             const unsigned t = (d * 4682u) >> 16; // d / 14 for d < 4096
@@ -2962,6 +2962,8 @@ int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat, boo
         else hipLaunchKernelGGL((update_splat_kernel<true, false, true>), grid, block, lds, ctx->stream, a);
     } else if (slice && splat) hipLaunchKernelGGL((update_splat_kernel<true, true>), grid, block, lds, ctx->stream, a);
     else if (slice) hipLaunchKernelGGL((update_splat_kernel<true, false>), grid, block, lds, ctx->stream, a);
+    else if (splat && !(de && atoi(de) == 0)) // the first update: U rows staged by LDS-DMA like the E rows of the later ones
+        hipLaunchKernelGGL((update_splat_kernel<false, true, false, true>), grid, block, lds, ctx->stream, a);
     else if (splat) hipLaunchKernelGGL((update_splat_kernel<false, true>), grid, block, lds, ctx->stream, a);
     else hipLaunchKernelGGL((update_splat_kernel<false, false>), grid, block, lds, ctx->stream, a);
     WSC_HIP(hipGetLastError());
