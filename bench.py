@@ -44,7 +44,7 @@ GFLOP_PER_IMAGE = 54.923
 S = 321
 NUM_CLASSES = 20
 CRF_CFG = (1.5, 3.0, 40.0, 13.0, 10.0, 10)  # 03c_hsn/demo.py:157-165 VOC-VGG16 / DeepGlobe
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0}
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x3": 2500.0}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="images per step per GPU")
-    ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "bf16x3"])
+    ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "bf16x3", "f16x3"])
     ap.add_argument("--workload", default="cam_crf", choices=["cam_crf", "cam", "hsn"],
                     help="cam_crf: the BASELINE.json metric; cam: make_cam only; hsn: BASELINE config 5 (HistoSegNet on ADP-like "
                          "321x321 patches: VGG16 Grad-CAM -> modify_by_htt -> cs-gradcam -> dense CRF for the 29 morphological "
@@ -112,7 +112,7 @@ class Workload:
         # step i+1's conv stack (self.ctx) and lattice build (self.ctx_build) are already under way.
         self.ctx_crf = _lib.Context(device)
         self.pending = None  # lattices of the step whose mean-field loop is still in flight
-        prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3}[precision]
+        prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "f16x3": _lib.PREC_F16X3}[precision]
         # seeded random weights of the named architecture (no checkpoints offline), wsscam.synth
         if arch == "resnet50":
             self.sd = synth.resnet50_cam_state_dict(NUM_CLASSES, seed=0)
@@ -468,7 +468,7 @@ def run_hsn(args, device):
     from wsscam.net.common import grad_cam_alpha
 
     C, S_ = 31, 321
-    prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3}[args.precision]
+    prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "f16x3": _lib.PREC_F16X3}[args.precision]
     sd = synth.plain_state_dict("vgg16", C, batchnorm=False, seed=0)  # ADP models have no BatchNorm (vgg16_cam.py:16-19)
     model = vgg16_cam.CAM(None, "adp_morph", "ADP_VGG16", C, None, precision=prec)
     model.load_state_dict(sd)

@@ -60,7 +60,9 @@ typedef enum wsc_arch {
 typedef enum wsc_precision {
     WSC_PREC_BF16 = 0,  /* bf16 operands, fp32 MFMA accumulation, bf16 activations in HBM */
     WSC_PREC_BF16X3 = 1, /* split-bf16 (hi+lo) operands, 3 MFMA products: fp32-class accuracy */
-    WSC_PREC_F16 = 2     /* IEEE half operands (11-bit significand, saturating), fp32 accumulation */
+    WSC_PREC_F16 = 2,    /* IEEE half operands (11-bit significand, saturating), fp32 accumulation */
+    WSC_PREC_F16X3 = 3   /* split-half (hi+lo, 22-bit significand) operands and activations, 3 MFMA products per K-slice with
+                            both planes staged once: the fp32-class mode (reference arithmetic is fp32, SURVEY 8 header) */
 } wsc_precision;
 
 typedef struct wsc_ctx wsc_ctx; /* device + stream + workspace arena */

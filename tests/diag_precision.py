@@ -1,4 +1,4 @@
-"""Diagnostic (not a test): error statistics of the three precision modes on a 321x321 batch."""
+"""Diagnostic (not a test): error statistics of the four precision modes on a 321x321 batch."""
 import sys, os
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ for i, sz in enumerate(sizes):
     packs.append({"name": "i%d" % i, "img": cnn_ref.msf_pack(cnn_ref.synth_image(rng, *sz), (321, 321)), "size": sz, "label": lb})
 class Args: split = "train_aug"; dataset = "voc12"; cam_out_dir = None
 refs = [cnn_ref.make_cam_image(torch.from_numpy(p["img"]), sd, p["size"], torch.from_numpy(p["label"])) for p in packs]
-for name, prec in (("bf16", _lib.PREC_BF16), ("f16", _lib.PREC_F16), ("bf16x3", _lib.PREC_BF16X3)):
+for name, prec in (("bf16", _lib.PREC_BF16), ("f16", _lib.PREC_F16), ("bf16x3", _lib.PREC_BF16X3), ("f16x3", _lib.PREC_F16X3)):
     m = resnet50_cam.CAM(None, "voc12", "", 20, None, precision=prec); m.load_state_dict(sd); m.cuda(0)
     outs = make_cam.process_batch(m, packs, Args, save=False)
     raw = m.forward_batch(np.stack([p["img"] for p in packs]))

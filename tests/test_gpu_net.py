@@ -4,9 +4,10 @@ Stated tolerances on the per-class max-normalised CAM maps make_cam writes (valu
 max over every pixel of every class of every image, vs the fp32 oracle:
   f16    (default product precision): max|d| <= 2e-2      (measured 1.5e-2, mean 3e-4)
   bf16   (fast mode)                : max|d| <= 1e-1      (measured 8.3e-2, mean 2e-3)
-  bf16x3 (fp32-class mode)          : max|d| <= 2e-4      (measured 1.2e-4; the torch-CPU oracle itself
-                                                           moves by 3e-5 with its reduction order)
-and on the raw (un-normalised) CAM: f16 5e-3, bf16 3e-2, bf16x3 2e-4 (x max(cam)).
+  bf16x3 (split bf16, 16-bit operands): max|d| <= 2e-4      (measured 1.5e-4)
+  f16x3  (fp32-class mode, headline)  : max|d| <= 1e-4      (BASELINE.md section 4's bar for the FP32 mode; measured 4.4e-5 --
+                                                           the torch-CPU oracle itself moves by 3e-5 with its reduction order)
+and on the raw (un-normalised) CAM: f16 5e-3, bf16 3e-2, bf16x3 2e-4, f16x3 2e-5 (x max(cam); measured 3e-6).
 """
 import os
 
@@ -20,9 +21,9 @@ from wsscam.net import resnet50_cam, vgg16_cam, m7_cam
 
 pytestmark = pytest.mark.gpu
 
-TOL_NORM = {_lib.PREC_BF16: 1e-1, _lib.PREC_F16: 2e-2, _lib.PREC_BF16X3: 2e-4}
-TOL_RAW = {_lib.PREC_BF16: 3e-2, _lib.PREC_F16: 5e-3, _lib.PREC_BF16X3: 2e-4}
-PRECISIONS = [_lib.PREC_BF16, _lib.PREC_F16, _lib.PREC_BF16X3]
+TOL_NORM = {_lib.PREC_BF16: 1e-1, _lib.PREC_F16: 2e-2, _lib.PREC_BF16X3: 2e-4, _lib.PREC_F16X3: 1e-4}
+TOL_RAW = {_lib.PREC_BF16: 3e-2, _lib.PREC_F16: 5e-3, _lib.PREC_BF16X3: 2e-4, _lib.PREC_F16X3: 2e-5}
+PRECISIONS = [_lib.PREC_BF16, _lib.PREC_F16, _lib.PREC_BF16X3, _lib.PREC_F16X3]
 
 
 @pytest.fixture(scope="module")
@@ -81,7 +82,7 @@ def test_resnet50_make_cam_321(golden, resnet_sd, precision):
         # arg-max label agreement of the high-res maps (what eval_cam / cam_to_ir_label consume)
         if len(ref["keys"]) > 1:
             agree = (o["high_res"].argmax(0) == ref["high_res"].argmax(0)).mean()
-            assert agree >= {_lib.PREC_BF16: 0.98, _lib.PREC_F16: 0.995, _lib.PREC_BF16X3: 0.9999}[precision], agree
+            assert agree >= {_lib.PREC_BF16: 0.98, _lib.PREC_F16: 0.995, _lib.PREC_BF16X3: 0.9999, _lib.PREC_F16X3: 0.9999}[precision], agree
 
 
 def test_cam_tail_exact_vs_torch(ctx, golden):
@@ -175,7 +176,7 @@ def test_vgg16_cam(precision, batchnorm):
     assert cam[0].shape == tuple(rcam.shape) == (C, 8, 8)  # 65 -> 32 -> 16 -> 8 (three 2x2 pools)
     assert np.abs(cam[0] - rcam.numpy()).max() <= TOL_RAW[precision] * float(rcam.max())
     assert np.abs(score[0] - rscore.numpy()).max() <= {_lib.PREC_BF16: 5e-3, _lib.PREC_F16: 1e-3,
-                                                       _lib.PREC_BF16X3: 1e-4}[precision]
+                                                       _lib.PREC_BF16X3: 1e-4, _lib.PREC_F16X3: 2e-5}[precision]
 
 
 def test_m7_cam():

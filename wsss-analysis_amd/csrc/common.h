@@ -176,7 +176,8 @@ int wsc_ctx_upload_small(wsc_ctx *ctx, void *dst_dev, const void *src_host, size
 // precision every activation has a second ("lo") plane.
 struct ConvLaunch {
     const bf16_t *x, *x_lo;     // input  [N][H][W][Cin]   (Cin = 4 in small-Cin mode)
-    const bf16_t *w;            // packed [CoutPad][Kw] bf16, K order (cin/64, kh, kw, cin%64); split: [hi K | lo K]
+    const bf16_t *w;            // packed [CoutPad][Kw] 16-bit, K order (cin/64, kh, kw, cin%64); split 1 (and the small-Cin layers of
+                                // split 2): [hi K | lo K]; split 2 generic: K order (cin/32, kh, kw) x [32 hi | 32 lo]
     const float *s1, *b1;       // y = acc*s1 + b1 (folded BN, or conv bias with s1 = 1)
     const float *s2, *b2;       // optional post-ReLU affine (VGG's conv->ReLU->BN order), or null
     const bf16_t *res, *res_lo; // optional residual [M][Cout]
@@ -186,8 +187,8 @@ struct ConvLaunch {
     int kh, kw, stride, pad;
     int relu;
     int small_cin; // 0: generic (Cin % 64 == 0); else log2(slots per kernel row): 2 = 7x7 stem, 1 = 3x3 Cin<=4
-    int split;     // 1: bf16x3
-    int fmt;       // 16-bit operand format: 0 bf16, 1 f16 (split requires bf16)
+    int split;     // 0: one plane; 1: bf16x3 (three K segments); 2: f16x3 (hi + lo staged once per K-step).  The lo plane has the hi plane's format
+    int fmt;       // 16-bit operand format: 0 bf16, 1 f16 (split 1 requires bf16, split 2 f16)
 };
 int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p);
 

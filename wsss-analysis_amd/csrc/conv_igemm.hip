@@ -60,6 +60,7 @@ struct ConvKArgs {
     int fast;           // host side only: FAST variant of the kernel this launch may use (0 = generic)
     int debug;          // WSC_CONV_DEBUG ablations (timing only, results are wrong): 1 = no DMA after the
                         // first two stages, 2 = no fragment reads / MFMAs
+    long long lo_delta; // SPLIT 2: x_lo - x in elements (both planes live in one workspace block)
 };
 
 __device__ __forceinline__ int lds_off(int row, int slot) {
@@ -80,11 +81,19 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 //          prologue, no tap bounds test per DMA piece (rows past the end are clamped to the last row; their results
 //          are never stored).
 // One-K-step FAST tiles are compiled for 4 waves per SIMD (<= 128 VGPRs) so that 4 blocks of 34 KB share a CU.
-template <int BM, int BN, int MODE, bool SPLIT, int ET, bool GLDS, int STAGES, int WMT = 64, int FAST = 0>
+//
+// SPLIT: 0 = one precision plane.  1 = two planes, the K loop runs three segments x_hi*w_hi + x_lo*w_hi + x_hi*w_lo, each
+// staging its own tiles (bf16x3, and the small-Cin layers of f16x3).  2 = two planes staged ONCE (f16x3, generic layers):
+// a K-step is one (tap, 32-channel chunk); its 128-byte LDS row holds the chunk's 32 hi values in 16-byte slots 0-3 and
+// its 32 lo values in slots 4-7 (weights packed the same way), so one K-step's 4 + NB DMA pieces feed 2 k-slices x 3
+// MFMA products: 1.5x the matrix work per LDS byte of the one-plane kernel instead of 3x its staging.
+template <int BM, int BN, int MODE, int SPLIT, int ET, bool GLDS, int STAGES, int WMT = 64, int FAST = 0>
 __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void conv_igemm_kernel(ConvKArgs p) {
     constexpr bool FEPI = (FAST & 1) != 0, PW = (FAST & 2) != 0;
-    static_assert(FAST == 0 || (!SPLIT && ET == 1 && ((GLDS && MODE == 0) || FAST == 1)),
-                  "FAST paths: f16, one precision plane; the pointwise prologue belongs to the LDS-DMA layers");
+    static_assert(FAST == 0 || (SPLIT != 1 && ET == 1 && ((GLDS && MODE == 0) || FAST == 1)),
+                  "FAST paths: f16, one plane or the single-staged split; the pointwise prologue belongs to the LDS-DMA layers");
+    static_assert(SPLIT != 2 || (GLDS && MODE == 0 && STAGES == 2), "single-staged split: LDS-DMA layers, two LDS buffers");
+    constexpr int CK = SPLIT == 2 ? 32 : 64; // channels of one K-step
     constexpr int NT = BM * 2;   // threads
     constexpr int NW = BM / 32;  // waves
     // waves are laid out WR (along M) x WC (along N); a wave owns a WMT x WN tile = MI x NI MFMA tiles.
@@ -174,7 +183,9 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = lrow + RSTEP * i;
-        aoff[i] = base[i] + (slot ^ ((r >> 1) & 7)) * 8;
+        const int ks = slot ^ ((r >> 1) & 7);
+        if (SPLIT == 2) aoff[i] = base[i] + (ks & 3) * 8 + ((ks & 4) ? p.lo_delta : 0ll);
+        else aoff[i] = base[i] + ks * 8;
     }
 
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -383,9 +394,9 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
         long long n_tap = 0;
         int n_wk = 0;
         auto prep = [&]() {
-            n_src = (SPLIT && n_seg == 1) ? p.x_lo : p.x;
-            n_tap = ((long long)n_khi * p.W + n_kwi) * p.Cin + n_cc * 64;
-            n_wk = ((SPLIT && n_seg == 2) ? p.Kbase : 0) + n_ktl * 64;
+            n_src = (SPLIT == 1 && n_seg == 1) ? p.x_lo : p.x;
+            n_tap = ((long long)n_khi * p.W + n_kwi) * p.Cin + n_cc * CK;
+            n_wk = ((SPLIT == 1 && n_seg == 2) ? p.Kbase : 0) + n_ktl * 64;
         };
         auto advance = [&]() {
             // K order (channel chunk, kh, kw): the taps of one 64-channel chunk are consecutive K-steps
@@ -443,7 +454,47 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
 #pragma unroll
                 for (int i = 0; i < NB; ++i) issue_b(i, cur ^ 1);
             }
-            if (STAGES == 1 || !(p.debug & 2)) {
+            if constexpr (SPLIT == 2) {
+                // slot pairs 0, 1 = hi halves of k-slices 0, 1; slot pairs 2, 3 = their lo halves
+                u32x4_t fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];
+                auto rd = [&](int set, int sl) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fah[set][mi]) : "v"(oA[sl]), "n"(cur * A_BYTES + mi * 4096) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fal[set][mi]) : "v"(oA[2 + sl]), "n"(cur * A_BYTES + mi * 4096) : "memory");
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbh[set][ni]) : "v"(oB[sl]), "n"(cur * B_BYTES + ni * 4096) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbl[set][ni]) : "v"(oB[2 + sl]), "n"(cur * B_BYTES + ni * 4096) : "memory");
+                    }
+                };
+                rd(0, 0);
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    if (sl == 0) {
+                        rd(1, 1);
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (MI + NI)) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the two correction products first, then the main one; each product runs over all MI x NI accumulators
+                    // before the next touches them again (an accumulator's MFMAs are MI * NI issue slots apart)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) mfma(fal[sl][mi], fbh[sl][ni], acc[mi][ni]);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) mfma(fah[sl][mi], fbl[sl][ni], acc[mi][ni]);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) mfma(fah[sl][mi], fbh[sl][ni], acc[mi][ni]);
+                }
+            } else if (STAGES == 1 || !(p.debug & 2)) {
                 u32x4_t fa[2][MI], fb[2][NI];
                 auto rd = [&](int set, int ks) {
 #pragma unroll
@@ -527,6 +578,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                 if (has_res) {
                     const int mc = m < p.m_end ? m : p.m_end - 1; // clamped: always a valid row, never stored past the end
                     rres[i] = *reinterpret_cast<const uint4 *>(p.res + ((unsigned)mc * (unsigned)p.Cout + (unsigned)c));
+                    if (SPLIT) rres_lo[i] = *reinterpret_cast<const uint4 *>(p.res_lo + ((unsigned)mc * (unsigned)p.Cout + (unsigned)c));
                 }
             } else if (has_res && m < p.m_end) {
                 const long long o = (long long)m * p.Cout + c;
@@ -612,6 +664,14 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                         v[2 * j] += f16_to_f32((bf16_t)(rw[j] & 0xffffu));
                         v[2 * j + 1] += f16_to_f32((bf16_t)(rw[j] >> 16));
                     }
+                    if (SPLIT) {
+                        const uint32_t lw[4] = {rres_lo[ri].x, rres_lo[ri].y, rres_lo[ri].z, rres_lo[ri].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[2 * j] += f16_to_f32((bf16_t)(lw[j] & 0xffffu));
+                            v[2 * j + 1] += f16_to_f32((bf16_t)(lw[j] >> 16));
+                        }
+                    }
                 }
                 // ReLU and the saturation of f32_to_f16 (+-65504, no infinities) in ONE median: med3(v, lo, 65504) with
                 // lo = 0 under ReLU (max(v, 0) then min(., 65504)) and -65504 otherwise -- same values as fmaxf + the clamp,
@@ -628,15 +688,23 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                         v[4 + j] = __builtin_amdgcn_fmed3f(v[4 + j], rl, 3.0e38f) * s2b[j] + b2b[j];
                     }
                 }
-                uint32_t hw[4];
+                uint32_t hw[4], lw[SPLIT ? 4 : 1];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const _Float16 h0 = (_Float16)__builtin_amdgcn_fmed3f(v[2 * j], sat_lo, 65504.f);
-                    const _Float16 h1 = (_Float16)__builtin_amdgcn_fmed3f(v[2 * j + 1], sat_lo, 65504.f);
+                    const float c0 = __builtin_amdgcn_fmed3f(v[2 * j], sat_lo, 65504.f), c1 = __builtin_amdgcn_fmed3f(v[2 * j + 1], sat_lo, 65504.f);
+                    const _Float16 h0 = (_Float16)c0;
+                    const _Float16 h1 = (_Float16)c1;
                     hw[j] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+                    if (SPLIT) {
+                        // lo = half(value - hi): |value - hi| <= 2^-11 |value|, exact in fp32, then rounded to a (sub)normal half
+                        const _Float16 l0 = (_Float16)(c0 - (float)h0), l1 = (_Float16)(c1 - (float)h1);
+                        lw[j] = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+                    }
                 }
-                if (m < p.m_end)
+                if (m < p.m_end) {
                     *reinterpret_cast<uint4 *>(p.y + ((unsigned)m * (unsigned)p.Cout + (unsigned)c)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                    if (SPLIT) *reinterpret_cast<uint4 *>(p.y_lo + ((unsigned)m * (unsigned)p.Cout + (unsigned)c)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                }
                 continue;
             }
             if (m < p.m_end) {
@@ -663,8 +731,8 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                         const uint32_t lw[4] = {rres_lo[ri].x, rres_lo[ri].y, rres_lo[ri].z, rres_lo[ri].w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            v[2 * j] += bf16_to_f32((bf16_t)(lw[j] & 0xffffu));
-                            v[2 * j + 1] += bf16_to_f32((bf16_t)(lw[j] >> 16));
+                            v[2 * j] += h16_to_f32((bf16_t)(lw[j] & 0xffffu), ET);
+                            v[2 * j + 1] += h16_to_f32((bf16_t)(lw[j] >> 16), ET);
                         }
                     }
                 }
@@ -692,8 +760,11 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                         const bf16_t h0 = f32_to_h16(v[2 * j], ET), h1 = f32_to_h16(v[2 * j + 1], ET);
                         hw[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
                         if (SPLIT) {
-                            const bf16_t l0 = f32_to_bf16(v[2 * j] - bf16_to_f32(h0));
-                            const bf16_t l1 = f32_to_bf16(v[2 * j + 1] - bf16_to_f32(h1));
+                            // the lo plane has the hi plane's format; a value beyond the half range saturates as a whole (hi = +-65504, lo = 0)
+                            const float c0 = ET ? fminf(fmaxf(v[2 * j], -65504.f), 65504.f) : v[2 * j];
+                            const float c1 = ET ? fminf(fmaxf(v[2 * j + 1], -65504.f), 65504.f) : v[2 * j + 1];
+                            const bf16_t l0 = f32_to_h16(c0 - h16_to_f32(h0, ET), ET);
+                            const bf16_t l1 = f32_to_h16(c1 - h16_to_f32(h1, ET), ET);
                             lw[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
                         }
                     }
@@ -705,7 +776,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
     }
 }
 
-template <int BM, int BN, int MODE, bool SPLIT, int ET, int STAGES, int WMT = 64, int FAST = 0>
+template <int BM, int BN, int MODE, int SPLIT, int ET, int STAGES, int WMT = 64, int FAST = 0>
 int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     constexpr bool GLDS = MODE == 0; // LDS-DMA staging for every generic layer; small-Cin layers stage via registers
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -731,7 +802,7 @@ int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     return WSC_OK;
 }
 
-template <int BM, int BN, int MODE, bool SPLIT, int ET, int FAST = 0>
+template <int BM, int BN, int MODE, int SPLIT, int ET, int FAST = 0>
 int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
     if constexpr (BM == 256 && BN == 256) {
         return launch_stages<BM, BN, MODE, SPLIT, ET, 2, 128, FAST>(ctx, a);
@@ -739,7 +810,9 @@ int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
         return launch_stages<BM, BN, MODE, SPLIT, ET, 3, 64, FAST>(ctx, a);
     } else if constexpr (MODE == 0) {
         // a one-K-step layer (1x1 conv, 64 input channels) needs one LDS buffer: 34 KB per block, 4 blocks per CU
-        if (a.nk == 1) return launch_stages<BM, BN, MODE, SPLIT, ET, 1, 64, FAST>(ctx, a);
+        // (the single-staged split has 32-channel K-steps: never fewer than two)
+        if constexpr (SPLIT != 2)
+            if (a.nk == 1) return launch_stages<BM, BN, MODE, SPLIT, ET, 1, 64, FAST>(ctx, a);
         return launch_stages<BM, BN, MODE, SPLIT, ET, 2, 64, FAST>(ctx, a);
     } else {
         // one-K-step small-Cin layer (3x3 on <= 4 channels: VGG16 / M7 first conv): single LDS buffer, 64-row epilogue
@@ -757,6 +830,13 @@ int launch_fast(wsc_ctx *ctx, const ConvKArgs &a, int fast) {
 
 template <int BN>
 int launch_bn(wsc_ctx *ctx, const ConvKArgs &a, int small_cin, int split, int fmt) {
+    if (split == 2) { // f16x3: generic layers single-staged, small-Cin layers in three segments on half planes
+        if (small_cin == 0 && a.fast == 3) return launch_variant<128, BN, 0, 2, 1, 3>(ctx, a);
+        if (small_cin == 0 && a.fast) return launch_variant<128, BN, 0, 2, 1, 1>(ctx, a);
+        if (small_cin == 0) return launch_variant<128, BN, 0, 2, 1>(ctx, a);
+        if (small_cin == 1) return launch_variant<128, BN, 1, 1, 1>(ctx, a);
+        return launch_variant<128, BN, 2, 1, 1>(ctx, a);
+    }
     if (split) {
         if (small_cin == 0) return launch_variant<128, BN, 0, true, 0>(ctx, a);
         if (small_cin == 1) return launch_variant<128, BN, 1, true, 0>(ctx, a);
@@ -813,9 +893,12 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     };
     fastdiv((unsigned)(a.HoWo > 0 ? a.HoWo : 1), a.div_howo_mul, a.div_howo_s1, a.div_howo_s2);
     fastdiv((unsigned)(p.Wo > 0 ? p.Wo : 1), a.div_wo_mul, a.div_wo_s1, a.div_wo_s2);
+    WSC_CHECK(p.split >= 0 && p.split <= 2 && !(p.split == 1 && p.fmt) && !(p.split == 2 && !p.fmt), WSC_ERR_INVALID,
+              "conv: split mode %d with operand format %d (bf16x3 = split 1 on bf16 planes, f16x3 = split 2 on half planes)", p.split, p.fmt);
+    const bool single_staged = p.split == 2 && p.small_cin == 0;
     if (p.small_cin == 0) {
         WSC_CHECK(p.Cin % 64 == 0, WSC_ERR_INVALID, "conv: Cin=%d not a multiple of 64", p.Cin);
-        a.cchunks = p.Cin / 64;
+        a.cchunks = p.Cin / (single_staged ? 32 : 64);
         a.ntaps = p.kh * p.kw;
         a.ksteps_base = p.kh * p.kw * a.cchunks;
     } else {
@@ -825,9 +908,10 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
         // kh kernel rows, 2^small_cin slots each, 8 slots per K-step
         a.ksteps_base = ((p.kh << p.small_cin) + 7) / 8;
     }
-    a.Kbase = a.ksteps_base * 64;
-    a.Kw = a.Kbase * (p.split ? 2 : 1);
-    a.nk = a.ksteps_base * (p.split ? 3 : 1);
+    a.Kbase = a.ksteps_base * 64; // (single-staged split: a K-step's 64 weight elements are 32 hi + 32 lo)
+    a.Kw = a.Kbase * ((p.split && !single_staged) ? 2 : 1);
+    a.nk = a.ksteps_base * ((p.split && !single_staged) ? 3 : 1);
+    a.lo_delta = single_staged ? (long long)(p.x_lo - p.x) : 0;
     const int BN = p.CoutPad % 128 == 0 ? 128 : 64;
     WSC_CHECK(p.CoutPad % 64 == 0, WSC_ERR_INVALID, "conv: CoutPad=%d not a multiple of 64", p.CoutPad);
     a.ntiles_n = p.CoutPad / BN;
@@ -842,7 +926,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     const char *nfe = getenv("WSC_CONV_NOFAST"); // read per call, so a test can compare the two paths
     const int nofast = nfe ? atoi(nfe) : 0;
     a.fast = 0;
-    if (!nofast && p.fmt && !p.split && p.y != nullptr && p.y_f32 == nullptr &&
+    if (!nofast && p.fmt && (p.split == 0 || single_staged) && p.y != nullptr && p.y_f32 == nullptr &&
         p.Cout == p.CoutPad && (long long)a.M * p.Cout < (1ll << 31)) {
         a.fast = 1;
         if (p.small_cin == 0 && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1) a.fast = 3;
@@ -870,8 +954,8 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     bool square = p.small_cin == 0 && p.CoutPad % 256 == 0 && a.nk >= 4 && blocks_sq >= 192;
     if (force == 512) square = p.small_cin == 0 && p.CoutPad % 256 == 0;
     if (force != 0 && force != 512) square = false;
+    if (p.split == 2) square = big = false; // 128-row tiles only (two fragment sets of both planes + 128 accumulators do not fit)
     if (square) {
-        WSC_CHECK(!(p.split && p.fmt), WSC_ERR_INVALID, "conv: split precision requires bf16 planes");
         const int ntn = p.CoutPad / 256;
         // One block per CU: a grid of r * 256 + rem tiles takes r + 1 rounds.  When the last round would be less
         // than half full, the square tiles take whole rounds only and the remaining rows go to the 128 x 128 kernel
@@ -896,11 +980,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     }
     const int BMsel = big ? 256 : 128;
     a.nblocks = ((a.M + BMsel - 1) / BMsel) * a.ntiles_n;
-    if (big) {
-        WSC_CHECK(!(p.split && p.fmt), WSC_ERR_INVALID, "conv: split precision requires bf16 planes");
-        return launch_big(ctx, a, p.split, p.fmt);
-    }
-    WSC_CHECK(!(p.split && p.fmt), WSC_ERR_INVALID, "conv: split precision requires bf16 planes");
+    if (big) return launch_big(ctx, a, p.split, p.fmt);
     if (BN == 128) return launch_bn<128>(ctx, a, p.small_cin, p.split, p.fmt);
     return launch_bn<64>(ctx, a, p.small_cin, p.split, p.fmt);
 }

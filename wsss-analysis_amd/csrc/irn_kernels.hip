@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
         const long long o = (((long long)n * a.Hd + ho) * a.Wd + wo) * a.Ctot + a.coff + c;
         const bf16_t h = f32_to_h16(v, a.fmt);
         a.y[o] = h;
-        if (a.split) a.y_lo[o] = f32_to_bf16(v - bf16_to_f32(h));
+        if (a.split) a.y_lo[o] = f32_to_h16(v - h16_to_f32(h, a.fmt), a.fmt); // the lo plane has the hi plane's format
     }
 }
 

@@ -17,8 +17,8 @@ __global__ void nchw_to_nhwc4_kernel(const float *__restrict__ x, int N, int HW,
         const bf16_t h0 = f32_to_h16(c0, fmt), h1 = f32_to_h16(c1, fmt), h2 = f32_to_h16(c2, fmt);
         reinterpret_cast<uint2 *>(y)[i] = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2);
         if (y_lo != nullptr) {
-            const bf16_t l0 = f32_to_bf16(c0 - h16_to_f32(h0, fmt)), l1 = f32_to_bf16(c1 - h16_to_f32(h1, fmt)),
-                         l2 = f32_to_bf16(c2 - h16_to_f32(h2, fmt));
+            const bf16_t l0 = f32_to_h16(c0 - h16_to_f32(h0, fmt), fmt), l1 = f32_to_h16(c1 - h16_to_f32(h1, fmt), fmt),
+                         l2 = f32_to_h16(c2 - h16_to_f32(h2, fmt), fmt);
             reinterpret_cast<uint2 *>(y_lo)[i] = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2);
         }
     }
@@ -62,8 +62,8 @@ __global__ void maxpool_kernel(const bf16_t *__restrict__ x, const bf16_t *__res
                     const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        f[2 * j] += bf16_to_f32((bf16_t)(lw[j] & 0xffffu));
-                        f[2 * j + 1] += bf16_to_f32((bf16_t)(lw[j] >> 16));
+                        f[2 * j] += h16_to_f32((bf16_t)(lw[j] & 0xffffu), fmt);
+                        f[2 * j + 1] += h16_to_f32((bf16_t)(lw[j] >> 16), fmt);
                     }
                 }
 #pragma unroll
@@ -75,8 +75,8 @@ __global__ void maxpool_kernel(const bf16_t *__restrict__ x, const bf16_t *__res
         for (int j = 0; j < 4; ++j) {
             const bf16_t h0 = f32_to_h16(best[2 * j], fmt), h1 = f32_to_h16(best[2 * j + 1], fmt);
             hw[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            const bf16_t l0 = f32_to_bf16(best[2 * j] - h16_to_f32(h0, fmt));
-            const bf16_t l1 = f32_to_bf16(best[2 * j + 1] - h16_to_f32(h1, fmt));
+            const bf16_t l0 = f32_to_h16(best[2 * j] - h16_to_f32(h0, fmt), fmt);
+            const bf16_t l1 = f32_to_h16(best[2 * j + 1] - h16_to_f32(h1, fmt), fmt);
             lw[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
         }
         const long long oo = (((long long)n * Ho + ho) * Wo + wo) * C + c8 * 8;
@@ -169,14 +169,14 @@ __global__ __launch_bounds__(64 * GAP_WAVES) void gap_kernel(const bf16_t *__res
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 v[u] = h16_to_f32(f0[(long long)(p + u) * F], fmt);
-                if (l0) v[u] += bf16_to_f32(l0[(long long)(p + u) * F]);
+                if (l0) v[u] += h16_to_f32(l0[(long long)(p + u) * F], fmt);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) s = use_max ? fmaxf(s, v[u]) : s + v[u];
         }
         for (; p < pe; ++p) {
             float v = h16_to_f32(f0[(long long)p * F], fmt);
-            if (l0) v += bf16_to_f32(l0[(long long)p * F]);
+            if (l0) v += h16_to_f32(l0[(long long)p * F], fmt);
             s = use_max ? fmaxf(s, v) : s + v;
         }
     }
@@ -208,7 +208,7 @@ __global__ void bf16_to_f32_kernel(const bf16_t *__restrict__ x, const bf16_t *_
                                    float *__restrict__ y, int fmt) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float v = h16_to_f32(x[i], fmt);
-        if (x_lo) v += bf16_to_f32(x_lo[i]);
+        if (x_lo) v += h16_to_f32(x_lo[i], fmt);
         y[i] = v;
     }
 }
@@ -226,7 +226,7 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, int N, int C, i
         const float v = x[(n * C + c) * HW + p];
         const bf16_t h = f32_to_h16(v, fmt);
         y[i] = h;
-        if (y_lo) y_lo[i] = f32_to_bf16(v - h16_to_f32(h, fmt));
+        if (y_lo) y_lo[i] = f32_to_h16(v - h16_to_f32(h, fmt), fmt);
     }
 }
 __global__ void nhwc_to_nchw_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ x_lo, int N, int C,
@@ -240,7 +240,7 @@ __global__ void nhwc_to_nchw_kernel(const bf16_t *__restrict__ x, const bf16_t *
         const long long n = r / C;
         const long long src = (n * HW + p) * C + c;
         float v = h16_to_f32(x[src], fmt);
-        if (x_lo) v += bf16_to_f32(x_lo[src]);
+        if (x_lo) v += h16_to_f32(x_lo[src], fmt);
         y[i] = v;
     }
 }

@@ -146,19 +146,25 @@ int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, 
     }
     const int planes = net->split ? 2 : 1;
     const int Kw = Kbase * planes;
+    // f16x3 (split 2), generic layers: K order (cin / 32, kh, kw) and per K-step 32 hi values followed by their 32 lo values
+    // (conv_igemm.hip, SPLIT 2); everything else: [hi K | lo K]
+    const bool interleaved = net->split == 2 && small_cin == 0;
     std::vector<bf16_t> wp((size_t)c.CoutPad * Kw, 0);
     for (int co = 0; co < Cout; ++co) {
         bf16_t *row = wp.data() + (size_t)co * Kw;
         auto put = [&](int k, float v) {
             const bf16_t h = f32_to_h16(v, net->fmt);
+            const int lo_at = interleaved ? 32 : Kbase;
             row[k] = h;
-            if (net->split) row[Kbase + k] = f32_to_bf16(v - bf16_to_f32(h));
+            if (net->split) row[lo_at + k] = f32_to_h16(v - h16_to_f32(h, net->fmt), net->fmt);
         };
         for (int ci = 0; ci < Cin; ++ci)
             for (int r = 0; r < kh; ++r)
                 for (int s = 0; s < kw; ++s) {
                     const float v = w->data[(((size_t)co * Cin + ci) * kh + r) * kw + s];
-                    if (small_cin == 0) {
+                    if (interleaved) {
+                        put((((ci >> 5) * kh + r) * kw + s) * 64 + (ci & 31), v);
+                    } else if (small_cin == 0) {
                         put((((ci >> 6) * kh + r) * kw + s) * 64 + (ci & 63), v);
                     } else {
                         // kernel row r owns 2^small_cin slots of 8 = (2 pixels x 4 channels)
@@ -633,7 +639,8 @@ int wsc_net_create(wsc_ctx *ctx, int arch, const wsc_tensor_desc *weights, int n
                    int precision, wsc_net **out) {
     WSC_CHECK(ctx && weights && out && n_weights > 0, WSC_ERR_INVALID, "wsc_net_create: null argument");
     WSC_CHECK(num_classes > 0 && num_classes <= 64, WSC_ERR_INVALID, "num_classes=%d outside [1,64]", num_classes);
-    WSC_CHECK(precision == WSC_PREC_BF16 || precision == WSC_PREC_BF16X3 || precision == WSC_PREC_F16,
+    WSC_CHECK(precision == WSC_PREC_BF16 || precision == WSC_PREC_BF16X3 || precision == WSC_PREC_F16 ||
+                  precision == WSC_PREC_F16X3,
               WSC_ERR_INVALID, "unknown precision %d", precision);
     WSC_HIP(hipSetDevice(ctx->device));
     Dict d;
@@ -652,8 +659,8 @@ int wsc_net_create(wsc_ctx *ctx, int arch, const wsc_tensor_desc *weights, int n
     net->ctx = ctx;
     net->arch = arch;
     net->C = num_classes;
-    net->split = precision == WSC_PREC_BF16X3 ? 1 : 0;
-    net->fmt = precision == WSC_PREC_F16 ? 1 : 0;
+    net->split = precision == WSC_PREC_BF16X3 ? 1 : (precision == WSC_PREC_F16X3 ? 2 : 0);
+    net->fmt = (precision == WSC_PREC_F16 || precision == WSC_PREC_F16X3) ? 1 : 0;
     int st;
     switch (arch) {
     case WSC_ARCH_RESNET50_CAM: st = build_resnet50(net, d); break;
@@ -884,8 +891,8 @@ int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int
     WSC_HIP(hipSetDevice(ctx->device));
     wsc_net tmp;
     tmp.ctx = ctx;
-    tmp.split = precision == WSC_PREC_BF16X3 ? 1 : 0;
-    tmp.fmt = precision == WSC_PREC_F16 ? 1 : 0;
+    tmp.split = precision == WSC_PREC_BF16X3 ? 1 : (precision == WSC_PREC_F16X3 ? 2 : 0);
+    tmp.fmt = (precision == WSC_PREC_F16 || precision == WSC_PREC_F16X3) ? 1 : 0;
     HostTensor wt;
     wt.data = w_host; wt.ndim = 4; wt.shape[0] = Cout; wt.shape[1] = Cin; wt.shape[2] = kh; wt.shape[3] = kw;
     std::vector<float> s1(Cout, 1.f), b1(Cout, 0.f);

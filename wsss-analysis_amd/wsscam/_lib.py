@@ -33,6 +33,7 @@ ARCH_M7_IRN = 5
 PREC_BF16 = 0
 PREC_BF16X3 = 1
 PREC_F16 = 2
+PREC_F16X3 = 3  # split-half operands and activations (hi + lo), three MFMA products: the fp32-class mode
 
 
 class WscError(RuntimeError):
