@@ -203,7 +203,10 @@ int wsc_net_forward_gradcam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev
 /* One nn.Conv2d (+ per-channel scale/shift, residual add, ReLU) through the production
  * implicit-GEMM kernel with NCHW float32 tensors on the device -- the unit the per-layer
  * numerics tests drive (conv shape classes of SURVEY.md section 8 a4/a6).  w_host is OIHW.
- * Cin must be <= 4 (stem-style, small-Cin path) or a multiple of 64; Cout a multiple of 8. */
+ * Cin must be <= 4 (stem-style, small-Cin path) or a multiple of 64; Cout a multiple of 8.
+ * precision may be OR-ed with WSC_CONV_GENERIC: the layer then runs on the kernel's generic variants instead of the
+ * specialised ones the host picks for common layers (same arithmetic; a test holds the two to identical bits). */
+#define WSC_CONV_GENERIC 0x100
 int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int W, const float *w_host,
                     int Cout, int kh, int kw, int stride, int pad, const float *scale_host,
                     const float *shift_host, const float *residual_dev, int relu, int precision,

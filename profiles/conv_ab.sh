@@ -1,12 +1,12 @@
 #!/bin/bash
-# per-layer conv table of one build: bash profiles/conv_ab.sh <tag> [ENV=VAL ...]
-tag=$1; shift
-out=gpurun_out
-mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for v in "$@"; do export "$v"; done
-rm -rf $out/prof_$tag
-timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline --quick --workload cam > $out/${tag}_prof.log 2>&1
-python profiles/conv_layer_table.py $out/prof_$tag/*/*_results.db > $out/${tag}_conv.txt 2>&1
-rm -rf $out/prof_$tag
-cat $out/${tag}_conv.txt
+# Ablations of one conv layer with the A/B build: gpurun -- 'bash profiles/conv_ab.sh "<layer args>" [precision] [debug values]'
+# WSC_CONV_DEBUG bits: 1 no DMA after the prologue, 2 no fragment reads / MFMAs (non-rolling loops), 4 no MFMAs,
+# 8 no barrier in the rolling loop, 16 no fragment reads in the rolling loop (results are wrong by design)
+cp wsss-analysis_amd/wsscam/libwsscam.so /tmp/lib_ship.so
+cp ab_tmp/libwsscam_ab.so wsss-analysis_amd/wsscam/libwsscam.so
+L=${1:-"64 512 21 21 512 3 1 1"}
+P=${2:-f16x3}
+D=${3:-"0 1 4 5"}
+for d in $D; do WSC_CONV_DEBUG=$d python profiles/conv_one.py $L $P 0 5 | tail -1; done
+for t in 1 512; do WSC_CONV_TILE=$t python profiles/conv_one.py $L $P 0 5 | tail -1; done
+cp /tmp/lib_ship.so wsss-analysis_amd/wsscam/libwsscam.so

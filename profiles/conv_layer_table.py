@@ -1,6 +1,7 @@
 """Per-layer table of one ResNet50-CAM forward from a rocprofv3 --kernel-trace database.
 
-usage: python profiles/conv_layer_table.py <results.db> [samples=64] [size=321]
+usage: python profiles/conv_layer_table.py <results.db> [samples=64] [size=321] [planes=1]
+(planes = 2: the f16x3 trace -- 32-channel K-steps, two 16-bit planes per activation)
 The launch order of wsc_net_forward_cam (csrc/net.hip run_backbone) is fixed, so the i-th conv kernel
 after the nchw->nhwc4 layout kernel is the i-th entry of the list built here.
 """
@@ -34,21 +35,21 @@ def resnet50_layers(S):
     return L
 
 
-def n_dispatches(M, cin, cout, k, num_cus=256):
+def n_dispatches(M, cin, cout, k, num_cus=256, planes=1):
     """Launches conv_igemm_launch makes for one generic layer (csrc/conv_igemm.hip tile choice): a layer on the
     256 x 256 tile whose grid is r * 256 + rem tiles with 0 < rem <= 128 is cut into the square kernel (r whole
     rounds) and a 128 x 128 remainder launch."""
     if cin % 64 or cout % 256:
         return 1
-    nk = k * k * cin // 64
+    nk = k * k * cin // (32 if planes == 2 else 64)
     blocks_sq = ((M + 255) // 256) * (cout // 256)
-    if nk < 4 or blocks_sq < 256:
+    if nk < 4 or blocks_sq < 192:
         return 1
     rounds, rem = divmod(blocks_sq, num_cus)
     return 2 if rounds >= 1 and 0 < rem and rem * 2 <= num_cus else 1
 
 
-def main(db, N=64, S=321):
+def main(db, N=64, S=321, planes=1):
     c = sqlite3.connect(db)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if "kernel_dispatch" in t][0]
@@ -63,7 +64,7 @@ def main(db, N=64, S=321):
     pos = 0
     for (name, ho, cin, cout, k) in layers:
         M = N * ho * ho
-        nd = n_dispatches(M, cin, cout, k)
+        nd = n_dispatches(M, cin, cout, k, planes=planes)
         rs = convs[pos:pos + nd]
         pos += nd
         us = sum(r[2] - r[1] for r in rs) / 1000.0
@@ -71,6 +72,7 @@ def main(db, N=64, S=321):
         fl = 2.0 * M * cout * k * k * cin
         # 16-bit activations in + out (+ residual); weights ignored
         by = 2.0 * M * cout * (2 if "+res" in name else 1) + 2.0 * N * (ho * (2 if "s2" in name else 1)) ** 2 * cin
+        by *= planes
         print("%-44s %8.1f %8.0f %9.2f %7s %6s" % (name, us, fl / us / 1e6, by / us / 1e6, "+".join(str(r[3]) for r in rs),
                                                     "/".join("%.0f" % (r[4] / 1024.0) for r in rs)))
     print("conv kernels total %.1f us" % tot)

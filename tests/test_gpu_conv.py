@@ -130,7 +130,7 @@ def test_conv_random_shapes_sweep(ctx, precision, tol):
         assert np.abs(y - ref).max() <= tol * max(np.abs(ref).max(), 1e-3), (it, N, Cin, H, W, Cout, k, stride, pad, np.abs(y - ref).max() / np.abs(ref).max())
 
 
-@pytest.mark.parametrize("precision", [_lib.PREC_F16, _lib.PREC_BF16X3])
+@pytest.mark.parametrize("precision", [_lib.PREC_F16, _lib.PREC_BF16X3, _lib.PREC_F16X3])
 def test_conv_square_tile_large_layer(ctx, precision):
     """A layer big enough for the 256 x 256 tile (CoutPad % 256 == 0, >= 4 K-steps, >= 256 tiles: conv_igemm.hip tile
     choice; 776 tiles = 3 whole rounds on the square kernel + a 128 x 128 remainder launch), with a ragged last tile row, residual and ReLU; fp32 oracle (float64 is too slow at 58 GFLOP)."""
@@ -153,7 +153,8 @@ def test_conv_square_tile_large_layer(ctx, precision):
                      torch.from_numpy(rr)).numpy()
     mx = np.abs(ref).max()
     err = np.abs(y - ref)
-    bound = 2.0 ** -11 * np.abs(ref) + 3e-4 * mx if precision == _lib.PREC_F16 else np.full_like(ref, 1e-4 * mx)
+    # (f16x3: the fp32 oracle's own accumulation error is the larger part of the 1e-5)
+    bound = 2.0 ** -11 * np.abs(ref) + 3e-4 * mx if precision == _lib.PREC_F16 else np.full_like(ref, 1e-5 * mx if precision == _lib.PREC_F16X3 else 1e-4 * mx)
     assert not (err > bound).any(), "max err %.4g (max|ref| %.3g)" % (err.max(), mx)
 
 
@@ -161,9 +162,9 @@ def test_conv_square_tile_large_layer(ctx, precision):
                                    (2, 64, 19, 19, 64, 3, 1, 1), (2, 128, 21, 21, 128, 3, 2, 1), (2, 256, 16, 16, 512, 1, 2, 0),
                                    (3, 512, 13, 11, 512, 3, 1, 1), (2, 1024, 9, 9, 256, 1, 1, 0)])
 @pytest.mark.parametrize("precision", [_lib.PREC_F16, _lib.PREC_F16X3])
-def test_conv_fast_variants_equal_generic_path(ctx, shape, precision, monkeypatch):
+def test_conv_fast_variants_equal_generic_path(ctx, shape, precision):
     """The FAST kernel variants (case-free epilogue with ReLU + saturation as one median, pointwise prologue, one-K-step
-    tiles at 128 VGPRs, unrolled K loop) against the generic path of the same kernel (WSC_CONV_NOFAST=1, read per call):
+    tiles at 128 VGPRs, unrolled K loop) against the generic path of the same kernel (precision | CONV_GENERIC):
     the same fp16 values (0.0 == -0.0), with and without residual / ReLU, including outputs that saturate at 65504."""
     N, Cin, H, W, Cout, k, stride, pad = shape
     rng = np.random.default_rng(Cin * 7 + Cout + k)
@@ -175,9 +176,7 @@ def test_conv_fast_variants_equal_generic_path(ctx, shape, precision, monkeypatc
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     res = rng.normal(0, 1, (N, Cout, Ho, Wo)).astype(np.float32)
     for use_res, relu in [(False, True), (True, True), (True, False)]:
-        monkeypatch.setenv("WSC_CONV_NOFAST", "1")
-        y_ref = _run(ctx, x, w, stride, pad, scale, shift, res if use_res else None, relu, precision)
-        monkeypatch.setenv("WSC_CONV_NOFAST", "0")
+        y_ref = _run(ctx, x, w, stride, pad, scale, shift, res if use_res else None, relu, precision | _lib.CONV_GENERIC)
         y = _run(ctx, x, w, stride, pad, scale, shift, res if use_res else None, relu, precision)
         # (f16x3: hi saturates at 65504 and lo adds what is left of the clamped value: 65504 again)
         assert np.isfinite(y).all() and np.abs(y).max() == 65504.0

@@ -189,6 +189,7 @@ struct ConvLaunch {
     int small_cin; // 0: generic (Cin % 64 == 0); else log2(slots per kernel row): 2 = 7x7 stem, 1 = 3x3 Cin<=4
     int split;     // 0: one plane; 1: bf16x3 (three K segments); 2: f16x3 (hi + lo staged once per K-step).  The lo plane has the hi plane's format
     int fmt;       // 16-bit operand format: 0 bf16, 1 f16 (split 1 requires bf16, split 2 f16)
+    int generic;   // 1: keep the generic kernel variants (testing: the FAST variants give the same bits)
 };
 int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p);
 

@@ -32,6 +32,14 @@
 #include <cstdlib>
 #include <type_traits>
 
+// A/B knobs (tile overrides, timing-only ablations that produce wrong results) exist only in builds with -DWSC_AB_KNOBS
+// (profiles/conv_ab.sh); the shipped library has one code path per decision.
+#ifdef WSC_AB_KNOBS
+#define WSC_DBG(p, bit) ((p).debug & (bit))
+#else
+#define WSC_DBG(p, bit) 0
+#endif
+
 namespace {
 
 constexpr int BK = 64;
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
     const int kgrp = lane >> 5;
 
     auto mfma = [&](const u32x4_t &a, const u32x4_t &b, f32x16_t &c) {
+        if (WSC_DBG(p, 4)) return; // (ablation: no matrix work)
         if (ET == 0)
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
                                                         c, 0, 0, 0);
@@ -376,8 +385,8 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
             const bool ahead = kt + 2 < nk;
-            if (ahead && !(p.debug & 1)) issue_dma(kt + 2, cur == 0 ? 2 : cur - 1);
-            if (!(p.debug & 2)) compute(cur);
+            if (ahead && !WSC_DBG(p, 1)) issue_dma(kt + 2, cur == 0 ? 2 : cur - 1);
+            if (!WSC_DBG(p, 2)) compute(cur);
             if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -426,13 +435,26 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                                              (__attribute__((address_space(3))) void *)(smem + STAGES * A_BYTES + buf * B_BYTES + wv * (NB * 1024) + i * 1024),
                                              16, 0, 0);
         };
+        // ROLL (single-staged split on the 256 x 256 block): the fragment reads roll across the K-steps, see below
+        constexpr bool ROLL = SPLIT == 2 && WMT == 128;
         prep();
 #pragma unroll
         for (int i = 0; i < 4; ++i) issue_a(i, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i) issue_b(i, 0);
         advance();
-        __syncthreads();
+        if (ROLL && nk > 1) { // two stages ahead; the first one has landed when all but the newest 4 + NB pieces have
+            prep();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_a(i, 1);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) issue_b(i, 1);
+            advance();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NB) : "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            __syncthreads();
+        }
         // Fragment read addresses: lds_off(row + 32 mi, sl) = lds_off(row, sl) + 4096 mi (the swizzle term (row >> 1) & 7 does not
         // see multiples of 32), so one VGPR per k-slice and operand serves every mi / ni through the instruction's immediate
         // offset, which also carries the buffer (the K loop is unrolled by two so that `cur` is a constant): no address VALU
@@ -446,17 +468,30 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
         auto kstep = [&](auto cur_c, int kt) __attribute__((always_inline)) {
             constexpr int cur = decltype(cur_c)::value;
             const unsigned(&oA)[4] = offA, (&oB)[4] = offB; // (named here: the nested lambda below must not be the first use)
-            const bool more = kt + 1 < nk && !(p.debug & 1);
+            const bool more = kt + 1 < nk && !WSC_DBG(p, 1);
             if (more) {
                 prep();
+                if (SPLIT != 2) { // (the single-staged split spreads its pieces over the MFMAs, below)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) issue_a(i, cur ^ 1);
+                    for (int i = 0; i < 4; ++i) issue_a(i, cur ^ 1);
 #pragma unroll
-                for (int i = 0; i < NB; ++i) issue_b(i, cur ^ 1);
+                    for (int i = 0; i < NB; ++i) issue_b(i, cur ^ 1);
+                }
             }
             if constexpr (SPLIT == 2) {
                 // slot pairs 0, 1 = hi halves of k-slices 0, 1; slot pairs 2, 3 = their lo halves
                 u32x4_t fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];
+                // the next K-step's 4 + NB DMA pieces go out one at a time between this K-step's 6 MI NI MFMAs (issued back to
+                // back at the top of the step they queue in front of the texture addresser and hold the wave in its issue stage)
+                constexpr int EVERY = (6 * MI * NI) / (4 + NB);
+                static_assert(EVERY >= 1, "a K-step has room for every DMA piece");
+                auto piece = [&](int j) {
+                    if (!more || j % EVERY != 0) return;
+                    const int q = j / EVERY;
+                    if (q < 4) issue_a(q, cur ^ 1);
+                    else if (q < 4 + NB) issue_b(q - 4, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
                 auto rd = [&](int set, int sl) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
@@ -484,17 +519,26 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) mfma(fal[sl][mi], fbh[sl][ni], acc[mi][ni]);
+                        for (int ni = 0; ni < NI; ++ni) {
+                            mfma(fal[sl][mi], fbh[sl][ni], acc[mi][ni]);
+                            piece((sl * 3 + 0) * MI * NI + mi * NI + ni);
+                        }
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) mfma(fah[sl][mi], fbl[sl][ni], acc[mi][ni]);
+                        for (int ni = 0; ni < NI; ++ni) {
+                            mfma(fah[sl][mi], fbl[sl][ni], acc[mi][ni]);
+                            piece((sl * 3 + 1) * MI * NI + mi * NI + ni);
+                        }
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) mfma(fah[sl][mi], fbh[sl][ni], acc[mi][ni]);
+                        for (int ni = 0; ni < NI; ++ni) {
+                            mfma(fah[sl][mi], fbh[sl][ni], acc[mi][ni]);
+                            piece((sl * 3 + 2) * MI * NI + mi * NI + ni);
+                        }
                 }
-            } else if (STAGES == 1 || !(p.debug & 2)) {
+            } else if (STAGES == 1 || !WSC_DBG(p, 2)) {
                 u32x4_t fa[2][MI], fb[2][NI];
                 auto rd = [&](int set, int ks) {
 #pragma unroll
@@ -529,6 +573,111 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
             __syncthreads();
         };
         static_assert(A_BYTES + (MI - 1) * 4096 < 65536 && B_BYTES + (NI - 1) * 4096 < 65536, "ds_read immediate offset range");
+        if constexpr (ROLL) {
+            // 128 x 64 per wave: 128 accumulators leave room for ONE set of fragments (lo(A), hi(A): MI, lo(B), hi(B): NI
+            // registers x 4), so a slice's operands are re-requested for the NEXT slice as soon as the last MFMA that reads
+            // them has been issued -- lo(A) after the first product, lo(B) after the second, the hi pair after the third --
+            // and the requests roll on across the K-steps: the ONE barrier of a K-step sits between its two k-slices, when
+            // every read of its LDS buffer has been issued.  Behind it the buffer is refilled (K-step kt + 2) and the second
+            // slice's MFMAs cover the first reads of the next buffer, whose DMA was issued a whole K-step earlier.
+            // (With the barrier at the end of the K-step all eight waves waited together for 12 KB of fragments each.)
+            // LDS returns in order: lgkmcnt(n) = "all but the n newest reads have landed".
+            u32x4_t fah[MI], fal[MI], fbh[NI], fbl[NI];
+            // `dma` (the K-step's second slice): the 4 + NB LDS-DMA pieces of K-step kt + 2 go out one at a time between the MFMAs
+            // (one piece per three MFMAs).  Issued back to back behind the barrier, the 64 pieces of the eight waves queued
+            // in front of the texture addresser and every wave sat in its issue stage meanwhile -- no wave fed the matrix
+            // pipe (DMA and MFMA time ADDED up: ablations in profiles/README.md).
+            auto slice = [&](auto buf_c, auto pair_c, bool more, bool dma, int dbuf) __attribute__((always_inline)) {
+                constexpr int nbuf = decltype(buf_c)::value, npair = decltype(pair_c)::value; // where the NEXT slice lives
+                const unsigned(&oA)[4] = offA, (&oB)[4] = offB;
+                auto piece = [&](int j) { // after MFMA j of the slice (0 .. 3 MI NI - 1)
+                    if (!dma || j % 3 != 0) return;
+                    const int q = j / 3;
+                    if (q < 4) issue_a(q, dbuf);
+                    else if (q < 4 + NB) issue_b(q - 4, dbuf);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                static_assert(3 * MI * NI >= 3 * (4 + NB), "a slice has room for every DMA piece");
+                auto rdA = [&](u32x4_t(&f)[MI], int pair) {
+                    if (WSC_DBG(p, 16)) return; // (ablation: no fragment reads)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[mi]) : "v"(oA[pair]), "n"(nbuf * A_BYTES + mi * 4096) : "memory");
+                };
+                auto rdB = [&](u32x4_t(&f)[NI], int pair) {
+                    if (WSC_DBG(p, 16)) return;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[ni]) : "v"(oB[pair]), "n"(nbuf * B_BYTES + ni * 4096) : "memory");
+                };
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI) : "memory"); // lo(A), lo(B), hi(B) are here, hi(A) may be in flight
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        mfma(fal[mi], fbh[ni], acc[mi][ni]);
+                        piece(mi * NI + ni);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    rdA(fal, 2 + npair);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI) : "memory"); // hi(A)
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        mfma(fah[mi], fbl[ni], acc[mi][ni]);
+                        piece(MI * NI + mi * NI + ni);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) rdB(fbl, 2 + npair);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        mfma(fah[mi], fbh[ni], acc[mi][ni]);
+                        piece(2 * MI * NI + mi * NI + ni);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    rdB(fbh, npair);
+                    rdA(fah, npair);
+                }
+            };
+            {   // first slice of K-step 0, in the order the rolling requests have: lo(A), lo(B), hi(B), hi(A)
+                const unsigned(&oA)[4] = offA, (&oB)[4] = offB;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fal[mi]) : "v"(oA[2]), "n"(mi * 4096) : "memory");
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbl[ni]) : "v"(oB[2]), "n"(ni * 4096) : "memory");
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbh[ni]) : "v"(oB[0]), "n"(ni * 4096) : "memory");
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fah[mi]) : "v"(oA[0]), "n"(mi * 4096) : "memory");
+            }
+            auto rstep = [&](auto cur_c, int kt) __attribute__((always_inline)) {
+                constexpr int cur = decltype(cur_c)::value;
+                slice(std::integral_constant<int, cur>{}, std::integral_constant<int, 1>{}, true, false, 0); // slice 0; requests slice 1
+                if (WSC_DBG(p, 8)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // (ablation: no barrier)
+                else
+                __syncthreads(); // every read of buffer `cur` has landed, for every wave; so has the DMA of K-step kt + 1
+                const bool refill = kt + 2 < nk && !WSC_DBG(p, 1);
+                if (refill) prep();
+                // slice 1; requests the next K-step's slice 0 and refills buffer `cur`
+                slice(std::integral_constant<int, cur ^ 1>{}, std::integral_constant<int, 0>{}, kt + 1 < nk, refill, cur);
+                if (refill) advance();
+            };
+            for (int kt = 0; kt < nk; kt += 2) {
+                rstep(std::integral_constant<int, 0>{}, kt);
+                if (kt + 1 < nk) rstep(std::integral_constant<int, 1>{}, kt + 1);
+            }
+            __syncthreads(); // the epilogue reuses the LDS
+        } else
         for (int kt = 0; kt < nk; kt += 2) {
             kstep(std::integral_constant<int, 0>{}, kt);
             if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
@@ -822,10 +971,10 @@ int launch_variant(wsc_ctx *ctx, const ConvKArgs &a) {
 }
 
 // f16 LDS-DMA layer on its FAST variant (fast = 1: epilogue, 3: epilogue + pointwise)
-template <int BM, int BN>
+template <int BM, int BN, int SPLIT = 0>
 int launch_fast(wsc_ctx *ctx, const ConvKArgs &a, int fast) {
-    if (fast == 3) return launch_variant<BM, BN, 0, false, 1, 3>(ctx, a);
-    return launch_variant<BM, BN, 0, false, 1, 1>(ctx, a);
+    if (fast == 3) return launch_variant<BM, BN, 0, SPLIT, 1, 3>(ctx, a);
+    return launch_variant<BM, BN, 0, SPLIT, 1, 1>(ctx, a);
 }
 
 template <int BN>
@@ -864,6 +1013,7 @@ int launch_big(wsc_ctx *ctx, const ConvKArgs &a, int split, int fmt) {
 }
 // 256 x 256 tile, 128 x 64 per wave (generic layers with CoutPad % 256 == 0 only)
 int launch_square(wsc_ctx *ctx, const ConvKArgs &a, int split, int fmt) {
+    if (split == 2) return a.fast ? launch_fast<256, 256, 2>(ctx, a, a.fast) : launch_variant<256, 256, 0, 2, 1>(ctx, a);
     if (split) return launch_variant<256, 256, 0, true, 0>(ctx, a);
     if (fmt && a.fast) return launch_fast<256, 256>(ctx, a, a.fast);
     if (fmt) return launch_variant<256, 256, 0, false, 1>(ctx, a);
@@ -916,15 +1066,17 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     WSC_CHECK(p.CoutPad % 64 == 0, WSC_ERR_INVALID, "conv: CoutPad=%d not a multiple of 64", p.CoutPad);
     a.ntiles_n = p.CoutPad / BN;
     a.zero = (const bf16_t *)ctx->zero_page;
-    // timing-only ablations; honoured only together with WSC_ALLOW_WRONG_RESULTS=1
-    static const int debug = [] {
-        const char *e = getenv("WSC_CONV_DEBUG"), *ok = getenv("WSC_ALLOW_WRONG_RESULTS");
-        return (e && ok && atoi(ok) == 1) ? atoi(e) : 0;
-    }();
+#ifdef WSC_AB_KNOBS
+    // timing-only ablations (wrong results): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = no MFMAs
+    static const int debug = [] { const char *e = getenv("WSC_CONV_DEBUG"); return e ? atoi(e) : 0; }();
     a.debug = debug;
-    // FAST variants (see the kernel): f16, one precision plane, fp16 output only, full column tiles, no post-ReLU affine
-    const char *nfe = getenv("WSC_CONV_NOFAST"); // read per call, so a test can compare the two paths
-    const int nofast = nfe ? atoi(nfe) : 0;
+#else
+    a.debug = 0;
+#endif
+    // FAST variants (see the kernel): f16, one precision plane (or the single-staged split), fp16 output only, full column
+    // tiles, no post-ReLU affine.  p.generic (wsc_conv2d_nchw's WSC_CONV_GENERIC flag) keeps the generic variants: a test
+    // holds the two to the same bits.
+    const int nofast = p.generic;
     a.fast = 0;
     if (!nofast && p.fmt && (p.split == 0 || single_staged) && p.y != nullptr && p.y_f32 == nullptr &&
         p.Cout == p.CoutPad && (long long)a.M * p.Cout < (1ll << 31)) {
@@ -940,7 +1092,11 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     // lost 10 %.
     // WSC_CONV_TILE (A/B runs): 256 selects the 256x128 tile wherever it applies, -1 where K >= 512, 512 the
     // 256x256 tile wherever CoutPad % 256 == 0, 1 (any other value) the 128-row tiles everywhere.
+#ifdef WSC_AB_KNOBS
     static const int force = [] { const char *e = getenv("WSC_CONV_TILE"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int force = 0;
+#endif
     const long long blocks256 = ((a.M + 255) / 256) * (long long)a.ntiles_n;
     bool big = false;
     if (force == -1) big = p.small_cin == 0 && BN == 128 && a.Kbase >= 512 && blocks256 >= 200;
@@ -954,7 +1110,8 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     bool square = p.small_cin == 0 && p.CoutPad % 256 == 0 && a.nk >= 4 && blocks_sq >= 192;
     if (force == 512) square = p.small_cin == 0 && p.CoutPad % 256 == 0;
     if (force != 0 && force != 512) square = false;
-    if (p.split == 2) square = big = false; // 128-row tiles only (two fragment sets of both planes + 128 accumulators do not fit)
+    if (p.split == 2) big = false; // (the three-buffer 256 x 128 tile has no single-staged variant)
+    if (p.split == 2 && !a.fast) square = false; // (its generic epilogue next to 128 accumulators + both planes' fragments spills)
     if (square) {
         const int ntn = p.CoutPad / 256;
         // One block per CU: a grid of r * 256 + rem tiles takes r + 1 rounds.  When the last round would be less
@@ -962,7 +1119,11 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
         // (<= 512 tiles = one round at 2 blocks per CU, ~0.56 of a square round): VGG16 conv4 (840 tiles) 4 -> 3.6
         // rounds.  The two launches write disjoint output rows.
         const long long rounds = blocks_sq / ctx->num_cus, rem = blocks_sq - rounds * ctx->num_cus;
+#ifdef WSC_AB_KNOBS
         static const int nosplit = [] { const char *e = getenv("WSC_CONV_NOSPLIT"); return e ? atoi(e) : 0; }();
+#else
+        constexpr int nosplit = 0;
+#endif
         if (!nosplit && rounds >= 1 && rem > 0 && rem * 2 <= ctx->num_cus && ctx->num_cus > 0) {
             const int big_rows = (int)((rounds * ctx->num_cus) / ntn); // 256-row tile rows given to the square kernel
             ConvKArgs b = a;

@@ -891,6 +891,9 @@ int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int
     WSC_HIP(hipSetDevice(ctx->device));
     wsc_net tmp;
     tmp.ctx = ctx;
+    const int generic = (precision & WSC_CONV_GENERIC) ? 1 : 0;
+    precision &= ~WSC_CONV_GENERIC;
+    WSC_CHECK(precision >= WSC_PREC_BF16 && precision <= WSC_PREC_F16X3, WSC_ERR_INVALID, "unknown precision %d", precision);
     tmp.split = precision == WSC_PREC_BF16X3 ? 1 : (precision == WSC_PREC_F16X3 ? 2 : 0);
     tmp.fmt = (precision == WSC_PREC_F16 || precision == WSC_PREC_F16X3) ? 1 : 0;
     HostTensor wt;
@@ -932,6 +935,7 @@ int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int
         L.N = N; L.H = H; L.W = W; L.Cin = c.Cin; L.Ho = Ho; L.Wo = Wo; L.Cout = Cout; L.CoutPad = c.CoutPad;
         L.kh = kh; L.kw = kw; L.stride = stride; L.pad = pad; L.relu = relu; L.small_cin = small; L.split = tmp.split;
         L.fmt = tmp.fmt;
+        L.generic = generic;
         st = conv_igemm_launch(ctx, L);
     }
     if (st == WSC_OK) st = launch_nhwc_to_nchw(ctx, yo, yo_lo, N, Cout, Ho * Wo, y_dev, tmp.fmt);

@@ -34,6 +34,7 @@ PREC_BF16 = 0
 PREC_BF16X3 = 1
 PREC_F16 = 2
 PREC_F16X3 = 3  # split-half operands and activations (hi + lo), three MFMA products: the fp32-class mode
+CONV_GENERIC = 0x100  # conv2d_nchw only: OR into precision to keep the kernel's generic variants (testing)
 
 
 class WscError(RuntimeError):
