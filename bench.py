@@ -16,10 +16,16 @@ in HBM (BASELINE config 2/3: ResNet50 CAM + dense-CRF, 321x321, batch 32 images 
 N > 1: one process per GPU (torch.distributed.run), every rank owns its own batch (the dataset is
 image-sharded, images[g::G]); no data-path collective, only the timing barrier.  scaling = weak.
 
-Besides the headline (`value`: inputs resident in HBM, f16 operands) the same JSON line carries, under `stages`
-(rank 0, N = 1; --quick skips them): `value_bf16x3` (the fp32-class precision mode), `value_M_eq_Kplus1` (SURVEY
-config 3's other variant: one CRF per group of images with the same K, M = K+1), `value_end_to_end` (pageable host
-batch -> pinned staging -> H2D, D2H of cam / high_res / labels, np.save through writer threads).
+The headline (`value`, `dtype` "f16x3") runs the conv stack in the fp32-class mode -- split-half operands and activations,
+three MFMA products per term (the reference's arithmetic is fp32); the mean-field loop is fp32 throughout.  Inputs are
+resident in HBM.  The same JSON line carries (rank 0, N = 1; --quick skips the extras): `value_steady` (>= 10 s of steps
+cycling over four distinct resident batches), `roofline` with the two fractions the north star names (`conv_mfma`,
+`crf_hbm`; `frac` = algorithmic rate / peak, `frac_traffic` = measured HBM traffic / peak), `parity` (final label maps of
+the product chain against the all-fp32 oracle chain on images of this batch -- computed inside the cpu_baseline leg, the
+only place bench.py touches oracle/), and under `stages`: `sum_ms` (sum of the stage times: what the step would take
+without overlap), `value_f16` (the fast half-precision mode), `value_M_eq_Kplus1` (SURVEY config 3's other variant:
+M = K + 1 per image), `value_end_to_end` (pageable host batch -> pinned staging -> H2D, D2H of cam / high_res / labels,
+np.save through writer threads).
 --scaling strong: the K steps are a FIXED set of K*batch images sharded over the ranks (rank g runs ceil(K/N) steps).
 
 Prints ONE JSON line on rank 0.
@@ -44,7 +50,9 @@ GFLOP_PER_IMAGE = 54.923
 S = 321
 NUM_CLASSES = 20
 CRF_CFG = (1.5, 3.0, 40.0, 13.0, 10.0, 10)  # 03c_hsn/demo.py:157-165 VOC-VGG16 / DeepGlobe
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x3": 2500.0}
+# dense 16-bit MFMA peak (MI355X_MICROARCH.md); the split modes spend three MFMA products per algorithmic multiply-add, so
+# the peak of THAT arithmetic is a third of it (the native fp32-input MFMA peak is 157 TFLOP/s)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0 / 3, "f16x3": 2500.0 / 3}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -54,7 +62,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="images per step per GPU")
-    ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "bf16x3", "f16x3"])
+    ap.add_argument("--precision", default="f16x3", choices=["bf16", "f16", "bf16x3", "f16x3"],
+                    help="conv operand mode: f16x3 = fp32-class (headline), f16 / bf16 = fast 16-bit modes, bf16x3 = the round-1 split")
     ap.add_argument("--workload", default="cam_crf", choices=["cam_crf", "cam", "hsn"],
                     help="cam_crf: the BASELINE.json metric; cam: make_cam only; hsn: BASELINE config 5 (HistoSegNet on ADP-like "
                          "321x321 patches: VGG16 Grad-CAM -> modify_by_htt -> cs-gradcam -> dense CRF for the 29 morphological "
@@ -63,7 +72,8 @@ def parse():
                     help="CAM network (resnet50 is the BASELINE.json configuration; vgg16 / m7 are extra "
                          "measurements of the other conv stacks of the reference, 03b_irn/net/{vgg16,m7}.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--quick", action="store_true", help="skip the extra stage measurements (bf16x3, M=K+1, end-to-end)")
+    ap.add_argument("--quick", action="store_true", help="skip the extra measurements (steady-state leg, f16, M=K+1, end-to-end)")
+    ap.add_argument("--steady-seconds", type=float, default=10.0, help="length of the value_steady leg (0 = skip)")
     ap.add_argument("--seconds", type=float, default=0.0,
                     help="steady-state run: raise --steps so that the timed region lasts at least this long")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -139,6 +149,7 @@ class Workload:
         ctx = self.ctx
         self.x_dev = ctx.to_device(self.x_host)
         self.rgb_dev = ctx.to_device(self.rgb_host)
+        self.x_devs, self.rgb_devs = [self.x_dev], [self.rgb_dev]  # resident batches; add_resident_batches() adds more
         self.cam_dev = ctx.alloc(batch * NUM_CLASSES * self.h * self.h * 4)
         # native-size make_cam outputs
         self.s_tot = sum(len(k) * ((H - 1) // 4 + 1) * ((W - 1) // 4 + 1) for k, (H, W) in zip(self.keys, self.sizes))
@@ -154,6 +165,21 @@ class Workload:
         self.parity = 0
         self.vg = self.vb = None
         self.e2e = None
+
+    def add_resident_batches(self, n, seed):
+        """n - 1 more batches of DIFFERENT images (same native sizes and labels, so the tail's geometry is unchanged) for the
+        steady-state leg: the step then cannot live on inputs that stay in the 256 MB Infinity Cache."""
+        from wsscam import synth
+
+        for j in range(1, n):
+            x, rgb, sizes = synth.image_batch(self.B, S, seed + j * len(synth.VOC_SIZES))
+            assert sizes == self.sizes
+            self.x_devs.append(self.ctx.to_device(x))
+            self.rgb_devs.append(self.ctx.to_device(rgb))
+
+    def next_batch(self):
+        self.bi = (getattr(self, "bi", 0) + 1) % len(self.x_devs)
+        self.x_dev, self.rgb_dev = self.x_devs[self.bi], self.rgb_devs[self.bi]
 
     def close(self):
         self.drain()
@@ -384,12 +410,14 @@ class Workload:
         return self.ctx.timer_end() / reps
 
 
-def cpu_baseline(wl, budget_s):
-    """Oracle on the host cores (the only place bench.py touches oracle/): torch-CPU fp32 restatement of
+def cpu_baseline(wl, budget_s, product_labels=None):
+    """-> (cpu_baseline object, parity object or None).
+    Oracle on the host cores (the only place bench.py touches oracle/): torch-CPU fp32 restatement of
     make_cam._work (batch = 1 image, as the reference runs it) + the C dense-CRF restatement, once single-threaded
     (pydensecrf is single-threaded per image) and once over images in parallel (one image per thread: what an
     OpenMP-over-images loop around the reference's per-image CRF gives).  kind = "port": the reference itself cannot
-    travel to the GPU box."""
+    travel to the GPU box.  The label maps the oracle chain produces for the first images of the batch are compared with
+    `product_labels` (the product chain's labels of the same images, int32 [B][S*S]): the `parity` object."""
     import numpy as np
     import torch
     from concurrent.futures import ThreadPoolExecutor
@@ -430,7 +458,7 @@ def cpu_baseline(wl, budget_s):
         n_cam += 1
     if wl.workload != "cam_crf":
         return {"value": round(n_cam / t_cam, 4), "unit": "images/s", "cores": cores, "kind": "port",
-                "sample": "%d images torch-CPU fp32 ResNet50-CAM+tail (%.2f s/img, %d threads)" % (n_cam, t_cam / n_cam, cores)}
+                "sample": "%d images torch-CPU fp32 ResNet50-CAM+tail (%.2f s/img, %d threads)" % (n_cam, t_cam / n_cam, cores)}, None
 
     def unary_of(i):
         with torch.no_grad():
@@ -444,17 +472,25 @@ def cpu_baseline(wl, budget_s):
     threads = max(1, min(ncpu, 64))
     n_par = max(threads, int(budget_s * 0.4 / max(t_crf1, 1e-3)) * threads)
     n_par = min(n_par, 4 * threads)
-    us = [unary_of(i) for i in range(min(n_cam, 4))]
+    n_lab = min(n_cam, 8)                                               # images whose oracle labels are kept (image i with ITS unaries)
+    us = [unary_of(i) for i in range(n_lab)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C oracle
-        list(ex.map(lambda i: helpers.crf_oracle(wl.rgb_host[i % wl.B], us[i % len(us)], CRF_CFG), range(n_par)))
+        res = list(ex.map(lambda i: helpers.crf_oracle(wl.rgb_host[i % n_lab], us[i % n_lab], CRF_CFG)[1], range(n_par)))
     crf_rate = n_par / (time.perf_counter() - t0)                       # images/s, `threads` images in flight
     per_img = t_cam / n_cam + 1.0 / crf_rate
+    parity = None
+    if product_labels is not None:
+        n_chk = min(n_lab, n_par)
+        parity = helpers.label_parity(product_labels[:n_chk], np.stack(res[:n_chk]), NUM_CLASSES + 1)
+        parity = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in parity.items()}
+        parity["against"] = ("all-fp32 oracle chain (torch-CPU ResNet50-CAM -> make_cam tail -> [bg | maps] unaries -> C dense-CRF) "
+                             "on the first %d images of this batch; labels scored as eval_cam scores pseudo-labels" % n_chk)
     return {"value": round(1.0 / per_img, 4), "unit": "images/s", "cores": max(cores, threads), "kind": "port",
             "value_crf_single_thread": round(1.0 / (t_cam / n_cam + t_crf1), 4),
             "sample": "%d images torch-CPU fp32 ResNet50-CAM+tail (%.3f s/img, %d threads) + C dense-CRF M=21 T=10: %d images over "
                       "%d threads, one image per thread (%.1f images/s; %.2f s/img on one thread)"
-                      % (n_cam, t_cam / n_cam, cores, n_par, threads, crf_rate, t_crf1)}
+                      % (n_cam, t_cam / n_cam, cores, n_par, threads, crf_rate, t_crf1)}, parity
 
 
 def run_hsn(args, device):
@@ -584,6 +620,23 @@ def main():
         elapsed = float(t.item())
         dist.barrier()
 
+    # ---- steady state: >= --steady-seconds of steps cycling over four distinct resident batches (rank 0 of a 1-GPU run) ----
+    steady = None
+    if world == 1 and args.workload == "cam_crf" and not args.quick and args.steady_seconds > 0:
+        wl.add_resident_batches(4, seed=rank)
+
+        def cycle_step():
+            wl.next_batch()
+            do_step()
+
+        probe = timed_run(wl, cycle_step, 4, 2, wl.drain) / 4
+        n_st = int(1.03 * args.steady_seconds / probe) + 1
+        t_st = timed_run(wl, cycle_step, n_st, 0, wl.drain)
+        steady = {"value": round(args.batch * n_st / t_st, 3), "steps": n_st, "seconds": round(t_st, 3),
+                  "ms_per_step": round(t_st / n_st * 1e3, 4), "resident_batches": len(wl.x_devs)}
+        wl.bi = len(wl.x_devs) - 1
+        wl.next_batch()  # back to batch 0 for the stage measurements below
+
     # ---- per-stage device times (HIP events on the ctx stream), same resident inputs -------------
     reps = 5
     t_cnn = wl.timed(wl.run_cnn, reps)
@@ -601,6 +654,7 @@ def main():
         crf.close()
         vg, vb = float(wl.vg.mean()), float(wl.vb.mean())
         by = crf_bytes_per_image(S * S, NUM_CLASSES + 1, CRF_CFG[5], vg, vb)
+        stages["sum_ms"] = round(t_cnn + t_tail + t_un + t_create + t_inf, 4)  # the step without any overlap
         stages.update({"unary_ms": round(t_un, 4), "crf_create_ms": round(t_create, 4), "crf_infer_ms": round(t_inf, 4),
                        "lattice_vertices_gauss": round(vg, 1), "lattice_vertices_bilat": round(vb, 1),
                        "crf_loop_algorithmic_GBps": round(by * wl.B / (t_inf * 1e-3) / 1e9, 2)})
@@ -622,7 +676,7 @@ def main():
     dom = max((n for n in prof if n != "crf_build(all)"), key=lambda n: prof[n][1])
     calls, ms, work = prof[dom]
     if dom.startswith("conv_igemm"):
-        roofline = {"bound": "mfma", "achieved": round(work / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[args.precision],
+        roofline = {"bound": "mfma", "achieved": round(work / (ms * 1e-3) / 1e12, 2), "peak": round(PEAK_TFLOPS[args.precision], 1),
                     "unit": "TFLOP/s", "traffic": None}
     else:
         roofline = {"bound": "hbm", "achieved": round(work / (ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
@@ -634,26 +688,59 @@ def main():
     # inside the process; the figure is the one committed under profiles/ from the PMC passes of the same command
     # (profiles/collect.sh -> profiles/hbm_traffic.json).  Only the default workload is profiled there.
     tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
-    default_wl = (args.workload == "cam_crf" and args.arch == "resnet50" and args.batch == 32 and args.precision == "f16")
+    default_wl = (args.workload == "cam_crf" and args.arch == "resnet50" and args.batch == 32 and args.precision == "f16x3")
+    traffic_classes = {}
     if default_wl and os.path.exists(tj):
         with open(tj) as fh:
-            cls = json.load(fh).get("classes", {}).get(dom)
-        if cls:
-            roofline["traffic"] = cls["bytes_per_launch"]
-            roofline["traffic_source"] = ("committed: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE "
-                                          "passes of this command, %s); not re-measured in this run" % cls.get("round", "r02"))
+            traffic_classes = json.load(fh).get("classes", {})
+
+    def add_traffic(obj, cls_name, per_launch_us):
+        """HBM bytes per launch of the class from the committed PMC passes -> traffic, frac_traffic (real bytes / peak)."""
+        cls = traffic_classes.get(cls_name)
+        if not cls:
+            return
+        obj["traffic"] = cls["bytes_per_launch"]
+        obj["frac_traffic"] = round(cls["bytes_per_launch"] / (per_launch_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
+        obj["traffic_source"] = ("committed: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this "
+                                 "command, %s); not re-measured in this run" % cls.get("round", "r02"))
+
     roofline["avg_launch_us"] = round(ms / calls * 1e3, 2)
     roofline["launches_per_step"] = calls // 2
+    if roofline["bound"] == "hbm":
+        add_traffic(roofline, dom, ms / calls * 1e3)
+    # the two fractions the north star names, whichever class dominates:
+    #   conv_mfma -- the whole conv stack (every conv_igemm launch of a step): algorithmic FLOPs (one product per term) over
+    #                the summed kernel time against the dense 16-bit MFMA peak; `executed` counts the three products of f16x3
+    #   crf_hbm   -- update_splat_kernel, the mean-field loop's dominant kernel: SURVEY 8(d) bytes it covers per launch
+    conv = [(c, m, w) for n, (c, m, w) in prof.items() if n.startswith("conv_igemm")]
+    if conv:
+        c_ms, c_fl = sum(m for _, m, _ in conv), sum(w for _, _, w in conv)
+        mult = 3 if args.precision in ("f16x3", "bf16x3") else 1
+        roofline["conv_mfma"] = {"kernel": "conv_igemm_kernel (all %d launches of the conv stack)" % (sum(c for c, _, _ in conv) // 2),
+                                 "achieved": round(c_fl / (c_ms * 1e-3) / 1e12, 2), "peak": round(PEAK_TFLOPS[args.precision], 1),
+                                 "unit": "TFLOP/s", "frac": round(c_fl / (c_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision], 4),
+                                 "ms_per_step": round(c_ms / 2, 4), "mfma_products_per_term": mult,
+                                 "executed": round(mult * c_fl / (c_ms * 1e-3) / 1e12, 2), "peak_executed": 2500.0,
+                                 "peak_note": "dense f16 MFMA peak 2500 TFLOP/s / %d products per algorithmic multiply-add" % mult}
+    if "update_splat_kernel" in prof:
+        uc, ums, uw = prof["update_splat_kernel"]
+        roofline["crf_hbm"] = {"kernel": "update_splat_kernel", "achieved": round(uw / (ums * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": round(uw / (ums * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                               "algorithmic_bytes_per_launch": round(uw / uc), "avg_launch_us": round(ums / uc * 1e3, 2),
+                               "launches_per_step": uc // 2, "traffic": None}
+        add_traffic(roofline["crf_hbm"], "update_splat_kernel", ums / uc * 1e3)
+        if args.workload == "cam_crf":
+            roofline["crf_hbm"]["loop_algorithmic_GBps"] = stages.get("crf_loop_algorithmic_GBps")
     stages["kernels"] = kernels
 
     # ---- the other numbers SURVEY 8(d) asks for, same images (rank 0 of a 1-GPU run) ---------------------------
     if world == 1 and args.workload == "cam_crf" and args.arch == "resnet50" and not args.quick:
         k_extra = max(3, min(args.steps, 10))
-        if args.precision != "bf16x3":  # fp32-class mode: split-bf16 operands, three MFMA products per term
-            w3 = Workload(device, args.batch, "bf16x3", args.workload, seed=rank, arch=args.arch, share=wl)
+        if args.precision != "f16":  # the fast mode: half operands, one MFMA product per term (1.5e-2 on the CAM maps)
+            w3 = Workload(device, args.batch, "f16", args.workload, seed=rank, arch=args.arch, share=wl)
             t3 = timed_run(w3, w3.step_pipelined if pipelined else w3.step, k_extra, 2, w3.drain)
-            stages["value_bf16x3"] = round(args.batch * k_extra / t3, 3)
-            stages["cnn_ms_bf16x3"] = round(w3.timed(w3.run_cnn, 3), 4)
+            stages["value_f16"] = round(args.batch * k_extra / t3, 3)
+            stages["cnn_ms_f16"] = round(w3.timed(w3.run_cnn, 3), 4)
             w3.close()
             del w3
         wl.setup_kplus1()
@@ -709,8 +796,19 @@ def main():
             "roofline": roofline,
             "stages": stages,
         }
+        if steady is not None:
+            out["value_steady"] = steady["value"]
+            out["steady"] = steady
         if not args.no_cpu_baseline and world == 1 and args.arch == "resnet50":
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+            labels = None
+            if args.workload == "cam_crf":  # the product chain's label maps of this batch, for the parity object
+                import numpy as np
+
+                wl.step()
+                labels = wl.ctx.to_host(wl.label_dev, (args.batch, S * S), np.int32)
+            out["cpu_baseline"], parity = cpu_baseline(wl, args.cpu_seconds, labels)
+            if parity is not None:
+                out["parity"] = parity
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

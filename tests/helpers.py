@@ -104,3 +104,62 @@ def synth_crf_case(rng, H, W, M, sharp=3.0):
     p /= p.sum(0, keepdims=True)
     U = -np.log(np.clip(p, 1e-5, 1.0)).reshape(M, -1).astype(np.float32)
     return rgb, np.ascontiguousarray(U), p
+
+
+# ---- chain-level parity on BASELINE config 3 (CNN -> unaries -> dense CRF -> labels) ---------------------------------
+def oracle_chain(x_pair, rgb, sd, cfg, num_classes=20, bg=0.15, cam=None):
+    """The reference chain for ONE image, all fp32 on the CPU: resnet50_cam.CAM.forward (net/resnet50_cam.py:55-70) ->
+    make_cam's upsample + per-class max-normalisation for ALL classes at the image size (step/make_cam.py:64-76) ->
+    [bg | maps] probabilities -> -log(clip(p)) unaries (eval_cam.py:49-51, 03c_hsn/utilities.py:431) -> DenseCRF
+    (oracle/densecrf_ref.c).  Returns (labels (H*W,) int32, unaries (M, H*W), cam)."""
+    import torch
+
+    from oracle import cnn_ref
+
+    H, W, _ = rgb.shape
+    if cam is None:
+        with torch.no_grad():
+            cam = cnn_ref.resnet50_cam_forward(torch.from_numpy(np.ascontiguousarray(x_pair)), sd)
+    with torch.no_grad():
+        _, hi = cnn_ref.make_cam_tail(cam, (H, W), torch.arange(num_classes))
+    v = np.concatenate([np.full((1, H * W), bg, np.float32), hi.numpy().reshape(num_classes, -1)], 0)
+    U = np.ascontiguousarray(-np.log(np.clip(v / v.sum(0, keepdims=True), 1e-5, 1.0)).astype(np.float32))
+    _, lab, _ = crf_oracle(rgb, U, cfg)
+    return lab, U, cam
+
+
+def product_chain(ctx, net, x, rgb, cfg, num_classes=20, bg=0.15):
+    """The product chain for a batch through the C ABI: wsc_net_forward_cam -> wsc_cam_unary_pm -> wsc_crf_create ->
+    wsc_crf_inference_pm (labels only).  x float32 [B][2][3][S][S], rgb uint8 [B][S][S][3] -> labels int32 [B][S*S]."""
+    from wsscam import _lib
+
+    B, S = x.shape[0], x.shape[-1]
+    h = net.cam_size(S)
+    Mp = (num_classes + 1 + 3) // 4 * 4
+    x_dev, rgb_dev = ctx.to_device(np.ascontiguousarray(x)), ctx.to_device(np.ascontiguousarray(rgb))
+    cam_dev = ctx.alloc(B * num_classes * h * h * 4)
+    u_dev, l_dev = ctx.alloc(B * Mp * S * S * 4), ctx.alloc(B * S * S * 4)
+    net.forward_cam(x_dev, B, S, cam_dev, None)
+    _lib.cam_unary(ctx, cam_dev, B, num_classes, h, h, S, S, bg, u_dev, pixel_major=True)
+    crf = _lib.Crf(ctx, rgb_dev, B, S, S, cfg[0], cfg[2], cfg[3])
+    crf.inference(u_dev, num_classes + 1, cfg[1], cfg[4], int(cfg[5]), None, l_dev, pixel_major=True)
+    lab = ctx.to_host(l_dev, (B, S * S), np.int32)
+    crf.close()
+    for d in (x_dev, rgb_dev, cam_dev, u_dev, l_dev):
+        d.free()
+    return lab
+
+
+def label_parity(lab, ref, n_class):
+    """Per-image label agreement and the mIoU of `lab` scored against `ref` as ground truth, the way eval_cam scores
+    pseudo-labels (03b_irn/step/eval_cam.py:89-115: confusion matrix, IoU = TP / (TP + FP + FN) per class, mean over the
+    classes that occur)."""
+    lab, ref = np.asarray(lab).reshape(len(ref), -1), np.asarray(ref).reshape(len(ref), -1)
+    agree = [(a == b).mean() for a, b in zip(lab, ref)]
+    conf = np.bincount((ref.ravel() * n_class + lab.ravel()).astype(np.int64), minlength=n_class * n_class).reshape(n_class, n_class)
+    tp = np.diag(conf).astype(np.float64)
+    denom = conf.sum(0) + conf.sum(1) - tp
+    present = denom > 0
+    return {"label_agreement_min": float(min(agree)), "label_agreement_mean": float(np.mean(agree)),
+            "miou_vs_oracle": float((tp[present] / denom[present]).mean()), "classes_present": int(present.sum()),
+            "images": int(len(ref))}
