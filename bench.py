@@ -493,6 +493,70 @@ def cpu_baseline(wl, budget_s, product_labels=None):
                       % (n_cam, t_cam / n_cam, cores, n_par, threads, crf_rate, t_crf1)}, parity
 
 
+def build_roofline(prof, n_steps, precision, traffic_classes=None, loop_gbps=None):
+    """-> (kernels, roofline) from a per-class HIP-event profile {class: (launches, total ms, algorithmic work)} of `n_steps`
+    steps whose stages did not overlap.  `roofline` describes the class with the largest time per step and carries the two
+    fractions the north star names as sub-objects:
+      conv_mfma -- the whole conv stack (every conv_igemm launch of a step): algorithmic FLOPs (one multiply-add per term)
+                   over the summed kernel time against the peak of the precision mode; `executed` counts the three MFMA
+                   products per term of the split modes against the dense 16-bit peak
+      crf_hbm   -- update_splat_kernel, the mean-field loop's dominant kernel: the SURVEY 8(d) bytes it covers per launch
+                   against 8 TB/s; `traffic` / `frac_traffic`: HBM bytes per launch from the committed PMC passes
+                   (profiles/hbm_traffic.json -- counters cannot be read from inside the process)."""
+    traffic_classes = traffic_classes or {}
+    kernels = {}
+    for name, (calls, ms, work) in prof.items():
+        is_conv = name.startswith("conv_igemm")
+        rate = work / (ms * 1e-3) / (1e12 if is_conv else 1e9) if ms > 0 else 0.0
+        kernels[name] = {"launches_per_step": calls // n_steps, "avg_us": round(ms / calls * 1e3, 2),
+                         "ms_per_step": round(ms / n_steps, 4), ("TFLOP/s" if is_conv else "GB/s"): round(rate, 2)}
+    dom = max((n for n in prof if n != "crf_build(all)"), key=lambda n: prof[n][1])
+    calls, ms, work = prof[dom]
+    if dom.startswith("conv_igemm"):
+        roofline = {"bound": "mfma", "achieved": round(work / (ms * 1e-3) / 1e12, 2), "peak": round(PEAK_TFLOPS[precision], 1),
+                    "unit": "TFLOP/s", "traffic": None}
+    else:
+        roofline = {"bound": "hbm", "achieved": round(work / (ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "traffic": None}
+    roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
+    roofline["kernel"] = dom
+    roofline["algorithmic_bytes_per_launch" if roofline["bound"] == "hbm" else "flop_per_launch"] = round(work / calls)
+
+    def add_traffic(obj, cls_name, per_launch_us):
+        cls = traffic_classes.get(cls_name)
+        if not cls:
+            return
+        obj["traffic"] = cls["bytes_per_launch"]
+        obj["frac_traffic"] = round(cls["bytes_per_launch"] / (per_launch_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
+        obj["traffic_source"] = ("committed: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this "
+                                 "command, %s); not re-measured in this run" % cls.get("round", "r02"))
+
+    roofline["avg_launch_us"] = round(ms / calls * 1e3, 2)
+    roofline["launches_per_step"] = calls // n_steps
+    if roofline["bound"] == "hbm":
+        add_traffic(roofline, dom, ms / calls * 1e3)
+    conv = [(c, m, w) for n, (c, m, w) in prof.items() if n.startswith("conv_igemm")]
+    if conv:
+        c_ms, c_fl = sum(m for _, m, _ in conv), sum(w for _, _, w in conv)
+        mult = 3 if precision in ("f16x3", "bf16x3") else 1
+        roofline["conv_mfma"] = {"kernel": "conv_igemm_kernel (all %d launches of the conv stack)" % (sum(c for c, _, _ in conv) // n_steps),
+                                 "achieved": round(c_fl / (c_ms * 1e-3) / 1e12, 2), "peak": round(PEAK_TFLOPS[precision], 1),
+                                 "unit": "TFLOP/s", "frac": round(c_fl / (c_ms * 1e-3) / 1e12 / PEAK_TFLOPS[precision], 4),
+                                 "ms_per_step": round(c_ms / n_steps, 4), "mfma_products_per_term": mult,
+                                 "executed": round(mult * c_fl / (c_ms * 1e-3) / 1e12, 2), "peak_executed": 2500.0,
+                                 "peak_note": "dense f16 MFMA peak 2500 TFLOP/s / %d products per algorithmic multiply-add" % mult}
+    if "update_splat_kernel" in prof:
+        uc, ums, uw = prof["update_splat_kernel"]
+        roofline["crf_hbm"] = {"kernel": "update_splat_kernel", "achieved": round(uw / (ums * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": round(uw / (ums * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                               "algorithmic_bytes_per_launch": round(uw / uc), "avg_launch_us": round(ums / uc * 1e3, 2),
+                               "launches_per_step": uc // n_steps, "traffic": None}
+        add_traffic(roofline["crf_hbm"], "update_splat_kernel", ums / uc * 1e3)
+        if loop_gbps is not None:
+            roofline["crf_hbm"]["loop_algorithmic_GBps"] = loop_gbps
+    return kernels, roofline
+
+
 def run_hsn(args, device):
     """BASELINE config 5 on one GPU: `segment_adp` (03c_hsn/demo.py:271-380) on batches of ADP-like patches, device
     resident from the batch upload to the label maps.  One step = one batch of --batch images (reference: 16)."""
@@ -506,20 +570,33 @@ def run_hsn(args, device):
     C, S_ = 31, 321
     prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "f16x3": _lib.PREC_F16X3}[args.precision]
     sd = synth.plain_state_dict("vgg16", C, batchnorm=False, seed=0)  # ADP models have no BatchNorm (vgg16_cam.py:16-19)
+    rng = np.random.default_rng(4242)
+    images = [synth.adp_image(rng, S_, S_) for _ in range(args.batch)]
+    # classifier head calibrated to the random features (synth.specialise_classifier: with i.i.d. weights the Grad-CAM arg-max
+    # degenerates to 2-4 morphological classes and 1 functional class per image): final feature maps of four patches
+    model = vgg16_cam.CAM(None, "adp_morph", "ADP_VGG16", C, None, precision=prec)
+    model.load_state_dict(sd)
+    model.cuda(device)
+    n_cal = min(4, args.batch)
+    xs = np.stack([np.transpose((im.astype(np.float32) - 193.09203) / 56.450138, (2, 0, 1)) for im in images[:n_cal]])
+    hf, F = model._net.cam_size(S_), model._net.feat_channels()
+    fd = model.ctx.alloc(n_cal * hf * hf * F * 4)
+    model._net.forward_features(model.ctx.to_device(np.ascontiguousarray(xs)), n_cal, S_, fd)
+    synth.specialise_classifier(sd, "vgg16", C, model.ctx.to_host(fd, (n_cal, hf, hf, F), np.float32), seed=0)
     model = vgg16_cam.CAM(None, "adp_morph", "ADP_VGG16", C, None, precision=prec)
     model.load_state_dict(sd)
     model.cuda(device)
     alpha = grad_cam_alpha(sd["vgg16.classifier.0.weight"], S_ // 8, S_ // 8, "avg")
-    rng = np.random.default_rng(4242)
-    images = [synth.adp_image(rng, S_, S_) for _ in range(args.batch)]
     thr = np.full((1, C), 0.5)
     cfgs = {"morph": np.array([3 / 2, 3, 80 / 2, 13, 10, 10]), "func": np.array([3 / 2, 3, 80 / 2, 13, 10, 10])}
+    eff_m = {}
 
-    def step():
-        return hsn_demo.segment_adp(model, alpha, thr, images, cfgs, S_, args.batch)
+    def step(stats=None):
+        return hsn_demo.segment_adp(model, alpha, thr, images, cfgs, S_, args.batch, stats=stats)
 
     for _ in range(max(args.warmup, 1)):
-        out = step()
+        eff_m = {}
+        out = step(eff_m)
     model.ctx.sync()
     ctx = model.ctx
     t0 = time.perf_counter()
@@ -530,8 +607,31 @@ def run_hsn(args, device):
     ctx.profile_begin()
     step()
     prof = ctx.profile_end()
-    kernels = {n: {"launches_per_step": c, "ms_per_step": round(ms, 4)} for n, (c, ms, w) in prof.items()}
+    kernels, roofline = build_roofline(prof, 1, args.precision)
     m_classes = {h: sorted({int(len(np.unique(lab))) for lab in out[h]}) for h in out}
+    extra = {}
+    if not args.no_cpu_baseline:
+        # the oracle chain (the only place this workload touches oracle/): torch-CPU VGG16 + numpy HSN post-processing + C
+        # dense-CRF for both HTT types on a bounded sample; its label maps score the product's (parity)
+        import torch
+
+        from tests import helpers
+
+        n_cpu = min(2, args.batch)
+        sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+        t0 = time.perf_counter()
+        ref = helpers.oracle_chain_hsn_adp(images[:n_cpu], sdt, alpha, 0.5, cfgs)
+        t_cpu = time.perf_counter() - t0
+        extra["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                                 "sample": "%d patches: torch-CPU fp32 VGG16 + numpy/scipy HSN post-processing + C dense-CRF x2 "
+                                           "(morph + func, one thread), %.2f s/img" % (n_cpu, t_cpu / n_cpu)}
+        par = {}
+        for h in ("morph", "func"):
+            n_cls = len(hsn_demo.ADPClasses().classes["valid_" + h])
+            pp = helpers.label_parity([np.asarray(m) for m in out[h][:n_cpu]], [np.asarray(m) for m in ref[h]], n_cls)
+            par[h] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in pp.items()}
+        par["against"] = "all-fp32 oracle chain (tests/helpers.py::oracle_chain_hsn_adp) on the first %d patches" % n_cpu
+        extra["parity"] = par
     print(json.dumps({
         "metric": "images/sec HistoSegNet CAM+CRF (BASELINE config 5, ADP-like 321x321 patches, morph + func label maps)",
         "value": round(args.batch * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
@@ -539,8 +639,12 @@ def run_hsn(args, device):
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "vgg16 (31 classes, no BN) HSN Grad-CAM + modify_by_htt + cs-gradcam + dense-CRF x2 (morph 29 / "
                                "func 5 classes, 10 iters), 321x321, batch %d" % args.batch, "batch_images": args.batch,
-                   "distinct_labels_per_image": m_classes},
-        "stages": {"kernel_classes": kernels}}))
+                   "distinct_labels_per_image": m_classes,
+                   "effective_M": {h: {"min": int(min(v)), "mean": round(float(np.mean(v)), 2), "max": int(max(v))} for h, v in eff_m.items()},
+                   "effective_M_note": "classes with mass per image = the M its dense CRF runs with (dcrf_process keeps the classes "
+                                       "whose class-specific Grad-CAM is not all zero, 03c_hsn/utilities.py:425); classifier head "
+                                       "calibrated to the random features (wsscam.synth.specialise_classifier)"},
+        "roofline": roofline, "stages": {"kernels": kernels}, **extra}))
 
 
 def main():
@@ -667,25 +771,8 @@ def main():
         wl.step(sequential=True)
     prof = wl.ctx.profile_end()
     prof.update(wl.ctx_build.profile_end())
-    kernels = {}
-    for name, (calls, ms, work) in prof.items():
-        is_conv = name.startswith("conv_igemm")
-        rate = work / (ms * 1e-3) / (1e12 if is_conv else 1e9) if ms > 0 else 0.0
-        kernels[name] = {"launches_per_step": calls // 2, "avg_us": round(ms / calls * 1e3, 2),
-                         "ms_per_step": round(ms / 2, 4), ("TFLOP/s" if is_conv else "GB/s"): round(rate, 2)}
-    dom = max((n for n in prof if n != "crf_build(all)"), key=lambda n: prof[n][1])
-    calls, ms, work = prof[dom]
-    if dom.startswith("conv_igemm"):
-        roofline = {"bound": "mfma", "achieved": round(work / (ms * 1e-3) / 1e12, 2), "peak": round(PEAK_TFLOPS[args.precision], 1),
-                    "unit": "TFLOP/s", "traffic": None}
-    else:
-        roofline = {"bound": "hbm", "achieved": round(work / (ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "traffic": None}
-    roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
-    roofline["kernel"] = dom
-    roofline["algorithmic_bytes_per_launch" if roofline["bound"] == "hbm" else "flop_per_launch"] = round(work / calls)
-    # HBM bytes per launch of that kernel class: NOT observed in this run -- FETCH_SIZE / WRITE_SIZE cannot be read from
-    # inside the process; the figure is the one committed under profiles/ from the PMC passes of the same command
+    # HBM bytes per launch of a class: NOT observed in this run -- FETCH_SIZE / WRITE_SIZE cannot be read from inside the
+    # process; the figures are the ones committed under profiles/ from the PMC passes of the same command
     # (profiles/collect.sh -> profiles/hbm_traffic.json).  Only the default workload is profiled there.
     tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
     default_wl = (args.workload == "cam_crf" and args.arch == "resnet50" and args.batch == 32 and args.precision == "f16x3")
@@ -693,44 +780,8 @@ def main():
     if default_wl and os.path.exists(tj):
         with open(tj) as fh:
             traffic_classes = json.load(fh).get("classes", {})
-
-    def add_traffic(obj, cls_name, per_launch_us):
-        """HBM bytes per launch of the class from the committed PMC passes -> traffic, frac_traffic (real bytes / peak)."""
-        cls = traffic_classes.get(cls_name)
-        if not cls:
-            return
-        obj["traffic"] = cls["bytes_per_launch"]
-        obj["frac_traffic"] = round(cls["bytes_per_launch"] / (per_launch_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
-        obj["traffic_source"] = ("committed: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this "
-                                 "command, %s); not re-measured in this run" % cls.get("round", "r02"))
-
-    roofline["avg_launch_us"] = round(ms / calls * 1e3, 2)
-    roofline["launches_per_step"] = calls // 2
-    if roofline["bound"] == "hbm":
-        add_traffic(roofline, dom, ms / calls * 1e3)
-    # the two fractions the north star names, whichever class dominates:
-    #   conv_mfma -- the whole conv stack (every conv_igemm launch of a step): algorithmic FLOPs (one product per term) over
-    #                the summed kernel time against the dense 16-bit MFMA peak; `executed` counts the three products of f16x3
-    #   crf_hbm   -- update_splat_kernel, the mean-field loop's dominant kernel: SURVEY 8(d) bytes it covers per launch
-    conv = [(c, m, w) for n, (c, m, w) in prof.items() if n.startswith("conv_igemm")]
-    if conv:
-        c_ms, c_fl = sum(m for _, m, _ in conv), sum(w for _, _, w in conv)
-        mult = 3 if args.precision in ("f16x3", "bf16x3") else 1
-        roofline["conv_mfma"] = {"kernel": "conv_igemm_kernel (all %d launches of the conv stack)" % (sum(c for c, _, _ in conv) // 2),
-                                 "achieved": round(c_fl / (c_ms * 1e-3) / 1e12, 2), "peak": round(PEAK_TFLOPS[args.precision], 1),
-                                 "unit": "TFLOP/s", "frac": round(c_fl / (c_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision], 4),
-                                 "ms_per_step": round(c_ms / 2, 4), "mfma_products_per_term": mult,
-                                 "executed": round(mult * c_fl / (c_ms * 1e-3) / 1e12, 2), "peak_executed": 2500.0,
-                                 "peak_note": "dense f16 MFMA peak 2500 TFLOP/s / %d products per algorithmic multiply-add" % mult}
-    if "update_splat_kernel" in prof:
-        uc, ums, uw = prof["update_splat_kernel"]
-        roofline["crf_hbm"] = {"kernel": "update_splat_kernel", "achieved": round(uw / (ums * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
-                               "unit": "GB/s", "frac": round(uw / (ums * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                               "algorithmic_bytes_per_launch": round(uw / uc), "avg_launch_us": round(ums / uc * 1e3, 2),
-                               "launches_per_step": uc // 2, "traffic": None}
-        add_traffic(roofline["crf_hbm"], "update_splat_kernel", ums / uc * 1e3)
-        if args.workload == "cam_crf":
-            roofline["crf_hbm"]["loop_algorithmic_GBps"] = stages.get("crf_loop_algorithmic_GBps")
+    kernels, roofline = build_roofline(prof, 2, args.precision, traffic_classes,
+                                       stages.get("crf_loop_algorithmic_GBps") if args.workload == "cam_crf" else None)
     stages["kernels"] = kernels
 
     # ---- the other numbers SURVEY 8(d) asks for, same images (rank 0 of a 1-GPU run) ---------------------------

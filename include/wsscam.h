@@ -262,6 +262,15 @@ int wsc_cam_eval_confusion_nn(wsc_ctx *ctx, const float *maps_dev, int B, const 
                               const int64_t *maps_off_host /*[B]*/, const uint8_t *gt_dev, int n_class, int ignore_label,
                               uint8_t *pred_dev, int64_t *confusion_dev);
 
+/* The evaluation tail of the HistoSegNet drivers (03c_hsn/demo.py:386-408): the CRF's label maps (int32, image b's h_b x w_b
+ * map at int32 offset labels_off[b]) are resized to the ground truth's size with cv2's INTER_NEAREST rule (as above) and
+ * counted:  confusion[gt][pred] += 1 where gt != ignore_label.  The reference's per-class intersections / unions / ground-
+ * truth counts are sums over this matrix when every pixel whose colour matches no class is given the extra ground-truth
+ * index n_class - 1 (wsscam.hsn.demo.evaluate_labels).  gt_dev / pred_dev uint8 at the output size, packed in batch order. */
+int wsc_label_confusion_nn(wsc_ctx *ctx, const int32_t *labels_dev, int B, const int32_t *src_hw_host /*[B][2]*/,
+                           const int32_t *out_hw_host /*[B][2]*/, const int64_t *labels_off_host /*[B]*/, const uint8_t *gt_dev,
+                           int n_class, int ignore_label, uint8_t *pred_dev, int64_t *confusion_dev);
+
 /* The tail of make_sem_seg_labels for a batch of images (03b_irn/step/make_sem_seg_labels.py:74-79 voc12, :91-96 ADP,
  * :113-118 DeepGlobe), straight from the random-walk maps wsc_rw_propagate_batch left in HBM:
  *   rw_up = F.interpolate(rw, size=up_hw, mode='bilinear', align_corners=False)[..., 0, :H0, :W0]

@@ -163,3 +163,56 @@ def label_parity(lab, ref, n_class):
     return {"label_agreement_min": float(min(agree)), "label_agreement_mean": float(np.mean(agree)),
             "miou_vs_oracle": float((tp[present] / denom[present]).mean()), "classes_present": int(present.sum()),
             "images": int(len(ref))}
+
+
+def oracle_chain_hsn_adp(images, sd, alpha, thr, cfgs, all_classes=None):
+    """The reference chain of 03c_hsn/demo.py:271-380 (ADP) for a list of (S, S, 3) uint8 patches, all fp32 / float64 on the
+    CPU: VGG16 features (torch) -> sigmoid scores -> Grad-CAM einsum -> bilinear upsample, ReLU, / max, x score x pass ->
+    per HTT type: valid-class stack, modify_by_htt (background / other channels, 03c_hsn/utilities.py:306-364),
+    get_cs_gradcam (:367-397), dense CRF on the classes with mass (:399-445, oracle/densecrf_ref.c).
+    sd: torch state dict; alpha (F, C); thr: scalar threshold; cfgs {'morph', 'func'} 6-vectors.
+    Returns {'morph': [label maps], 'func': [label maps]}."""
+    import scipy.ndimage
+    import scipy.special
+    import torch
+
+    from oracle import cnn_ref
+    from wsscam.hsn import demo as hsn_demo
+
+    raw = np.stack(images)
+    n, S = raw.shape[0], raw.shape[1]
+    x = (raw - 193.09203) / 56.450138
+    xt = torch.from_numpy(np.transpose(x, (0, 3, 1, 2)).astype(np.float32).copy())
+    with torch.no_grad():
+        feat = cnn_ref.plain_features(xt, sd, "vgg16", cnn_ref.VGG16_CFG)
+        sc = torch.sigmoid(torch.nn.functional.linear(feat.mean((2, 3)), sd["vgg16.classifier.0.weight"],
+                                                      sd["vgg16.classifier.0.bias"])).numpy().astype(np.float64)
+    cams = np.einsum("ijkl,lm->ijkm", np.transpose(feat.numpy(), (0, 2, 3, 1)).astype(np.float64), alpha)
+    up = np.maximum(torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cams, (0, 3, 1, 2))), (S, S),
+                                                    mode="bilinear", align_corners=False).numpy(), 0)
+    H = up / np.maximum(up.max(axis=(1, 2, 3), keepdims=True), 1e-7) * (sc * (sc >= thr))[:, :, None, None]
+    ac = hsn_demo.ADPClasses(all_classes)
+    Y, out = {}, {"morph": [], "func": []}
+    for htt in ("morph", "func"):
+        valid = ac.classes["valid_" + htt]
+        Y[htt] = np.zeros((n, len(valid), S, S))
+        Y[htt][:, ac.classinds[htt + "2valid"]] = H[:, ac.classinds["all2" + htt]]
+        bgm = np.stack([scipy.ndimage.gaussian_filter(0.75 * scipy.special.expit(4 * (raw[i].mean(-1) - 240)), sigma=2)
+                        for i in range(n)])
+        if htt == "morph":
+            Y[htt][:, 0] = bgm - Y[htt][:, [valid.index(c) for c in ("A.W", "A.B", "A.M")]].max(1)
+        else:
+            Y[htt][:, 0] = bgm - Y[htt][:, [valid.index(c) for c in ("G.O", "G.N", "T")]].max(1)
+            other = 0.05 * (1 - Y[htt].max(1))
+            adi = Y["morph"][:, [ac.classes["morph"].index(c) for c in ("A.W", "A.B", "A.M")]]
+            Y[htt][:, 1] = np.maximum(other, adi.max(1))
+        srt = np.sort(Y[htt], axis=1)
+        cs = (srt[:, -1] - srt[:, -2])[:, None] * (np.arange(len(valid))[None, :, None, None] == Y[htt].argmax(1)[:, None])
+        if htt == "func":
+            cs[:, 1] = Y[htt][:, 1]
+        for b in range(n):
+            keep = np.where(cs[b].sum(axis=(1, 2)) > 0)[0]
+            U = np.ascontiguousarray(-np.log(np.clip(cs[b][keep], 1e-5, 1.0)).reshape(len(keep), -1).astype(np.float32))
+            _, ar, _ = crf_oracle(images[b], U, tuple(cfgs[htt]))
+            out[htt].append(keep[ar.reshape(S, S)])
+    return out

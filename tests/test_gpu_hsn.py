@@ -109,3 +109,46 @@ def test_hsn_modify_and_cs_gradcam_vs_oracle(ctx, htt):
     U = ctx.to_host(u_dev, (len(keep), N), np.float32)
     Ur = -np.log(np.clip(cs[1, keep].reshape(len(keep), N), 1e-5, 1.0))
     assert np.abs(U - Ur).max() <= 2e-6
+
+
+def test_hsn_evaluation_tail_1088(ctx):
+    """03c_hsn/demo.py:386-408, 424-428 (the '1088 x 1088' of BASELINE config 5): label maps at 321 x 321 -> cv2 INTER_NEAREST
+    to 1088 x 1088 -> per-class confusion rows / intersections / unions / ground-truth counts / IoU / mIoU, on the device
+    (wsc_label_confusion_nn through hsn.demo.LabelEvaluator) against the reference's loop restated in numpy, over two batches
+    (the counters accumulate), with ground-truth pixels whose colour matches no class."""
+    from wsscam.hsn import demo as hsn_demo
+    from wsscam.step.eval_cam import ADP_CLS_COLOURS
+
+    rng = np.random.default_rng(5)
+    for htt in ("morph", "func"):
+        colours = np.array(ADP_CLS_COLOURS[htt])
+        n = len(colours)
+        ev = hsn_demo.LabelEvaluator(ctx, colours)
+        conf = np.zeros((n, n))
+        inter, union, gtc = np.zeros(n), np.zeros(n), np.zeros(n)
+        for batch in range(2):
+            B = 2 + batch
+            labs = [np.kron(rng.integers(0, n, (11, 11)), np.ones((30, 30), np.int64))[:321, :321] for _ in range(B)]
+            gts = []
+            for _ in range(B):
+                gi = np.kron(rng.integers(0, n + 1, (17, 17)), np.ones((64, 64), np.int64))  # index n: a colour of no class
+                pal = np.concatenate([colours, [[1, 2, 3]]], 0)
+                gts.append(pal[gi].astype(np.uint8))
+            preds = ev.update(labs, gts, want_pred=True)
+            for b in range(B):
+                # demo.py:392-405 verbatim (cv2.resize nearest: source index min(floor(x * (1. / (dst / src))), src - 1))
+                sy = np.minimum(np.floor(np.arange(1088) * (1.0 / (1088 / 321))).astype(np.int64), 320)
+                pred_idx = labs[b][sy][:, sy]
+                assert np.array_equal(preds[b], pred_idx)
+                gt_r, gt_g, gt_b = gts[b][:, :, 0], gts[b][:, :, 1], gts[b][:, :, 2]
+                for k, c in enumerate(colours):
+                    gt_mask = (gt_r == c[0]) & (gt_g == c[1]) & (gt_b == c[2])
+                    pred_mask = pred_idx == k
+                    conf[k, :] += np.bincount(pred_idx[gt_mask], minlength=n)
+                    inter[k] += np.sum(gt_mask & pred_mask)
+                    union[k] += np.sum(gt_mask | pred_mask)
+                    gtc[k] += np.sum(gt_mask)
+        m = ev.metrics()
+        assert np.array_equal(m["confusion_matrix"], conf) and np.array_equal(m["intersects"], inter)
+        assert np.array_equal(m["unions"], union) and np.array_equal(m["gt_count"], gtc)
+        assert m["mIoU"] == float(np.mean(inter / (union + 1e-7)))

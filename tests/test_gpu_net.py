@@ -16,6 +16,7 @@ import pytest
 import torch
 
 from oracle import cnn_ref
+from tests import helpers
 from wsscam import _lib
 from wsscam.net import resnet50_cam, vgg16_cam, m7_cam
 
@@ -468,10 +469,13 @@ def helpers_crf(rgb, U, cfg):
     return helpers.crf_oracle(rgb, U, cfg)
 
 
-def test_hsn_segment_adp_driver():
+@pytest.mark.parametrize("precision,min_agree", [(_lib.PREC_F16X3, 0.99), (_lib.PREC_BF16X3, 0.99), (_lib.PREC_F16, 0.97)])
+def test_hsn_segment_adp_driver(precision, min_agree):
     """03c_hsn/demo.py:271-380 (ADP, BASELINE config 5 without the 1088 x 1088 evaluation upsample): one 31-class
     VGG16 (no BatchNorm), Grad-CAM at 321 x 321, morph (29 classes) and func (5 classes) stacks with synthesised
-    Background / Other channels, class-specific Grad-CAM, dense CRF per type; labels vs the oracle chain."""
+    Background / Other channels, class-specific Grad-CAM, dense CRF per type; FINAL labels vs the all-fp32 oracle chain, in
+    the fp32-class modes and in the fast half-precision mode (`bench.py --workload hsn --precision f16`), each with its
+    stated per-image label agreement."""
     import scipy.ndimage
     import scipy.special
 
@@ -481,7 +485,7 @@ def test_hsn_segment_adp_driver():
 
     C, S = 31, 321
     sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, False, seed=21)
-    model = _model(vgg16_cam.CAM, sd, C, _lib.PREC_BF16X3)
+    model = _model(vgg16_cam.CAM, sd, C, precision)
     rng = np.random.default_rng(22)
     images = [_adp_like_image(rng, S, S) for _ in range(2)]
     alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 33, C)
@@ -490,43 +494,12 @@ def test_hsn_segment_adp_driver():
     out = hsn_demo.segment_adp(model, alpha, thr, images, cfgs, S, 2)
     assert len(out["morph"]) == len(out["func"]) == 2 and out["morph"][0].shape == (S, S)
 
-    raw = np.stack(images)
-    x = (raw - 193.09203) / 56.450138
-    xt = torch.from_numpy(np.transpose(x, (0, 3, 1, 2)).astype(np.float32).copy())
-    with torch.no_grad():
-        feat = cnn_ref.plain_features(xt, sd, "vgg16", cnn_ref.VGG16_CFG)
-        sc = torch.sigmoid(torch.nn.functional.linear(feat.mean((2, 3)), sd["vgg16.classifier.0.weight"],
-                                                      sd["vgg16.classifier.0.bias"])).numpy().astype(np.float64)
-    cams = np.einsum("ijkl,lm->ijkm", np.transpose(feat.numpy(), (0, 2, 3, 1)).astype(np.float64), alpha)
-    up = np.maximum(torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cams, (0, 3, 1, 2))), (S, S),
-                                                    mode="bilinear", align_corners=False).numpy(), 0)
-    H = up / np.maximum(up.max(axis=(1, 2, 3), keepdims=True), 1e-7) * (sc * (sc >= 0.5))[:, :, None, None]
-    ac = hsn_demo.ADPClasses()
-    Y = {}
+    ref = helpers.oracle_chain_hsn_adp(images, sd, alpha, 0.5, cfgs)
     for htt in ("morph", "func"):
-        valid = ac.classes["valid_" + htt]
-        Y[htt] = np.zeros((2, len(valid), S, S))
-        Y[htt][:, ac.classinds[htt + "2valid"]] = H[:, ac.classinds["all2" + htt]]
-        bgm = np.stack([scipy.ndimage.gaussian_filter(0.75 * scipy.special.expit(4 * (raw[i].mean(-1) - 240)), sigma=2)
-                        for i in range(2)])
-        if htt == "morph":
-            Y[htt][:, 0] = bgm - Y[htt][:, [valid.index(c) for c in ("A.W", "A.B", "A.M")]].max(1)
-        else:
-            Y[htt][:, 0] = bgm - Y[htt][:, [valid.index(c) for c in ("G.O", "G.N", "T")]].max(1)
-            other = 0.05 * (1 - Y[htt].max(1))
-            adi = Y["morph"][:, [ac.classes["morph"].index(c) for c in ("A.W", "A.B", "A.M")]]
-            Y[htt][:, 1] = np.maximum(other, adi.max(1))
-        srt = np.sort(Y[htt], axis=1)
-        cs = (srt[:, -1] - srt[:, -2])[:, None] * (np.arange(len(valid))[None, :, None, None] == Y[htt].argmax(1)[:, None])
-        if htt == "func":
-            cs[:, 1] = Y[htt][:, 1]
-        cfg = cfgs[htt]
         for b in range(2):
-            keep = np.where(cs[b].sum(axis=(1, 2)) > 0)[0]
-            U = np.ascontiguousarray(-np.log(np.clip(cs[b][keep], 1e-5, 1.0)).reshape(len(keep), -1).astype(np.float32))
-            _, ar, _ = helpers_crf(images[b], U, tuple(cfg))
-            ref = keep[ar.reshape(S, S)]
-            assert (out[htt][b] == ref).mean() >= 0.99, (htt, b, (out[htt][b] == ref).mean())
+            agree = (out[htt][b] == ref[htt][b]).mean()
+            print("hsn adp chain precision %d %s image %d: label agreement %.5f" % (precision, htt, b, agree))
+            assert agree >= min_agree, (htt, b, agree)
 
 
 def test_gen_cues_adp_driver(tmp_path):

@@ -389,6 +389,9 @@ struct EvalNNJob {
     double inv_y, inv_x;
 };
 
+// LABELS: the source is an int32 label map (K = 0; `maps` reinterpreted) instead of K class maps -- the evaluation tail of
+// 03c_hsn/demo.py:386-408, whose predictions are the CRF's label maps.
+template <bool LABELS>
 __global__ __launch_bounds__(256) void cam_eval_nn_kernel(const float *__restrict__ maps, const EvalNNJob *__restrict__ jobs,
                                                           const int32_t *__restrict__ keys, const uint8_t *__restrict__ gt,
                                                           int n_class, int ignore_label, uint8_t *__restrict__ pred,
@@ -405,20 +408,25 @@ __global__ __launch_bounds__(256) void cam_eval_nn_kernel(const float *__restric
         const int sy = min((int)floor((double)Y * job.inv_y), job.h - 1);
         const int sx = min((int)floor((double)X * job.inv_x), job.w - 1);
         const long long sp = (long long)sy * job.w + sx;
-        float best = maps[job.maps_off + sp];
-        int idx = 0;
-        for (int k = 1; k < job.K; ++k) {
-            const float v = maps[job.maps_off + (long long)k * n_src + sp];
-            if (v > best) { // strict: np.argmax keeps the first maximum
-                best = v;
-                idx = k;
+        int cls;
+        if (LABELS) {
+            cls = reinterpret_cast<const int32_t *>(maps)[job.maps_off + sp];
+        } else {
+            float best = maps[job.maps_off + sp];
+            int idx = 0;
+            for (int k = 1; k < job.K; ++k) {
+                const float v = maps[job.maps_off + (long long)k * n_src + sp];
+                if (v > best) { // strict: np.argmax keeps the first maximum
+                    best = v;
+                    idx = k;
+                }
             }
+            cls = keys[job.key_base + idx];
         }
-        const int cls = keys[job.key_base + idx];
         if (pred != nullptr) pred[job.pix_off + p] = (uint8_t)cls;
         const int g = gt != nullptr ? (int)gt[job.pix_off + p] : ignore_label;
         if (g != ignore_label) {
-            if (g < n_class && cls < n_class) atomicAdd(&hist[g * n_class + cls], 1u);
+            if (g < n_class && (unsigned)cls < (unsigned)n_class) atomicAdd(&hist[g * n_class + cls], 1u);
             else atomicAdd(n_bad, 1u);
         }
     }
@@ -582,7 +590,7 @@ int wsc_cam_eval_confusion_nn(wsc_ctx *ctx, const float *maps_dev, int B, const 
     memcpy(stage.data() + jb, keys_host, (size_t)nkeys * sizeof(int32_t));
     WSC_TRY(wsc_ctx_upload_small(ctx, d, stage.data(), stage.size()));
     const dim3 grid((unsigned)std::min<long long>((max_pix + 255) / 256, 1024), (unsigned)B);
-    hipLaunchKernelGGL(cam_eval_nn_kernel, grid, dim3(256), (size_t)n_class * n_class * sizeof(unsigned), ctx->stream, maps_dev,
+    hipLaunchKernelGGL(cam_eval_nn_kernel<false>, grid, dim3(256), (size_t)n_class * n_class * sizeof(unsigned), ctx->stream, maps_dev,
                        (const EvalNNJob *)d, (const int32_t *)(d + jb), gt_dev, n_class, ignore_label, pred_dev,
                        (unsigned long long *)confusion_dev, (unsigned *)(d + jb + kb));
     WSC_HIP(hipGetLastError());
@@ -592,6 +600,51 @@ int wsc_cam_eval_confusion_nn(wsc_ctx *ctx, const float *maps_dev, int B, const 
     wsc_ctx_cached_free(ctx, d);
     WSC_CHECK(n_bad == 0, WSC_ERR_INVALID,
               "wsc_cam_eval_confusion_nn: %u pixels carry a ground-truth label outside [0, %d) (and != ignore_label %d)", n_bad,
+              n_class, ignore_label);
+    return WSC_OK;
+}
+
+int wsc_label_confusion_nn(wsc_ctx *ctx, const int32_t *labels_dev, int B, const int32_t *src_hw_host, const int32_t *out_hw_host,
+                           const int64_t *labels_off_host, const uint8_t *gt_dev, int n_class, int ignore_label, uint8_t *pred_dev,
+                           int64_t *confusion_dev) {
+    WSC_CHECK(ctx && labels_dev && src_hw_host && out_hw_host && labels_off_host && confusion_dev, WSC_ERR_INVALID,
+              "wsc_label_confusion_nn: null argument");
+    WSC_CHECK(B > 0 && n_class > 0 && n_class <= 64, WSC_ERR_INVALID, "wsc_label_confusion_nn: B=%d n_class=%d", B, n_class);
+    WSC_HIP(hipSetDevice(ctx->device));
+    std::vector<EvalNNJob> jobs(B);
+    long long pix = 0, max_pix = 0;
+    for (int b = 0; b < B; ++b) {
+        EvalNNJob &j = jobs[b];
+        j.h = src_hw_host[2 * b]; j.w = src_hw_host[2 * b + 1];
+        j.out_h = out_hw_host[2 * b]; j.out_w = out_hw_host[2 * b + 1];
+        WSC_CHECK(j.h > 0 && j.w > 0 && j.out_h > 0 && j.out_w > 0, WSC_ERR_INVALID, "image %d: %dx%d -> %dx%d", b, j.h, j.w,
+                  j.out_h, j.out_w);
+        j.K = 0;
+        j.key_base = 0;
+        j.maps_off = labels_off_host[b];
+        j.pix_off = pix;
+        j.inv_y = 1.0 / ((double)j.out_h / (double)j.h); // cv2.resize: inv_scale = 1. / (dsize / ssize), both in double
+        j.inv_x = 1.0 / ((double)j.out_w / (double)j.w);
+        pix += (long long)j.out_h * j.out_w;
+        max_pix = std::max(max_pix, (long long)j.out_h * j.out_w);
+    }
+    const size_t jb = (jobs.size() * sizeof(EvalNNJob) + 15) / 16 * 16;
+    char *d = nullptr;
+    WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + 16, (void **)&d));
+    std::vector<char> stage(jb + 16, 0); // the last 16 bytes: out-of-range counter, zeroed
+    memcpy(stage.data(), jobs.data(), jobs.size() * sizeof(EvalNNJob));
+    WSC_TRY(wsc_ctx_upload_small(ctx, d, stage.data(), stage.size()));
+    const dim3 grid((unsigned)std::min<long long>((max_pix + 255) / 256, 1024), (unsigned)B);
+    hipLaunchKernelGGL(cam_eval_nn_kernel<true>, grid, dim3(256), (size_t)n_class * n_class * sizeof(unsigned), ctx->stream,
+                       reinterpret_cast<const float *>(labels_dev), (const EvalNNJob *)d, (const int32_t *)nullptr, gt_dev, n_class,
+                       ignore_label, pred_dev, (unsigned long long *)confusion_dev, (unsigned *)(d + jb));
+    WSC_HIP(hipGetLastError());
+    unsigned n_bad = 0;
+    WSC_HIP(hipMemcpyAsync(&n_bad, d + jb, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    wsc_ctx_cached_free(ctx, d);
+    WSC_CHECK(n_bad == 0, WSC_ERR_INVALID,
+              "wsc_label_confusion_nn: %u pixels carry a label or a ground-truth label outside [0, %d) (and != ignore_label %d)", n_bad,
               n_class, ignore_label);
     return WSC_OK;
 }

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "wsc_cam_unary_pm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wsc_cam_sum_scales": (_i, [_vp, _vp, _i, _i, ctypes.c_longlong, _vp]),
     "wsc_cam_eval_confusion_nn": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "wsc_label_confusion_nn": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "wsc_sem_seg_finish": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     "wsc_msf_input_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
@@ -500,6 +501,17 @@ def cam_eval_confusion_nn(ctx, maps_dev, src_sizes, out_sizes, keys_per_image, m
     check(ctx._lib.wsc_cam_eval_confusion_nn(ctx.h, _ptr(maps_dev), B, src_hw.ctypes.data, out_hw.ctypes.data, keys.ctypes.data,
                                              key_off.ctypes.data, m_off.ctypes.data, _ptr(gt_dev), int(n_class),
                                              int(ignore_label), _ptr(pred_dev), _ptr(confusion_dev)))
+
+
+def label_confusion_nn(ctx, labels_dev, src_sizes, out_sizes, labels_off, gt_dev, n_class, confusion_dev, pred_dev=None,
+                       ignore_label=255):
+    """HSN evaluation tail: int32 label maps -> cv2 nearest resize to out_sizes -> confusion[gt][pred] (accumulated)."""
+    B = len(src_sizes)
+    src_hw = np.asarray(src_sizes, dtype=np.int32).reshape(B, 2)
+    out_hw = np.asarray(out_sizes, dtype=np.int32).reshape(B, 2)
+    off = np.ascontiguousarray(labels_off, dtype=np.int64)
+    check(ctx._lib.wsc_label_confusion_nn(ctx.h, _ptr(labels_dev), B, src_hw.ctypes.data, out_hw.ctypes.data, off.ctypes.data,
+                                          _ptr(gt_dev), int(n_class), int(ignore_label), _ptr(pred_dev), _ptr(confusion_dev)))
 
 
 def sem_seg_finish(ctx, rw_dev, rw_off, khw, up_hw, out_hw, keys_per_image, has_bg, bg_thres, label_dev):

@@ -24,13 +24,15 @@ def dcrf_config_for(dataset, model_type):
 
 
 def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True, is_verbose=True, *, models=None, alphas=None,
-            images=None, n_seg_classes=None, settings=None, reference_normalize_quirk=False):
+            images=None, n_seg_classes=None, settings=None, reference_normalize_quirk=None):
     """`reference_normalize_quirk`: the reference's VOC2012 normalisation (03c_hsn/utilities.py:142-146) runs
     `x[:, :, 0] -= 104; x[:, :, 1] -= 117; x[:, :, 2] -= 123` on the 4-D uint8 BATCH -- that indexes image COLUMNS 0..2 of
     every row and channel, wraps around in uint8, and works in place, so the array later handed to the CRF is modified
-    too; the result is divided by 255.  The default here is the intended per-channel (x - [104, 117, 123]) / 255 on an
-    untouched image (what the 02_cues twin does, 02_cues/demo.py:163-164); True reproduces the reference's actual
-    arithmetic for parity runs against it (deviations).
+    too; the result is divided by 255.  This arithmetic is the DEFAULT (True): the package is a drop-in, its VOC2012 label
+    maps are the upstream ones.  False selects the per-channel (x - [104, 117, 123]) / 255 on an untouched image that the
+    author evidently intended (what the 02_cues twin does, 02_cues/demo.py:163-164).  None (default) reads the optional key
+    `hsn_voc_normalize = reference | intended` of settings.ini's [Data Folders] section when a settings file is in play,
+    else True (INTEGRATION.md, deviations).
 
     Device resident between the batch upload and the label maps, like segment_adp: both models' Grad-CAM stacks are
     written straight into one [B][1 + C][S*S] stack (wsc_hsn_gradcam_post with a channel offset), the VOC background
@@ -58,6 +60,14 @@ def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True,
             for m in (["fg", "bg"] if dataset == "VOC2012" else ["fg"]):  # demo.py:80-85: one directory, both modes
                 models[m], alphas[m], _, _ = ks.load_model(model_dir, sess_id, model_type, dataset)
     voc = dataset == "VOC2012"
+    if reference_normalize_quirk is None:
+        reference_normalize_quirk = True
+        try:
+            from .. import keras_store as ks
+
+            reference_normalize_quirk = ks.read_option(settings, "hsn_voc_normalize", "reference") != "intended"
+        except FileNotFoundError:
+            pass
     mean, std = ([104, 117, 123], [255, 255, 255]) if voc else ([0, 0, 0], [255, 255, 255])
     cfg = dcrf_config_for(dataset, model_type)
     out = []
@@ -74,17 +84,18 @@ def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True,
         else:  # the resize of read_batch stays on the host (float64, kept un-rounded like the reference's batch)
             norm, raw = read_batch(chunk, (img_size, img_size), mean, std)
             raw_u8 = raw.astype(np.uint8)
+        b_mean = mean  # per batch: the quirk path normalises the modified uint8 batch with a zero mean
         if voc and reference_normalize_quirk:
             raw_u8 = np.ascontiguousarray(raw_u8)
             raw_u8[:, :, 0] -= 104  # (B, H, 3): image column 0 of every row and channel, uint8 wrap-around, in place
             raw_u8[:, :, 1] -= 117
             raw_u8[:, :, 2] -= 123
-            norm, mean = None, [0, 0, 0]
+            norm, b_mean = None, [0, 0, 0]
         C = np.asarray(alphas["fg"]).shape[1]
         if voc:
             Cv = n_seg_classes or C + 1
             y_dev = ctx.alloc(B * Cv * N * 4, pooled=True)
-            kw = dict(raw_u8=raw_u8, mean_std=(mean, std)) if norm is None else {}
+            kw = dict(raw_u8=raw_u8, mean_std=(b_mean, std)) if norm is None else {}
             hu.grad_cam_device(models["fg"], alphas["fg"], norm, thr_of(alphas["fg"]), [img_size, img_size], out=(y_dev, Cv, 1),
                                ctx=ctx, **kw)
             Cb = np.asarray(alphas["bg"]).shape[1]
@@ -93,7 +104,7 @@ def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True,
             valid = list(range(Cv))
         else:
             Cv = C
-            kw = dict(raw_u8=raw_u8, mean_std=(mean, std)) if norm is None else {}
+            kw = dict(raw_u8=raw_u8, mean_std=(b_mean, std)) if norm is None else {}
             y_dev = hu.grad_cam_device(models["fg"], alphas["fg"], norm, thr_of(alphas["fg"]), [img_size, img_size], ctx=ctx,
                                        **kw)[0]
             valid = list(range(C - 1))  # Y = H_fg[:, :-1]: the 'unknown' class is dropped (demo.py:153)
@@ -130,7 +141,7 @@ class ADPClasses:
         }
 
 
-def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size, is_verbose=False, all_classes=None):
+def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size, is_verbose=False, all_classes=None, stats=None):
     """demo.py:271-380 for one ADP model: per batch scores >= thresholds -> HSN Grad-CAM at (size, size) -> per
     HTT type {morph, func}: scatter into the valid-class stack, modify_by_htt (background / other channels),
     get_cs_gradcam, dense CRF with that type's configuration.  `images` are uint8 RGB (any size; resized like
@@ -139,7 +150,8 @@ def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size
 
     Device resident between the batch upload and the label maps: wsc_net_forward_gradcam -> wsc_hsn_gradcam_post ->
     wsc_hsn_background -> wsc_hsn_cs_gradcam -> wsc_hsn_gather_unary -> wsc_crf_*; the host sees the (B, C) scores, the
-    (B, Cv) class-mass flags and the final labels."""
+    (B, Cv) class-mass flags and the final labels.  `stats` (optional dict): per HTT type the list of every image's number of
+    classes with mass -- the M its dense CRF ran with (dcrf_process keeps the classes whose maps are not all zero, :425)."""
     from .. import _lib
 
     ac = ADPClasses(all_classes)
@@ -172,7 +184,64 @@ def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size
             _lib.hsn_cs_gradcam(ctx, H_dev, B, C_all, N, bg_dev, src_of, bg_ind, other_ind, ex_inds,
                                 adipose_all if htt == "func" else None, cs_dev, None, mass_dev)
             mass = ctx.to_host(mass_dev, (B, Cv), np.uint32)
+            if stats is not None:
+                stats.setdefault(htt, []).extend(int(v) for v in (mass > 0).sum(1))
             out[htt].extend(list(hu.dcrf_process_device(ctx, cs_dev, mass, raw, Cv, size, size, dcrf_configs[htt])))
         if is_verbose:
             print("\tBatch %d-%d" % (lo, hi))
     return out
+
+
+# ---- evaluation tail of the HistoSegNet drivers (03c_hsn/demo.py:386-408, 424-428; VOC / DeepGlobe: :176-197) -----------
+def gt_index_from_colours(gt_rgb, colours):
+    """Colour-coded ground truth (H, W, 3) -> uint8 class index; a pixel of no listed colour gets len(colours) -- the
+    reference tests `gt == colour k` per class (demo.py:392-397), so such a pixel is in no ground-truth mask but still
+    counts in the unions through the prediction masks."""
+    gt_rgb = np.asarray(gt_rgb, dtype=np.uint8)
+    idx = np.full(gt_rgb.shape[:2], len(colours), dtype=np.uint8)
+    for k in range(len(colours) - 1, -1, -1):  # (distinct colours; the first listed class wins if two ever coincide)
+        idx[np.all(gt_rgb == np.asarray(colours[k], dtype=np.uint8)[None, None, :], axis=2)] = k
+    return idx
+
+
+class LabelEvaluator:
+    """Carries one HTT type's confusion matrix on the device over a whole run and turns it into the reference's numbers.
+
+    update(label_maps, gt_rgb): demo.py:386-408 for a batch -- cv2.resize(pred, (1088, 1088), INTER_NEAREST) of every
+    (S, S) label map and the per-class counts, as ONE pass per batch on the device (wsc_label_confusion_nn).
+    metrics(): intersects / unions / gt_count / confusion_matrix / IoU per class / mIoU exactly as :399-405 and :424-428
+    define them (IoU = intersect / (union + 1e-7), mIoU = their mean over ALL valid classes)."""
+
+    def __init__(self, ctx, colours, out_size=(1088, 1088)):
+        self.ctx, self.colours, self.out_size = ctx, [tuple(int(v) for v in c) for c in colours], tuple(out_size)
+        self.n = len(self.colours)
+        self.conf_dev = ctx.alloc((self.n + 1) * (self.n + 1) * 8)
+        from .. import _lib
+
+        _lib.check(ctx._lib.wsc_memset(ctx.h, self.conf_dev.ptr, 0, (self.n + 1) * (self.n + 1) * 8))
+
+    def update(self, label_maps, gt_rgb, want_pred=False):
+        from .. import _lib
+
+        B = len(label_maps)
+        lab = np.ascontiguousarray(np.stack([np.asarray(m) for m in label_maps]).astype(np.int32))
+        h, w = lab.shape[1:]
+        gt = np.ascontiguousarray(np.stack([gt_index_from_colours(g, self.colours) for g in gt_rgb]))
+        assert gt.shape == (B,) + self.out_size, (gt.shape, self.out_size)
+        lab_dev, gt_dev = self.ctx.to_device(lab, pooled=True), self.ctx.to_device(gt, pooled=True)
+        pred_dev = self.ctx.alloc(B * self.out_size[0] * self.out_size[1], pooled=True) if want_pred else None
+        _lib.label_confusion_nn(self.ctx, lab_dev, [(h, w)] * B, [self.out_size] * B, [b * h * w for b in range(B)], gt_dev,
+                                self.n + 1, self.conf_dev, pred_dev=pred_dev, ignore_label=255)
+        if want_pred:
+            return self.ctx.to_host(pred_dev, (B,) + self.out_size, np.uint8)
+
+    def metrics(self):
+        conf = self.ctx.to_host(self.conf_dev, (self.n + 1, self.n + 1), np.int64)
+        n = self.n
+        inter = np.diag(conf)[:n].astype(np.float64)
+        gt_count = conf[:n, :].sum(1).astype(np.float64)
+        pred_count = conf[:, :n].sum(0).astype(np.float64)  # over every pixel, whatever its ground-truth colour
+        union = gt_count + pred_count - inter
+        iou = inter / (union + 1e-7)
+        return {"confusion_matrix": conf[:n, :n].astype(np.float64), "intersects": inter, "unions": union, "gt_count": gt_count,
+                "IoU": iou, "mIoU": float(np.mean(iou))}

@@ -33,6 +33,15 @@ def read_settings(path=None):
             "CUES_ROOT": os.path.join(data, cfg["Data Folders"]["cues_dir"])}
 
 
+def read_option(path, key, default):
+    """An optional key of settings.ini's [Data Folders] section (keys the reference's file does not have: defaults apply)."""
+    path = path or os.environ.get("WSSCAM_SETTINGS", os.path.join("..", "settings.ini"))
+    cfg = configparser.ConfigParser()
+    if not cfg.read(path):
+        raise FileNotFoundError(path)
+    return cfg["Data Folders"].get(key, default) if cfg.has_section("Data Folders") else default
+
+
 class SetList:
     """The three attributes the drivers read off a Keras DataFrameIterator: `directory`, `filenames`, `data` (labels)."""
 

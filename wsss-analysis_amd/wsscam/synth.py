@@ -127,3 +127,30 @@ def adp_image(rng, H, W):
         m = ((yy - cy) ** 2 + (xx - cx) ** 2) < r * r
         img[m] = rng.uniform([150, 60, 130], [220, 130, 200]) + rng.normal(0, 6, (int(m.sum()), 3))
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def specialise_classifier(sd, root, num_classes, features, seed=0, amplitude=0.5):
+    """Replaces `<root>.classifier.0.weight` (C x F) by a head calibrated to the (random) features: every class responds to
+    the MEAN feature vector m of a sample batch with the same logit 1, plus a class-specific random direction orthogonal to
+    m (whitened per channel, `amplitude` logit units of standard deviation over the sample's pixels).
+    Why: with i.i.d. weights the few classes whose alpha has the largest component along m -- the features are post-ReLU,
+    so m is large -- have the largest Grad-CAM map at EVERY pixel, and a Grad-CAM -> arg-max -> CRF chain degenerates to 2-4
+    classes per image (1 for the functional types).  A trained classifier's classes win in different places; exchangeable
+    class maps reproduce that with random weights: 10-15 morphological and 3 functional classes carry mass per ADP-like patch
+    (HSN bench, BASELINE config 5: the dense CRFs then run at a realistic M).
+    features: float array (..., F) of final feature maps over a sample batch."""
+    rng = np.random.default_rng(977 + seed)
+    W = np.asarray(sd[root + ".classifier.0.weight"])
+    C, F = W.shape
+    assert C == num_classes
+    feats = np.asarray(features, dtype=np.float64).reshape(-1, F)
+    m, s_f = feats.mean(0), np.maximum(feats.std(0), 1e-6)
+    mn = max(float(np.linalg.norm(m)), 1e-12)
+    mh = m / mn
+    Wn = np.zeros((C, F))
+    for c in range(C):
+        g = rng.standard_normal(F) / s_f / np.sqrt(F)
+        g -= (g @ mh) * mh
+        Wn[c] = mh / mn + amplitude * g
+    sd[root + ".classifier.0.weight"] = Wn.astype(np.float32)
+    return sd
