@@ -275,30 +275,41 @@ class Workload:
             b1 = b0
             while b1 < self.B and len(self.kp_keys[b1]) == K:
                 b1 += 1
-            if K > 0:
-                self.kp_groups.append((b0, b1 - b0, K))
+            self.kp_groups.append((b0, b1 - b0, K))
             b0 = b1
         N = S * S
         self.kp_maps_dev = self.ctx.alloc(self.B * 6 * N * 4 + 4)
         self.kp_strided_dev = self.ctx.alloc(self.B * 6 * ((S - 1) // 4 + 1) ** 2 * 4 + 4)
-        self.kp_unary_dev = self.ctx.alloc(self.B * 7 * N * 4)
-        self.kp_label_dev = self.ctx.alloc(self.B * N * 4)
-        assert max(len(k) for k in self.kp_keys) <= 6
+        self.kp_unary_bufs = [self.ctx.alloc(self.B * 7 * N * 4) for _ in range(2)]  # double-buffered like the M = 21 step
+        self.kp_label_bufs = [self.ctx.alloc(self.B * N * 4) for _ in range(2)]
+        assert max(len(k) for k in self.kp_keys) <= 6 and min(len(k) for k in self.kp_keys) >= 1
 
     def step_kplus1(self):
+        """One step of the M = K + 1 variant, pipelined like step_pipelined(): ONE ragged CRF object for the whole batch
+        (wsc_crf_v: every image its own class count), its lattices built on stream B while the conv stack runs on A, its
+        mean-field loop on C while the host already enqueues the next step."""
         N = S * S
+        self.parity ^= 1
+        p = self.parity
         self.net.forward_cam(self.kp_x_dev, self.B, S, self.cam_dev, None)
+        crf = self._lib.CrfV(self.ctx_build, [self.kp_rgb_dev.ptr + b * N * 3 for b in range(self.B)], [(S, S)] * self.B,
+                             CRF_CFG[0], CRF_CFG[2], CRF_CFG[3])
+        # make_cam tail for every image's own classes at S x S (maps packed back to back), then [bg | maps] unaries per K-group
+        self._lib.cam_postprocess(self.ctx, self.cam_dev, self.B, NUM_CLASSES, self.h, self.h, [(S, S)] * self.B, self.kp_keys,
+                                  self.kp_strided_dev, self.kp_maps_dev)
+        u_ptrs, m_off, u_off = [], 0, 0
         for (b0, nb, K) in self.kp_groups:
-            cam_g = self.cam_dev.ptr + b0 * NUM_CLASSES * self.h * self.h * 4
-            crf = self._lib.Crf(self.ctx_build, self.kp_rgb_dev.ptr + b0 * N * 3, nb, S, S, CRF_CFG[0], CRF_CFG[2], CRF_CFG[3])
-            self._lib.cam_postprocess(self.ctx, cam_g, nb, NUM_CLASSES, self.h, self.h, [(S, S)] * nb, self.kp_keys[b0:b0 + nb],
-                                      self.kp_strided_dev, self.kp_maps_dev)
-            self._lib.unary_from_maps(self.ctx, self.kp_maps_dev, nb, K, N, 0.15, self.kp_unary_dev)
-            self.ctx.wait_for(self.ctx_build)
-            crf.inference(self.kp_unary_dev, K + 1, CRF_CFG[1], CRF_CFG[4], CRF_CFG[5], None,
-                          self.kp_label_dev.ptr + b0 * N * 4, ctx=self.ctx)
-            self.ctx.sync()
-            crf.close()
+            self._lib.unary_from_maps(self.ctx, self.kp_maps_dev.ptr + m_off * N * 4, nb, K, N, 0.15,
+                                      self.kp_unary_bufs[p].ptr + u_off * N * 4)
+            u_ptrs += [self.kp_unary_bufs[p].ptr + (u_off + i * (K + 1)) * N * 4 for i in range(nb)]
+            m_off += nb * K
+            u_off += nb * (K + 1)
+        self.drain()
+        self.ctx_crf.wait_for(self.ctx)
+        self.ctx_crf.wait_for(self.ctx_build)
+        crf.inference(u_ptrs, [len(k) + 1 for k in self.kp_keys], CRF_CFG[1], CRF_CFG[4], CRF_CFG[5], None,
+                      [self.kp_label_bufs[p].ptr + b * N * 4 for b in range(self.B)], ctx=self.ctx_crf)
+        self.pending = crf
 
     # -- end to end: host batch in, files out ---------------------------------------------------------------
     def setup_e2e(self, out_dir, n_writers=8, u8=False):
@@ -795,7 +806,7 @@ def main():
             w3.close()
             del w3
         wl.setup_kplus1()
-        tk = timed_run(wl, wl.step_kplus1, k_extra, 2, lambda: None)
+        tk = timed_run(wl, wl.step_kplus1, k_extra, 2, wl.drain)
         stages["value_M_eq_Kplus1"] = round(args.batch * k_extra / tk, 3)
         stages["M_eq_Kplus1_groups"] = ["K=%d x %d images" % (K, nb) for (_, nb, K) in wl.kp_groups]
         import shutil

@@ -68,6 +68,7 @@ typedef enum wsc_precision {
 typedef struct wsc_ctx wsc_ctx; /* device + stream + workspace arena */
 typedef struct wsc_net wsc_net; /* immutable packed weights of one CNN */
 typedef struct wsc_crf wsc_crf; /* lattices (Gaussian + bilateral) of a batch of images */
+typedef struct wsc_crf_v wsc_crf_v; /* the same for a RAGGED batch: every image its own (H, W) and class count */
 
 /* A named host tensor of a torch state_dict (float32, C-contiguous). */
 typedef struct wsc_tensor_desc {
@@ -416,6 +417,25 @@ int wsc_crf_inference(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, int M,
  * (wsc_cam_unary_pm).  The buffer is read in place during the whole loop and never written. */
 int wsc_crf_inference_pm(wsc_ctx *ctx, wsc_crf *crf, const float *unary_pm_dev, int M, float g_compat,
                          float bi_compat, int n_iters, float *q_dev, int32_t *argmax_dev);
+
+/* ---- ragged batch ----------------------------------------------------------------------------------------------------
+ * The reference runs its CRF one image at a time, every image with its own size and class count
+ * (03b_irn/step/cam_to_ir_label.py:25-58: crf_inference_label per image, K_b + 1 labels; 03c_hsn/utilities.py:420-445:
+ * DenseCRF2D(W, H, len(pass_inds[i])) per image).  A wsc_crf_v takes such a list as it comes:
+ *   rgb_dev[b]   device pointer of image b, uint8 [H_b][W_b][3];  hw_host[2b], hw_host[2b+1] = H_b, W_b
+ * Images of equal size share a lattice build and a mean-field loop; the groups are issued back to back on the ctx's stream
+ * (no host synchronisation between them).  wsc_crf_v_inference:
+ *   unary_dev[b] device pointer of image b's unaries, float32 [M_b][H_b*W_b] (class-major, as wsc_crf_inference takes them)
+ *   M_host[b]    its class count (1..32);  q_dev[b] (float32 [M_b][H_b*W_b]) and / or argmax_dev[b] (int32 [H_b*W_b]);
+ *                either pointer ARRAY may be NULL, single entries too
+ * Inside a group the loop runs at the largest M_b; a smaller image's missing classes enter with probability zero, which
+ * leaves every bit of its result what a call with its own M_b gives (tests/test_gpu_crf.py::test_crf_ragged_batch). */
+int wsc_crf_v_create(wsc_ctx *ctx, const uint8_t *const *rgb_dev, const int32_t *hw_host /*[B][2]*/, int B, float g_sxy,
+                     float bi_sxy, float bi_srgb, wsc_crf_v **out);
+void wsc_crf_v_destroy(wsc_crf_v *crf);
+int wsc_crf_v_num_groups(const wsc_crf_v *crf); /* lattice builds / loops the batch needs (distinct image sizes) */
+int wsc_crf_v_inference(wsc_ctx *ctx, wsc_crf_v *crf, const float *const *unary_dev, const int32_t *M_host, float g_compat,
+                        float bi_compat, int n_iters, float *const *q_dev, int32_t *const *argmax_dev);
 
 #ifdef __cplusplus
 }

@@ -397,3 +397,32 @@ def test_crf_gaussian_cache_overflow_takes_the_unfused_path():
     q2, a2, _, _ = _gpu_crf(ctx_b, [last[0]], [last[1]], cfg)
     assert _gpu_crf.on_chip
     assert np.array_equal(q2, last[2]) and np.array_equal(a2, last[3])
+
+
+def test_crf_ragged_batch(ctx):
+    """wsc_crf_v: a list of images with their own sizes AND class counts in one object (the reference's per-image loops:
+    cam_to_ir_label.py:25-58, 03c_hsn/utilities.py:420-445).  Seven images of three sizes, M from 1 to 21, in mixed order,
+    non-contiguous device buffers: Q and labels of every image must be BIT-identical to a wsc_crf call on that image alone
+    with its own M (the group loop runs at the group's largest M with the smaller images' missing classes at probability
+    zero), and a labels-only ragged call must give the same labels."""
+    rng = np.random.default_rng(4711)
+    cfg = (1.5, 3, 40, 13, 10, 10)
+    specs = [(57, 75, 3), (40, 33, 21), (57, 75, 6), (64, 64, 2), (57, 75, 1), (40, 33, 5), (57, 75, 21)]
+    cases = [helpers.synth_crf_case(rng, h, w, m) for (h, w, m) in specs]
+    rgb_devs = [ctx.to_device(np.ascontiguousarray(c[0])) for c in cases]
+    u_devs = [ctx.to_device(np.ascontiguousarray(c[1])) for c in cases]
+    q_devs = [ctx.alloc(m * h * w * 4) for (h, w, m) in specs]
+    a_devs = [ctx.alloc(h * w * 4) for (h, w, m) in specs]
+    cv = _lib.CrfV(ctx, rgb_devs, [(h, w) for (h, w, m) in specs], cfg[0], cfg[2], cfg[3])
+    assert cv.num_groups() == 3
+    cv.inference(u_devs, [m for (_, _, m) in specs], cfg[1], cfg[4], cfg[5], q_devs, a_devs)
+    qs = [ctx.to_host(q, (m, h * w), np.float32) for q, (h, w, m) in zip(q_devs, specs)]
+    labs = [ctx.to_host(a, (h * w,), np.int32) for a, (h, w, m) in zip(a_devs, specs)]
+    a2_devs = [ctx.alloc(h * w * 4) for (h, w, m) in specs]
+    cv.inference(u_devs, [m for (_, _, m) in specs], cfg[1], cfg[4], cfg[5], None, a2_devs)
+    labs2 = [ctx.to_host(a, (h * w,), np.int32) for a, (h, w, m) in zip(a2_devs, specs)]
+    cv.close()
+    for i, (rgb, U, _) in enumerate(cases):
+        q1, a1, _, _ = _gpu_crf(ctx, [rgb], [U], cfg)
+        assert np.array_equal(qs[i], q1[0]), (i, specs[i], np.abs(qs[i] - q1[0]).max())
+        assert np.array_equal(labs[i], a1[0]) and np.array_equal(labs2[i], a1[0]), (i, specs[i])

@@ -79,3 +79,26 @@ def test_cam_to_ir_label_run(tmp_path, dataset):
         clr = np.asarray(Image.open(os.path.join(clr_dir, name + ".png")))
         assert clr.shape == ref.shape + (3,) and np.all(clr[got == 255] == 255)
         assert os.path.exists(os.path.join(clr_dir, name + "_overlay.png"))
+
+
+@pytest.mark.parametrize("mode", ["voc12", "fg"])
+def test_ir_label_ragged_equals_per_group(ctx, mode):
+    """A mixed-size, mixed-class-count list through ONE ragged CRF object (what cam_to_ir_label._work now issues per device
+    batch) gives, bit for bit, the label maps of the per-(H, W, K) group path (ir_label_batch), which is the reference's
+    per-image loop (cam_to_ir_label.py:25-58) batched."""
+    rng = np.random.default_rng(99)
+    specs = [(47, 59, 2), (59, 47, 1), (47, 59, 3), (47, 59, 2), (40, 40, 4), (59, 47, 1), (47, 59, 2)]
+    items = []
+    for (H, W, K) in specs:
+        rgb, _, p = helpers.synth_crf_case(rng, H, W, K + 1)
+        maps = (p[:K] / p[:K].max(axis=(1, 2), keepdims=True)).astype(np.float32)
+        items.append((rgb, maps, np.sort(rng.choice(20, K, replace=False))))
+    got = cam_to_ir_label.ir_label_ragged(ctx, items, mode, 0.30, 0.05)
+    groups = {}
+    for i, s in enumerate(specs):
+        groups.setdefault(s, []).append(i)
+    for s, idx in groups.items():
+        ref = cam_to_ir_label.ir_label_batch(ctx, np.stack([items[i][0] for i in idx]), np.stack([items[i][1] for i in idx]),
+                                             [items[i][2] for i in idx], mode, 0.30, 0.05)
+        for j, i in enumerate(idx):
+            assert got[i].shape == ref[j].shape and np.array_equal(got[i], ref[j]), (s, i)

@@ -71,22 +71,25 @@ void wsc_ctx_cached_free(wsc_ctx *ctx, void *p) {
 
 int wsc_ctx_upload_small(wsc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
     if (bytes == 0) return WSC_OK;
-    if (ctx->pinned_busy) {
-        WSC_HIP(hipEventSynchronize(ctx->pinned_ev));
-        ctx->pinned_busy = false;
+    wsc_ctx::PinSlot &s = ctx->pin_ring[ctx->pin_next];
+    ctx->pin_next = (ctx->pin_next + 1) % wsc_ctx::PIN_SLOTS;
+    if (s.busy) { // the ring has gone round: this slot's previous copy must have left it
+        WSC_HIP(hipEventSynchronize(s.ev));
+        s.busy = false;
     }
-    if (bytes > ctx->pinned_bytes) {
-        if (ctx->pinned) WSC_HIP(hipHostFree(ctx->pinned));
-        ctx->pinned = nullptr;
-        ctx->pinned_bytes = 0;
+    if (!s.ev) WSC_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    if (bytes > s.bytes) {
+        if (s.p) WSC_HIP(hipHostFree(s.p));
+        s.p = nullptr;
+        s.bytes = 0;
         const size_t want = bytes * 2 < (64u << 10) ? (64u << 10) : bytes * 2;
-        WSC_HIP(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
-        ctx->pinned_bytes = want;
+        WSC_HIP(hipHostMalloc(&s.p, want, hipHostMallocDefault));
+        s.bytes = want;
     }
-    memcpy(ctx->pinned, src_host, bytes);
-    WSC_HIP(hipMemcpyAsync(dst_dev, ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
-    WSC_HIP(hipEventRecord(ctx->pinned_ev, ctx->stream));
-    ctx->pinned_busy = true;
+    memcpy(s.p, src_host, bytes);
+    WSC_HIP(hipMemcpyAsync(dst_dev, s.p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    WSC_HIP(hipEventRecord(s.ev, ctx->stream));
+    s.busy = true;
     return WSC_OK;
 }
 
@@ -215,6 +218,10 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
     for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
     for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (wsc_ctx::PinSlot &s : ctx->pin_ring) {
+        if (s.p) (void)hipHostFree(s.p);
+        if (s.ev) (void)hipEventDestroy(s.ev);
+    }
     if (ctx->pinned_ev) (void)hipEventDestroy(ctx->pinned_ev);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);

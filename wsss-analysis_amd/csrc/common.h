@@ -133,8 +133,19 @@ struct wsc_ctx {
     // grow-only workspace arena (activations, CRF scratch); never freed before destroy
     void *ws = nullptr;
     size_t ws_bytes = 0;
-    // small pinned staging buffer for descriptor uploads
-    void *pinned = nullptr;
+    // small pinned staging buffers for descriptor uploads: a ring of slots, so that an upload waits for an earlier one only
+    // when the ring has gone round (a copy is ordered behind everything enqueued on the stream before it: with one slot the
+    // host blocked on the previous call's whole device work)
+    static constexpr int PIN_SLOTS = 8;
+    struct PinSlot {
+        void *p = nullptr;
+        size_t bytes = 0;
+        hipEvent_t ev = nullptr; // completion of the last copy out of this slot
+        bool busy = false;
+    };
+    PinSlot pin_ring[PIN_SLOTS];
+    int pin_next = 0;
+    void *pinned = nullptr; // (legacy single buffer: unused)
     size_t pinned_bytes = 0;
     void *zero_page = nullptr; // 256 bytes of zeros in HBM (source of padded conv taps)
     hipEvent_t pinned_ev = nullptr; // completion of the last copy out of `pinned`

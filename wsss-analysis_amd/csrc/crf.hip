@@ -2329,6 +2329,31 @@ __global__ __launch_bounds__(TP) void init_q_kernel(const float *__restrict__ un
     }
 }
 
+// Ragged batch (wsc_crf_v): the images of one (H, W) group bring their own class-major unaries [M_b][N] and class counts;
+// the group runs at Mg = max M_b.  U[pixel][Mp]: the image's own classes, then classes M_b .. Mg - 1 with a unary of 1e30
+// (probability 0: exp2(-huge) = 0 in every soft-max, so they never carry mass -- the Potts model couples a class only to
+// itself, and adding exact zeros in the soft-max's fixed reduction tree changes no bit of the other classes), then zeros.
+struct UnaryVJob {
+    const float *u; // [M][N]
+    int M;
+};
+__global__ __launch_bounds__(256) void gather_unary_v_kernel(const UnaryVJob *__restrict__ jobs, int Mg, int Mp, int N,
+                                                             float *__restrict__ out) {
+    const UnaryVJob job = jobs[blockIdx.y];
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float *dst = out + ((long long)blockIdx.y * N + n) * Mp;
+    for (int m0 = 0; m0 < Mp; m0 += 4) {
+        f32x4_t v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m0 + k;
+            v[k] = m < job.M ? job.u[(long long)m * N + n] : (m < Mg ? 1.0e30f : 0.f);
+        }
+        *reinterpret_cast<f32x4_t *>(dst + m0) = v;
+    }
+}
+
 // Q [pixel][M] -> q_out [B][M][N] and/or argmax [B][N]
 __global__ __launch_bounds__(TP) void finish_kernel(const float *__restrict__ q, int M, int Mp, int N,
                                                     float *__restrict__ q_out, int32_t *__restrict__ argmax) {
@@ -3234,6 +3259,135 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
         if (!crf->use_ev) WSC_HIP(hipEventCreateWithFlags(&crf->use_ev, hipEventDisableTiming));
         WSC_HIP(hipEventRecord(crf->use_ev, ctx->stream));
         crf->used_elsewhere = true;
+    }
+    return WSC_OK;
+}
+
+
+// ---- ragged batch: per-image (H, W, M) in one object ---------------------------------------------------------------------
+// 03b_irn/step/cam_to_ir_label.py:25-58 and 03c_hsn/utilities.py:420-445 run the CRF one image at a time, every image with
+// its own size and its own class count.  A wsc_crf_v takes such a list as it comes: images of equal (H, W) form a group
+// (one lattice build, one mean-field loop per group, issued back to back on the ctx's stream with no host synchronisation
+// between them), and inside a group every image keeps its own class count -- the loop runs at the group's largest M with
+// the missing classes of the smaller images at probability zero, which changes no bit of their results (see
+// gather_unary_v_kernel).
+struct CrfVGroup {
+    wsc_crf *crf = nullptr;
+    std::vector<int> members; // image indices, in input order
+    uint8_t *rgb = nullptr;   // [members][H][W][3] (cached block of the build ctx), or null when the inputs were contiguous
+};
+} // extern "C"
+struct wsc_crf_v {
+    wsc_ctx *ctx = nullptr;
+    int B = 0;
+    std::vector<int> H, W;
+    std::vector<CrfVGroup> groups;
+};
+extern "C" {
+
+void wsc_crf_v_destroy(wsc_crf_v *cv) {
+    if (!cv) return;
+    for (CrfVGroup &g : cv->groups) {
+        if (g.crf) wsc_crf_destroy(g.crf);
+        if (g.rgb) wsc_ctx_cached_free(cv->ctx, g.rgb);
+    }
+    delete cv;
+}
+
+int wsc_crf_v_create(wsc_ctx *ctx, const uint8_t *const *rgb_dev, const int32_t *hw_host, int B, float g_sxy, float bi_sxy,
+                     float bi_srgb, wsc_crf_v **out) {
+    WSC_CHECK(ctx && rgb_dev && hw_host && out, WSC_ERR_INVALID, "wsc_crf_v_create: null argument");
+    WSC_CHECK(B > 0, WSC_ERR_INVALID, "wsc_crf_v_create: B=%d", B);
+    WSC_HIP(hipSetDevice(ctx->device));
+    wsc_crf_v *cv = new wsc_crf_v();
+    cv->ctx = ctx; cv->B = B;
+    for (int b = 0; b < B; ++b) {
+        const int H = hw_host[2 * b], W = hw_host[2 * b + 1];
+        if (!(H > 0 && W > 0 && rgb_dev[b])) {
+            wsc_crf_v_destroy(cv);
+            wsc_set_error("wsc_crf_v_create: image %d: %dx%d, rgb %p", b, H, W, (const void *)rgb_dev[b]);
+            return WSC_ERR_INVALID;
+        }
+        cv->H.push_back(H); cv->W.push_back(W);
+        size_t gi = 0;
+        for (; gi < cv->groups.size(); ++gi)
+            if (cv->H[cv->groups[gi].members[0]] == H && cv->W[cv->groups[gi].members[0]] == W) break;
+        if (gi == cv->groups.size()) cv->groups.emplace_back();
+        cv->groups[gi].members.push_back(b);
+    }
+    for (CrfVGroup &g : cv->groups) {
+        const int H = cv->H[g.members[0]], W = cv->W[g.members[0]];
+        const size_t ib = (size_t)H * W * 3;
+        const int nb = (int)g.members.size();
+        bool contiguous = true;
+        for (int i = 1; i < nb; ++i) contiguous = contiguous && rgb_dev[g.members[i]] == rgb_dev[g.members[0]] + (size_t)i * ib;
+        const uint8_t *src = rgb_dev[g.members[0]];
+        int st = WSC_OK;
+        if (!contiguous) {
+            st = wsc_ctx_cached_alloc(ctx, ib * nb, (void **)&g.rgb);
+            for (int i = 0; i < nb && st == WSC_OK; ++i)
+                if (hipMemcpyAsync(g.rgb + (size_t)i * ib, rgb_dev[g.members[i]], ib, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                    wsc_set_error("wsc_crf_v_create: device copy of image %d failed", g.members[i]);
+                    st = WSC_ERR_HIP;
+                }
+            src = g.rgb;
+        }
+        if (st == WSC_OK) st = wsc_crf_create(ctx, src, nb, H, W, g_sxy, bi_sxy, bi_srgb, &g.crf);
+        if (st != WSC_OK) {
+            wsc_crf_v_destroy(cv);
+            return st;
+        }
+    }
+    *out = cv;
+    return WSC_OK;
+}
+
+int wsc_crf_v_num_groups(const wsc_crf_v *cv) { return cv ? (int)cv->groups.size() : 0; }
+
+int wsc_crf_v_inference(wsc_ctx *ctx, wsc_crf_v *cv, const float *const *unary_dev, const int32_t *M_host, float g_compat,
+                        float bi_compat, int n_iters, float *const *q_dev, int32_t *const *argmax_dev) {
+    WSC_CHECK(ctx && cv && unary_dev && M_host, WSC_ERR_INVALID, "wsc_crf_v_inference: null argument");
+    WSC_CHECK(q_dev || argmax_dev, WSC_ERR_INVALID, "wsc_crf_v_inference: neither q_dev nor argmax_dev");
+    WSC_HIP(hipSetDevice(ctx->device));
+    for (int b = 0; b < cv->B; ++b)
+        WSC_CHECK(M_host[b] >= 1 && M_host[b] <= 32 && unary_dev[b], WSC_ERR_INVALID, "wsc_crf_v_inference: image %d: M=%d, unary %p", b,
+                  M_host[b], (const void *)unary_dev[b]);
+    for (CrfVGroup &g : cv->groups) {
+        const int nb = (int)g.members.size();
+        const int N = cv->H[g.members[0]] * cv->W[g.members[0]];
+        int Mg = 0;
+        for (int i : g.members) Mg = std::max(Mg, (int)M_host[i]);
+        const int Mp = (Mg + 3) / 4 * 4;
+        // per group: job table, pixel-major unaries, and the group's outputs (class-major Q / labels) before they are dealt out
+        const bool want_q = q_dev != nullptr;
+        const size_t jb = ((size_t)nb * sizeof(UnaryVJob) + 255) / 256 * 256, ub = ((size_t)nb * N * Mp * 4 + 255) / 256 * 256;
+        const size_t qb = want_q ? ((size_t)nb * N * Mg * 4 + 255) / 256 * 256 : 0, ab = argmax_dev ? ((size_t)nb * N * 4 + 255) / 256 * 256 : 0;
+        char *blk = nullptr;
+        WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + ub + qb + ab, (void **)&blk));
+        std::vector<UnaryVJob> jobs(nb);
+        for (int i = 0; i < nb; ++i) jobs[i] = UnaryVJob{unary_dev[g.members[i]], (int)M_host[g.members[i]]};
+        int st = wsc_ctx_upload_small(ctx, blk, jobs.data(), jobs.size() * sizeof(UnaryVJob));
+        float *u_pm = (float *)(blk + jb), *q_g = want_q ? (float *)(blk + jb + ub) : nullptr;
+        int32_t *a_g = argmax_dev ? (int32_t *)(blk + jb + ub + qb) : nullptr;
+        if (st == WSC_OK) {
+            WscKernelTimer timer(ctx, WSC_K_CRF_MISC, (double)nb * N * (Mg + Mp) * 4);
+            hipLaunchKernelGGL(gather_unary_v_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nb), dim3(256), 0, ctx->stream,
+                               (const UnaryVJob *)blk, Mg, Mp, N, u_pm);
+            if (hipGetLastError() != hipSuccess) st = WSC_ERR_HIP;
+        }
+        if (st == WSC_OK) st = crf_inference_impl(ctx, g.crf, u_pm, true, Mg, g_compat, bi_compat, n_iters, q_g, a_g);
+        for (int i = 0; i < nb && st == WSC_OK; ++i) {
+            const int b = g.members[i];
+            if (want_q && q_dev[b] &&
+                hipMemcpyAsync(q_dev[b], q_g + (size_t)i * Mg * N, (size_t)M_host[b] * N * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                st = WSC_ERR_HIP;
+            if (argmax_dev && argmax_dev[b] &&
+                hipMemcpyAsync(argmax_dev[b], a_g + (size_t)i * N, (size_t)N * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                st = WSC_ERR_HIP;
+        }
+        wsc_ctx_cached_free(ctx, blk); // stream-ordered: reused only by work enqueued later on this ctx
+        if (st == WSC_ERR_HIP) wsc_set_error("wsc_crf_v_inference: a launch or device copy failed");
+        if (st != WSC_OK) return st;
     }
     return WSC_OK;
 }

@@ -118,6 +118,10 @@ _SIGNATURES = {
     "wsc_crf_gaussian_on_chip": (_i, [_vp, _i]),
     "wsc_crf_inference": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
     "wsc_crf_inference_pm": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
+    "wsc_crf_v_create": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, ctypes.POINTER(_vp)]),
+    "wsc_crf_v_destroy": (None, [_vp]),
+    "wsc_crf_v_num_groups": (_i, [_vp]),
+    "wsc_crf_v_inference": (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),
 }
 
 
@@ -589,6 +593,56 @@ class Crf:
         fn = self.ctx._lib.wsc_crf_inference_pm if pixel_major else self.ctx._lib.wsc_crf_inference
         check(fn(run.h, self.h, _ptr(unary_dev), M, float(g_compat), float(bi_compat), int(n_iters), _ptr(q_dev),
                  _ptr(argmax_dev)))
+
+
+def _ptr_array(ptrs):
+    """list of DeviceBuffer / int addresses / None -> ctypes array of void* (kept alive by the caller)."""
+    arr = (ctypes.c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = None if p is None else (p.ptr if hasattr(p, "ptr") else int(p))
+    return arr
+
+
+class CrfV:
+    """wsc_crf_v: lattices of a RAGGED batch -- every image its own (H, W) and, at inference, its own class count.
+    rgb_ptrs: one device pointer (DeviceBuffer or address) per image, uint8 [H_b][W_b][3]; sizes: [(H_b, W_b)]."""
+
+    def __init__(self, ctx, rgb_ptrs, sizes, g_sxy, bi_sxy, bi_srgb):
+        self.ctx = ctx
+        self.B = len(rgb_ptrs)
+        self.sizes = [(int(h), int(w)) for h, w in sizes]
+        assert len(self.sizes) == self.B
+        hw = np.ascontiguousarray(self.sizes, dtype=np.int32).reshape(self.B, 2)
+        arr = _ptr_array(rgb_ptrs)
+        h = _vp()
+        check(ctx._lib.wsc_crf_v_create(ctx.h, arr, hw.ctypes.data, self.B, float(g_sxy), float(bi_sxy), float(bi_srgb),
+                                        ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx._lib.wsc_crf_v_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_groups(self):
+        return int(self.ctx._lib.wsc_crf_v_num_groups(self.h))
+
+    def inference(self, unary_ptrs, Ms, g_compat, bi_compat, n_iters, q_ptrs=None, argmax_ptrs=None, ctx=None):
+        """unary_ptrs[b]: float32 [M_b][H_b*W_b] on the device; q_ptrs / argmax_ptrs: per-image outputs (lists, or None)."""
+        run = ctx or self.ctx
+        m = np.ascontiguousarray(Ms, dtype=np.int32)
+        assert len(unary_ptrs) == self.B and len(m) == self.B
+        ua = _ptr_array(unary_ptrs)
+        qa = _ptr_array(q_ptrs) if q_ptrs is not None else None
+        aa = _ptr_array(argmax_ptrs) if argmax_ptrs is not None else None
+        check(self.ctx._lib.wsc_crf_v_inference(run.h, self.h, ua, m.ctypes.data, float(g_compat), float(bi_compat), int(n_iters),
+                                                qa, aa))
 
 
 def rw_propagate(ctx, x_dev, edge_dev, K, h, w, dirs, path_start, path_yx, beta, n_steps, rw_dev=None):

@@ -3,8 +3,9 @@
 Per image the reference runs pydensecrf once (ADP, DeepGlobe) or twice (VOC: confident-foreground and
 confident-background label maps, cam_to_ir_label.py:42-58), building the same two lattices both times, on
 cpu_count/2 worker processes.  Here:
-  * images of one size and one class count are batched through ONE wsc_crf (the lattices are built once per batch and
-    shared by the VOC branch's two mean-field runs);
+  * the images of a device batch go through ONE ragged CRF object as they come from the dataset -- every image its own size
+    and its own class count (wsc_crf_v; lattices built once per batch and shared by the VOC branch's two mean-field runs);
+    `ir_label_batch` is the same for a batch of one size and one class count (one wsc_crf);
   * the arg-max over [threshold | high_res], the label unaries, the key lookup and the fg/bg merge run on the device
     (wsc_label_unary_from_cam, wsc_crf_inference, wsc_ir_label_combine): per image the host sees the uint8 label map;
   * the dataset is sharded images[g::G] over args.num_workers GPU workers like every other step (run() below).
@@ -64,6 +65,42 @@ def ir_label_batch(ctx, imgs, maps, keys_list, mode, conf_fg_thres, conf_bg_thre
     return conf
 
 
+def ir_label_ragged(ctx, items, mode, conf_fg_thres, conf_bg_thres):
+    """A device batch exactly as the dataset yields it: items = [(img uint8 (H_b, W_b, 3), maps float32 (K_b, H_b, W_b),
+    keys (K_b,))], every image with its own size and class count (cam_to_ir_label.py:25-58 runs them one by one) -> list of
+    uint8 conf maps (H_b, W_b).  One wsc_crf_v for the batch; bit-identical to ir_label_batch on each (H, W, K) group."""
+    g_sxy, g_compat, bi_sxy, bi_srgb, bi_compat, t = CRF_PARAMS
+    B = len(items)
+    sizes = [it[0].shape[:2] for it in items]
+    Ns = [h * w for h, w in sizes]
+    Ks = [int(np.asarray(it[1]).shape[0]) for it in items]
+    rgb = [ctx.to_device(np.ascontiguousarray(it[0], dtype=np.uint8), pooled=True) for it in items]
+    hr = [ctx.to_device(np.ascontiguousarray(it[1], dtype=np.float32), pooled=True) for it in items]
+    crf = _lib.CrfV(ctx, rgb, sizes, g_sxy, bi_sxy, bi_srgb)
+    try:
+        u = [ctx.alloc((K + 1) * N * 4, pooled=True) for K, N in zip(Ks, Ns)]
+        fg = [ctx.alloc(N * 4, pooled=True) for N in Ns]
+        for b in range(B):
+            _lib.label_unary_from_cam(ctx, hr[b], 1, Ks[b], Ns[b], conf_fg_thres, GT_PROB, u[b])
+        crf.inference(u, [K + 1 for K in Ks], g_compat, bi_compat, t, None, fg)
+        bg = [None] * B
+        if mode == "voc12":
+            bg = [ctx.alloc(N * 4, pooled=True) for N in Ns]
+            for b in range(B):
+                _lib.label_unary_from_cam(ctx, hr[b], 1, Ks[b], Ns[b], conf_bg_thres, GT_PROB, u[b])
+            crf.inference(u, [K + 1 for K in Ks], g_compat, bi_compat, t, None, bg)
+        offs = np.concatenate(([0], np.cumsum(Ns))).astype(np.int64)
+        conf_dev = ctx.alloc(int(offs[-1]), pooled=True)
+        for b, it in enumerate(items):
+            k = np.asarray(it[2], dtype=np.int64)
+            keys = np.pad(k + 1, (1, 0), mode="constant") if mode == "voc12" else np.concatenate((np.array([-1]), k))
+            _lib.ir_label_combine(ctx, fg[b], bg[b], keys[None], Ns[b], conf_dev.ptr + int(offs[b]))
+        flat = ctx.to_host(conf_dev, (int(offs[-1]),), np.uint8)
+    finally:
+        crf.close()
+    return [flat[offs[b]:offs[b + 1]].reshape(sizes[b]).copy() for b in range(B)]
+
+
 def ir_label_voc12(img, cam_dict, conf_fg_thres=0.30, conf_bg_thres=0.05, ctx=None):
     """cam_to_ir_label.py:42-58 for one VOC image: uint8 (H, W) label map, 255 = unreliable region."""
     ctx = ctx or imutils.default_context()
@@ -108,13 +145,13 @@ def _work(process_id, infer_dataset, args):
     if not (voc or dg or args.dataset in ("adp_morph", "adp_func")):
         raise KeyError("Dataset %s not yet implemented" % args.dataset)
     max_batch = int(getattr(args, "ir_label_batch_images", 16))
-    pending = {}  # (H, W, K) -> [(name, img, maps, keys)]
+    pending = []  # [(name, img, maps, keys)] in dataset order: mixed sizes and class counts, one ragged CRF per device batch
 
-    def flush(key):
-        items = pending.pop(key)
-        conf = ir_label_batch(ctx, np.stack([it[1] for it in items]), np.stack([it[2] for it in items]),
-                              [it[3] for it in items], "voc12" if voc else "fg", args.conf_fg_thres,
-                              getattr(args, "conf_bg_thres", 0.05))
+    def flush():
+        items = list(pending)
+        del pending[:]
+        conf = ir_label_ragged(ctx, [(it[1], it[2], it[3]) for it in items], "voc12" if voc else "fg", args.conf_fg_thres,
+                               getattr(args, "conf_bg_thres", 0.05))
         for it, c in zip(items, conf):
             _save(args, it[0], c, it[1])
 
@@ -134,12 +171,11 @@ def _work(process_id, infer_dataset, args):
                 _save(args, name, np.full(img.shape[:2], 0 if voc else 255, np.uint8), img)
                 continue
             maps = maps.reshape((len(keys),) + img.shape[:2])
-            key = (img.shape[0], img.shape[1], len(keys))
-            pending.setdefault(key, []).append((name, img, maps, keys))
-            if len(pending[key]) >= max_batch:
-                flush(key)
-        for key in list(pending):
-            flush(key)
+            pending.append((name, img, maps, keys))
+            if len(pending) >= max_batch:
+                flush()
+        if pending:
+            flush()
     finally:
         ctx.close()
 
