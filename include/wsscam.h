@@ -67,6 +67,21 @@ typedef enum wsc_precision {
 
 typedef struct wsc_ctx wsc_ctx; /* device + stream + workspace arena */
 typedef struct wsc_net wsc_net; /* immutable packed weights of one CNN */
+/* Path selectors of a context (wsc_ctx_set_option).  Each one chooses between two code paths that BOTH serve some inputs
+ * in the default configuration (e.g. the Gaussian message is formed on chip only while a tile's vertex set fits the LDS) and
+ * are held to identical bits by tests/test_gpu_crf.py and tests/test_gpu_irn.py; the selector forces the fallback for every
+ * input so that a test (or a debugging session) can compare.  There are no environment switches in the library; tuning
+ * knobs and timing-only ablations exist only in builds with -DWSC_AB_KNOBS (python __graft_entry__.py --ab). */
+typedef enum {
+    WSC_OPT_CRF_GAUSS_ON_CHIP = 0, /* default 1; 0: blur kernels + value-row gathers instead of gauss_msg_kernel */
+    WSC_OPT_CRF_FUSED_BLUR = 1,    /* default 1; 0: three blur4 passes instead of blur3_tile_kernel (Gaussian lattice) */
+    WSC_OPT_CRF_BLUR_ON_CHIP = 2,  /* default 1; 0: one blur4 launch per pass instead of blur_lds_kernel (bilateral lattice) */
+    WSC_OPT_CRF_RANK_BALLOT = 3,   /* default 0; 1: ballot-matching rank walk for every tile of the lattice build */
+    WSC_OPT_CRF_EMBED_FULL = 4,    /* default 0; 1: the 2048-slot LDS table for every tile of the lattice build */
+    WSC_OPT_RW_TILED = 5,          /* default -1 (by batch size); 0: flat random-walk step; 1: tiled step */
+    WSC_OPT_COUNT = 6
+} wsc_option;
+
 typedef struct wsc_crf wsc_crf; /* lattices (Gaussian + bilateral) of a batch of images */
 typedef struct wsc_crf_v wsc_crf_v; /* the same for a RAGGED batch: every image its own (H, W) and class count */
 
@@ -89,6 +104,8 @@ const char *wsc_last_error(void);
  * (03b_irn/step/make_cam.py:31-33). */
 int wsc_ctx_create(int device, void *stream, wsc_ctx **out);
 void wsc_ctx_destroy(wsc_ctx *ctx);
+/* Sets a path selector (wsc_option) of the context; WSC_ERR_INVALID for an unknown option. */
+int wsc_ctx_set_option(wsc_ctx *ctx, int option, int value);
 int wsc_sync(wsc_ctx *ctx);
 /* Make all work enqueued on `ctx` after this call wait (on the device, without blocking the host) for
  * everything enqueued so far on `other`: lets one process overlap independent stages on two contexts

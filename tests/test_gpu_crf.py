@@ -215,9 +215,9 @@ def test_crf_random_sweep(ctx):
 
 @pytest.mark.parametrize("case", [(47, 61, 5, 2, (1.5, 3, 40, 13, 10, 5)), (96, 130, 21, 3, (3, 3, 50, 5, 10, 4)),
                                   (9, 7, 2, 1, (3 / 12, 3, 80 / 12, 13, 10, 3)), (33, 200, 29, 1, (5, 3, 40, 13, 10, 2))])
-def test_crf_fused_gaussian_blur_is_bit_identical(ctx, case, monkeypatch):
+def test_crf_fused_gaussian_blur_is_bit_identical(ctx, case):
     """The tiled three-pass blur of the Gaussian lattice (blur3_tile_kernel: one read + one write of the rows) against
-    the three separate blur4 passes (WSC_CRF_NO_FUSED_BLUR=1, read per call): identical bits, on sizes whose lattices
+    the three separate blur4 passes (ctx option OPT_CRF_FUSED_BLUR = 0): identical bits, on sizes whose lattices
     have ragged edge tiles, several replicas, wide (sxy = 5) and narrow (sxy = 0.25) kernels, M = 29 (LP = 8: two
     groups of float4s per row in the fused kernel)."""
     H, W, M, B, cfg = case
@@ -227,11 +227,10 @@ def test_crf_fused_gaussian_blur_is_bit_identical(ctx, case, monkeypatch):
         rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
         rgbs.append(rgb)
         Us.append(U)
-    monkeypatch.setenv("WSC_CRF_NO_GFUSE", "1")  # the blur kernels under test only run when the update kernel leaves the blur to them
-    monkeypatch.setenv("WSC_CRF_NO_FUSED_BLUR", "1")
-    q_ref, a_ref, vg, _ = _gpu_crf(ctx, rgbs, Us, cfg)
-    monkeypatch.setenv("WSC_CRF_NO_FUSED_BLUR", "0")
-    q, a, vg2, _ = _gpu_crf(ctx, rgbs, Us, cfg)
+    with ctx.option(_lib.OPT_CRF_GAUSS_ON_CHIP, 0):  # the blur kernels under test only run when the update kernel leaves the blur to them
+        with ctx.option(_lib.OPT_CRF_FUSED_BLUR, 0):
+            q_ref, a_ref, vg, _ = _gpu_crf(ctx, rgbs, Us, cfg)
+        q, a, vg2, _ = _gpu_crf(ctx, rgbs, Us, cfg)
     assert list(vg) == list(vg2)
     assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)
 
@@ -240,10 +239,9 @@ def test_crf_fused_gaussian_blur_is_bit_identical(ctx, case, monkeypatch):
                                   (9, 7, 2, 1, (3 / 12, 3, 80 / 12, 13, 10, 3)), (33, 200, 29, 1, (5, 3, 40, 13, 10, 2)),
                                   (321, 321, 21, 2, (1.5, 3, 40, 13, 10, 3)), (41, 41, 21, 4, (3 / 12, 3, 80 / 12, 13, 10, 5)),
                                   (64, 80, 1, 2, (1.5, 3, 40, 13, 10, 2)), (100, 75, 12, 1, (0.7, 3, 30, 10, 10, 3))])
-def test_crf_gaussian_blur_inside_update_is_bit_identical(ctx, case, monkeypatch):
+def test_crf_gaussian_blur_inside_update_is_bit_identical(ctx, case):
     """update_splat_kernel<.., GF>: the Gaussian lattice summed from its slot partials, blurred and sliced inside the update
-    kernel (per-tile closed vertex sets, LDS) against the separate blur kernel + value-row gathers (WSC_CRF_NO_GFUSE=1, read
-    per call): identical Q bits and labels -- one image and several, ragged edge tiles, wide / narrow kernels (the narrow ones
+    kernel (per-tile closed vertex sets, LDS) against the separate blur kernel + value-row gathers (ctx option OPT_CRF_GAUSS_ON_CHIP = 0): identical Q bits and labels -- one image and several, ragged edge tiles, wide / narrow kernels (the narrow ones
     have vertex sets too large for the LDS at M = 21 and silently take the unfused path), LP = 1 ... 8, and the labels-only
     call whose last update writes the arg-max."""
     H, W, M, B, cfg = case
@@ -253,10 +251,9 @@ def test_crf_gaussian_blur_inside_update_is_bit_identical(ctx, case, monkeypatch
         rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
         rgbs.append(rgb)
         Us.append(U)
-    monkeypatch.setenv("WSC_CRF_NO_GFUSE", "1")
-    q_ref, a_ref, vg, vb = _gpu_crf(ctx, rgbs, Us, cfg)
-    assert not _gpu_crf.on_chip
-    monkeypatch.setenv("WSC_CRF_NO_GFUSE", "0")
+    with ctx.option(_lib.OPT_CRF_GAUSS_ON_CHIP, 0):
+        q_ref, a_ref, vg, vb = _gpu_crf(ctx, rgbs, Us, cfg)
+        assert not _gpu_crf.on_chip
     q, a, vg2, vb2 = _gpu_crf(ctx, rgbs, Us, cfg)
     if cfg[0] >= 1.0:  # (narrow kernels: on chip only while a tile's vertex set fits the LDS -- the 9 x 7 image does)
         assert _gpu_crf.on_chip, cfg
@@ -269,9 +266,9 @@ def test_crf_gaussian_blur_inside_update_is_bit_identical(ctx, case, monkeypatch
                                   (96, 130, 21, 3, (3, 3, 50, 5, 10, 5)), (18, 23, 2, 37, (1.5, 3, 20, 10, 10, 2)),
                                   (70, 64, 3, 2, (3, 3, 6, 1.5, 10, 2)), (5, 4, 3, 300, (1.5, 3, 20, 10, 10, 2)),
                                   (300, 400, 4, 2, (3, 3, 10, 3, 10, 2)), (321, 321, 29, 2, (1.5, 3, 20, 6, 10, 2))])
-def test_crf_bilateral_blur_on_chip_is_bit_identical(ctx, case, monkeypatch):
+def test_crf_bilateral_blur_on_chip_is_bit_identical(ctx, case):
     """blur_lds_kernel: the six passes of the bilateral lattice in one launch, one image x GW classes per workgroup as float
-    planes in LDS, against one blur4_kernel launch per pass (WSC_CRF_BLUR_LDS=0, read per call): identical Q bits and labels.
+    planes in LDS, against one blur4_kernel launch per pass (ctx option OPT_CRF_BLUR_ON_CHIP = 0): identical Q bits and labels.
     Cases: the VOC size (3 classes per workgroup, 13 rows per thread), small images (4 classes, 4 rows), images of unequal
     vertex counts, more workgroups than CUs (several rounds), noisy / narrow-kernel images whose ~20-60 k vertices leave
     room for 1-2 classes per workgroup (40 rows per thread), M = 29."""
@@ -282,9 +279,8 @@ def test_crf_bilateral_blur_on_chip_is_bit_identical(ctx, case, monkeypatch):
         rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
         rgbs.append(rgb)
         Us.append(U)
-    monkeypatch.setenv("WSC_CRF_BLUR_LDS", "0")
-    q_ref, a_ref, vg, vb = _gpu_crf(ctx, rgbs, Us, cfg)
-    monkeypatch.setenv("WSC_CRF_BLUR_LDS", "1")
+    with ctx.option(_lib.OPT_CRF_BLUR_ON_CHIP, 0):
+        q_ref, a_ref, vg, vb = _gpu_crf(ctx, rgbs, Us, cfg)
     q, a, vg2, vb2 = _gpu_crf(ctx, rgbs, Us, cfg)
     print("bilateral vertices per image:", list(vb)[:4])
     assert list(vg) == list(vg2) and list(vb) == list(vb2)
@@ -293,9 +289,9 @@ def test_crf_bilateral_blur_on_chip_is_bit_identical(ctx, case, monkeypatch):
 
 @pytest.mark.parametrize("case", [(47, 61, 5, 2, (1.5, 3, 40, 13, 10, 3)), (96, 130, 21, 3, (3, 3, 50, 5, 10, 2)),
                                   (33, 200, 4, 1, (5, 3, 40, 13, 10, 2)), (70, 64, 3, 2, (3, 3, 6, 1.5, 10, 2))])
-def test_crf_lattice_build_rank_paths_agree(ctx, case, monkeypatch):
+def test_crf_lattice_build_rank_paths_agree(ctx, case):
     """Lattice build, stable rank of a tile's entries inside their vertex group: the pixel-mask path (a group holds one entry
-    per pixel: rank = popcount of the lower pixels) against the ballot-matching walk (WSC_CRF_RANK_BALLOT=1, read per build).
+    per pixel: rank = popcount of the lower pixels) against the ballot-matching walk (ctx option OPT_CRF_RANK_BALLOT = 1).
     Same lattice sizes, same Q bits.  The last case (bilateral sxy = 6, srgb = 1.5 on a noisy image) has tiles with more
     distinct vertices than the masks hold, so the default build itself takes the ballot path there."""
     H, W, M, B, cfg = case
@@ -305,9 +301,8 @@ def test_crf_lattice_build_rank_paths_agree(ctx, case, monkeypatch):
         rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
         rgbs.append(rgb)
         Us.append(U)
-    monkeypatch.setenv("WSC_CRF_RANK_BALLOT", "1")
-    q_ref, a_ref, vg, vb = _gpu_crf(ctx, rgbs, Us, cfg)
-    monkeypatch.setenv("WSC_CRF_RANK_BALLOT", "0")
+    with ctx.option(_lib.OPT_CRF_RANK_BALLOT, 1):
+        q_ref, a_ref, vg, vb = _gpu_crf(ctx, rgbs, Us, cfg)
     q, a, vg2, vb2 = _gpu_crf(ctx, rgbs, Us, cfg)
     assert list(vg) == list(vg2) and list(vb) == list(vb2)
     assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)
@@ -315,9 +310,8 @@ def test_crf_lattice_build_rank_paths_agree(ctx, case, monkeypatch):
         assert max(vb) > 2.5 * H * W  # nearly every pixel owns its vertices: > 640 groups per 16 x 16 tile
     # the tile pass on the 2048-slot LDS table for every tile (one launch) against the default: 512 slots first, the tiles
     # with more than 384 distinct vertices (all of them in the noisy case) redone by the full-table launch
-    monkeypatch.setenv("WSC_CRF_EMBED_FULL", "1")
-    q3, a3, vg3, vb3 = _gpu_crf(ctx, rgbs, Us, cfg)
-    monkeypatch.setenv("WSC_CRF_EMBED_FULL", "0")
+    with ctx.option(_lib.OPT_CRF_EMBED_FULL, 1):
+        q3, a3, vg3, vb3 = _gpu_crf(ctx, rgbs, Us, cfg)
     assert list(vg) == list(vg3) and list(vb) == list(vb3)
     assert np.array_equal(q, q3) and np.array_equal(a, a3)
 
@@ -378,21 +372,25 @@ def test_pixel_major_unary_path_is_bit_identical(ctx):
         assert np.array_equal(ctx.to_host(u_pm, (B, N, Mp), np.float32), Upm)  # read in place, never written
 
 
-def test_crf_gaussian_cache_overflow_takes_the_unfused_path():
+def test_crf_gaussian_cache_evicts_least_recently_used():
     """A ctx keeps the Gaussian lattices of 64 image sizes (with the host-built tile vertex sets of the on-chip message
-    path).  Later sizes are rebuilt per call WITHOUT those tables and run the separate blur kernel: same bits as the cached,
-    on-chip form of the same size on a fresh ctx."""
+    path).  A 65th, 66th ... size evicts the least recently used entry no live wsc_crf refers to, so EVERY size keeps the
+    on-chip path (round 3: later sizes were rebuilt per call and ran the separate blur kernel); a size that was evicted is
+    rebuilt on its next use and gives the same bits as before, and as on a fresh ctx."""
     ctx_a = _lib.Context(0)
     rng = np.random.default_rng(77)
     cfg = (1.5, 3, 20, 10, 10, 2)
     M = 3
-    last = None
-    for i in range(66):
+    first = last = None
+    for i in range(70):
         H, W = 18 + i, 20
         rgb, U, _ = helpers.synth_crf_case(rng, H, W, M)
         q, a, _, _ = _gpu_crf(ctx_a, [rgb], [U], cfg)
-        assert _gpu_crf.on_chip == (i < 64), (i, _gpu_crf.on_chip)
+        assert _gpu_crf.on_chip, i
         last = (rgb, U, q, a)
+        first = first or last
+    q1, a1, _, _ = _gpu_crf(ctx_a, [first[0]], [first[1]], cfg)  # the first size was evicted long ago: rebuilt
+    assert _gpu_crf.on_chip and np.array_equal(q1, first[2]) and np.array_equal(a1, first[3])
     ctx_b = _lib.Context(0)
     q2, a2, _, _ = _gpu_crf(ctx_b, [last[0]], [last[1]], cfg)
     assert _gpu_crf.on_chip

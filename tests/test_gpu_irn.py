@@ -117,9 +117,9 @@ def test_propagate_batch_equals_single(ctx):
         assert o.shape == single.shape and np.array_equal(o, single)
 
 
-def test_propagate_tiled_step_is_bit_identical(ctx, monkeypatch):
+def test_propagate_tiled_step_is_bit_identical(ctx):
     """rw_step_tile_kernel (16 x 16 pixel tiles, values through LDS, all maps of a pixel per thread) against the flat
-    one-thread-per-value kernel (WSC_RW_TILED=0, read per call): same bits -- maps of 1 ... 7 classes (more than one group of
+    one-thread-per-value kernel (ctx option OPT_RW_TILED = 0): same bits -- maps of 1 ... 7 classes (more than one group of
     four), sizes that are not multiples of the tile, a one-pixel image."""
     from wsscam.misc import indexing
 
@@ -127,10 +127,10 @@ def test_propagate_tiled_step_is_bit_identical(ctx, monkeypatch):
     shapes = [(2, 94, 125), (7, 33, 47), (1, 16, 16), (5, 1, 1), (3, 17, 5)]
     xs = [rng.random(s).astype(np.float32) for s in shapes]
     es = [(rng.random((1,) + s[1:]) ** 2).astype(np.float32) for s in shapes]
-    monkeypatch.setenv("WSC_RW_TILED", "0")
-    ref = indexing.propagate_to_edge_batch(xs, es, beta=10, exp_times=5, ctx=ctx)
-    monkeypatch.setenv("WSC_RW_TILED", "1")
-    out = indexing.propagate_to_edge_batch(xs, es, beta=10, exp_times=5, ctx=ctx)
+    with ctx.option(_lib.OPT_RW_TILED, 0):
+        ref = indexing.propagate_to_edge_batch(xs, es, beta=10, exp_times=5, ctx=ctx)
+    with ctx.option(_lib.OPT_RW_TILED, 1):
+        out = indexing.propagate_to_edge_batch(xs, es, beta=10, exp_times=5, ctx=ctx)
     for r, o in zip(ref, out):
         assert r.shape == o.shape and np.array_equal(r, o)
 

@@ -32,3 +32,16 @@ def test_mirror_modules_import(built):
     assert imutils.get_strided_up_size((375, 500), 16) == (384, 512)
     shards = torchutils.split_dataset(list(range(10)), 4)
     assert [list(s.indices) for s in shards] == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
+
+
+def test_shipped_library_has_no_environment_switches(built):
+    """The shipped libwsscam.so reads no WSC_* environment variable: tuning knobs and timing-only ablations exist only in the
+    A/B build (-DWSC_AB_KNOBS, `python __graft_entry__.py --ab`), path selectors are explicit context options
+    (wsc_ctx_set_option).  Checked on the binary: no 'WSC_<NAME>' string literal is left in it."""
+    import re
+
+    from wsscam import _lib
+
+    data = open(_lib.LIB_PATH, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"WSC_[A-Z][A-Z0-9_]{2,}(?=\x00)", data))
+    assert not names, "environment-style names in the shipped library: %s" % sorted(names)

@@ -208,6 +208,13 @@ int wsc_ctx_create(int device, void *stream, wsc_ctx **out) {
     return WSC_OK;
 }
 
+int wsc_ctx_set_option(wsc_ctx *ctx, int option, int value) {
+    WSC_CHECK(ctx != nullptr, WSC_ERR_INVALID, "wsc_ctx_set_option: null context");
+    WSC_CHECK(option >= 0 && option < WSC_OPT_COUNT, WSC_ERR_INVALID, "wsc_ctx_set_option: unknown option %d", option);
+    ctx->opt[option] = value;
+    return WSC_OK;
+}
+
 void wsc_ctx_destroy(wsc_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

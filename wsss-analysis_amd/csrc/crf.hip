@@ -150,6 +150,7 @@ struct wsc_crf {
     // the Gaussian message kernel's E (GF variants); built when the Gaussian lattice has its tile vertex sets
     uint32_t *pix_rec_b = nullptr;
     std::vector<void *> allocs;
+    void *gauss_entry = nullptr;        // the ctx's GaussCache entry lat[0] aliases (its `users` count is ours to drop)
     std::vector<void *> persist_allocs; // blocks of a cached Gaussian lattice under construction (freed if the build fails)
     bool persist = false; // allocations made while set belong to the ctx (cached Gaussian lattice)
     // set by wsc_crf_inference on a ctx other than the build ctx: the last loop's completion on that stream
@@ -1316,8 +1317,15 @@ __device__ __forceinline__ void blur_lds_body(const BlurLdsArgs &p, float *pl, i
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int r = tid + i * BL_THREADS;
-        if (r < nr) { // (the rows are Mp >= c0 + GW floats long: classes past M are padding, read and dropped)
-            const FloatRun<GW> run = load_run<GW>(vb + (size_t)r * p.Mp);
+        if (r < nr) { // (classes past M are padding: read where the row has them, and dropped)
+            FloatRun<GW> run;
+            if (GW == 3 && c0 + GW > p.Mp) { // the last class group of a row whose length is no multiple of 3 (Mp = 20: classes
+                                             // 18, 19): a 3-float access would run into the next row -- uniform over the workgroup
+#pragma unroll
+                for (int g = 0; g < GW; ++g) run.v[g] = c0 + g < p.Mp ? vb[(size_t)r * p.Mp + g] : 0.f;
+            } else {
+                run = load_run<GW>(vb + (size_t)r * p.Mp);
+            }
 #pragma unroll
             for (int g = 0; g < GW; ++g) pl[g * stride + r] = c0 + g < p.M ? run.v[g] : 0.f;
         }
@@ -2443,7 +2451,11 @@ void splat_ones(wsc_ctx *ctx, const LatticeDev &L, const TileGeom &tg, float *va
 // rows of a lattice from the slot partials of the splat
 void combine4(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, const float *part, int LP, float *val) {
     WscKernelTimer timer(ctx, WSC_K_BLUR, ((double)L.n_slots + L.rows) * L.rep * L.M_cur * 4);
+#ifdef WSC_AB_KNOBS
     const char *be = getenv("WSC_CRF_COMBINE_BALANCED"); // A/B: 0 keeps the lane-group-per-row kernel
+#else
+    const char *be = nullptr;
+#endif
     if (L.sorted_dest)
         hipLaunchKernelGGL(combine4_kernel<true>, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
                            st, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
@@ -2500,9 +2512,8 @@ int blur_lds_prepare(wsc_ctx *ctx, const LatticeDev &L, int M) {
     return WSC_OK;
 }
 bool blur_lds(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int LP, float *val) {
-    const char *e = getenv("WSC_CRF_BLUR_LDS");
     const int M = L.M_cur;
-    if ((e && atoi(e) == 0) || L.rep != 1 || !L.img_row || !L.bl_ok || L.bl_M != M) return false;
+    if (!ctx->opt[WSC_OPT_CRF_BLUR_ON_CHIP] || L.rep != 1 || !L.img_row || !L.bl_ok || L.bl_M != M) return false;
     if (L.bl_nblk == 0) return true;
     static bool attr_set[64] = {};
     const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
@@ -2525,15 +2536,18 @@ bool blur_lds(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int LP, float *
 // re-pointed, so an error return or another thread's wsc_sync always sees ctx->stream = the main stream.  The timers are
 // live only while profiling, which runs without the fork (st == ctx->stream then).
 float *combine_blur_all4(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, int LP, const float *part, float *a, float *b) {
-    // WSC_CRF_NO_FUSED_BLUR=1 (read per call, so a test can flip it) keeps the three separate passes
-    const char *fe = getenv("WSC_CRF_NO_FUSED_BLUR");
-    const bool fused_off = fe && atoi(fe) != 0;
+    // WSC_OPT_CRF_FUSED_BLUR = 0 keeps the three separate passes
+    const bool fused_off = !ctx->opt[WSC_OPT_CRF_FUSED_BLUR];
     if (L.d == 2 && L.tile_rows && L.tile_pstart && L.n_tiles_occ > 0 && !fused_off) {
         // one read of the partials + one write of the value rows (the halo re-reads come out of L2).  Whole rows
         // per group (6 float4 = 49 KB of LDS, 3 blocks per CU) beat 3 / 2 / 1 float4 per group at 6+ blocks per CU
         WscKernelTimer timer(ctx, WSC_K_BLUR, ((double)L.n_slots + L.rows) * L.rep * L.M_cur * 4);
+#ifdef WSC_AB_KNOBS
         const char *ge = getenv("WSC_CRF_GLH");
         const int glh = ge ? atoi(ge) : WSC_GLH;
+#else
+        constexpr int glh = WSC_GLH;
+#endif
         if (glh == 3)
             hipLaunchKernelGGL(blur3_tile_kernel<3>, dim3((unsigned)(L.n_tiles_occ * L.rep)), dim3(GBI * GBJ), 0, st,
                                (const f32x4_t *)nullptr, L.tile_rows, L.tile_list, L.n_tiles_occ, LP, L.rows, L.rep, (f32x4_t *)b,
@@ -2741,13 +2755,11 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(tmp.alloc(sizeof(int32_t) * total, (void **)&sslot));
     WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.n_tiles + 1), (void **)&tile_nslots));
     WSC_HIP(hipMemsetAsync(tile_nslots, 0, sizeof(unsigned) * (L.n_tiles + 1), ctx->stream));
-    const char *rbe = getenv("WSC_CRF_RANK_BALLOT"); // read per build: a test compares the two ranking paths
     {
-        // small-table launch for every tile, full-table launch for the ones that gave up (WSC_CRF_EMBED_FULL=1: full table
-        // for every tile, the single-launch form; read per build so that a test can compare)
-        const char *efe = getenv("WSC_CRF_EMBED_FULL");
-        const int fb = (rbe && atoi(rbe) != 0) ? 1 : 0;
-        if (efe && atoi(efe) != 0) {
+        // small-table launch for every tile, full-table launch for the ones that gave up (WSC_OPT_CRF_EMBED_FULL: full table
+        // for every tile, the single-launch form); WSC_OPT_CRF_RANK_BALLOT: the ballot-matching rank walk for every tile
+        const int fb = ctx->opt[WSC_OPT_CRF_RANK_BALLOT] ? 1 : 0;
+        if (ctx->opt[WSC_OPT_CRF_EMBED_FULL]) {
             hipLaunchKernelGGL(tile_embed_full_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent_w,
                                L.tent_p, sslot, tile_nslots, fb, (const int32_t *)nullptr, (const unsigned *)nullptr, L.n_tiles);
         } else {
@@ -2924,27 +2936,36 @@ struct GaussCache {
     int H, W;
     float sxy;
     LatticeDev L;
+    std::vector<void *> blocks; // its device arrays (cached-alloc blocks of the ctx): handed back when the entry is evicted
+    int users = 0;              // live wsc_crf objects whose lat[0] aliases L
+    unsigned long long last_use = 0;
 };
-// distinct image sizes kept per ctx (~25 MB each at 375 x 500); later sizes are rebuilt per call, without the host-built
-// tile vertex sets of the on-chip message path (a rebuild per call must stay cheap: cam_to_ir_label walks hundreds of sizes)
+// distinct image sizes kept per ctx (~25 MB each at 375 x 500).  When the table is full the least recently used entry that
+// no live wsc_crf refers to makes room (round 3 had no eviction: after 64 sizes every later size was rebuilt per call,
+// without the on-chip message path -- cam_to_ir_label walks hundreds of sizes).  Only when all entries are in use is a
+// lattice built for the one call, without the host-built tile vertex sets of the on-chip message path.
 constexpr int GAUSS_CACHE_MAX = 64;
+unsigned long long g_gauss_use_clock = 0;
 void gauss_cache_delete(void *p) { delete static_cast<GaussCache *>(p); }
 
 // slice: messages of both lattices are read (false before the first iteration); splat: the result is splatted
 // (false in the last iteration, whose Q is written to a.q instead)
 // block size of the update kernel (WSC_CRF_UPD_THREADS: A/B runs)
 int update_threads() {
+#ifdef WSC_AB_KNOBS
     const char *te = getenv("WSC_CRF_UPD_THREADS");
     const int nthr = te ? atoi(te) : 256;
     return nthr == 512 ? 512 : 256; // (the kernel's per-thread table registers cover a tile with >= 256 threads)
+#else
+    return 256;
+#endif
 }
 size_t update_splat_lds(int LP) { return sizeof(f32x4_t) * TILE_PIX * LP + sizeof(uint2) * GATHER_ENT + sizeof(int2) * GATHER_SB; }
 size_t gauss_msg_lds(int LP, int gt_stride) { return ((size_t)LP * sizeof(f32x4_t) + sizeof(uint4)) * (size_t)gt_stride; }
 // can the Gaussian message be formed on chip (gauss_msg_kernel) for this call?  The tile vertex sets must exist (sets within
 // the local-id range) and fit the kernel's LDS and its per-thread item bound.
-bool update_gf_ok(const LatticeDev &G, int LP) {
-    const char *e = getenv("WSC_CRF_NO_GFUSE"); // read per call: a test compares the two paths
-    if (e && atoi(e) != 0) return false;
+bool update_gf_ok(const wsc_ctx *ctx, const LatticeDev &G, int LP) {
+    if (!ctx->opt[WSC_OPT_CRF_GAUSS_ON_CHIP]) return false;
     if (!G.gt_rows || G.rep < 1 || G.gt_stride <= 0) return false;
     if ((long long)G.gt_stride * LP > 6ll * GM_THREADS || (long long)G.gt_stride * LP >= 8192) return false;
     return gauss_msg_lds(LP, G.gt_stride) <= 64 * 1024;
@@ -2954,8 +2975,10 @@ int launch_gauss_msg(wsc_ctx *ctx, hipStream_t st, const GaussMsgArgs &g, double
     WscKernelTimer timer(ctx, WSC_K_GAUSS_MSG, bytes);
     const dim3 grid((unsigned)(g.B * g.tg.tpi)), block(GM_THREADS);
     size_t lds = gauss_msg_lds(g.LP, g.gt_stride);
+#ifdef WSC_AB_KNOBS
     const char *le = getenv("WSC_CRF_GM_LDS"); // A/B: pad the LDS request (bytes) to cap the blocks per CU
     if (le && (size_t)atoi(le) > lds && atoi(le) <= 64 * 1024) lds = (size_t)atoi(le);
+#endif
     if ((long long)g.gt_stride * g.LP <= 4ll * GM_THREADS && g.LP <= 6)
         hipLaunchKernelGGL((gauss_msg_kernel<4, 3>), grid, block, lds, st, g);
     else
@@ -2976,7 +2999,11 @@ int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat, boo
     WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, by);
     const dim3 grid((unsigned)(a.B * a.tg.tpi)), block(update_threads());
     size_t lds = splat ? update_splat_lds(a.LP) : 0;
+#ifdef WSC_AB_KNOBS
     const char *de = getenv("WSC_CRF_UPD_DMA"); // A/B: 0 keeps the register loads of E and the records
+#else
+    const char *de = nullptr;
+#endif
     const bool dma = slice && gf && !(de && atoi(de) == 0);
     if (dma) lds = update_splat_lds(a.LP); // the last update stages E + records too
     if (dma) {
@@ -3046,22 +3073,41 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
     // that image size (the reference rebuilds it per image, addPairwiseGaussian in dcrf_process /
     // crf_inference_label, and gets the same table every time).
     int st = WSC_OK;
-    GaussCache *hit = nullptr;
+    GaussCache *hit = nullptr, *lru = nullptr;
     int n_cached = 0;
-    for (auto &a : ctx->attachments)
+    size_t lru_at = 0;
+    for (size_t i = 0; i < ctx->attachments.size(); ++i) {
+        auto &a = ctx->attachments[i];
         if (a.second == &gauss_cache_delete) {
             ++n_cached;
             GaussCache *g = static_cast<GaussCache *>(a.first);
             if (g->H == H && g->W == W && g->sxy == g_sxy) hit = g;
+            if (g->users == 0 && (!lru || g->last_use < lru->last_use)) {
+                lru = g;
+                lru_at = i;
+            }
         }
+    }
+    if (!hit && n_cached >= GAUSS_CACHE_MAX && lru) {
+        // evict: its blocks go back to the build ctx's stream-ordered cache.  No live wsc_crf refers to it, and every
+        // wsc_crf that did has been destroyed -- which made this stream wait for loops it ran on other streams.
+        for (void *p : lru->blocks) wsc_ctx_cached_free(ctx, p);
+        delete lru;
+        ctx->attachments.erase(ctx->attachments.begin() + (long)lru_at);
+        --n_cached;
+    }
     if (hit) {
         crf->lat[0] = hit->L;
+        hit->users += 1;
+        hit->last_use = ++g_gauss_use_clock;
+        crf->gauss_entry = hit;
     } else {
         crf->persist = n_cached < GAUSS_CACHE_MAX;
         st = build_lattice<2>(crf, crf->lat[0], rgb_dev, g_sxy, 1.f, true, true); // built once: worst-case table
         if (st == WSC_OK && crf->persist) {
-            GaussCache *g = new GaussCache{H, W, g_sxy, crf->lat[0]};
+            GaussCache *g = new GaussCache{H, W, g_sxy, crf->lat[0], crf->persist_allocs, 1, ++g_gauss_use_clock};
             ctx->attachments.emplace_back(g, &gauss_cache_delete);
+            crf->gauss_entry = g;
         }
         if (st != WSC_OK) // a failed build must not leave its arrays with the ctx for the rest of its life
             for (void *p : crf->persist_allocs) wsc_ctx_cached_free(ctx, p);
@@ -3084,7 +3130,7 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
     // The 80-byte record (both lattices) serves the updates that gather the Gaussian rows themselves.  When the Gaussian
     // message can be formed on chip for every class count (the tile vertex sets fit at LP = 8), it is not built here: a
     // call that still wants it (WSC_CRF_NO_GFUSE=1) builds it on first use (crf_full_records).
-    if (st == WSC_OK && !(crf->lat[0].gt_rows && update_gf_ok(crf->lat[0], 8))) st = crf_full_records(crf, ctx->stream);
+    if (st == WSC_OK && !(crf->lat[0].gt_rows && update_gf_ok(ctx, crf->lat[0], 8))) st = crf_full_records(crf, ctx->stream);
     if (st == WSC_OK && crf->lat[0].gt_rows) st = crf_bilateral_records(crf, ctx->stream);
     if (st != WSC_OK) {
         wsc_crf_destroy(crf);
@@ -3099,6 +3145,7 @@ void wsc_crf_destroy(wsc_crf *crf) {
     // The blocks go back to the build ctx's stream-ordered cache.  A mean-field loop enqueued on ANOTHER ctx may still
     // be reading them: make the build stream wait for it before anything it launches later can reuse the memory.
     if (crf->used_elsewhere && crf->use_ev) (void)hipStreamWaitEvent(crf->ctx->stream, crf->use_ev, 0);
+    if (crf->gauss_entry) static_cast<GaussCache *>(crf->gauss_entry)->users -= 1;
     for (void *p : crf->allocs) wsc_ctx_cached_free(crf->ctx, p); // reused in stream order
     if (crf->use_ev) (void)hipEventDestroy(crf->use_ev);
     delete crf;
@@ -3115,7 +3162,7 @@ int wsc_crf_lattice_sizes(wsc_ctx *ctx, const wsc_crf *crf, int32_t *v_gauss_hos
 
 int wsc_crf_gaussian_on_chip(const wsc_crf *crf, int M) {
     if (!crf || M < 1 || M > 32) return 0;
-    return update_gf_ok(crf->lat[0], (M + 3) / 4) ? 1 : 0;
+    return update_gf_ok(crf->ctx, crf->lat[0], (M + 3) / 4) ? 1 : 0;
 }
 
 static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev, bool pixel_major, int M, float g_compat,
@@ -3179,9 +3226,12 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     // The side stream pays off only for the per-pass bilateral launches (seven short kernels beside the Gaussian message);
     // with the on-chip blur (two launches whose workgroups fill the CUs' LDS) one stream and two are the same to +-0.5 %
     // (profiles/README.md), so that path stays on one stream.  WSC_CRF_NO_FORK=1 / 0 forces either.
+#ifdef WSC_AB_KNOBS
     const char *nf = getenv("WSC_CRF_NO_FORK");
-    const char *ble_ = getenv("WSC_CRF_BLUR_LDS");
-    const bool lds_blur = Bl.bl_ok && Bl.img_row && !(ble_ && atoi(ble_) == 0);
+#else
+    const char *nf = nullptr;
+#endif
+    const bool lds_blur = Bl.bl_ok && Bl.img_row && ctx->opt[WSC_OPT_CRF_BLUR_ON_CHIP];
     const bool no_fork = (nf ? atoi(nf) != 0 : lds_blur) || ctx->profiling; // per-kernel timing wants the launches one after the other
     if (!no_fork && !ctx->aux_stream) {
         // (default priority: a high-priority side stream, or any other priority split between the stages of a pipelined
@@ -3204,7 +3254,7 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     // Gaussian message on chip (tile vertex sets that fit the LDS): no Gaussian value rows, no Gaussian blur launch --
     // gauss_msg_kernel turns the Gaussian slot partials into E = -U + message (in the Q buffer: an update reads its slot of
     // E before it writes Q there) beside the bilateral lattice's combine + six passes, and the update starts from E
-    const bool gf = update_gf_ok(G, LP);
+    const bool gf = update_gf_ok(ctx, G, LP);
     if (gf && n_iters > 0) { // (built by wsc_crf_create whenever the lattice has its tile vertex sets; here for completeness)
         WSC_TRY(crf_bilateral_records(crf, ctx->stream));
         a.pix_rec_b = crf->pix_rec_b;

@@ -272,7 +272,7 @@ extern "C" int wsc_rw_propagate_batch(wsc_ctx *ctx, int n_img, const int32_t *K_
                        n_steps == 0 ? rw_dev : (float *)nullptr);
     double *cur = va, *nxt = vbuf;
     // tiled step (values through LDS) when every direction stays inside its halo; WSC_RW_TILED=0 keeps the flat kernel
-    bool tiled = !(getenv("WSC_RW_TILED") && atoi(getenv("WSC_RW_TILED")) == 0);
+    bool tiled = ctx->opt[WSC_OPT_RW_TILED] != 0;
     for (int d = 0; d < D; ++d) tiled = tiled && dirs_host[2 * d] <= RW_R && std::abs(dirs_host[2 * d + 1]) <= RW_R;
     int max_tiles = 1, max_K = 1;
     long long all_tiles = 0;
@@ -285,7 +285,7 @@ extern "C" int wsc_rw_propagate_batch(wsc_ctx *ctx, int n_img, const int32_t *K_
     // a thread of the tiled kernel owns ALL maps of a pixel: it needs a batch that fills the chip with tiles several times
     // over (32 images of 94 x 125 = 1536 tiles: 0.48 -> 0.31 ms per image; 16 images, 768 tiles: 2 % slower than the flat
     // kernel; a single image, 48 tiles: 4.0 -> 5.3 ms): smaller calls keep the flat kernel
-    if (!getenv("WSC_RW_TILED")) tiled = tiled && all_tiles >= 5ll * ctx->num_cus;
+    if (ctx->opt[WSC_OPT_RW_TILED] < 0) tiled = tiled && all_tiles >= 5ll * ctx->num_cus;
     for (int s = 0; s < n_steps; ++s) {
         if (tiled) {
             const dim3 tg((unsigned)max_tiles, (unsigned)n_img);

@@ -34,6 +34,10 @@ PREC_BF16 = 0
 PREC_BF16X3 = 1
 PREC_F16 = 2
 PREC_F16X3 = 3  # split-half operands and activations (hi + lo), three MFMA products: the fp32-class mode
+# path selectors of a context (include/wsscam.h wsc_option; Context.set_option / Context.option)
+OPT_CRF_GAUSS_ON_CHIP, OPT_CRF_FUSED_BLUR, OPT_CRF_BLUR_ON_CHIP, OPT_CRF_RANK_BALLOT, OPT_CRF_EMBED_FULL, OPT_RW_TILED = range(6)
+OPT_DEFAULTS = {OPT_CRF_GAUSS_ON_CHIP: 1, OPT_CRF_FUSED_BLUR: 1, OPT_CRF_BLUR_ON_CHIP: 1, OPT_CRF_RANK_BALLOT: 0,
+                OPT_CRF_EMBED_FULL: 0, OPT_RW_TILED: -1}
 CONV_GENERIC = 0x100  # conv2d_nchw only: OR into precision to keep the kernel's generic variants (testing)
 
 
@@ -73,6 +77,7 @@ _SIGNATURES = {
     "wsc_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "wsc_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "wsc_memset": (_i, [_vp, _vp, _i, _sz]),
+    "wsc_ctx_set_option": (_i, [_vp, _i, _i]),
     "wsc_host_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     "wsc_host_free": (_i, [_vp, _vp]),
     "wsc_memcpy_h2d_async": (_i, [_vp, _vp, _vp, _sz]),
@@ -263,6 +268,24 @@ class Context:
 
     def d2h_async(self, pinned, src_dev, nbytes, dst_offset=0, src_offset=0):
         check(self._lib.wsc_memcpy_d2h_async(self.h, pinned.ptr + dst_offset, _ptr(src_dev) + src_offset, int(nbytes)))
+
+    def set_option(self, option, value):
+        """A path selector of this context (OPT_*): forces a fallback path that gives the same bits (testing / debugging)."""
+        check(self._lib.wsc_ctx_set_option(self.h, int(option), int(value)))
+
+    def option(self, option, value):
+        """Context manager: the selector is set inside the block and back to its default afterwards."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            self.set_option(option, value)
+            try:
+                yield self
+            finally:
+                self.set_option(option, OPT_DEFAULTS[option])
+
+        return _cm()
 
     def profile_begin(self):
         check(self._lib.wsc_profile_begin(self.h))

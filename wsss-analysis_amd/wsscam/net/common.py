@@ -290,7 +290,12 @@ def pre_bn_head(alpha, affine):
     if affine is None:
         return alpha, np.zeros(alpha.shape[1])
     s, t = affine
+    s = np.asarray(s, dtype=np.float64)
     if np.any(s == 0):
         raise ValueError("BatchNorm scale of the final layer has zeros: the pre-BN activation cannot be recovered")
-    w = alpha / s[:, None]
+    # a channel whose scale is tiny next to the others (|s_f| < 1e-6 max|s|) would get head weights of 1e6 alpha and beyond
+    # the half range, and its t / s cancellation amplifies the 16-bit feature quantisation by the same factor; alpha from
+    # grad_cam_alpha carries the factor s_f itself, so such a channel contributes ~ s_f^2: dropped (weight and bias term 0)
+    small = np.abs(s) < 1e-6 * np.abs(s).max()
+    w = np.where(small[:, None], 0.0, alpha / np.where(small, 1.0, s)[:, None])
     return w, -(t[:, None] * w).sum(axis=0)
