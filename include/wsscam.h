@@ -171,6 +171,12 @@ int wsc_net_feat_channels(const wsc_net *net, int *f_out);
  * Asynchronous on the ctx stream. */
 int wsc_net_forward_cam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int S,
                         float *cam_dev, float *score_dev);
+/* The same for NON-SQUARE network inputs x_dev float32 [B][2][3][H][W] -- the reference's resnet50 configuration
+ * outsize = None (03b_irn/func_sample.py:143-148): every image goes through the network at its own size, so a device batch
+ * holds images of one (H, W).  cam_dev float32 [B][C][h][w] with (h, w) from wsc_net_cam_size_hw. */
+int wsc_net_cam_size_hw(const wsc_net *net, int H, int W, int *h_out, int *w_out);
+int wsc_net_forward_cam_hw(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int H, int W, float *cam_dev,
+                           float *score_dev);
 
 /* Last-conv feature map for Grad-CAM style heads (02_cues/utilities.py:129-132,
  * K.function([input],[conv_output])): feat_dev float32 [N][h][w][F] (NHWC as Keras). */

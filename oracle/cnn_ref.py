@@ -335,6 +335,7 @@ def normalize_int(img):
 def msf_pack(img_u8, outsize=(321, 321)):
     """VOC12ClassificationDatasetMSF.__getitem__ for scales=(1.0,), voc12/dataloader.py:225-246:
     resize -> normalise -> HWC_to_CHW -> stack([x, flip(x, -1)])  => float32 (2,3,S,S)."""
-    x = normalize_int(resize_bilinear_f64(img_u8, outsize))
+    # outsize None: TorchvisionResize is a no-op, the image keeps its own size (voc12/dataloader.py:74)
+    x = normalize_int(resize_bilinear_f64(img_u8, outsize) if outsize is not None else np.asarray(img_u8, np.float64))
     x = np.transpose(x, (2, 0, 1))
     return np.stack([x, np.flip(x, -1)], axis=0).astype(np.float32)

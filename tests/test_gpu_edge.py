@@ -484,3 +484,31 @@ def test_eval_cam_adp_deepglobe_branch(tmp_path, dataset):
     for name, pred in zip(ids, preds_ref):
         clr = np.asarray(Image.open(os.path.join(args.cam_clr_out_dir, name + ".png")))
         assert np.array_equal(clr, np.asarray(colours, np.uint8)[pred])
+
+
+def test_make_cam_native_sizes_outsize_none(tmp_path):
+    """args.outsize = None -- the reference's resnet50 configuration (03b_irn/func_sample.py:143-148): no resize, every image
+    goes through the network at its OWN, non-square size (wsc_net_forward_cam_hw; batches bucketed by size).  make_cam.run on
+    images of four sizes (two share one), one .npy each, values vs the oracle's make_cam_image on the same native-size input,
+    at the fp32-class bound."""
+    sd = cnn_ref.make_resnet50_cam_state_dict(20, seed=0)
+    rng = np.random.default_rng(12)
+    sizes = [(75, 100), (100, 75), (75, 100), (66, 81), (97, 97)]
+    labels = [np.zeros(20, np.float32) for _ in sizes]
+    for i, cls in enumerate([[1, 4], [7], [2], [0, 19], [12]]):
+        labels[i][cls] = 1
+    data = [{"name": "2008_%06d" % i, "img": cnn_ref.msf_pack(cnn_ref.synth_image(rng, *sz), None), "size": sz, "label": lb}
+            for i, (sz, lb) in enumerate(zip(sizes, labels))]
+    assert data[0]["img"].shape == (2, 3, 75, 100)
+    args = types.SimpleNamespace(cam_network="net.resnet50_cam", model_dir=None, dataset="voc12", tag="", num_classes=20,
+                                 use_cls=None, model_id="resnet50", cam_weights_name=None, state_dict=sd, outsize=None,
+                                 dataset_obj=data, split="train_aug", cam_out_dir=str(tmp_path), n_gpus=1, cam_batch_images=4)
+    make_cam.run(args)
+    assert sorted(os.listdir(tmp_path)) == [d["name"] + ".npy" for d in data]
+    for d in data:
+        rec = np.load(os.path.join(tmp_path, d["name"] + ".npy"), allow_pickle=True).item()
+        ref = cnn_ref.make_cam_image(torch.from_numpy(d["img"]), sd, d["size"], torch.from_numpy(d["label"]))
+        assert np.array_equal(rec["keys"], ref["keys"])
+        assert rec["cam"].shape == ref["cam"].shape and rec["high_res"].shape == ref["high_res"].shape
+        assert np.abs(rec["high_res"] - ref["high_res"]).max() <= 1e-4, np.abs(rec["high_res"] - ref["high_res"]).max()
+        assert np.abs(rec["cam"] - ref["cam"]).max() <= 1e-4

@@ -121,3 +121,156 @@ def test_npy_layouts(tmp_path):
     assert list(a) == ["keys", "cam", "high_res"] and a["cam"].shape == (2, 4, 5)
     assert all(v.shape == (0,) for v in b.values()) and list(b) == ["keys", "cam", "high_res"]
     assert list(c) == ["keys", "cam"]
+
+
+# ---- 8 workers on one host: the host side of CamPipeline with the device stubbed out --------------------------------------
+class _StubBuf:
+    """Page-locked buffer stand-in: numpy bytes with DeviceBuffer / HostBuffer's .view()."""
+
+    def __init__(self, nbytes):
+        self.a = np.zeros(int(nbytes), np.uint8)
+
+    def view(self, shape, dtype, offset_bytes=0):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return self.a[offset_bytes:offset_bytes + n].view(dtype).reshape(shape)
+
+    def free(self):
+        pass
+
+
+class _StubLane:
+    class _Ctx:
+        def sync(self):
+            pass
+
+        def close(self):
+            pass
+
+    def __init__(self, B, S, n_sc):
+        import threading
+
+        self.ctx = self._Ctx()
+        self.pin_in = _StubBuf(B * n_sc * 2 * 3 * S * S * 4)
+        self.x_view = self.pin_in.view((B, n_sc, 2, 3, S, S), np.float32)
+        self.out_cap = 0
+        self.pin_out = None
+        self.free = threading.Event()
+        self.free.set()
+
+    def ensure_out(self, s_tot, h_tot):
+        need = (max(s_tot, 1) + max(h_tot, 1)) * 4
+        if need > self.out_cap:
+            self.out_cap = int(need * 1.5) + (1 << 20)
+            self.pin_out = _StubBuf(self.out_cap)
+
+    def close(self):
+        pass
+
+
+def _stub_pipeline(world, out_dir, S):
+    from wsscam.step.pipeline import CamPipeline
+
+    class _Model:
+        num_classes = 20
+
+        def cam_size(self, s):
+            return (s - 1) // 16 + 1
+
+    class StubPipeline(CamPipeline):
+        def _make_lane(self, device, batch_images, S_):
+            return _StubLane(batch_images, S_, self.n_sc)
+
+        def _device_step(self, lane, n, metas):  # the device's part of a batch: sizes only, outputs stay zero
+            keys = [self.keys_fn(m, None) for m in metas]
+            sizes = [tuple(int(v) for v in m["size"]) for m in metas]
+            shapes, s_off, h_off, so, ho = [], [], [], 0, 0
+            for k, (H, W) in zip(keys, sizes):
+                h4, w4 = (H - 1) // 4 + 1, (W - 1) // 4 + 1
+                shapes.append((len(k), h4, w4, H, W))
+                s_off.append(so)
+                h_off.append(ho)
+                so += len(k) * h4 * w4
+                ho += len(k) * H * W
+            lane.ensure_out(so, ho)
+            return keys, shapes, s_off, h_off, so
+
+    class Args:
+        dataset = "voc12"
+        cam_out_dir = out_dir
+
+    return StubPipeline(_Model(), 0, 4, S, keys_fn=lambda pack, score: np.nonzero(pack["label"])[0].astype(np.int64),
+                        save_fn=lambda name, keys, sc, hc: make_cam._save(Args, name, keys, sc, hc), needs_score=False,
+                        n_lanes=3, world=world)
+
+
+class _HostWorkDataset:
+    """Items cost real host work, like decode + float64 resize + normalise do (numpy releases the GIL for it)."""
+
+    def __init__(self, n, S, seed):
+        self.n, self.S, self.seed = n, S, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        rng = np.random.default_rng(self.seed + i)
+        img = rng.random((96, 120, 3))
+        for _ in range(6):
+            img = np.sqrt(img * img + 1e-3)  # ~ the arithmetic of a resize pass, GIL released
+        x = np.resize(img.astype(np.float32), (3, self.S, self.S))
+        return {"name": "w%03d" % i, "img": np.stack([x, x[:, :, ::-1]]), "size": (90 + i % 7, 120),
+                "label": np.eye(20, dtype=np.float32)[i % 20]}
+
+
+def _host_rank_main(rank, world, port, out_dir, n_items, S, result_file):
+    import time
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shards = torchutils.split_dataset(_HostWorkDataset(n_items, S, 7), world)
+        pipe = _stub_pipeline(world, out_dir, S)
+        dist.barrier()
+        t0 = time.perf_counter()
+        pipe.run(shards[rank])
+        dt = time.perf_counter() - t0
+        pipe.close()
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py's reduction: the slowest rank sets the time
+        threads = torch.tensor([pipe.n_loaders + pipe.n_writers], dtype=torch.int64)
+        dist.all_reduce(threads, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            with open(result_file, "w") as fh:
+                fh.write("%f %d %d %d\n" % (float(t.item()), int(threads.item()), pipe.n_loaders, pipe.n_writers))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_host_budget(tmp_path):
+    """Eight workers of the make_cam host pipeline on ONE host (gloo, device stubbed): every worker sizes its loader / writer
+    pools from its share of the cores (host_thread_budget: the eight pools together fit the machine instead of 8 x 16 threads),
+    every image is written exactly once, and the aggregate host throughput of the eight workers is not below what one worker
+    with the whole machine reaches (no collapse from oversubscription)."""
+    from wsscam.step.pipeline import host_thread_budget
+
+    cores = len(os.sched_getaffinity(0))
+    b1, b8 = host_thread_budget(1, cores), host_thread_budget(8, cores)
+    assert b1["n_loaders"] + b1["n_writers"] <= max(2, min(16, cores))
+    assert 8 * (b8["n_loaders"] + b8["n_writers"]) <= max(16, 2 * cores)
+    assert host_thread_budget(8, 128) == {"cores": 128, "cores_per_rank": 16, "n_loaders": 8, "n_writers": 8}
+    assert host_thread_budget(8, 64) == {"cores": 64, "cores_per_rank": 8, "n_loaders": 5, "n_writers": 3}
+    n_items, S = 96, 64
+    times = {}
+    for world in (1, 8):
+        out = tmp_path / ("w%d" % world)
+        out.mkdir()
+        res = str(tmp_path / ("res%d.txt" % world))
+        mp.spawn(_host_rank_main, nprocs=world, args=(world, _free_port(), str(out), n_items, S, res), join=True)
+        assert sorted(os.listdir(out)) == ["w%03d.npy" % i for i in range(n_items)]
+        t, nthreads, nl, nw = open(res).read().split()
+        times[world] = float(t)
+        assert int(nthreads) == world * (int(nl) + int(nw))
+        assert (int(nl), int(nw)) == ((b1 if world == 1 else b8)["n_loaders"], (b1 if world == 1 else b8)["n_writers"])
+    # same images, same cores: eight sharded workers must not be slower than one worker by more than process start-up noise
+    assert n_items / times[8] >= 0.6 * n_items / times[1], times

@@ -526,11 +526,14 @@ struct Plan {
     int hf = 0, wf = 0;       // final feature map size
 };
 
-int plan_dims(const wsc_net *net, int N, int S, Plan *pl) {
+// (SH x SW network input: square for the fixed-size configurations, the image's own size for outsize = None)
+int plan_dims(const wsc_net *net, int N, int SH, int SW, Plan *pl);
+int plan_dims(const wsc_net *net, int N, int S, Plan *pl) { return plan_dims(net, N, S, S, pl); }
+int plan_dims(const wsc_net *net, int N, int SH, int SW, Plan *pl) {
     int bh[4] = {0, 0, 0, 0}, bw[4] = {0, 0, 0, 0}, bc[4] = {0, 0, 0, 0};
     pl->max_act = 0;
     for (const Op &op : net->ops) {
-        int H = op.in < 0 ? S : bh[op.in], W = op.in < 0 ? S : bw[op.in], C = op.in < 0 ? 4 : bc[op.in];
+        int H = op.in < 0 ? SH : bh[op.in], W = op.in < 0 ? SW : bw[op.in], C = op.in < 0 ? 4 : bc[op.in];
         int Ho, Wo, Co;
         if (op.type == OP_CONV) {
             const ConvW &c = net->convs[op.conv];
@@ -543,7 +546,7 @@ int plan_dims(const wsc_net *net, int N, int S, Plan *pl) {
             Wo = (W + 2 * op.pp - op.pk) / op.ps + 1;
             Co = C;
         }
-        WSC_CHECK(Ho > 0 && Wo > 0, WSC_ERR_INVALID, "input size %d too small for this network", S);
+        WSC_CHECK(Ho > 0 && Wo > 0, WSC_ERR_INVALID, "input size %d x %d too small for this network", SH, SW);
         bh[op.out] = Ho; bw[op.out] = Wo; bc[op.out] = Co;
         pl->H.push_back(Ho); pl->W.push_back(Wo); pl->C.push_back(Co);
         const size_t e = (size_t)N * Ho * Wo * Co;
@@ -564,11 +567,12 @@ size_t tap_plane_bytes(const wsc_net *net, const Plan &pl, int N, int k) {
 // the stage outputs x1..x5 (net->taps) are copied, plane by plane (hi [, lo]), to the start of the extra
 // region in stage order -- the rotating activation buffers are overwritten as the stack proceeds.
 int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, int S, size_t extra_bytes,
-                 const bf16_t **feat, const bf16_t **feat_lo, int *hf, int *wf, void **extra, bool copy_taps = false) {
+                 const bf16_t **feat, const bf16_t **feat_lo, int *hf, int *wf, void **extra, bool copy_taps = false, int SW = 0) {
+    if (SW <= 0) SW = S; // S x SW input (SW given for the non-square, native-size path)
     Plan pl;
-    WSC_TRY(plan_dims(net, N, S, &pl));
+    WSC_TRY(plan_dims(net, N, S, SW, &pl));
     const int planes = net->split ? 2 : 1;
-    const size_t in_bytes = align_up((size_t)N * S * S * 4 * sizeof(bf16_t), 256);
+    const size_t in_bytes = align_up((size_t)N * S * SW * 4 * sizeof(bf16_t), 256);
     const size_t act_bytes = align_up(pl.max_act * sizeof(bf16_t), 256);
     const size_t total = in_bytes * planes + act_bytes * 4 * planes + align_up(extra_bytes, 256);
     void *ws;
@@ -584,11 +588,11 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
     }
     *extra = (void *)p;
 
-    WSC_TRY(launch_nchw_to_nhwc4(ctx, x_dev, N, S, S, xin, xin_lo, net->fmt));
+    WSC_TRY(launch_nchw_to_nhwc4(ctx, x_dev, N, S, SW, xin, xin_lo, net->fmt));
     int bh[4] = {0, 0, 0, 0}, bw[4] = {0, 0, 0, 0}, bc[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < net->ops.size(); ++i) {
         const Op &op = net->ops[i];
-        const int H = op.in < 0 ? S : bh[op.in], W = op.in < 0 ? S : bw[op.in], C = op.in < 0 ? 4 : bc[op.in];
+        const int H = op.in < 0 ? S : bh[op.in], W = op.in < 0 ? SW : bw[op.in], C = op.in < 0 ? 4 : bc[op.in];
         const bf16_t *src = op.in < 0 ? xin : buf[op.in];
         const bf16_t *src_lo = op.in < 0 ? xin_lo : buf_lo[op.in];
         if (op.type == OP_CONV) {
@@ -701,21 +705,35 @@ int wsc_net_feat_channels(const wsc_net *net, int *f_out) {
     return WSC_OK;
 }
 
+int wsc_net_cam_size_hw(const wsc_net *net, int H, int W, int *h_out, int *w_out) {
+    WSC_CHECK(net && h_out && w_out, WSC_ERR_INVALID, "wsc_net_cam_size_hw: null argument");
+    Plan pl;
+    WSC_TRY(plan_dims(net, 1, H, W, &pl));
+    *h_out = pl.hf;
+    *w_out = pl.wf;
+    return WSC_OK;
+}
+
 int wsc_net_forward_cam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int S, float *cam_dev,
                         float *score_dev) {
+    return wsc_net_forward_cam_hw(ctx, net, x_dev, B, S, S, cam_dev, score_dev);
+}
+
+int wsc_net_forward_cam_hw(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int S, int SW, float *cam_dev,
+                           float *score_dev) {
     WSC_CHECK(ctx && net && x_dev && cam_dev, WSC_ERR_INVALID, "wsc_net_forward_cam: null argument");
-    WSC_CHECK(B > 0 && S > 0, WSC_ERR_INVALID, "wsc_net_forward_cam: B=%d S=%d", B, S);
+    WSC_CHECK(B > 0 && S > 0 && SW > 0, WSC_ERR_INVALID, "wsc_net_forward_cam: B=%d input %d x %d", B, S, SW);
     WSC_CHECK(score_dev == nullptr || net->cls_w != nullptr, WSC_ERR_INVALID,
               "this architecture has no classifier branch (score_dev must be NULL)");
     WSC_HIP(hipSetDevice(ctx->device));
     const int N = 2 * B;
     Plan pl;
-    WSC_TRY(plan_dims(net, N, S, &pl));
+    WSC_TRY(plan_dims(net, N, S, SW, &pl));
     const size_t head_bytes = (size_t)N * pl.hf * pl.wf * net->C * sizeof(float);
     const bf16_t *feat, *feat_lo;
     int hf, wf;
     void *extra;
-    WSC_TRY(run_backbone(ctx, net, x_dev, N, S, head_bytes, &feat, &feat_lo, &hf, &wf, &extra));
+    WSC_TRY(run_backbone(ctx, net, x_dev, N, S, head_bytes, &feat, &feat_lo, &hf, &wf, &extra, false, SW));
     float *head_out = (float *)extra;
     ConvLaunch L;
     memset(&L, 0, sizeof(L));

@@ -94,6 +94,8 @@ _SIGNATURES = {
     "wsc_net_forward_cam": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "wsc_net_forward_gradcam": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "wsc_net_forward_features": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "wsc_net_cam_size_hw": (_i, [_vp, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "wsc_net_forward_cam_hw": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "wsc_net_forward_edge": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "wsc_rw_propagate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i, _vp]),
     "wsc_rw_propagate_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp]),
@@ -390,7 +392,7 @@ def make_tensor_descs(state_dict):
 class Net:
     """wsc_net: packed weights of one CAM network."""
 
-    def __init__(self, ctx, arch, state_dict, num_classes, precision=PREC_BF16):
+    def __init__(self, ctx, arch, state_dict, num_classes, precision=PREC_F16X3):
         self.ctx = ctx
         self.arch = arch
         self.num_classes = num_classes
@@ -428,6 +430,16 @@ class Net:
         run = ctx or self.ctx
         check(self.ctx._lib.wsc_net_forward_cam(run.h, self.h, _ptr(x_dev), B, S, _ptr(cam_dev),
                                                 _ptr(score_dev)))
+
+    def cam_size_hw(self, H, W):
+        h, w = _i(), _i()
+        check(self.ctx._lib.wsc_net_cam_size_hw(self.h, int(H), int(W), ctypes.byref(h), ctypes.byref(w)))
+        return h.value, w.value
+
+    def forward_cam_hw(self, x_dev, B, H, W, cam_dev, score_dev=None, ctx=None):
+        """Non-square network input [B][2][3][H][W] (outsize = None: the image's own size)."""
+        run = ctx or self.ctx
+        check(self.ctx._lib.wsc_net_forward_cam_hw(run.h, self.h, _ptr(x_dev), B, int(H), int(W), _ptr(cam_dev), _ptr(score_dev)))
 
     def forward_gradcam(self, x_dev, N, S, relu, cams_dev, score_dev=None, ctx=None):
         run = ctx or self.ctx

@@ -20,7 +20,9 @@ class DeviceCAMBase:
     """Common plumbing: a lazily created wsc_ctx + wsc_net, numpy/torch in, same kind out."""
 
     arch = None
-    precision = _lib.PREC_BF16
+    # the fp32-class mode: the reference's arithmetic is fp32 and the package is a drop-in (PREC_F16 / PREC_BF16: fast 16-bit
+    # modes, 1.5e-2 / 8e-2 on the normalised CAM maps -- args.cam_precision or the constructor's `precision`)
+    precision = _lib.PREC_F16X3
 
     def __init__(self, num_classes, precision=None):
         self.num_classes = num_classes
@@ -74,6 +76,9 @@ class DeviceCAMBase:
     def cam_size(self, S):
         return self._ensure_net().cam_size(S)
 
+    def cam_size_hw(self, H, W):
+        return self._ensure_net().cam_size_hw(H, W)
+
     def gradcam_net(self, weights, ctx=None, pre_bn=True):
         """(wsc_net with `weights` (F x C Grad-CAM alpha) as its 1x1 head, ctx); cached per alpha.  `ctx`: run on
         this context instead of the model's own (two models of one driver share a stream and its buffers).
@@ -96,9 +101,12 @@ class DeviceCAMBase:
         return cache[key], (ctx or self._ctx)
 
     # -- batched device forward ---------------------------------------------------------------
-    def forward_batch_device(self, x_dev, B, S, cam_dev, score_dev=None):
-        """x_dev float32 [B][2][3][S][S] -> cam_dev float32 [B][C][h][w] (device pointers/buffers)."""
-        self._ensure_net().forward_cam(x_dev, B, S, cam_dev, score_dev)
+    def forward_batch_device(self, x_dev, B, S, cam_dev, score_dev=None, SW=None):
+        """x_dev float32 [B][2][3][S][SW or S] -> cam_dev float32 [B][C][h][w] (device pointers/buffers)."""
+        if SW is None or SW == S:
+            self._ensure_net().forward_cam(x_dev, B, S, cam_dev, score_dev)
+        else:
+            self._ensure_net().forward_cam_hw(x_dev, B, S, SW, cam_dev, score_dev)
 
     def forward_batch(self, x, want_score=False):
         """x: numpy/torch float32 (B,2,3,S,S) on host -> numpy cam (B,C,h,w) [, score (B,C)]."""

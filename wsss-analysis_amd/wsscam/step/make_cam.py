@@ -62,20 +62,31 @@ def process_batch(model, packs, args, save=True):
     # multi-scale items carry a list of (2,3,S,S) pairs (one per args.cam_scales entry, all resized to the same S): the scales
     # of an image run as consecutive "images" of one device batch and their CAMs are summed before the tail
     n_sc = len(_scales_of(packs[0]["img"]))
-    x = np.stack([np.stack([np.asarray(v, dtype=np.float32) for v in _scales_of(p["img"])]) for p in packs])  # (B,n_sc,2,3,S,S)
-    if x.ndim != 6 or x.shape[2:4] != (2, 3) or x.shape[-2] != x.shape[-1]:
-        # wsc_net_forward_cam takes square S x S inputs: the reference's outsize=None configuration (native, non-square
-        # image sizes, func_sample.py:143-145) is not supported -- INTEGRATION.md, "limits"
-        raise ValueError("make_cam: network inputs must be (B, 2, 3, S, S) with one square size per run "
-                         "(args.outsize = (321, 321) or (224, 224)); got %s" % (x.shape,))
-    S = x.shape[-1]
+    shapes_in = [tuple(np.asarray(_scales_of(p["img"])[0]).shape) for p in packs]
+    if len(set(shapes_in)) > 1:
+        # outsize = None (the reference's resnet50 configuration, func_sample.py:143-148): every image keeps its own size, so
+        # the items of a batch are bucketed by network input size -- one device batch per size, results in input order
+        if n_sc > 1:
+            raise ValueError("make_cam: several cam_scales need one network input size per run (args.outsize)")
+        out = [None] * B
+        buckets = {}
+        for i, sh in enumerate(shapes_in):
+            buckets.setdefault(sh, []).append(i)
+        for idx in buckets.values():
+            for i, o in zip(idx, process_batch(model, [packs[i] for i in idx], args, save=save)):
+                out[i] = o
+        return out
+    x = np.stack([np.stack([np.asarray(v, dtype=np.float32) for v in _scales_of(p["img"])]) for p in packs])  # (B,n_sc,2,3,H,W)
+    if x.ndim != 6 or x.shape[2:4] != (2, 3):
+        raise ValueError("make_cam: network inputs must be (B, 2, 3, H, W); got %s" % (x.shape,))
+    S, SW = int(x.shape[-2]), int(x.shape[-1])  # square for args.outsize = (321, 321) / (224, 224); the image's size for None
     C = model.num_classes
-    h = model.cam_size(S)
+    h, w = model.cam_size_hw(S, SW)
     has_cls = model.arch != _lib.ARCH_RESNET50_CAM
     x_dev = ctx.to_device(x)
-    cam_dev = ctx.alloc(B * n_sc * C * h * h * 4)
+    cam_dev = ctx.alloc(B * n_sc * C * h * w * 4)
     score_dev = ctx.alloc(B * n_sc * C * 4) if has_cls else None
-    model.forward_batch_device(x_dev, B * n_sc, S, cam_dev, score_dev)
+    model.forward_batch_device(x_dev, B * n_sc, S, cam_dev, score_dev, SW=SW)
     # make_cam.py:52: `label = labels[0][args.use_cls]` -- the prediction of the FIRST scale decides the classes
     score = ctx.to_host(score_dev, (B, n_sc, C), np.float32)[:, 0] if has_cls else None
     keys = [_valid_cat(args, p, None if score is None else score[b], model) for b, p in enumerate(packs)]
@@ -85,7 +96,7 @@ def process_batch(model, packs, args, save=True):
         # ORIGINAL image (of that scale) on the host (scipy Gaussian filter) and joined with the use_cls CAM channels
         # before the tail; the modified maps (summed over the scales) go back to the device for the two resizes +
         # normalisation.
-        cam = ctx.to_host(cam_dev, (B, n_sc, C, h, h), np.float32)
+        cam = ctx.to_host(cam_dev, (B, n_sc, C, h, w), np.float32)
         mod = []
         for b, p in enumerate(packs):
             origs = _scales_of(p["orig_img"])
@@ -98,10 +109,10 @@ def process_batch(model, packs, args, save=True):
         C = mod.shape[1]
         cam_dev = ctx.to_device(np.ascontiguousarray(mod, dtype=np.float32))
     elif n_sc > 1:
-        sum_dev = ctx.alloc(B * C * h * h * 4)
-        _lib.cam_sum_scales(ctx, cam_dev, B, n_sc, C * h * h, sum_dev)
+        sum_dev = ctx.alloc(B * C * h * w * 4)
+        _lib.cam_sum_scales(ctx, cam_dev, B, n_sc, C * h * w, sum_dev)
         cam_dev = sum_dev
-    s_dev, h_dev, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, B, C, h, h, sizes, keys)
+    s_dev, h_dev, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, B, C, h, w, sizes, keys)
     s_tot = sum(k * a * b for (k, a, b, _, _) in shapes)
     h_tot = sum(k * a * b for (k, _, _, a, b) in shapes)
     strided = ctx.to_host(s_dev, (max(s_tot, 1),), np.float32)
@@ -130,7 +141,8 @@ def _work(process_id, model, dataset, args):
     if n == 0:
         return
     adp = args.dataset in ("adp_morph", "adp_func")
-    if adp or not getattr(args, "cam_pipeline", True):
+    native = getattr(args, "outsize", (321, 321)) is None  # every image at its own size: batches bucketed by size, no pinned lanes
+    if adp or native or not getattr(args, "cam_pipeline", True):
         # ADP: the background / 'other' channels are synthesised on the host between the CAM head and the tail
         # (common_cam.py:31-92), so the batches run one after the other
         for i0 in range(0, n, bs):
@@ -160,10 +172,13 @@ def _work(process_id, model, dataset, args):
     needs_score = "train" not in args.split
     if needs_score and not has_cls:
         raise ValueError("split %r needs predicted labels but %s has no classifier branch" % (args.split, type(model).__name__))
+    # loader / writer pools: sized from the host cores per worker unless the caller fixes them (pipeline.host_thread_budget)
+    lt, wt = getattr(args, "cam_loader_threads", None), getattr(args, "cam_writer_threads", None)
     pipe = CamPipeline(model, device, bs, S, keys_fn=lambda pack, score: _valid_cat(args, pack, score, model),
                        save_fn=lambda name, keys, sc, hc: _save(args, name, keys, sc, hc), needs_score=needs_score,
-                       n_lanes=int(getattr(args, "cam_pipeline_lanes", 3)), n_loaders=int(getattr(args, "cam_loader_threads", 8)),
-                       n_writers=int(getattr(args, "cam_writer_threads", 8)), norm=norm, n_scales=n_sc)
+                       n_lanes=int(getattr(args, "cam_pipeline_lanes", 3)), n_loaders=None if lt is None else int(lt),
+                       n_writers=None if wt is None else int(wt), norm=norm, n_scales=n_sc,
+                       world=int(getattr(args, "n_gpus", 0)) or len(dataset))
     try:
         pipe.run(databin)
     finally:
@@ -176,6 +191,17 @@ def _device_count():
     return torch.cuda.device_count()
 
 
+def _device_transform_default(args):
+    """args.cam_device_transform when given; otherwise ON for multi-GPU runs: N workers share the host, and the decoded uint8
+    image is 8x fewer PCIe bytes and no float64 host resize per image (wsc_msf_input_u8 is bit-identical to the host transform,
+    tests/test_gpu_input.py).  A single worker keeps the host transform (the reference's data path)."""
+    v = getattr(args, "cam_device_transform", None)
+    if v is not None:
+        return bool(v)
+    n = int(getattr(args, "n_gpus", 0))
+    return n > 1
+
+
 def build_dataset(args):
     if getattr(args, "dataset_obj", None) is not None:
         return args.dataset_obj
@@ -186,7 +212,7 @@ def build_dataset(args):
                                                         outsize=args.outsize, dev_root=args.dev_root,
                                                         scales=args.cam_scales,
                                                         cls_labels_path=getattr(args, "cls_labels_path", None),
-                                                        device_transform=bool(getattr(args, "cam_device_transform", False)))
+                                                        device_transform=_device_transform_default(args))
     if args.dataset in ("adp_morph", "adp_func"):
         from ..adp import dataloader
 
@@ -207,15 +233,12 @@ def build_dataset(args):
 
 def run(args):
     """03b_irn/step/make_cam.py:95-124."""
-    if getattr(args, "outsize", (321, 321)) is None:
-        raise ValueError("make_cam: args.outsize=None (native, non-square network inputs) is not supported; "
-                         "use (321, 321) or (224, 224)")
     mod = args.cam_network
     if not mod.startswith("wsscam."):
         mod = "wsscam." + mod  # the reference passes 'net.resnet50_cam'
     model = getattr(importlib.import_module(mod), "CAM")(args.model_dir, args.dataset, args.tag,
                                                          args.num_classes, args.use_cls)
-    if getattr(args, "cam_precision", None) is not None:  # optional: _lib.PREC_F16 (default) / BF16 / BF16X3
+    if getattr(args, "cam_precision", None) is not None:  # optional: _lib.PREC_F16X3 (default, fp32-class) / F16 / BF16 / BF16X3
         model.precision = args.cam_precision
     if getattr(args, "state_dict", None) is not None:
         model.load_state_dict(args.state_dict, strict=True)  # weights handed over in memory (tests, dry runs)

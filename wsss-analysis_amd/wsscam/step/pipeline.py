@@ -18,6 +18,22 @@ import numpy as np
 from .. import _lib
 
 
+def host_thread_budget(world, cores=None):
+    """Loader / writer threads of ONE worker when `world` workers (one per GPU) share the host: the cores this process may
+    run on (sched_getaffinity) divided by the workers, 5/8 of them decoding + resizing (loaders), the rest pickling + writing
+    (writers), each capped at 8 -- a single worker on a 128-core host keeps round 3's 8 + 8; 8 workers on a 64-core host get
+    5 + 3 each instead of 8 x 16 threads on 64 cores.  (The lanes' finisher threads sleep in wsc_sync and cost no core.)"""
+    if cores is None:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+    per = max(1, int(cores) // max(1, int(world)))
+    loaders = max(1, min(8, (per * 5) // 8))
+    writers = max(1, min(8, per - loaders))
+    return {"cores": int(cores), "cores_per_rank": per, "n_loaders": loaders, "n_writers": writers}
+
+
 class _Lane:
     def __init__(self, device, B, S, C, h, n_sc=1):
         self.ctx = _lib.Context(device)
@@ -73,20 +89,29 @@ class CamPipeline:
     """Batched, overlapped make_cam worker for one GPU.  `keys_fn(pack, score_row_or_None) -> int64 keys`,
     `save_fn(name, keys, strided, highres)` are the driver's own (make_cam._valid_cat / _save)."""
 
-    def __init__(self, model, device, batch_images, S, keys_fn, save_fn, needs_score, n_lanes=3, n_loaders=8, n_writers=8,
-                 norm=None, n_scales=1):
+    def __init__(self, model, device, batch_images, S, keys_fn, save_fn, needs_score, n_lanes=3, n_loaders=None, n_writers=None,
+                 norm=None, n_scales=1, world=1):
+        """n_loaders / n_writers None: sized from the host cores this worker may use when `world` workers share the host
+        (host_thread_budget)."""
+        budget = host_thread_budget(world)
+        n_loaders = budget["n_loaders"] if n_loaders is None else int(n_loaders)
+        n_writers = budget["n_writers"] if n_writers is None else int(n_writers)
+        self.n_loaders, self.n_writers, self.world = n_loaders, n_writers, int(world)
         self.model, self.device, self.B, self.S = model, device, batch_images, S
         self.norm = norm  # TorchvisionNormalize of the dataset (device transform of "img_u8" items)
         self.keys_fn, self.save_fn, self.needs_score = keys_fn, save_fn, needs_score
         self.C = model.num_classes
         self.h = model.cam_size(S)
         self.n_sc = int(n_scales)  # args.cam_scales: every image contributes n_sc network inputs, their CAMs are summed
-        self.lanes = [_Lane(device, batch_images, S, self.C, self.h, self.n_sc) for _ in range(n_lanes)]
+        self.lanes = [self._make_lane(device, batch_images, S) for _ in range(n_lanes)]
         self.loaders = ThreadPoolExecutor(n_loaders, thread_name_prefix="wsc-load")
         self.writers = ThreadPoolExecutor(n_writers, thread_name_prefix="wsc-save")
         self.finishers = ThreadPoolExecutor(n_lanes, thread_name_prefix="wsc-finish")
         self.errors = []
         self.images_done = 0
+
+    def _make_lane(self, device, batch_images, S):
+        return _Lane(device, batch_images, S, self.C, self.h, self.n_sc)
 
     # -- stages --------------------------------------------------------------------------------------------
     def _load_into(self, lane, k, dataset, idx):
@@ -123,6 +148,14 @@ class CamPipeline:
     def _start(self, lane, dataset, indices):
         n = len(indices)
         metas = [f.result() for f in [self.loaders.submit(self._load_into, lane, k, dataset, i) for k, i in enumerate(indices)]]
+        keys, shapes, s_off, h_off, s_tot = self._device_step(lane, n, metas)
+        lane.free.clear()
+        self.finishers.submit(self._finish, lane, metas, keys, shapes, s_off, h_off, s_tot)
+
+    def _device_step(self, lane, n, metas):
+        """Everything a batch does on its lane's stream (H2D, conv stack, CAM head, tail, D2H -- all asynchronous): returns what
+        the finisher needs to cut the outputs out of the lane's staging buffer.  (The CPU tests of the N-worker host side
+        replace this method and _make_lane; nothing else of the pipeline touches the device.)"""
         ctx = lane.ctx
         if "img_u8" in metas[0]:
             # decoded images: (sum H0 W0 3) bytes over PCIe instead of n x 2.47 MB of float32; resize + normalise + flip
@@ -163,8 +196,7 @@ class CamPipeline:
                                                           lane.s_dev, lane.h_dev)
         ctx.d2h_async(lane.pin_out, lane.s_dev, max(s_tot, 1) * 4)
         ctx.d2h_async(lane.pin_out, lane.h_dev, max(h_tot, 1) * 4, dst_offset=max(s_tot, 1) * 4)
-        lane.free.clear()
-        self.finishers.submit(self._finish, lane, metas, keys, shapes, s_off, h_off, s_tot)
+        return keys, shapes, s_off, h_off, s_tot
 
     # -- driver --------------------------------------------------------------------------------------------
     def run(self, dataset, indices=None):
