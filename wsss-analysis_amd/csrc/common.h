@@ -200,7 +200,8 @@ struct ConvLaunch {
     int N, H, W, Cin, Ho, Wo, Cout, CoutPad;
     int kh, kw, stride, pad;
     int relu;
-    int small_cin; // 0: generic (Cin % 64 == 0); else log2(slots per kernel row): 2 = 7x7 stem, 1 = 3x3 Cin<=4
+    int small_cin; // 0: generic (Cin % 64 == 0); else log2(slots per kernel row): 2 = 7x7 stem, 1 = 3x3 Cin<=4;
+                   // 3: f16x3 stem on a zero-padded NHWC4 input (H, W = the padded size, pad = 0; conv_igemm.hip)
     int split;     // 0: one plane; 1: bf16x3 (three K segments); 2: f16x3 (hi + lo staged once per K-step).  The lo plane has the hi plane's format
     int fmt;       // 16-bit operand format: 0 bf16, 1 f16 (split 1 requires bf16, split 2 f16)
     int generic;   // 1: keep the generic kernel variants (testing: the FAST variants give the same bits)
@@ -209,6 +210,9 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p);
 
 // ---- misc kernels ---------------------------------------------------------------------
 int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo, int fmt);
+// [N][Hp][Wp][4] with a zero border of `pad` pixels on the top / left (and whatever Hp, Wp leave on the bottom / right)
+int launch_nchw_to_nhwc4_pad(wsc_ctx *ctx, const float *x, int N, int H, int W, int Hp, int Wp, int pad, bf16_t *y, bf16_t *y_lo,
+                             int fmt);
 int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, int C, int k,
                    int stride, int pad, int Ho, int Wo, bf16_t *y, bf16_t *y_lo, int fmt);
 // cam[b][c][y][x] = relu(head[2b][y][x][c]) + relu(head[2b+1][y][w-1-x][c])   (head fp32 NHWC, stride Cs)

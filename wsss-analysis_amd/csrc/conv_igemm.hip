@@ -69,6 +69,8 @@ struct ConvKArgs {
     int debug;          // WSC_CONV_DEBUG ablations (timing only, results are wrong): 1 = no DMA after the
                         // first two stages, 2 = no fragment reads / MFMAs
     long long lo_delta; // SPLIT 2: x_lo - x in elements (both planes live in one workspace block)
+    int stem_rows;      // host side only: the padded-input stem form (a K-step = one kernel row of 8 pixels x 4 channels)
+    int kw_real;        // host side only: kernel width of the layer (FLOP accounting; kw is 1 in the stem form)
 };
 
 __device__ __forceinline__ int lds_off(int row, int slot) {
@@ -944,8 +946,9 @@ int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
         attr_set[dev] = true;
     }
     // algorithmic FLOPs: 2 * M * Cout * (kh*kw*Cin_real), x1 regardless of the precision mode
-    const double flops = 2.0 * (a.m_end - a.m_base) * a.Cout * (MODE == 0 ? (double)a.kh * a.kw * a.Cin : (double)a.kh * a.kw * 3);
-    WscKernelTimer timer(ctx, MODE != 0 ? WSC_K_CONV_SMALLCIN : (BM == 256 ? WSC_K_CONV256 : (BN == 128 ? WSC_K_CONV128 : WSC_K_CONV64)), flops);
+    const double flops = 2.0 * (a.m_end - a.m_base) * a.Cout *
+                         ((MODE == 0 && !a.stem_rows) ? (double)a.kh * a.kw * a.Cin : (double)a.kh * (a.stem_rows ? a.kw_real : a.kw) * 3);
+    WscKernelTimer timer(ctx, (MODE != 0 || a.stem_rows) ? WSC_K_CONV_SMALLCIN : (BM == 256 ? WSC_K_CONV256 : (BN == 128 ? WSC_K_CONV128 : WSC_K_CONV64)), flops);
     hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(BM * 2), LDS, ctx->stream, a);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
@@ -1045,8 +1048,25 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     fastdiv((unsigned)(p.Wo > 0 ? p.Wo : 1), a.div_wo_mul, a.div_wo_s1, a.div_wo_s2);
     WSC_CHECK(p.split >= 0 && p.split <= 2 && !(p.split == 1 && p.fmt) && !(p.split == 2 && !p.fmt), WSC_ERR_INVALID,
               "conv: split mode %d with operand format %d (bf16x3 = split 1 on bf16 planes, f16x3 = split 2 on half planes)", p.split, p.fmt);
-    const bool single_staged = p.split == 2 && p.small_cin == 0;
-    if (p.small_cin == 0) {
+    // small_cin == 3: the stem of the f16x3 mode on a zero-PADDED NHWC4 input (net.hip run_backbone): the 8-pixel x 4-channel
+    // window of kernel row r of an output pixel is 32 contiguous elements of either plane, 16-byte aligned (stride 2: the
+    // window starts at an even pixel), so a K-step = one kernel row = 32 hi + 32 lo values -- exactly the single-staged
+    // split's K-step.  The layer then IS a generic single-staged layer with kh K-steps: no bounds tests (the padding is
+    // in the buffer), LDS-DMA staging, the FAST epilogue (round 3 ran it in three register-staged K segments: 342 us).
+    const bool stem_rows = p.small_cin == 3;
+    if (stem_rows)
+        WSC_CHECK(p.split == 2 && p.Cin == 4 && p.pad == 0 && p.kw <= 7 && (p.stride & 1) == 0, WSC_ERR_INVALID,
+                  "conv: the padded-stem form needs split 2, a 4-channel padded input, kw <= 7 and an even stride");
+    const int small_cin_eff = stem_rows ? 0 : p.small_cin;
+    a.stem_rows = stem_rows ? 1 : 0;
+    a.kw_real = p.kw;
+    const bool single_staged = p.split == 2 && small_cin_eff == 0;
+    if (stem_rows) {
+        a.kw = 1;
+        a.cchunks = 1;
+        a.ntaps = p.kh;
+        a.ksteps_base = p.kh;
+    } else if (p.small_cin == 0) {
         WSC_CHECK(p.Cin % 64 == 0, WSC_ERR_INVALID, "conv: Cin=%d not a multiple of 64", p.Cin);
         a.cchunks = p.Cin / (single_staged ? 32 : 64);
         a.ntaps = p.kh * p.kw;
@@ -1081,7 +1101,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     if (!nofast && p.fmt && (p.split == 0 || single_staged) && p.y != nullptr && p.y_f32 == nullptr &&
         p.Cout == p.CoutPad && (long long)a.M * p.Cout < (1ll << 31)) {
         a.fast = 1;
-        if (p.small_cin == 0 && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1) a.fast = 3;
+        if (small_cin_eff == 0 && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1) a.fast = 3;
     }
     if (a.M == 0) return WSC_OK;
     // tile choice.  Measured on the ResNet50-CAM stack (64 samples @321^2, f16): 128-row tiles 4.31 ms,
@@ -1099,19 +1119,22 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
 #endif
     const long long blocks256 = ((a.M + 255) / 256) * (long long)a.ntiles_n;
     bool big = false;
-    if (force == -1) big = p.small_cin == 0 && BN == 128 && a.Kbase >= 512 && blocks256 >= 200;
-    if (force == 256) big = p.small_cin == 0 && BN == 128;
+    if (force == -1) big = small_cin_eff == 0 && BN == 128 && a.Kbase >= 512 && blocks256 >= 200;
+    if (force == 256) big = small_cin_eff == 0 && BN == 128;
     // 256 x 256 tile: half the L2->LDS bytes per FLOP of the 128 x 128 tile; needs enough K-steps to amortise
     // its 130 KB prologue/epilogue and enough tiles to fill 256 CUs at one block per CU.  VGG16 @321, 64
     // samples: 806 -> 920 TFLOP/s on the 11 layers it takes (stack 11.5 -> 10.8 ms).  Thresholds (>= 4 K-steps, >= one
     // round of tiles, later 3/4 of a round) from a sweep on ResNet50: (8, 768) 3.96 ms, (8, 256) 3.96, (4, 768) 3.94, (4, 256) 3.92; VGG16 +-0.
     // A grid of 192+ tiles (3/4 of a round: layer4's 3x3 and 1x1 -> 512 convs, 222 tiles) also wins: 4.11 -> 3.97 ms.
     const long long blocks_sq = ((a.M + 255) / 256) * (long long)(p.CoutPad / 256);
-    bool square = p.small_cin == 0 && p.CoutPad % 256 == 0 && a.nk >= 4 && blocks_sq >= 192;
-    if (force == 512) square = p.small_cin == 0 && p.CoutPad % 256 == 0;
+    bool square = small_cin_eff == 0 && p.CoutPad % 256 == 0 && a.nk >= 4 && blocks_sq >= 192;
+    if (force == 512) square = small_cin_eff == 0 && p.CoutPad % 256 == 0;
     if (force != 0 && force != 512) square = false;
     if (p.split == 2) big = false; // (the three-buffer 256 x 128 tile has no single-staged variant)
     if (p.split == 2 && !a.fast) square = false; // (its generic epilogue next to 128 accumulators + both planes' fragments spills)
+    // f16x3 K-steps are 32 channels: with fewer than 16 of them (K < 512: layer2's 128 -> 512 and 256 -> 512 convs) the 256 x 256
+    // block's prologue + two-group epilogue outweigh its smaller staging traffic (sweep: 109 vs 127 us, 149 vs 162 us)
+    if (p.split == 2 && force == 0 && a.nk < 16) square = false;
     if (square) {
         const int ntn = p.CoutPad / 256;
         // One block per CU: a grid of r * 256 + rem tiles takes r + 1 rounds.  When the last round would be less
@@ -1133,7 +1156,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
             WSC_TRY(launch_square(ctx, b, p.split, p.fmt));
             a.m_base = big_rows * 256;
             a.nblocks = ((a.M - a.m_base + 127) / 128) * a.ntiles_n; // BN = 128 here (CoutPad % 256 == 0)
-            return launch_bn<128>(ctx, a, p.small_cin, p.split, p.fmt);
+            return launch_bn<128>(ctx, a, small_cin_eff, p.split, p.fmt);
         }
         a.ntiles_n = ntn;
         a.nblocks = (int)blocks_sq;
@@ -1142,6 +1165,6 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     const int BMsel = big ? 256 : 128;
     a.nblocks = ((a.M + BMsel - 1) / BMsel) * a.ntiles_n;
     if (big) return launch_big(ctx, a, p.split, p.fmt);
-    if (BN == 128) return launch_bn<128>(ctx, a, p.small_cin, p.split, p.fmt);
-    return launch_bn<64>(ctx, a, p.small_cin, p.split, p.fmt);
+    if (BN == 128) return launch_bn<128>(ctx, a, small_cin_eff, p.split, p.fmt);
+    return launch_bn<64>(ctx, a, small_cin_eff, p.split, p.fmt);
 }

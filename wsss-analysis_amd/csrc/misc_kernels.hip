@@ -24,6 +24,35 @@ __global__ void nchw_to_nhwc4_kernel(const float *__restrict__ x, int N, int HW,
     }
 }
 
+// The same with a zero border baked in: out [N][Hp][Wp][4], pixel (py, px) = input (py - pad, px - pad) or zeros.  The f16x3
+// stem reads this buffer without bounds tests (conv_igemm.hip, small_cin == 3): the 8-pixel window of a kernel row is 64
+// contiguous, 16-byte aligned bytes of either plane.
+__global__ void nchw_to_nhwc4_pad_kernel(const float *__restrict__ x, int N, int H, int W, int Hp, int Wp, int pad,
+                                         bf16_t *__restrict__ y, bf16_t *__restrict__ y_lo, int fmt) {
+    const long long total = (long long)N * Hp * Wp;
+    const long long HW = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % Wp);
+        const long long r = i / Wp;
+        const int py = (int)(r % Hp);
+        const long long n = r / Hp;
+        const int iy = py - pad, ix = px - pad;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            const float *s = x + n * 3 * HW + (long long)iy * W + ix;
+            c0 = s[0]; c1 = s[HW]; c2 = s[2 * HW];
+        }
+        const bf16_t h0 = f32_to_h16(c0, fmt), h1 = f32_to_h16(c1, fmt), h2 = f32_to_h16(c2, fmt);
+        reinterpret_cast<uint2 *>(y)[i] = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2);
+        if (y_lo != nullptr) {
+            const bf16_t l0 = f32_to_h16(c0 - h16_to_f32(h0, fmt), fmt), l1 = f32_to_h16(c1 - h16_to_f32(h1, fmt), fmt),
+                         l2 = f32_to_h16(c2 - h16_to_f32(h2, fmt), fmt);
+            reinterpret_cast<uint2 *>(y_lo)[i] = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2);
+        }
+    }
+}
+
 // nn.MaxPool2d(k, stride, pad) on NHWC bf16, 8 channels per thread.
 // resnet50.py:64 (3x3 s2 p1), common_cnn.py:131-132 (2x2 s2).
 __global__ void maxpool_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ x_lo, int N, int H,
@@ -258,6 +287,16 @@ int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16
     const long long total = (long long)N * H * W;
     WscKernelTimer timer(ctx, WSC_K_POOL_MISC, (double)total * (12 + 8));
     hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, N, H * W, y,
+                       y_lo, fmt);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+int launch_nchw_to_nhwc4_pad(wsc_ctx *ctx, const float *x, int N, int H, int W, int Hp, int Wp, int pad, bf16_t *y, bf16_t *y_lo,
+                             int fmt) {
+    const long long total = (long long)N * Hp * Wp;
+    WscKernelTimer timer(ctx, WSC_K_POOL_MISC, (double)N * H * W * 12 + (double)total * (y_lo ? 16 : 8));
+    hipLaunchKernelGGL(nchw_to_nhwc4_pad_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, N, H, W, Hp, Wp, pad, y,
                        y_lo, fmt);
     WSC_HIP(hipGetLastError());
     return WSC_OK;

@@ -138,6 +138,10 @@ int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, 
         WSC_CHECK(Cin % 64 == 0, WSC_ERR_SHAPE, "conv with Cin=%d is not supported (need a multiple of 64)", Cin);
         c.Cin = Cin;
         Kbase = kh * kw * Cin;
+    } else if (small_cin == 3) { // f16x3 stem on the padded input: one K-step (32 hi + 32 lo) per kernel row
+        WSC_CHECK(Cin <= 4 && kw <= 7 && net->split == 2, WSC_ERR_SHAPE, "padded-stem conv needs Cin <= 4, kw <= 7, f16x3");
+        c.Cin = 4;
+        Kbase = kh * 32;
     } else {
         WSC_CHECK(Cin <= 4, WSC_ERR_SHAPE, "small-Cin conv needs Cin <= 4, got %d", Cin);
         WSC_CHECK(kw <= (2 << small_cin), WSC_ERR_SHAPE, "small-Cin conv: kw=%d too wide", kw);
@@ -148,7 +152,7 @@ int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, 
     const int Kw = Kbase * planes;
     // f16x3 (split 2), generic layers: K order (cin / 32, kh, kw) and per K-step 32 hi values followed by their 32 lo values
     // (conv_igemm.hip, SPLIT 2); everything else: [hi K | lo K]
-    const bool interleaved = net->split == 2 && small_cin == 0;
+    const bool interleaved = net->split == 2 && (small_cin == 0 || small_cin == 3);
     std::vector<bf16_t> wp((size_t)c.CoutPad * Kw, 0);
     for (int co = 0; co < Cout; ++co) {
         bf16_t *row = wp.data() + (size_t)co * Kw;
@@ -162,7 +166,9 @@ int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, 
             for (int r = 0; r < kh; ++r)
                 for (int s = 0; s < kw; ++s) {
                     const float v = w->data[(((size_t)co * Cin + ci) * kh + r) * kw + s];
-                    if (interleaved) {
+                    if (small_cin == 3) {
+                        put(r * 64 + s * 4 + ci, v); // kernel row r: 8 pixels x 4 channels (pixel 7, channel 3: zero weights)
+                    } else if (interleaved) {
                         put((((ci >> 5) * kh + r) * kw + s) * 64 + (ci & 31), v);
                     } else if (small_cin == 0) {
                         put((((ci >> 6) * kh + r) * kw + s) * 64 + (ci & 63), v);
@@ -216,7 +222,8 @@ int resnet_conv(wsc_net *net, const Dict &d, const std::string &conv, const std:
 
 int build_resnet50_backbone(wsc_net *net, const Dict &d) {
     // stem: conv1 7x7 s2 p3 + bn1 + relu, maxpool 3x3 s2 p1          (resnet50.py:62-64, 96-99)
-    WSC_TRY(resnet_conv(net, d, "resnet50.conv1", "resnet50.bn1", 2, 3, 1, /*small_cin*/ 2, -1, 0, -1));
+    // (f16x3: the padded-input form, staged like every other layer of that mode)
+    WSC_TRY(resnet_conv(net, d, "resnet50.conv1", "resnet50.bn1", 2, 3, 1, /*small_cin*/ net->split == 2 ? 3 : 2, -1, 0, -1));
     add_pool_op(net, 3, 2, 1, 0, 1);
     net->taps.push_back((int)net->ops.size() - 1); // stage1 = conv1, bn1, relu, maxpool (resnet50_irn.py:15)
     int cur = 1;
@@ -572,7 +579,16 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
     Plan pl;
     WSC_TRY(plan_dims(net, N, S, SW, &pl));
     const int planes = net->split ? 2 : 1;
-    const size_t in_bytes = align_up((size_t)N * S * SW * 4 * sizeof(bf16_t), 256);
+    // f16x3 stem (small_cin == 3): the NHWC4 input carries its zero border -- rows / columns the kernel rows of the last
+    // output pixel reach, an 8-pixel window per kernel row (conv_igemm.hip)
+    int in_h = S, in_w = SW, in_pad = 0;
+    if (!net->ops.empty() && net->ops[0].type == OP_CONV && net->ops[0].in < 0 && net->convs[net->ops[0].conv].small_cin == 3) {
+        const ConvW &c0 = net->convs[net->ops[0].conv];
+        in_h = (pl.H[0] - 1) * c0.stride + c0.kh;
+        in_w = (pl.W[0] - 1) * c0.stride + 8;
+        in_pad = c0.pad;
+    }
+    const size_t in_bytes = align_up((size_t)N * in_h * in_w * 4 * sizeof(bf16_t), 256);
     const size_t act_bytes = align_up(pl.max_act * sizeof(bf16_t), 256);
     const size_t total = in_bytes * planes + act_bytes * 4 * planes + align_up(extra_bytes, 256);
     void *ws;
@@ -588,7 +604,8 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
     }
     *extra = (void *)p;
 
-    WSC_TRY(launch_nchw_to_nhwc4(ctx, x_dev, N, S, SW, xin, xin_lo, net->fmt));
+    if (in_pad > 0) WSC_TRY(launch_nchw_to_nhwc4_pad(ctx, x_dev, N, S, SW, in_h, in_w, in_pad, xin, xin_lo, net->fmt));
+    else WSC_TRY(launch_nchw_to_nhwc4(ctx, x_dev, N, S, SW, xin, xin_lo, net->fmt));
     int bh[4] = {0, 0, 0, 0}, bw[4] = {0, 0, 0, 0}, bc[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < net->ops.size(); ++i) {
         const Op &op = net->ops[i];
@@ -608,6 +625,9 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
             L.Cout = c.Cout; L.CoutPad = c.CoutPad;
             L.kh = c.kh; L.kw = c.kw; L.stride = c.stride; L.pad = c.pad; L.relu = c.relu;
             L.small_cin = c.small_cin; L.split = net->split; L.fmt = net->fmt;
+            if (c.small_cin == 3 && op.in < 0) { // the padded input buffer: its own size, no padding left to apply
+                L.H = in_h; L.W = in_w; L.pad = 0;
+            }
             WSC_TRY(conv_igemm_launch(ctx, L));
         } else {
             WSC_TRY(launch_maxpool(ctx, src, src_lo, N, H, W, C, op.pk, op.ps, op.pp, pl.H[i], pl.W[i], buf[op.out],
@@ -921,6 +941,7 @@ int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int
     if (shift_host) b1.assign(shift_host, shift_host + Cout);
     int small = 0;
     if (Cin <= 4) small = kw <= 4 ? 1 : 2;
+    if (small == 2 && tmp.split == 2 && (stride & 1) == 0 && kw <= 7) small = 3; // the f16x3 stem form (padded input)
     ConvW c;
     int st = make_conv(&tmp, &wt, stride, pad, relu, small, s1, b1, nullptr, nullptr, &c);
     auto cleanup = [&]() {
@@ -930,7 +951,8 @@ int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int
     if (st != WSC_OK) { cleanup(); return st; }
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     const int planes = tmp.split ? 2 : 1;
-    const size_t in_e = (size_t)N * H * W * c.Cin, out_e = (size_t)N * Ho * Wo * Cout;
+    const int in_h = small == 3 ? (Ho - 1) * stride + kh : H, in_w = small == 3 ? (Wo - 1) * stride + 8 : W;
+    const size_t in_e = (size_t)N * in_h * in_w * c.Cin, out_e = (size_t)N * Ho * Wo * Cout;
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     void *ws;
     st = wsc_ctx_workspace(ctx, planes * (al(in_e * 2) + 2 * al(out_e * 2)), &ws);
@@ -942,7 +964,8 @@ int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int
     bf16_t *yo_lo = nullptr; if (tmp.split) { yo_lo = (bf16_t *)p; p += al(out_e * 2); }
     bf16_t *ri = nullptr, *ri_lo = nullptr;
     if (residual_dev) { ri = (bf16_t *)p; p += al(out_e * 2); if (tmp.split) { ri_lo = (bf16_t *)p; p += al(out_e * 2); } }
-    if (small) st = launch_nchw_to_nhwc4(ctx, x_dev, N, H, W, xi, xi_lo, tmp.fmt);
+    if (small == 3) st = launch_nchw_to_nhwc4_pad(ctx, x_dev, N, H, W, in_h, in_w, pad, xi, xi_lo, tmp.fmt);
+    else if (small) st = launch_nchw_to_nhwc4(ctx, x_dev, N, H, W, xi, xi_lo, tmp.fmt);
     else st = launch_nchw_to_nhwc(ctx, x_dev, N, Cin, H * W, xi, xi_lo, tmp.fmt);
     if (st == WSC_OK && residual_dev) st = launch_nchw_to_nhwc(ctx, residual_dev, N, Cout, Ho * Wo, ri, ri_lo, tmp.fmt);
     if (st == WSC_OK) {
@@ -950,8 +973,8 @@ int wsc_conv2d_nchw(wsc_ctx *ctx, const float *x_dev, int N, int Cin, int H, int
         memset(&L, 0, sizeof(L));
         L.x = xi; L.x_lo = xi_lo; L.w = c.w; L.s1 = c.s1; L.b1 = c.b1; L.res = ri; L.res_lo = ri_lo;
         L.y = yo; L.y_lo = yo_lo;
-        L.N = N; L.H = H; L.W = W; L.Cin = c.Cin; L.Ho = Ho; L.Wo = Wo; L.Cout = Cout; L.CoutPad = c.CoutPad;
-        L.kh = kh; L.kw = kw; L.stride = stride; L.pad = pad; L.relu = relu; L.small_cin = small; L.split = tmp.split;
+        L.N = N; L.H = in_h; L.W = in_w; L.Cin = c.Cin; L.Ho = Ho; L.Wo = Wo; L.Cout = Cout; L.CoutPad = c.CoutPad;
+        L.kh = kh; L.kw = kw; L.stride = stride; L.pad = small == 3 ? 0 : pad; L.relu = relu; L.small_cin = small; L.split = tmp.split;
         L.fmt = tmp.fmt;
         L.generic = generic;
         st = conv_igemm_launch(ctx, L);
