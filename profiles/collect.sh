@@ -1,21 +1,25 @@
 #!/bin/bash
 # Collects every round artifact under profiles/ in ONE gpurun call:
-#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r03'
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r04'
 # Outputs land in gpurun_out/<tag>_* (merged back by gpurun); copy the ones to keep into profiles/.
 tag=${1:-rXX}
 out=gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export WSC_PROFILE_ROUND=$tag
 timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/${tag}_pytest_gpu.txt
 timeout 300 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 python bench.py --no-cpu-baseline --no-pipeline --quick > $out/${tag}_bench_nopipeline.json 2>> $out/${tag}_bench.err
 timeout 300 python profiles/bench_irn.py > $out/${tag}_bench_irn.json 2>> $out/${tag}_bench.err
-timeout 300 python bench.py --workload hsn --arch vgg16 --batch 16 --steps 10 --warmup 2 > $out/${tag}_bench_hsn.json 2>> $out/${tag}_bench.err
+timeout 400 python bench.py --workload hsn --arch vgg16 --batch 16 --steps 10 --warmup 2 > $out/${tag}_bench_hsn.json 2>> $out/${tag}_bench.err
 timeout 600 python bench.py --no-cpu-baseline --quick --seconds 30 > $out/${tag}_bench_30s.json 2>> $out/${tag}_bench.err
 rm -rf $out/prof_stats $out/pmc_f $out/pmc_w
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --quick > $out/${tag}_prof_stats.log 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --quick"; python profiles/summarize_rocpd.py $out/prof_stats/*/*_results.db; } > $out/${tag}_kernel_stats_bench.txt 2>&1
-{ echo "# one ResNet50-CAM forward (64 samples @321^2, f16) out of the same trace"; python profiles/conv_layer_table.py $out/prof_stats/*/*_results.db; } > $out/${tag}_conv_layers.txt 2>&1
+{ echo "# one ResNet50-CAM forward (64 samples @321^2, f16x3: the headline mode) out of the same trace"; python profiles/conv_layer_table.py $out/prof_stats/*/*_results.db 64 321 2; } > $out/${tag}_conv_layers.txt 2>&1
+rm -rf $out/prof_f16
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/prof_f16 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline --quick --precision f16 --workload cam > $out/${tag}_prof_f16.log 2>&1
+{ echo "# the same in the fast f16 mode (bench.py --precision f16 --workload cam)"; python profiles/conv_layer_table.py $out/prof_f16/*/*_results.db 64 321 1; } > $out/${tag}_conv_layers_f16.txt 2>&1
 RX='update_splat_kernel|gauss_msg_kernel|combine4_kernel|combine4_balanced_kernel|blur_lds_kernel|blur4_kernel|blur3_tile_kernel|conv_igemm'
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$RX" -d $out/pmc_f -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --quick > $out/${tag}_pmc_f.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$RX" -d $out/pmc_w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --quick > $out/${tag}_pmc_w.log 2>&1

@@ -43,7 +43,7 @@ def n_dispatches(M, cin, cout, k, num_cus=256, planes=1):
         return 1
     nk = k * k * cin // (32 if planes == 2 else 64)
     blocks_sq = ((M + 255) // 256) * (cout // 256)
-    if nk < 4 or blocks_sq < 192:
+    if nk < (16 if planes == 2 else 4) or blocks_sq < 192:  # conv_igemm.hip tile choice (f16x3: square tile from 16 K-steps on)
         return 1
     rounds, rem = divmod(blocks_sq, num_cus)
     return 2 if rounds >= 1 and 0 < rem and rem * 2 <= num_cus else 1

@@ -1,6 +1,6 @@
 """Per-layer matrix-pipe utilisation of one ResNet50-CAM forward from two rocprofv3 --pmc passes.
 
-    python profiles/conv_pmc_table.py <set1_results.db> <set2_results.db>
+    python profiles/conv_pmc_table.py <set1_results.db> <set2_results.db>      (the f16x3 stack: two planes, 32-channel K-steps)
 set 1: SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES
 set 2: SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_ANY
 mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs): a 32x32x16 f16/bf16 MFMA holds its
@@ -21,10 +21,10 @@ def load(db):
     return [d[k] for k in sorted(d)]
 
 
-def main(db1, db2, N=64, S=321):
+def main(db1, db2, N=64, S=321, planes=2):
     a, b = load(db1), load(db2)
     L = resnet50_layers(S)
-    nds = [n_dispatches(N * ho * ho, cin, cout, k) for (_, ho, cin, cout, k) in L]
+    nds = [n_dispatches(N * ho * ho, cin, cout, k, planes=planes) for (_, ho, cin, cout, k) in L]
     a, b = a[-sum(nds):], b[-sum(nds):]
 
     def merge(rows):  # a layer cut into two launches: add durations and counters

@@ -1,6 +1,6 @@
 """HBM traffic per launch of a kernel class from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-    python profiles/make_traffic_json.py <fetch_results.db> <write_results.db> > profiles/hbm_traffic.json
+    WSC_PROFILE_ROUND=r04 python profiles/make_traffic_json.py <fetch_results.db> <write_results.db> > profiles/hbm_traffic.json
 
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KiB
 summed over the XCD instances of a dispatch, and FETCH_SIZE under-reports by 2x on gfx950 (doubled here).
@@ -32,7 +32,9 @@ def per_kernel(db, counter):
     return tot, {k: len(v) for k, v in disp.items()}
 
 
-ROUND = "r03"
+import os
+
+ROUND = os.environ.get("WSC_PROFILE_ROUND", "r04")
 
 
 def main(fetch_db, write_db):

@@ -473,7 +473,8 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
             const bool more = kt + 1 < nk && !WSC_DBG(p, 1);
             if (more) {
                 prep();
-                if (SPLIT != 2) { // (the single-staged split spreads its pieces over the MFMAs, below)
+                if (SPLIT != 2) { // (the single-staged split spreads its pieces over the MFMAs, below; spreading them in the
+                                  // one-plane kernels too was measured in round 4 and lost 3-4 %: ResNet50 f16 3.17 -> 3.29 ms)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) issue_a(i, cur ^ 1);
 #pragma unroll
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                 }
             } else if (STAGES == 1 || !WSC_DBG(p, 2)) {
                 u32x4_t fa[2][MI], fb[2][NI];
+
                 auto rd = [&](int set, int ks) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
