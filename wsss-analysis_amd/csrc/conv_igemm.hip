@@ -942,16 +942,22 @@ int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     static bool attr_set[64] = {};
     auto kern = conv_igemm_kernel<BM, BN, MODE, SPLIT, ET, GLDS, STAGES, WMT, FAST>;
     const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    int lds_req = LDS;
+#ifdef WSC_AB_KNOBS
+    // A/B: pad the LDS request of the multi-K-step tiles (caps the blocks per CU: room for another stream's workgroups)
+    static const int lds_pad = [] { const char *e = getenv("WSC_CONV_LDS_PAD"); return e ? atoi(e) : 0; }();
+    if (STAGES == 2 && lds_pad > lds_req && lds_pad <= 160 * 1024) lds_req = lds_pad;
+#endif
     if (!attr_set[dev] || ctx->device != dev) {
         WSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_req > LDS ? 160 * 1024 : LDS));
         attr_set[dev] = true;
     }
     // algorithmic FLOPs: 2 * M * Cout * (kh*kw*Cin_real), x1 regardless of the precision mode
     const double flops = 2.0 * (a.m_end - a.m_base) * a.Cout *
                          ((MODE == 0 && !a.stem_rows) ? (double)a.kh * a.kw * a.Cin : (double)a.kh * (a.stem_rows ? a.kw_real : a.kw) * 3);
     WscKernelTimer timer(ctx, (MODE != 0 || a.stem_rows) ? WSC_K_CONV_SMALLCIN : (BM == 256 ? WSC_K_CONV256 : (BN == 128 ? WSC_K_CONV128 : WSC_K_CONV64)), flops);
-    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(BM * 2), LDS, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(BM * 2), lds_req, ctx->stream, a);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }

@@ -27,6 +27,7 @@
 // boundary land in a different (equally valid) simplex than the CPU reference picks.
 #include "common.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -2945,7 +2946,7 @@ struct GaussCache {
 // without the on-chip message path -- cam_to_ir_label walks hundreds of sizes).  Only when all entries are in use is a
 // lattice built for the one call, without the host-built tile vertex sets of the on-chip message path.
 constexpr int GAUSS_CACHE_MAX = 64;
-unsigned long long g_gauss_use_clock = 0;
+std::atomic<unsigned long long> g_gauss_use_clock{0}; // (contexts of several host threads share it: only the order matters)
 void gauss_cache_delete(void *p) { delete static_cast<GaussCache *>(p); }
 
 // slice: messages of both lattices are read (false before the first iteration); splat: the result is splatted
