@@ -29,7 +29,7 @@ def run():
         dataset = "voc12"
         cam_out_dir = None
 
-    model = resnet50_cam.CAM(None, "voc12", "", C, None, precision=_lib.PREC_F16)
+    model = resnet50_cam.CAM(None, "voc12", "", C, None, precision=_lib.PREC_F16X3)  # the headline (fp32-class) mode
     model.load_state_dict(sd)
     model.eval().cuda(0)
     arch, cus = model.ctx.device_info()
@@ -40,7 +40,7 @@ def run():
         assert np.array_equal(o["keys"], ref["keys"])
         worst = max(worst, float(np.abs(o["high_res"] - ref["high_res"]).max()),
                     float(np.abs(o["cam"] - ref["cam"]).max()))
-    assert worst <= 2e-2, "CAM parity %.3g > 2e-2" % worst
+    assert worst <= 1e-4, "CAM parity %.3g > 1e-4" % worst
 
     # CRF on the second image at its native 97x97 with [bg | the GT class map] probabilities
     ctx = model.ctx
@@ -60,5 +60,5 @@ def run():
     dq = float(np.abs(q - qr).max())
     agree = float((a == ar).mean())
     assert dq <= 1e-3 and agree >= 0.995, (dq, agree)
-    print("smoke ok on %s (%d CUs): CAM max|d| %.2e (f16), CRF max|dQ| %.2e, label agreement %.4f"
+    print("smoke ok on %s (%d CUs): CAM max|d| %.2e (f16x3), CRF max|dQ| %.2e, label agreement %.4f"
           % (arch, cus, worst, dq, agree))

@@ -491,8 +491,9 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                 auto piece = [&](int j) {
                     if (!more || j % EVERY != 0) return;
                     const int q = j / EVERY;
-                    if (q < 4) issue_a(q, cur ^ 1);
-                    else if (q < 4 + NB) issue_b(q - 4, cur ^ 1);
+                    if (q < 4) {
+                        if (!(WSC_DBG(p, 32) && (n_khi | n_kwi) != 0)) issue_a(q, cur ^ 1); // (ablation 32: A staged for the first tap of a chunk only)
+                    } else if (q < 4 + NB) issue_b(q - 4, cur ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 auto rd = [&](int set, int sl) {
