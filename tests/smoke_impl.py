@@ -42,23 +42,28 @@ def run():
                     float(np.abs(o["cam"] - ref["cam"]).max()))
     assert worst <= 1e-4, "CAM parity %.3g > 1e-4" % worst
 
-    # CRF on the second image at its native 97x97 with [bg | the GT class map] probabilities
+    # CRF: a non-saturated case (soft class probabilities that follow, but do not equal, the image regions; M = 5) against
+    # the C oracle -- round 3's smoke fed both sides the near-one-hot [bg | GT map] unaries and landed at 1e-14
     ctx = model.ctx
-    hi = outs[1]["high_res"]  # (1, 97, 97)
-    v = np.concatenate([np.full((1, 97 * 97), 0.15, np.float32), hi.reshape(1, -1)], 0)
-    p = v / v.sum(0, keepdims=True)
-    U = np.ascontiguousarray(-np.log(np.clip(p, 1e-5, 1.0)).astype(np.float32))
+    rgb, U, _ = helpers.synth_crf_case(np.random.default_rng(5), 97, 97, 5, sharp=2.0)
     cfg = (1.5, 3, 40, 13, 10, 10)
-    crf = _lib.Crf(ctx, ctx.to_device(imgs[1]), 1, 97, 97, cfg[0], cfg[2], cfg[3])
-    q_dev = ctx.alloc(2 * 97 * 97 * 4)
+    crf = _lib.Crf(ctx, ctx.to_device(rgb), 1, 97, 97, cfg[0], cfg[2], cfg[3])
+    q_dev = ctx.alloc(5 * 97 * 97 * 4)
     a_dev = ctx.alloc(97 * 97 * 4)
-    crf.inference(ctx.to_device(U), 2, cfg[1], cfg[4], cfg[5], q_dev, a_dev)
-    q = ctx.to_host(q_dev, (2, 97 * 97), np.float32)
+    crf.inference(ctx.to_device(U), 5, cfg[1], cfg[4], cfg[5], q_dev, a_dev)
+    q = ctx.to_host(q_dev, (5, 97 * 97), np.float32)
     a = ctx.to_host(a_dev, (97 * 97,), np.int32)
     crf.close()
-    qr, ar, _ = helpers.crf_oracle(imgs[1], U, cfg)
+    qr, ar, _ = helpers.crf_oracle(rgb, U, cfg)
     dq = float(np.abs(q - qr).max())
     agree = float((a == ar).mean())
     assert dq <= 1e-3 and agree >= 0.995, (dq, agree)
-    print("smoke ok on %s (%d CUs): CAM max|d| %.2e (f16x3), CRF max|dQ| %.2e, label agreement %.4f"
-          % (arch, cus, worst, dq, agree))
+    assert len(np.unique(ar)) >= 3 and float(np.abs(qr - 0.5).min()) < 0.45, "degenerate smoke case"
+    # chain level: CNN -> unaries -> CRF labels of the first image at 97 x 97 against the all-fp32 oracle chain
+    x0 = packs[1]["img"][None]
+    lab = helpers.product_chain(ctx, model._ensure_net(), x0, imgs[1][None], cfg, C)
+    ref_lab, _, _ = helpers.oracle_chain(packs[1]["img"], imgs[1], {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, cfg, C)
+    chain = float((lab[0] == ref_lab).mean())
+    assert chain >= 0.995, chain
+    print("smoke ok on %s (%d CUs): CAM max|d| %.2e (f16x3), CRF max|dQ| %.2e, label agreement %.4f, chain label agreement %.5f"
+          % (arch, cus, worst, dq, agree, chain))
