@@ -512,3 +512,78 @@ def test_make_cam_native_sizes_outsize_none(tmp_path):
         assert rec["cam"].shape == ref["cam"].shape and rec["high_res"].shape == ref["high_res"].shape
         assert np.abs(rec["high_res"] - ref["high_res"]).max() <= 1e-4, np.abs(rec["high_res"] - ref["high_res"]).max()
         assert np.abs(rec["cam"] - ref["cam"]).max() <= 1e-4
+
+
+def test_round4_api_edges(ctx):
+    """Error behaviour and corner inputs of the round-4 entry points: wsc_ctx_set_option, wsc_crf_v_*, wsc_label_confusion_nn,
+    wsc_net_forward_cam_hw."""
+    # unknown option
+    with pytest.raises(_lib.WscError) as ei:
+        ctx.set_option(99, 1)
+    assert ei.value.status == _lib.WSC_ERR_INVALID
+    # ragged CRF: a single 1-class image (Q = 1 everywhere), a zero-sized image is an error, M = 0 is an error
+    rng = np.random.default_rng(3)
+    from tests import helpers
+
+    rgb, U, _ = helpers.synth_crf_case(rng, 9, 7, 1)
+    cv = _lib.CrfV(ctx, [ctx.to_device(rgb)], [(9, 7)], 1.5, 40, 13)
+    q_dev, a_dev = ctx.alloc(63 * 4), ctx.alloc(63 * 4)
+    cv.inference([ctx.to_device(U)], [1], 3, 10, 3, [q_dev], [a_dev])
+    assert np.allclose(ctx.to_host(q_dev, (63,), np.float32), 1.0) and not ctx.to_host(a_dev, (63,), np.int32).any()
+    with pytest.raises(_lib.WscError):
+        cv.inference([ctx.to_device(U)], [0], 3, 10, 3, [q_dev], [a_dev])
+    with pytest.raises(_lib.WscError):
+        cv.inference([ctx.to_device(U)], [1], 3, 10, 3, None, None)  # nothing to write
+    cv.close()
+    with pytest.raises(_lib.WscError):
+        _lib.CrfV(ctx, [ctx.to_device(rgb)], [(0, 7)], 1.5, 40, 13)
+    # label confusion: a label outside [0, n_class) is reported, not counted
+    lab = np.zeros((1, 4, 4), np.int32)
+    lab[0, 0, 0] = 7
+    gt = np.zeros((1, 8, 8), np.uint8)
+    conf = ctx.alloc(3 * 3 * 8)
+    _lib.check(ctx._lib.wsc_memset(ctx.h, conf.ptr, 0, 72))
+    with pytest.raises(_lib.WscError) as ei:
+        _lib.label_confusion_nn(ctx, ctx.to_device(lab), [(4, 4)], [(8, 8)], [0], ctx.to_device(gt), 3, conf)
+    assert ei.value.status == _lib.WSC_ERR_INVALID and "outside" in str(ei.value)
+    # ignore_label pixels are skipped; everything else lands in one cell
+    lab[0, 0, 0] = 1
+    gt[0, :4, :4] = 255
+    _lib.check(ctx._lib.wsc_memset(ctx.h, conf.ptr, 0, 72))
+    _lib.label_confusion_nn(ctx, ctx.to_device(lab), [(4, 4)], [(8, 8)], [0], ctx.to_device(gt), 3, conf)
+    c = ctx.to_host(conf, (3, 3), np.int64)
+    assert c.sum() == 48 and c[0, 0] == 48  # the 2 x 2 block of label 1 lies under the ignored quadrant
+
+
+@pytest.mark.parametrize("precision", [_lib.PREC_F16X3, _lib.PREC_F16])
+def test_forward_cam_hw_matches_square_call_and_oracle(precision):
+    """wsc_net_forward_cam_hw: on a square input it is the square entry point (same bits); on non-square inputs of odd sizes
+    (65 x 97, 97 x 33) the CAM matches the oracle's forward at the mode's bound."""
+    from wsscam.net import resnet50_cam
+
+    sd = cnn_ref.make_resnet50_cam_state_dict(20, seed=0)
+    m = resnet50_cam.CAM(None, "voc12", "", 20, None, precision=precision)
+    m.load_state_dict(sd)
+    m.eval().cuda(0)
+    ctx = m.ctx
+    net = m._ensure_net()
+    rng = np.random.default_rng(8)
+    x = rng.normal(0, 1, (2, 2, 3, 64, 64)).astype(np.float32)
+    h = net.cam_size(64)
+    assert net.cam_size_hw(64, 64) == (h, h)
+    c1, c2 = ctx.alloc(2 * 20 * h * h * 4), ctx.alloc(2 * 20 * h * h * 4)
+    net.forward_cam(ctx.to_device(x), 2, 64, c1)
+    net.forward_cam_hw(ctx.to_device(x), 2, 64, 64, c2)
+    assert np.array_equal(ctx.to_host(c1, (2, 20, h, h), np.float32), ctx.to_host(c2, (2, 20, h, h), np.float32))
+    tol = 2e-5 if precision == _lib.PREC_F16X3 else 5e-3
+    for (H, W) in ((65, 97), (97, 33)):
+        img = cnn_ref.synth_image(rng, H, W)
+        xp = cnn_ref.msf_pack(img, None)
+        hh, ww = net.cam_size_hw(H, W)
+        cd = ctx.alloc(20 * hh * ww * 4)
+        net.forward_cam_hw(ctx.to_device(xp[None]), 1, H, W, cd)
+        cam = ctx.to_host(cd, (20, hh, ww), np.float32)
+        with torch.no_grad():
+            ref = cnn_ref.resnet50_cam_forward(torch.from_numpy(xp), sd).numpy()
+        assert cam.shape == ref.shape, (cam.shape, ref.shape)
+        assert np.abs(cam - ref).max() <= tol * ref.max(), (H, W, np.abs(cam - ref).max() / ref.max())
