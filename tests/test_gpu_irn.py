@@ -15,10 +15,10 @@ from wsscam.net import m7_irn, resnet50_irn, vgg16_irn
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resnet50_irn.npz")
-TOL = {_lib.PREC_BF16X3: (2e-4, 2e-3), _lib.PREC_F16: (2e-2, 2e-1)}
+TOL = {_lib.PREC_F16X3: (1e-4, 1e-3), _lib.PREC_BF16X3: (2e-4, 2e-3), _lib.PREC_F16: (2e-2, 2e-1)}  # F16X3: the package default
 
 
-@pytest.mark.parametrize("precision", [_lib.PREC_BF16X3, _lib.PREC_F16])
+@pytest.mark.parametrize("precision", [_lib.PREC_F16X3, _lib.PREC_BF16X3, _lib.PREC_F16])
 def test_resnet50_irn_vs_reference_fixture(precision):
     g = np.load(GOLDEN)
     sd = irn_ref.make_resnet50_irn_state_dict(seed=int(g["seed"]))
@@ -32,11 +32,12 @@ def test_resnet50_irn_vs_reference_fixture(precision):
     assert np.abs(dp - g["dp"]).max() <= td * max(1.0, float(np.abs(g["dp"]).max())), np.abs(dp - g["dp"]).max()
 
 
+@pytest.mark.parametrize("precision", [_lib.PREC_F16X3, _lib.PREC_BF16X3])
 @pytest.mark.parametrize("batchnorm", [True, False])
-def test_vgg16_irn_vs_oracle(batchnorm):
+def test_vgg16_irn_vs_oracle(batchnorm, precision):
     sd = irn_ref.make_vgg16_irn_state_dict(seed=2, batchnorm=batchnorm)
     m = vgg16_irn.EdgeDisplacement(None, "voc12" if batchnorm else "adp_morph", "", 20, None, crop_size=96, stride=4,
-                                   precision=_lib.PREC_BF16X3)
+                                   precision=precision)
     m.load_state_dict(sd)
     m.eval().cuda(0)
     rng = np.random.default_rng(3)
@@ -54,7 +55,7 @@ def test_m7_irn_vs_oracle():
     """m7_irn: edge map at 1/2 resolution cropped with the stride-4 feature size (as the reference does), the
     displacement branch at 1/4; fc_dp4 chained on fc_dp3."""
     sd = irn_ref.make_m7_irn_state_dict(seed=4)
-    m = m7_irn.EdgeDisplacement(None, "voc12", "", 20, None, crop_size=64, stride=4, precision=_lib.PREC_BF16X3)
+    m = m7_irn.EdgeDisplacement(None, "voc12", "", 20, None, crop_size=64, stride=4)  # the package default: f16x3
     m.load_state_dict(sd)
     m.eval().cuda(0)
     rng = np.random.default_rng(6)
