@@ -522,9 +522,52 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const unsigned *__restr
     }
 }
 
+// scan_apply_kernel that forms its block's carry from the RAW block sums itself (nblk <= 256: one value per thread) -- the
+// scans of a lattice build have 4 ... 152 blocks, so the single-block pass over the sums (a launch of its own) is not needed.
+// Block 0 leaves the grand total in sums[nblk], where the three-kernel form puts it.
+__global__ __launch_bounds__(256) void scan_apply_fused_kernel(const unsigned *__restrict__ in, long long n,
+                                                               unsigned *__restrict__ sums, int nblk, unsigned *__restrict__ out) {
+    __shared__ unsigned lds[4];
+    __shared__ unsigned red[8];
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
+    const unsigned mine = (int)threadIdx.x < nblk ? sums[threadIdx.x] : 0u;
+    unsigned c = (int)threadIdx.x < (int)blockIdx.x ? mine : 0u, tot = mine;
+    for (int o = 32; o > 0; o >>= 1) {
+        c += __shfl_down(c, o, 64);
+        tot += __shfl_down(tot, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = c;
+        red[4 + (threadIdx.x >> 6)] = tot;
+    }
+    __syncthreads();
+    const unsigned carry = red[0] + red[1] + red[2] + red[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sums[nblk] = red[4] + red[5] + red[6] + red[7];
+    unsigned v[16];
+    unsigned s = 0;
+    const long long t0 = base + (long long)threadIdx.x * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        v[i] = (t0 + i < n) ? in[t0 + i] : 0u;
+        s += v[i];
+    }
+    unsigned total;
+    unsigned ex = carry + block_exclusive_scan_256(s, lds, total);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (t0 + i < n) out[t0 + i] = ex;
+        ex += v[i];
+    }
+}
+
 int exclusive_scan(wsc_ctx *ctx, const unsigned *in, long long n, unsigned *out, unsigned *sums /* nblk+1 */) {
     const int nblk = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk), dim3(256), 0, ctx->stream, in, n, sums);
+    if (nblk <= 256) {
+        hipLaunchKernelGGL(scan_apply_fused_kernel, dim3(nblk), dim3(256), 0, ctx->stream, in, n, sums, nblk, out);
+        WSC_HIP(hipGetLastError());
+        return WSC_OK;
+    }
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, ctx->stream, sums, nblk);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(256), 0, ctx->stream, in, n, sums, out);
     WSC_HIP(hipGetLastError());
@@ -1661,6 +1704,53 @@ __global__ __launch_bounds__(256) void slice_norm_kernel(const int32_t *__restri
     }
 }
 
+// The same per PIXEL TILE (one block per tile, a thread per pixel), followed by the tile's entry scaling
+// (tile_scale_entries_kernel: weight -> weight * norm[pixel]) from the norms the block has just computed -- the per-image
+// lattices of a batch (round 4: one launch and one pass over the norms less per build; same arithmetic per pixel and entry).
+__global__ __launch_bounds__(256) void slice_norm_tile_kernel(const int32_t *__restrict__ offset, const float *__restrict__ bary,
+                                                               int dp1, float alpha, const float *__restrict__ val, TileGeom tg,
+                                                               float *__restrict__ norm, uint32_t *__restrict__ rec,
+                                                               float *__restrict__ tent_w, const uint8_t *__restrict__ tent_p) {
+    __shared__ uint32_t lrec[256 * 13];
+    __shared__ float lnorm[256];
+    const int tile = blockIdx.x;
+    const int b = tile / tg.tpi, j = tile - b * tg.tpi;
+    const TileBox tb = tile_box(tg, j);
+    const int N = tg.H * tg.W;
+    const int np = tb.cw * tb.ch;
+    const unsigned cw_magic = tile_div_magic(tb.cw);
+    const int t = threadIdx.x;
+    const int ty = (int)(((unsigned)t * cw_magic) >> 16), tx = t - ty * tb.cw;
+    const long long p = (long long)b * N + (long long)(tb.y0 + ty) * tg.W + tb.x0 + tx;
+    if (t < np) {
+        float acc = 0.f;
+        for (int r = 0; r < dp1; ++r) {
+            const int o = offset[p * dp1 + r];
+            const float w = bary[p * dp1 + r];
+            acc += w * val[o] * alpha;
+            if (rec) {
+                lrec[t * 13 + r] = (uint32_t)o;
+                lrec[t * 13 + 6 + r] = __float_as_uint(w);
+            }
+        }
+        const float nv = (float)(1.0 / sqrt((double)acc + 1e-20));
+        norm[p] = nv;
+        lnorm[t] = nv;
+        if (rec) lrec[t * 13 + 12] = __float_as_uint(nv);
+    }
+    __syncthreads();
+    if (rec) { // a tile row's records are contiguous in the pixel-major record array: cw * 13 dwords per row
+        const int rowlen = tb.cw * 13;
+        for (int i = t; i < np * 13; i += 256) {
+            const int ry = i / rowlen, k = i - ry * rowlen;
+            rec[((long long)b * N + (long long)(tb.y0 + ry) * tg.W + tb.x0) * 13 + k] = lrec[i];
+        }
+    }
+    const int ne = np * dp1;
+    const long long ebase = ((long long)b * N + tb.ebase) * dp1;
+    for (int i = t; i < ne; i += 256) tent_w[ebase + i] = tent_w[ebase + i] * lnorm[(int)tent_p[ebase + i]];
+}
+
 // everything the update kernel needs to know about a pixel in 80 contiguous bytes: one thread per 16-byte piece
 // (coalesced stores; blockIdx.y = image, so no per-pixel 64-bit modulo for the shared Gaussian lattice's pixel)
 __global__ void pack_pixels_kernel(const int32_t *__restrict__ off_g, const float *__restrict__ bary_g,
@@ -2399,6 +2489,13 @@ __global__ void fill_u32_kernel(unsigned *p, unsigned v, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         p[i] = v;
 }
+// the hash table (EMPTY_KEY) and its first-toucher array (0x7fffffff) in one pass
+__global__ void fill_tables_kernel(unsigned long long *__restrict__ table, unsigned *__restrict__ first, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        table[i] = EMPTY_KEY;
+        first[i] = 0x7fffffffu;
+    }
+}
 __global__ void fill_u64_kernel(unsigned long long *p, unsigned long long v, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         p[i] = v;
@@ -2726,18 +2823,21 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     WSC_TRY(tmp.alloc(sizeof(unsigned) * (size_t)(B + 1), (void **)&bound_dev));
     const int nblk = (int)((nw + SCAN_CHUNK - 1) / SCAN_CHUNK);
     WSC_TRY(tmp.alloc(sizeof(unsigned) * (nblk + 2), (void **)&sums));
-    WSC_TRY(tmp.alloc(sizeof(int), (void **)&err));
+    // zero-initialised scratch in ONE block (one memset instead of three): err | redo_count | tile_nslots[n_tiles + 1]
+    const TileGeom tg0 = make_geom(crf->H, crf->W);
+    const int n_tiles0 = B * tg0.tpi;
+    unsigned *zblk;
+    WSC_TRY(tmp.alloc(sizeof(unsigned) * (size_t)(n_tiles0 + 1 + 4), (void **)&zblk));
+    err = reinterpret_cast<int *>(zblk);
     WSC_TRY(crf_alloc(crf, sizeof(int32_t) * total, (void **)&L.offset));
     WSC_TRY(crf_alloc(crf, sizeof(float) * total, (void **)&L.bary));
     WSC_TRY(crf_alloc(crf, sizeof(float) * npix, (void **)&L.norm));
     WSC_TRY(crf_alloc(crf, sizeof(float) * total, (void **)&L.tent_w));
     WSC_TRY(crf_alloc(crf, sizeof(uint8_t) * total, (void **)&L.tent_p));
 
-    hipLaunchKernelGGL(fill_u64_kernel, dim3(grid1d(B * cap)), dim3(256), 0, ctx->stream, table, EMPTY_KEY,
+    hipLaunchKernelGGL(fill_tables_kernel, dim3(grid1d(B * cap)), dim3(256), 0, ctx->stream, table, (unsigned *)first,
                        (long long)B * cap);
-    hipLaunchKernelGGL(fill_u32_kernel, dim3(grid1d(B * cap)), dim3(256), 0, ctx->stream, (unsigned *)first,
-                       0x7fffffffu, (long long)B * cap);
-    WSC_HIP(hipMemsetAsync(err, 0, sizeof(int), ctx->stream));
+    WSC_HIP(hipMemsetAsync(zblk, 0, sizeof(unsigned) * (size_t)(n_tiles0 + 1 + 4), ctx->stream));
 
     EmbedArgs ea;
     ea.rgb = rgb_dev; ea.B = B; ea.H = crf->H; ea.W = crf->W; ea.N = N;
@@ -2754,8 +2854,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
     int32_t *sslot;
     unsigned *tile_nslots;
     WSC_TRY(tmp.alloc(sizeof(int32_t) * total, (void **)&sslot));
-    WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.n_tiles + 1), (void **)&tile_nslots));
-    WSC_HIP(hipMemsetAsync(tile_nslots, 0, sizeof(unsigned) * (L.n_tiles + 1), ctx->stream));
+    tile_nslots = zblk + 4; // (zeroed above)
     {
         // small-table launch for every tile, full-table launch for the ones that gave up (WSC_OPT_CRF_EMBED_FULL: full table
         // for every tile, the single-launch form); WSC_OPT_CRF_RANK_BALLOT: the ballot-matching rank walk for every tile
@@ -2767,8 +2866,7 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
             int32_t *redo_list;
             unsigned *redo_count;
             WSC_TRY(tmp.alloc(sizeof(int32_t) * (size_t)L.n_tiles, (void **)&redo_list));
-            WSC_TRY(tmp.alloc(sizeof(unsigned), (void **)&redo_count));
-            WSC_HIP(hipMemsetAsync(redo_count, 0, sizeof(unsigned), ctx->stream));
+            redo_count = zblk + 1; // (zeroed above)
             hipLaunchKernelGGL(tile_embed_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent_w, L.tent_p,
                                sslot, tile_nslots, fb, redo_list, redo_count);
             hipLaunchKernelGGL(tile_embed_full_kernel<D>, dim3((unsigned)std::min(L.n_tiles, 2048)), dim3(256), 0, ctx->stream, ea,
@@ -2831,13 +2929,12 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
         unsigned *sums2, *row_nslots, *cursor, *sums3;
         const int nb2 = (L.n_tiles + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK, nb3 = (L.rows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
         WSC_TRY(tmp.alloc(sizeof(unsigned) * (nb2 + 2), (void **)&sums2));
-        WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&row_nslots));
-        WSC_TRY(tmp.alloc(sizeof(unsigned) * (L.rows + 1), (void **)&cursor));
+        WSC_TRY(tmp.alloc(sizeof(unsigned) * 2 * (size_t)(L.rows + 1), (void **)&row_nslots)); // row_nslots | cursor: one memset
+        cursor = row_nslots + (L.rows + 1);
         WSC_TRY(tmp.alloc(sizeof(unsigned) * (nb3 + 2), (void **)&sums3));
         WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (L.n_tiles + 2), (void **)&L.tslot_start));
         WSC_TRY(crf_alloc(crf, sizeof(int32_t) * (L.rows + 2), (void **)&L.row_slot_start));
-        WSC_HIP(hipMemsetAsync(row_nslots, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
-        WSC_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned) * (L.rows + 1), ctx->stream));
+        WSC_HIP(hipMemsetAsync(row_nslots, 0, sizeof(unsigned) * 2 * (size_t)(L.rows + 1), ctx->stream));
         WSC_TRY(exclusive_scan(ctx, tile_nslots, L.n_tiles + 1, (unsigned *)L.tslot_start, sums2));
         unsigned ns = 0;
         WSC_HIP(hipMemcpyAsync(&ns, sums2 + nb2, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
@@ -2924,10 +3021,15 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
         WSC_TRY(crf_alloc(crf, sizeof(uint32_t) * 13 * (size_t)npix, (void **)&crf->pix_rec_b));
         rec_b = crf->pix_rec_b;
     }
-    hipLaunchKernelGGL(slice_norm_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1,
-                       L.alpha, res, npix, L.norm, rec_b);
-    hipLaunchKernelGGL(tile_scale_entries_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.norm, dp1,
-                       make_geom(crf->H, crf->W), L.tent_w, L.tent_p);
+    if (!shared && D == 5) { // per-image lattices of a batch: norm + record + entry scaling in one pass per pixel tile
+        hipLaunchKernelGGL(slice_norm_tile_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1,
+                           L.alpha, res, make_geom(crf->H, crf->W), L.norm, rec_b, L.tent_w, L.tent_p);
+    } else {
+        hipLaunchKernelGGL(slice_norm_kernel, dim3(grid1d(npix)), dim3(256), 0, ctx->stream, L.offset, L.bary, dp1,
+                           L.alpha, res, npix, L.norm, rec_b);
+        hipLaunchKernelGGL(tile_scale_entries_kernel, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, L.norm, dp1,
+                           make_geom(crf->H, crf->W), L.tent_w, L.tent_p);
+    }
     WSC_HIP(hipGetLastError());
     if (D == 2 && shared && crf->persist) WSC_TRY(gauss_fuse_tables(crf, L, tg));
     return WSC_OK;
