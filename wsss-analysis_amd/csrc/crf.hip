@@ -3031,7 +3031,8 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
                            make_geom(crf->H, crf->W), L.tent_w, L.tent_p);
     }
     WSC_HIP(hipGetLastError());
-    if (D == 2 && shared && crf->persist) WSC_TRY(gauss_fuse_tables(crf, L, tg));
+    // (the tile vertex sets of the on-chip Gaussian message -- gauss_fuse_tables: a device -> host copy of the lattice and a
+    // host pass, 3-4 ms -- are added when a cached lattice is used a SECOND time: wsc_crf_create)
     return WSC_OK;
 }
 
@@ -3042,6 +3043,7 @@ struct GaussCache {
     std::vector<void *> blocks; // its device arrays (cached-alloc blocks of the ctx): handed back when the entry is evicted
     int users = 0;              // live wsc_crf objects whose lat[0] aliases L
     unsigned long long last_use = 0;
+    bool fuse_pending = true;   // the tile vertex sets of the on-chip message are built at the entry's second use
 };
 // distinct image sizes kept per ctx (~25 MB each at 375 x 500).  When the table is full the least recently used entry that
 // no live wsc_crf refers to makes room (round 3 had no eviction: after 64 sizes every later size was rebuilt per call,
@@ -3200,6 +3202,20 @@ int wsc_crf_create(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, fl
         --n_cached;
     }
     if (hit) {
+        if (hit->fuse_pending) {
+            // second use of this image size: now the host-built tile vertex sets pay (a size seen once -- cam_to_ir_label walks
+            // hundreds of native VOC sizes -- never pays the 3-4 ms; its loop takes the blur-kernel path, same bits)
+            hit->fuse_pending = false;
+            crf->persist = true;
+            const int st_f = gauss_fuse_tables(crf, hit->L, make_geom(H, W));
+            hit->blocks.insert(hit->blocks.end(), crf->persist_allocs.begin(), crf->persist_allocs.end());
+            crf->persist_allocs.clear();
+            crf->persist = false;
+            if (st_f != WSC_OK) { // (the lattice itself stays valid without the tables)
+                hit->L.gt_cnt = nullptr; hit->L.gt_rows = nullptr; hit->L.gt_nbr = nullptr; hit->L.gt_pix = nullptr;
+                hit->L.gt_stride = 0;
+            }
+        }
         crf->lat[0] = hit->L;
         hit->users += 1;
         hit->last_use = ++g_gauss_use_clock;
