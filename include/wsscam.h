@@ -424,7 +424,7 @@ int wsc_crf_lattice_sizes(wsc_ctx *ctx, const wsc_crf *crf, int32_t *v_gauss_hos
                           int32_t *v_bilat_host);
 /* 1 when wsc_crf_inference with M classes sums, blurs and slices the Gaussian (addPairwiseGaussian) lattice inside its
  * update kernel -- per pixel tile, in LDS, no value rows in HBM -- and 0 when the separate blur kernel runs (vertex sets of
- * a pixel tile too large for the kernel's LDS at this M: very narrow g_sxy; or WSC_CRF_NO_GFUSE=1).  Same Q bits either
+ * a pixel tile too large for the kernel's LDS at this M: very narrow g_sxy; the first use of an image size on a ctx; or WSC_OPT_CRF_GAUSS_ON_CHIP = 0).  Same Q bits either
  * way; a diagnostic for tests and benchmarks (03c_hsn/utilities.py:435 is the call this concerns). */
 int wsc_crf_gaussian_on_chip(const wsc_crf *crf, int M);
 
