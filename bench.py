@@ -559,7 +559,7 @@ def build_roofline(prof, n_steps, precision, traffic_classes=None, loop_gbps=Non
     if conv:
         c_ms, c_fl = sum(m for _, m, _ in conv), sum(w for _, _, w in conv)
         mult = 3 if precision in ("f16x3", "bf16x3") else 1
-        roofline["conv_mfma"] = {"kernel": "conv_igemm_kernel (all %d launches of the conv stack)" % (sum(c for c, _, _ in conv) // n_steps),
+        roofline["conv_mfma"] = {"kernel": "conv_igemm_kernel + stem_pool_kernel (all %d launches of the conv stack)" % (sum(c for c, _, _ in conv) // n_steps),
                                  "achieved": round(c_fl / (c_ms * 1e-3) / 1e12, 2), "peak": round(PEAK_TFLOPS[precision], 1),
                                  "unit": "TFLOP/s", "frac": round(c_fl / (c_ms * 1e-3) / 1e12 / PEAK_TFLOPS[precision], 4),
                                  "ms_per_step": round(c_ms / n_steps, 4), "mfma_products_per_term": mult,

@@ -57,8 +57,10 @@ def main(db, N=64, S=321, planes=1):
     rows = c.execute("select s.kernel_name, d.start, d.end, d.grid_size_x / d.workgroup_size_x, d.group_segment_size "
                      "from %s d join %s s on d.kernel_id = s.id order by d.start" % (kd, ks)).fetchall()
     start = [i for i, r in enumerate(rows) if "nchw_to_nhwc4" in r[0]][-1]
-    convs = [r for r in rows[start:] if "conv_igemm_kernel" in r[0]]
+    convs = [r for r in rows[start:] if "conv_igemm_kernel" in r[0] or "stem_pool_kernel" in r[0]]
     layers = resnet50_layers(S)
+    if "stem_pool_kernel" in convs[0][0]:  # f16x3: conv 7x7 + BN + ReLU + the 3x3/2 max-pool in one launch (csrc/stem_pool.hip)
+        layers[0] = ("stem 7x7 s2 3->64 + maxpool (fused)",) + layers[0][1:]
     print("%-44s %8s %8s %9s %7s %6s" % ("layer", "us", "TFLOP/s", "act TB/s", "blocks", "LDS KB"))
     tot = 0.0
     pos = 0
@@ -72,6 +74,8 @@ def main(db, N=64, S=321, planes=1):
         fl = 2.0 * M * cout * k * k * cin
         # 16-bit activations in + out (+ residual); weights ignored
         by = 2.0 * M * cout * (2 if "+res" in name else 1) + 2.0 * N * (ho * (2 if "s2" in name else 1)) ** 2 * cin
+        if "fused" in name:  # NHWC4 input planes in, pooled planes out
+            by = 8.0 * N * S * S + 2.0 * N * ((ho + 1) // 2) ** 2 * cout
         by *= planes
         print("%-44s %8.1f %8.0f %9.2f %7s %6s" % (name, us, fl / us / 1e6, by / us / 1e6, "+".join(str(r[3]) for r in rs),
                                                     "/".join("%.0f" % (r[4] / 1024.0) for r in rs)))

@@ -587,3 +587,31 @@ def test_forward_cam_hw_matches_square_call_and_oracle(precision):
             ref = cnn_ref.resnet50_cam_forward(torch.from_numpy(xp), sd).numpy()
         assert cam.shape == ref.shape, (cam.shape, ref.shape)
         assert np.abs(cam - ref).max() <= tol * ref.max(), (H, W, np.abs(cam - ref).max() / ref.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(64, 64), (65, 97), (97, 33), (225, 225), (24, 24)])
+def test_stem_pool_fused_equals_unfused(hw):
+    """stem_pool_kernel (conv 7x7/2 + BN + ReLU + MaxPool 3/2/1 in one launch, resnet50.py:54-64) against the two-launch form
+    it replaces (WSC_OPT_STEM_POOL_FUSED = 0): same accumulation sequence, same rounding to the hi/lo pair before the maximum,
+    so the CAM of the whole network has the same bits -- on sizes whose last tile is partial in either direction."""
+    from wsscam.net import resnet50_cam
+
+    sd = cnn_ref.make_resnet50_cam_state_dict(20, seed=1)
+    m = resnet50_cam.CAM(None, "voc12", "", 20, None, precision=_lib.PREC_F16X3)
+    m.load_state_dict(sd)
+    m.eval().cuda(0)
+    ctx = m.ctx
+    net = m._ensure_net()
+    H, W = hw
+    rng = np.random.default_rng(H * 1000 + W)
+    x = rng.normal(0, 1, (3, 2, 3, H, W)).astype(np.float32)
+    hh, ww = net.cam_size_hw(H, W)
+    outs = []
+    for fused in (1, 0):
+        with ctx.option(_lib.OPT_STEM_POOL_FUSED, fused):
+            cd = ctx.alloc(3 * 20 * hh * ww * 4)
+            net.forward_cam_hw(ctx.to_device(x), 3, H, W, cd)
+            outs.append(ctx.to_host(cd, (3, 20, hh, ww), np.float32))
+    assert np.isfinite(outs[0]).all() and outs[0].max() > 0
+    assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max() / outs[1].max()

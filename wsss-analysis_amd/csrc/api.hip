@@ -120,7 +120,7 @@ WscKernelTimer::~WscKernelTimer() {
 }
 
 static const char *kClassNames[WSC_K_COUNT] = {
-    "conv_igemm_kernel<256-row tiles,glds>", "conv_igemm_kernel<128x128,glds>", "conv_igemm_kernel<128x64,glds>", "conv_igemm_kernel<small-Cin>",
+    "conv_igemm_kernel<256-row tiles,glds>", "conv_igemm_kernel<128x128,glds>", "conv_igemm_kernel<128x64,glds>", "conv_igemm_kernel<small-Cin> / stem_pool_kernel",
     "pool/layout/flip-add", "cam_tail+unary", "crf_build(all)", "gauss_msg_kernel", "combine4+blur_lds+blur4+blur3_tile",
     "update_splat_kernel", "crf init/finish"};
 

@@ -107,7 +107,7 @@ enum WscKernelClass {
     WSC_K_CONV256 = 0,   // conv_igemm_kernel, 256x128 tile, 3-stage LDS-DMA pipeline
     WSC_K_CONV128,       // conv_igemm_kernel, 128x128 tile, LDS-DMA staging
     WSC_K_CONV64,        // conv_igemm_kernel, 128x64 tile
-    WSC_K_CONV_SMALLCIN, // conv_igemm_kernel, stem / first layer (register staging)
+    WSC_K_CONV_SMALLCIN, // conv_igemm_kernel, stem / first layer (register staging); stem_pool_kernel (f16x3 ResNet stem + max-pool)
     WSC_K_POOL_MISC,     // maxpool, layout changes, flip-add, classifier branch
     WSC_K_CAM_TAIL,      // cam_tail_kernel (both passes) + unary_from_maps
     WSC_K_CRF_BUILD,     // every kernel of wsc_crf_create
@@ -147,7 +147,7 @@ struct wsc_ctx {
     int pin_next = 0;
     // path selectors (wsc_ctx_set_option): every one picks between two paths that both exist for some inputs and give the
     // same bits -- the tests hold them to that.  Defaults: wsc_option in include/wsscam.h.
-    int opt[WSC_OPT_COUNT] = {1, 1, 1, 0, 0, -1};
+    int opt[WSC_OPT_COUNT] = {1, 1, 1, 0, 0, -1, 1};
     void *pinned = nullptr; // (legacy single buffer: unused)
     size_t pinned_bytes = 0;
     void *zero_page = nullptr; // 256 bytes of zeros in HBM (source of padded conv taps)
@@ -211,6 +211,10 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p);
 // ---- misc kernels ---------------------------------------------------------------------
 int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo, int fmt);
 // [N][Hp][Wp][4] with a zero border of `pad` pixels on the top / left (and whatever Hp, Wp leave on the bottom / right)
+// stem_pool.hip: conv 7x7/2 + BN + ReLU + MaxPool 3x3/2/1 of the f16x3 ResNet stem in one kernel
+void stem_pool_input_dims(int H, int W, int *Hp, int *Wp);
+int launch_stem_pool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, const bf16_t *w, int Kw, const float *s1,
+                     const float *b1, int relu, bf16_t *y, bf16_t *y_lo);
 int launch_nchw_to_nhwc4_pad(wsc_ctx *ctx, const float *x, int N, int H, int W, int Hp, int Wp, int pad, bf16_t *y, bf16_t *y_lo,
                              int fmt);
 int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, int C, int k,

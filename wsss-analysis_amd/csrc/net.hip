@@ -582,11 +582,24 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
     // f16x3 stem (small_cin == 3): the NHWC4 input carries its zero border -- rows / columns the kernel rows of the last
     // output pixel reach, an 8-pixel window per kernel row (conv_igemm.hip)
     int in_h = S, in_w = SW, in_pad = 0;
+    bool fused_stem = false;
     if (!net->ops.empty() && net->ops[0].type == OP_CONV && net->ops[0].in < 0 && net->convs[net->ops[0].conv].small_cin == 3) {
         const ConvW &c0 = net->convs[net->ops[0].conv];
         in_h = (pl.H[0] - 1) * c0.stride + c0.kh;
         in_w = (pl.W[0] - 1) * c0.stride + 8;
         in_pad = c0.pad;
+        // conv 7x7 / 2 / 3 (-> 64) + BN + ReLU followed by MaxPool 3 / 2 / 1 (resnet50.py:54-64): one kernel (stem_pool.hip),
+        // unless the conv's own output is wanted (a tap) or the path is switched off
+        bool tapped = false;
+        for (int tp : net->taps) tapped = tapped || tp == 0;
+        fused_stem = ctx->opt[WSC_OPT_STEM_POOL_FUSED] && net->ops.size() > 1 && net->ops[1].type == OP_POOL &&
+                     net->ops[1].in == net->ops[0].out && net->ops[1].pk == 3 && net->ops[1].ps == 2 && net->ops[1].pp == 1 &&
+                     c0.kh == 7 && c0.kw == 7 && c0.stride == 2 && c0.pad == 3 && c0.Cout == 64 && c0.s2 == nullptr &&
+                     net->ops[0].res < 0 && net->fmt == 1 && !tapped;
+        if (fused_stem) {
+            stem_pool_input_dims(S, SW, &in_h, &in_w);
+            in_pad = 5;
+        }
     }
     const size_t in_bytes = align_up((size_t)N * in_h * in_w * 4 * sizeof(bf16_t), 256);
     const size_t act_bytes = align_up(pl.max_act * sizeof(bf16_t), 256);
@@ -612,7 +625,11 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
         const int H = op.in < 0 ? S : bh[op.in], W = op.in < 0 ? SW : bw[op.in], C = op.in < 0 ? 4 : bc[op.in];
         const bf16_t *src = op.in < 0 ? xin : buf[op.in];
         const bf16_t *src_lo = op.in < 0 ? xin_lo : buf_lo[op.in];
-        if (op.type == OP_CONV) {
+        if (fused_stem && i == 0) continue; // computed together with the pool that follows
+        if (fused_stem && i == 1) {
+            const ConvW &c0 = net->convs[net->ops[0].conv];
+            WSC_TRY(launch_stem_pool(ctx, xin, xin_lo, N, S, SW, c0.w, c0.kh * 64, c0.s1, c0.b1, c0.relu, buf[op.out], buf_lo[op.out]));
+        } else if (op.type == OP_CONV) {
             const ConvW &c = net->convs[op.conv];
             ConvLaunch L;
             memset(&L, 0, sizeof(L));
