@@ -27,8 +27,10 @@ def resnet50_layers(S):
             L.append((n + "conv1 1x1 %d->%d" % (inp, planes), h, inp, planes, 1))
             L.append((n + "conv2 3x3 %d s%d" % (planes, s), ho, planes, planes, 3))
             if b == 0:
-                L.append((n + "downsample 1x1 %d->%d" % (inp, planes * 4), ho, inp, planes * 4, 1))
-            L.append((n + "conv3 1x1 %d->%d +res" % (planes, planes * 4), ho, planes, planes * 4, 1))
+                # conv3 and the 1x1 projection of the shortcut are one GEMM over the concatenated channels (csrc/net.hip)
+                L.append((n + "conv3+proj 1x1 (%d+%d)->%d" % (planes, inp, planes * 4), ho, planes + inp, planes * 4, 1))
+            else:
+                L.append((n + "conv3 1x1 %d->%d +res" % (planes, planes * 4), ho, planes, planes * 4, 1))
             inp = planes * 4
             h = ho
     L.append(("CAM head 1x1 2048->20", h, 2048, 20, 1))

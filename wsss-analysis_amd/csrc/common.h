@@ -205,16 +205,20 @@ struct ConvLaunch {
     int split;     // 0: one plane; 1: bf16x3 (three K segments); 2: f16x3 (hi + lo staged once per K-step).  The lo plane has the hi plane's format
     int fmt;       // 16-bit operand format: 0 bf16, 1 f16 (split 1 requires bf16, split 2 f16)
     int generic;   // 1: keep the generic kernel variants (testing: the FAST variants give the same bits)
+    int ldy;       // row pitch of y / y_lo in elements; 0 = Cout (wider: the output is a channel range of a concatenated tensor)
 };
 int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p);
 
 // ---- misc kernels ---------------------------------------------------------------------
 int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo, int fmt);
-// [N][Hp][Wp][4] with a zero border of `pad` pixels on the top / left (and whatever Hp, Wp leave on the bottom / right)
 // stem_pool.hip: conv 7x7/2 + BN + ReLU + MaxPool 3x3/2/1 of the f16x3 ResNet stem in one kernel
 void stem_pool_input_dims(int H, int W, int *Hp, int *Wp);
 int launch_stem_pool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, const bf16_t *w, int Kw, const float *s1,
                      const float *b1, int relu, bf16_t *y, bf16_t *y_lo);
+// x[n][ho * stride][wo * stride][0 .. C) -> y[(n, ho, wo)][0 .. C) with row pitch ldy (both planes; y points at the first channel)
+int launch_gather_strided(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, int C, int stride, int Ho, int Wo,
+                          bf16_t *y, bf16_t *y_lo, int ldy);
+// [N][Hp][Wp][4] with a zero border of `pad` pixels on the top / left (and whatever Hp, Wp leave on the bottom / right)
 int launch_nchw_to_nhwc4_pad(wsc_ctx *ctx, const float *x, int N, int H, int W, int Hp, int Wp, int pad, bf16_t *y, bf16_t *y_lo,
                              int fmt);
 int launch_maxpool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, int C, int k,

@@ -51,6 +51,7 @@ struct ConvKArgs {
     bf16_t *y, *y_lo;
     float *y_f32;
     int H, W, Cin, Ho, Wo, Cout;
+    int ldy;            // row pitch of y / y_lo in elements (Cout, or wider: the output is a channel range of a concatenated tensor)
     int kh, kw, stride, pad, relu;
     int M, HoWo;
     int m_base, m_end; // rows [m_base, m_end) of the M = N*Ho*Wo output rows are this launch's (a layer may be cut in two)
@@ -856,8 +857,8 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                     }
                 }
                 if (m < p.m_end) {
-                    *reinterpret_cast<uint4 *>(p.y + ((unsigned)m * (unsigned)p.Cout + (unsigned)c)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-                    if (SPLIT) *reinterpret_cast<uint4 *>(p.y_lo + ((unsigned)m * (unsigned)p.Cout + (unsigned)c)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                    *reinterpret_cast<uint4 *>(p.y + ((unsigned)m * (unsigned)p.ldy + (unsigned)c)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                    if (SPLIT) *reinterpret_cast<uint4 *>(p.y_lo + ((unsigned)m * (unsigned)p.ldy + (unsigned)c)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
                 continue;
             }
@@ -922,8 +923,9 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                             lw[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
                         }
                     }
-                    *reinterpret_cast<uint4 *>(p.y + o) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-                    if (SPLIT) *reinterpret_cast<uint4 *>(p.y_lo + o) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                    const long long oy = (long long)m * p.ldy + c;
+                    *reinterpret_cast<uint4 *>(p.y + oy) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                    if (SPLIT) *reinterpret_cast<uint4 *>(p.y_lo + oy) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
             }
         }
@@ -1041,6 +1043,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     a.res = p.res; a.res_lo = p.res_lo;
     a.y = p.y; a.y_lo = p.y_lo; a.y_f32 = p.y_f32;
     a.H = p.H; a.W = p.W; a.Cin = p.Cin; a.Ho = p.Ho; a.Wo = p.Wo; a.Cout = p.Cout;
+    a.ldy = p.ldy > 0 ? p.ldy : p.Cout;
     a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.relu = p.relu;
     a.M = p.N * p.Ho * p.Wo;
     a.m_base = 0;
@@ -1108,7 +1111,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     const int nofast = p.generic;
     a.fast = 0;
     if (!nofast && p.fmt && (p.split == 0 || single_staged) && p.y != nullptr && p.y_f32 == nullptr &&
-        p.Cout == p.CoutPad && (long long)a.M * p.Cout < (1ll << 31)) {
+        p.Cout == p.CoutPad && (long long)a.M * a.ldy < (1ll << 31)) {
         a.fast = 1;
         if (small_cin_eff == 0 && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1) a.fast = 3;
     }

@@ -53,6 +53,26 @@ __global__ void nchw_to_nhwc4_pad_kernel(const float *__restrict__ x, int N, int
     }
 }
 
+// Strided pixel gather into a channel range of a wider tensor: y[(n, ho, wo)][0 .. C) = x[n][ho * stride][wo * stride][0 .. C),
+// rows of y `ldy` elements apart -- the shortcut input of a ResNet stage's first block, placed beside conv2's output so that
+// conv3 and the 1x1 projection are ONE GEMM over the concatenated channels (net.hip build_resnet50_backbone).  16 bytes per thread.
+__global__ __launch_bounds__(256) void gather_strided_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ x_lo, int H, int W,
+                                                             int C8, int stride, int Ho, int Wo, bf16_t *__restrict__ y,
+                                                             bf16_t *__restrict__ y_lo, int ldy, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        long long m = i / C8;
+        const int wo = (int)(m % Wo);
+        const long long r = m / Wo;
+        const int ho = (int)(r % Ho);
+        const long long n = r / Ho;
+        const long long src = (((n * H + (long long)ho * stride) * W + (long long)wo * stride) * C8 + c8) * 8;
+        const long long dst = m * ldy + c8 * 8;
+        *reinterpret_cast<uint4 *>(y + dst) = *reinterpret_cast<const uint4 *>(x + src);
+        if (x_lo != nullptr) *reinterpret_cast<uint4 *>(y_lo + dst) = *reinterpret_cast<const uint4 *>(x_lo + src);
+    }
+}
+
 // nn.MaxPool2d(k, stride, pad) on NHWC bf16, 8 channels per thread.
 // resnet50.py:64 (3x3 s2 p1), common_cnn.py:131-132 (2x2 s2).
 __global__ void maxpool_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ x_lo, int N, int H,
@@ -343,6 +363,17 @@ int launch_nchw_to_nhwc4_pad(wsc_ctx *ctx, const float *x, int N, int H, int W, 
     WscKernelTimer timer(ctx, WSC_K_POOL_MISC, (double)N * H * W * 12 + (double)total * (y_lo ? 16 : 8));
     hipLaunchKernelGGL(nchw_to_nhwc4_pad_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, N, H, W, Hp, Wp, pad, y,
                        y_lo, fmt);
+    WSC_HIP(hipGetLastError());
+    return WSC_OK;
+}
+
+int launch_gather_strided(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, int H, int W, int C, int stride, int Ho, int Wo,
+                          bf16_t *y, bf16_t *y_lo, int ldy) {
+    WSC_CHECK(C % 8 == 0 && ldy % 8 == 0, WSC_ERR_INVALID, "gather: C=%d, pitch=%d not multiples of 8", C, ldy);
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    WscKernelTimer timer(ctx, WSC_K_POOL_MISC, (double)total * 32 * (x_lo ? 2 : 1));
+    hipLaunchKernelGGL(gather_strided_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, x_lo, H, W, C / 8, stride, Ho, Wo, y,
+                       y_lo, ldy, total);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
 }

@@ -48,12 +48,14 @@ struct IrnCat {
     int channels, stage, stride;
 };
 
-enum OpType { OP_CONV = 0, OP_POOL = 1 };
+enum OpType { OP_CONV = 0, OP_POOL = 1, OP_GATHER = 2 };
 struct Op {
     int type;
     int conv;         // index into convs (OP_CONV)
     int in, out, res; // activation buffer ids; res = -1 if none; in = -1 means the NHWC4 input
-    int pk, ps, pp;   // pool kernel / stride / pad
+    int pk, ps, pp;   // pool kernel / stride / pad (OP_GATHER: ps = pixel stride)
+    int pitch = 0;    // channels per output row when the op writes a channel range of a wider (concatenated) tensor, else 0
+    int coff = 0;     // first channel of that range
 };
 
 } // namespace
@@ -227,6 +229,10 @@ int build_resnet50_backbone(wsc_net *net, const Dict &d) {
     add_pool_op(net, 3, 2, 1, 0, 1);
     net->taps.push_back((int)net->ops.size() - 1); // stage1 = conv1, bn1, relu, maxpool (resnet50_irn.py:15)
     int cur = 1;
+    bool fuse_shortcut = true;
+#ifdef WSC_AB_KNOBS
+    if (const char *e = getenv("WSC_NET_SHORTCUT_FUSED")) fuse_shortcut = atoi(e) != 0; // A/B: the four-launch form of a stage's first block
+#endif
     const int planes[4] = {64, 128, 256, 512};
     const int blocks[4] = {3, 4, 6, 3};
     const int strides[4] = {1, 2, 2, 1}; // resnet50_cam.py:15 strides=(2,2,2,1): [0] is the stem
@@ -240,6 +246,46 @@ int build_resnet50_backbone(wsc_net *net, const Dict &d) {
                 if (i != cur) f[nf++] = i;
             // Bottleneck.forward, resnet50.py:34-54; the stride sits on conv2 (resnet50.py:24)
             WSC_TRY(resnet_conv(net, d, pre + ".conv1", pre + ".bn1", 1, 0, 1, 0, cur, f[0], -1));
+            if (has(d, pre + ".downsample.0.weight") && fuse_shortcut) {
+                // out = relu(bn3(conv3(y2)) + bn_d(conv_d(x)))  (resnet50.py:44-52) as ONE 1x1 conv over the concatenated channels
+                // [y2 | x at the block's stride]: conv2 writes its channel range of that tensor, the shortcut input is gathered
+                // beside it, and the two BatchNorm scales go into the weights -- relative to sigma_c = max(|s3_c|, |sd_c|), which
+                // stays in the epilogue, so that neither branch's weights leave the half range (W3 * s3/sigma | Wd * sd/sigma,
+                // shift b3 + bd).  The projection's output (215 MB per plane in layer1 at 64 samples) is never written or re-read
+                // as a residual, and the stage's first block has one epilogue instead of two.
+                const HostTensor *w3, *wd;
+                WSC_TRY(get(d, pre + ".conv3.weight", 4, &w3));
+                WSC_TRY(get(d, pre + ".downsample.0.weight", 4, &wd));
+                const int Co = (int)w3->shape[0], K1 = (int)w3->shape[1], K2 = (int)wd->shape[1];
+                WSC_CHECK(wd->shape[0] == Co && w3->shape[2] == 1 && w3->shape[3] == 1 && wd->shape[2] == 1 && wd->shape[3] == 1 &&
+                          K1 % 8 == 0 && K2 % 8 == 0, WSC_ERR_SHAPE, "'%s': conv3 / downsample shapes do not match", pre.c_str());
+                std::vector<float> s3, b3, sd, bd;
+                WSC_TRY(fold_bn(d, pre + ".bn3", Co, 1e-5, s3, b3));
+                WSC_TRY(fold_bn(d, pre + ".downsample.1", Co, 1e-5, sd, bd));
+                std::vector<float> wc((size_t)Co * (K1 + K2)), sig(Co), sh(Co);
+                for (int co = 0; co < Co; ++co) {
+                    float g = std::max(std::fabs(s3[co]), std::fabs(sd[co]));
+                    if (!(g > 0.f)) g = 1.f;
+                    sig[co] = g;
+                    sh[co] = b3[co] + bd[co];
+                    for (int k = 0; k < K1; ++k) wc[(size_t)co * (K1 + K2) + k] = w3->data[(size_t)co * K1 + k] * (s3[co] / g);
+                    for (int k = 0; k < K2; ++k) wc[(size_t)co * (K1 + K2) + K1 + k] = wd->data[(size_t)co * K2 + k] * (sd[co] / g);
+                }
+                HostTensor wt;
+                wt.data = wc.data(); wt.ndim = 4; wt.shape[0] = Co; wt.shape[1] = K1 + K2; wt.shape[2] = 1; wt.shape[3] = 1;
+                WSC_TRY(resnet_conv(net, d, pre + ".conv2", pre + ".bn2", s, 1, 1, 0, f[0], f[1], -1));
+                net->ops.back().pitch = K1 + K2;
+                net->ops.back().coff = 0;
+                Op g;
+                g.type = OP_GATHER; g.conv = -1; g.in = cur; g.out = f[1]; g.res = -1; g.pk = 1; g.ps = s; g.pp = 0;
+                g.pitch = K1 + K2; g.coff = K1;
+                net->ops.push_back(g);
+                ConvW c;
+                WSC_TRY(make_conv(net, &wt, 1, 0, 1, 0, sig, sh, nullptr, nullptr, &c));
+                WSC_TRY(add_conv_op(net, c, f[1], f[0], -1));
+                cur = f[0];
+                continue;
+            }
             WSC_TRY(resnet_conv(net, d, pre + ".conv2", pre + ".bn2", s, 1, 1, 0, f[0], f[1], -1));
             int res = cur;
             if (has(d, pre + ".downsample.0.weight")) {
@@ -546,8 +592,14 @@ int plan_dims(const wsc_net *net, int N, int SH, int SW, Plan *pl) {
             const ConvW &c = net->convs[op.conv];
             Ho = (H + 2 * c.pad - c.kh) / c.stride + 1;
             Wo = (W + 2 * c.pad - c.kw) / c.stride + 1;
-            Co = c.Cout;
+            Co = op.pitch ? op.pitch : c.Cout;
             WSC_CHECK(C == c.Cin, WSC_ERR_INVALID, "internal: channel mismatch %d vs %d", C, c.Cin);
+        } else if (op.type == OP_GATHER) {
+            Ho = (H - 1) / op.ps + 1;
+            Wo = (W - 1) / op.ps + 1;
+            Co = op.pitch;
+            WSC_CHECK(Ho == bh[op.out] && Wo == bw[op.out] && bc[op.out] == op.pitch && op.coff + C <= op.pitch, WSC_ERR_INVALID,
+                      "internal: gather into a %d x %d x %d tensor does not fit", bh[op.out], bw[op.out], bc[op.out]);
         } else {
             Ho = (H + 2 * op.pp - op.pk) / op.ps + 1;
             Wo = (W + 2 * op.pp - op.pk) / op.ps + 1;
@@ -638,6 +690,11 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
             L.res = op.res >= 0 ? buf[op.res] : nullptr;
             L.res_lo = op.res >= 0 ? buf_lo[op.res] : nullptr;
             L.y = buf[op.out]; L.y_lo = buf_lo[op.out]; L.y_f32 = nullptr;
+            L.ldy = op.pitch; // (0: dense)
+            if (op.pitch) {
+                L.y += op.coff;
+                if (L.y_lo) L.y_lo += op.coff;
+            }
             L.N = N; L.H = H; L.W = W; L.Cin = c.Cin; L.Ho = pl.H[i]; L.Wo = pl.W[i];
             L.Cout = c.Cout; L.CoutPad = c.CoutPad;
             L.kh = c.kh; L.kw = c.kw; L.stride = c.stride; L.pad = c.pad; L.relu = c.relu;
@@ -646,6 +703,9 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
                 L.H = in_h; L.W = in_w; L.pad = 0;
             }
             WSC_TRY(conv_igemm_launch(ctx, L));
+        } else if (op.type == OP_GATHER) {
+            WSC_TRY(launch_gather_strided(ctx, src, src_lo, N, H, W, C, op.ps, pl.H[i], pl.W[i], buf[op.out] + op.coff,
+                                          buf_lo[op.out] ? buf_lo[op.out] + op.coff : nullptr, op.pitch));
         } else {
             WSC_TRY(launch_maxpool(ctx, src, src_lo, N, H, W, C, op.pk, op.ps, op.pp, pl.H[i], pl.W[i], buf[op.out],
                                    buf_lo[op.out], net->fmt));
