@@ -26,6 +26,8 @@ def main(db1, db2, N=64, S=321, planes=2):
     L = resnet50_layers(S)
     nds = [n_dispatches(N * ho * ho, cin, cout, k, planes=planes) for (_, ho, cin, cout, k) in L]
     a, b = a[-sum(nds):], b[-sum(nds):]
+    if "stem_pool_kernel" in a[0]["name"]:  # conv 7x7 + BN + ReLU + max-pool in one launch (csrc/stem_pool.hip); per-wave columns: per 128-row-tile wave equivalent
+        L[0] = ("stem 7x7 s2 + maxpool (fused)",) + L[0][1:]
 
     def merge(rows):  # a layer cut into two launches: add durations and counters
         out = {"dur": sum(r["dur"] for r in rows)}
