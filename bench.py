@@ -24,8 +24,8 @@ cycling over four distinct resident batches), `roofline` with the two fractions 
 the product chain against the all-fp32 oracle chain on images of this batch -- computed inside the cpu_baseline leg, the
 only place bench.py touches oracle/), and under `stages`: `sum_ms` (sum of the stage times: what the step would take
 without overlap), `value_f16` (the fast half-precision mode), `value_M_eq_Kplus1` (SURVEY config 3's other variant:
-M = K + 1 per image), `value_end_to_end` (pageable host batch -> pinned staging -> H2D, D2H of cam / high_res / labels,
-np.save through writer threads).
+M = K + 1 per image), `value_end_to_end` (pageable host batch -> pinned staging -> H2D one step ahead on its own stream, D2H of
+cam / high_res / labels on their own streams, a finisher thread, .npy files through writer threads).
 --scaling strong: the K steps are a FIXED set of K*batch images sharded over the ranks (rank g runs ceil(K/N) steps).
 
 Prints ONE JSON line on rank 0.
@@ -113,7 +113,7 @@ class Workload:
         GFLOP_PER_IMAGE = GFLOP_PER_IMAGE_BY_ARCH[arch]
 
         self.np, self._lib = np, _lib
-        self.B, self.workload = batch, workload
+        self.B, self.workload, self.device = batch, workload, device
         self.ctx = _lib.Context(device)
         # second context (own stream) for the lattice build: it needs only the RGB images, so it runs
         # concurrently with the CNN forward pass of the same batch and joins before the inference
@@ -122,6 +122,11 @@ class Workload:
         # step i+1's conv stack (self.ctx) and lattice build (self.ctx_build) are already under way.
         self.ctx_crf = _lib.Context(device)
         self.pending = None  # lattices of the step whose mean-field loop is still in flight
+        # step_pipelined(): the loops of the last TWO steps may be in flight.  done[p] is a stream that only ever waits for the
+        # loop that last used parity p's buffers, so the host can wait for exactly that loop (two steps old: normally finished)
+        # instead of the newest one -- the mean-field stream always has the next loop queued behind the running one
+        self.done = [_lib.Context(device), _lib.Context(device)]
+        self.inflight = [None, None]
         prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "f16x3": _lib.PREC_F16X3}[precision]
         # seeded random weights of the named architecture (no checkpoints offline), wsscam.synth
         if arch == "resnet50":
@@ -183,7 +188,7 @@ class Workload:
 
     def close(self):
         self.drain()
-        for c in (self.ctx, self.ctx_build, self.ctx_crf):
+        for c in (self.ctx, self.ctx_build, self.ctx_crf, self.done[0], self.done[1]):
             c.sync()
         self.net.close()
 
@@ -215,6 +220,15 @@ class Workload:
             self.ctx_crf.sync()
             self.pending.close()
             self.pending = None
+        for p in (0, 1):
+            self._retire(p)
+
+    def _retire(self, p):
+        """Wait for the loop that last used parity p's unary / label buffers and release its lattices."""
+        if self.inflight[p] is not None:
+            self.done[p].sync()
+            self.inflight[p].close()
+            self.inflight[p] = None
 
     def step_pipelined(self):
         """Same work per step as step(), issued so that consecutive steps overlap:
@@ -222,19 +236,25 @@ class Workload:
         stream B (ctx_build) lattice build of step i
         stream C (ctx_crf)   mean-field loop of step i, after A and B  -- still running while the host
                              already enqueues step i+1 on A and B."""
+        if self.pending is not None:
+            self.drain()                 # (a loop left by another step function)
         self.parity ^= 1
-        self.unary_dev, self.label_dev = self.unary_bufs[self.parity], self.label_bufs[self.parity]
+        p = self.parity
+        self._retire(p)                  # step i-2's loop read / wrote this parity's buffers: done before they are rewritten
+        self.unary_dev, self.label_dev = self.unary_bufs[p], self.label_bufs[p]
         self.run_cnn()
         crf = self.crf_create()          # host blocks on the build stream only; A and C keep running
         if self.vg is None:
             self.vg, self.vb = crf.lattice_sizes()
         self.run_tail()
         self.run_unary()
-        self.drain()                     # step i-1's loop must be done before its workspace is reused
+        if os.environ.get("WSC_BENCH_INFLIGHT") == "1":
+            self._retire(p ^ 1)          # (A/B: at most one loop in flight -- the host waits for step i-1's loop: round 3's schedule)
         self.ctx_crf.wait_for(self.ctx)
         self.ctx_crf.wait_for(self.ctx_build)
-        self.crf_infer(crf, ctx=self.ctx_crf)
-        self.pending = crf
+        self.crf_infer(crf, ctx=self.ctx_crf)   # queued behind step i-1's loop on the same stream: no host round trip between them
+        self.done[p].wait_for(self.ctx_crf)
+        self.inflight[p] = crf
 
     def step(self, sequential=False):
         """One step, finished before it returns.  sequential=True additionally keeps the stages from
@@ -318,13 +338,18 @@ class Workload:
         np = self.np
         if self.e2e is not None:
             self.e2e["pool"].shutdown(wait=True)
+            self.e2e["finisher"].shutdown(wait=True)
         self.u8_offs = np.concatenate(([0], np.cumsum([im.size for im in self.native]))).astype(np.int64)
-        self.u8_dev = self.ctx.alloc(int(self.u8_offs[-1]))
-        self.e2e = {"dir": out_dir, "pool": ThreadPoolExecutor(n_writers), "futs": [[], []], "u8": u8,
+        self.e2e = {"dir": out_dir, "pool": ThreadPoolExecutor(n_writers), "u8": u8,
                     "pin_u8": [self.ctx.host_alloc(int(self.u8_offs[-1])) for _ in range(2)],
                     "pin_in": [self.ctx.host_alloc(self.x_host.nbytes) for _ in range(2)],
                     "pin_out": [self.ctx.host_alloc((max(self.s_tot, 1) + max(self.h_tot, 1)) * 4) for _ in range(2)],
-                    "pin_lab": [self.ctx_crf.host_alloc(self.B * S * S * 4) for _ in range(2)], "prev": None}
+                    "pin_lab": [self.ctx_crf.host_alloc(self.B * S * S * 4) for _ in range(2)],
+                    "stage": [None, None], "fin": [None, None], "crf": [None, None],
+                    "finisher": ThreadPoolExecutor(1), "out": [self._lib.Context(self.device) for _ in range(2)],
+                    "outc": [self._lib.Context(self.device) for _ in range(2)], "io": self._lib.Context(self.device), "fed": False,
+                    "x": [self.ctx.alloc(self.x_host.nbytes) for _ in range(2)],
+                    "u8d": [self.ctx.alloc(int(self.u8_offs[-1])) for _ in range(2)]}
         os.makedirs(out_dir, exist_ok=True)
 
     def _e2e_save(self, p, b, s_off, h_off, shapes):
@@ -333,21 +358,32 @@ class Workload:
         K, h4, w4, H0, W0 = shapes[b]
         st = e["pin_out"][p].view((max(self.s_tot, 1),), np.float32)
         hi = e["pin_out"][p].view((max(self.h_tot, 1),), np.float32, offset_bytes=max(self.s_tot, 1) * 4)
-        np.save(os.path.join(e["dir"], "img%03d.npy" % b),
+        from wsscam.step.make_cam import save_npy_object  # np.load-compatible, writer threads do not serialise on the GIL
+
+        save_npy_object(os.path.join(e["dir"], "img%03d.npy" % b),
                 {"keys": self.keys[b].astype(np.int64), "cam": st[s_off[b]:s_off[b] + K * h4 * w4].reshape(K, h4, w4),
                  "high_res": hi[h_off[b]:h_off[b] + K * H0 * W0].reshape(K, H0, W0)})  # make_cam.py:80-82
         lab = e["pin_lab"][p].view((self.B, S, S), np.int32)[b]
         np.save(os.path.join(e["dir"], "img%03d_crf.npy" % b), lab.astype(np.uint8))
 
-    def _e2e_finish(self, prev):
-        """The step whose mean-field loop was still in flight: labels to the host, then the writer threads."""
-        p, s_off, h_off, shapes = prev
+    def _e2e_finish(self, p, s_off, h_off, shapes):
+        """Finisher thread: sleeps until the outputs of the step that used parity p are in page-locked memory (its own stream
+        waits for exactly that step's copies), then hands the files to the writer threads.  The main thread never waits for
+        the newest mean-field loop."""
         e = self.e2e
-        self.ctx_crf.d2h_async(e["pin_lab"][p], self.label_bufs[p], self.B * S * S * 4)
-        self.ctx_crf.sync()
-        self.pending.close()
-        self.pending = None
-        e["futs"][p] = [e["pool"].submit(self._e2e_save, p, b, s_off, h_off, shapes) for b in range(self.B)]
+        e["out"][p].sync()
+        return [e["pool"].submit(self._e2e_save, p, b, s_off, h_off, shapes) for b in range(self.B)]
+
+    def _e2e_retire(self, p):
+        """The step that last used parity p (two steps ago): its files are on disk, its lattices can go."""
+        e = self.e2e
+        if e["fin"][p] is not None:
+            for f in e["fin"][p].result():
+                f.result()
+            e["fin"][p] = None
+        if e["crf"][p] is not None:
+            e["crf"][p].close()
+            e["crf"][p] = None
 
     def step_e2e(self):
         """step_pipelined() with the host boundary of the reference around it: a pageable float32 batch (what the
@@ -355,13 +391,64 @@ class Workload:
         are copied out and written as .npy files by writer threads while the next step computes."""
         np = self.np
         e = self.e2e
+        if self.pending is not None or self.inflight[0] is not None or self.inflight[1] is not None:
+            self.drain()  # (loops left by another step function)
         self.parity ^= 1
         p = self.parity
-        for f in e["futs"][p]:
-            f.result()  # the files of step i-2 are on disk: its staging buffers are free again
-        e["futs"][p] = []
+        self._e2e_retire(p)  # the files of step i-2 are on disk: its staging buffers are free again
         self.unary_dev, self.label_dev = self.unary_bufs[p], self.label_bufs[p]
+        # Input: the copy-in of batch i runs on its own stream ONE STEP AHEAD of the conv stack (two device input buffers), so the
+        # conv stream never waits behind a 79 MB PCIe transfer; the staging copy of batch i + 1 was submitted a step ago.
+        if not e["fed"]:
+            self._e2e_feed(p)            # (first step: nobody has fed this one)
+            e["fed"] = True
+        self.ctx.wait_for(e["io"])       # batch i is on the device
+        self._e2e_feed(p ^ 1)            # batch i + 1 follows while step i computes
+        x_keep, self.x_dev = self.x_dev, e["x"][p]
+        self.run_cnn()
+        self.x_dev = x_keep
+        crf = self.crf_create()
+        self.ctx.wait_for(e["outc"][p ^ 1])  # step i-1's cam / high_res copy-out has left the buffers the tail rewrites
+        self.run_tail()
+        _, _, s_off, h_off, shapes = self.tail_meta
+        oc = e["outc"][p]                # copy-out of cam / high_res on its own stream: the conv stream goes on with the unaries
+        oc.wait_for(self.ctx)
+        oc.d2h_async(e["pin_out"][p], self.strided_dev, max(self.s_tot, 1) * 4)
+        oc.d2h_async(e["pin_out"][p], self.highres_dev, max(self.h_tot, 1) * 4, dst_offset=max(self.s_tot, 1) * 4)
+        self.run_unary()
+        self.ctx_crf.wait_for(self.ctx)
+        self.ctx_crf.wait_for(self.ctx_build)
+        self.crf_infer(crf, ctx=self.ctx_crf)  # queued behind step i-1's loop, no host round trip
+        out = e["out"][p]
+        out.wait_for(oc)             # cam / high_res copies of this step
+        out.wait_for(self.ctx_crf)   # this step's labels
+        out.d2h_async(e["pin_lab"][p], self.label_bufs[p], self.B * S * S * 4)
+        e["crf"][p] = crf
+        e["fin"][p] = e["finisher"].submit(self._e2e_finish, p, s_off, h_off, shapes)
+        # batch i + 2 -> the page-locked staging buffers batch i came from (every copy-in issued so far has finished)
+        e["io"].sync()
+        e["stage"][p] = self._e2e_stage(p)
+
+    def _e2e_feed(self, q):
+        """Copy-in of the batch staged in parity q's page-locked buffers, on the input stream, into device input buffer q."""
+        e = self.e2e
+        for f in (e["stage"][q] or self._e2e_stage(q)):
+            f.result()
+        e["stage"][q] = None
+        io = e["io"]
+        io.wait_for(self.ctx)  # the conv stack that read buffer q (two steps ago) has been enqueued before this point
         if e["u8"]:  # decoded images in: the dataset transform (resize, normalise, flip pair) runs on the device
+            io.h2d_async(e["u8d"][q], e["pin_u8"][q], int(self.u8_offs[-1]))
+            self._lib.msf_input_u8(io, e["u8d"][q], [im.shape[:2] for im in self.native], self.u8_offs[:-1], S,
+                                   (104.0, 117.0, 123.0), (255.0, 255.0, 255.0), e["x"][q], pre_div255=False, pair=True)
+        else:
+            io.h2d_async(e["x"][q], e["pin_in"][q], self.x_host.nbytes)
+
+    def _e2e_stage(self, p):
+        """Submits the host -> page-locked copy of one batch to the pool's threads; -> futures."""
+        np = self.np
+        e = self.e2e
+        if e["u8"]:
             buf = e["pin_u8"][p].view((int(self.u8_offs[-1]),), np.uint8)
 
             def _cp(k0, k1):
@@ -370,46 +457,26 @@ class Workload:
 
             nn = len(self.native)
             nchunk = min(8, nn)
-            for f in [e["pool"].submit(_cp, nn * c // nchunk, nn * (c + 1) // nchunk) for c in range(nchunk)]:
-                f.result()
-            self.ctx.h2d_async(self.u8_dev, e["pin_u8"][p], int(self.u8_offs[-1]))
-            self._lib.msf_input_u8(self.ctx, self.u8_dev, [im.shape[:2] for im in self.native], self.u8_offs[:-1], S,
-                                   (104.0, 117.0, 123.0), (255.0, 255.0, 255.0), self.x_dev, pre_div255=False, pair=True)
-        else:
-            # pageable -> page-locked staging copy of the 79 MB batch, split over the pool's threads (numpy releases the GIL
-            # for the copy; one thread moves ~9 GB/s and held every step at 8 ms)
-            dst = e["pin_in"][p].view(self.x_host.shape, np.float32)
-            nchunk = min(8, self.x_host.shape[0])
-            bounds = [self.x_host.shape[0] * c // nchunk for c in range(nchunk + 1)]
-            for f in [e["pool"].submit(np.copyto, dst[bounds[c]:bounds[c + 1]], self.x_host[bounds[c]:bounds[c + 1]])
-                      for c in range(nchunk)]:
-                f.result()
-            self.ctx.h2d_async(self.x_dev, e["pin_in"][p], self.x_host.nbytes)
-        self.run_cnn()
-        crf = self.crf_create()
-        self.run_tail()
-        _, _, s_off, h_off, shapes = self.tail_meta
-        self.ctx.d2h_async(e["pin_out"][p], self.strided_dev, max(self.s_tot, 1) * 4)
-        self.ctx.d2h_async(e["pin_out"][p], self.highres_dev, max(self.h_tot, 1) * 4, dst_offset=max(self.s_tot, 1) * 4)
-        self.run_unary()
-        if e["prev"] is not None:
-            self._e2e_finish(e["prev"])
-        self.ctx_crf.wait_for(self.ctx)
-        self.ctx_crf.wait_for(self.ctx_build)
-        self.crf_infer(crf, ctx=self.ctx_crf)
-        self.pending = crf
-        e["prev"] = (p, s_off, h_off, shapes)
+            return [e["pool"].submit(_cp, nn * c // nchunk, nn * (c + 1) // nchunk) for c in range(nchunk)]
+        # pageable -> page-locked staging copy of the 79 MB batch, split over the pool's threads (numpy releases the GIL
+        # for the copy; one thread moves ~9 GB/s)
+        dst = e["pin_in"][p].view(self.x_host.shape, np.float32)
+        nchunk = min(8, self.x_host.shape[0])
+        bounds = [self.x_host.shape[0] * c // nchunk for c in range(nchunk + 1)]
+        return [e["pool"].submit(np.copyto, dst[bounds[c]:bounds[c + 1]], self.x_host[bounds[c]:bounds[c + 1]])
+                for c in range(nchunk)]
 
     def drain_e2e(self):
         e = self.e2e
-        if e["prev"] is not None:
-            self._e2e_finish(e["prev"])
-            e["prev"] = None
+        for p in (self.parity ^ 1, self.parity):
+            self._e2e_retire(p)
         self.ctx.sync()
-        for fl in e["futs"]:
-            for f in fl:
+        e["io"].sync()
+        for st in e["stage"]:
+            for f in st or []:
                 f.result()
-        e["futs"] = [[], []]
+        e["stage"] = [None, None]
+        e["fed"] = False
 
     def timed(self, fn, reps):
         """Average device time of fn() over reps, HIP events on the ctx stream."""
@@ -827,7 +894,7 @@ def main():
             te = timed_run(wl, wl.step_e2e, k_extra, 2, wl.drain_e2e)
             stages["value_end_to_end"] = round(args.batch * k_extra / te, 3)
             stages["end_to_end"] = ("per step: 79 MB pageable float32 batch -> pinned -> H2D; D2H of cam + high_res (%.1f MB) and "
-                                    "label maps (%.1f MB); %d .npy files through 8 writer threads; overlapped with the next step"
+                                    "label maps (%.1f MB); %d .npy files through 8 writer threads; overlapped with the next step, whose staging copy the same threads make ahead of time"
                                     % ((wl.s_tot + wl.h_tot) * 4 / 1e6, args.batch * S * S * 4 / 1e6, 2 * args.batch))
             wl.setup_e2e(tmp, u8=True)
             te = timed_run(wl, wl.step_e2e, k_extra, 2, wl.drain_e2e)
@@ -836,6 +903,7 @@ def main():
                                              "per step); float64 resize + normalise + flip pair on the device, bit-identical"
                                              % (wl.u8_offs[-1] / 1e6))
             wl.e2e["pool"].shutdown(wait=True)
+            wl.e2e["finisher"].shutdown(wait=True)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
 

@@ -40,14 +40,33 @@ def _valid_cat(args, pack, score, model):
     return cat
 
 
+def save_npy_object(path, obj):
+    """`np.save(path, obj)` for a Python object (the reference stores a dict of arrays that way, make_cam.py:80-88), written so
+    that writer THREADS scale: same .npy container (0-d object array, `np.load(path, allow_pickle=True).item()` gives the same
+    dict, dtypes and shapes), but the pickle inside uses protocol 5, whose in-band buffers go from the arrays straight to the
+    file -- np.save's protocol 3 first copies every array into a bytes object with the GIL held, which serialised eight
+    writer threads (0.3 ms per image alone, 1.3 ms under contention: 85 thread-ms per 32-image step)."""
+    import pickle
+
+    from numpy.lib import format as npy_format
+
+    arr = np.empty((), dtype=object)
+    arr[()] = obj
+    if not str(path).endswith(".npy"):
+        path = str(path) + ".npy"  # np.save appends the extension
+    with open(path, "wb") as fp:
+        npy_format.write_array_header_1_0(fp, npy_format.header_data_from_array_1_0(arr))
+        pickle.dump(arr, fp, protocol=5)
+
+
 def _save(args, name, keys, strided, highres):
     path = os.path.join(args.cam_out_dir, name + ".npy")
     if len(keys) == 0:  # make_cam.py:86-88
-        np.save(path, {"keys": np.empty(0), "cam": np.empty(0), "high_res": np.empty(0)})
+        save_npy_object(path, {"keys": np.empty(0), "cam": np.empty(0), "high_res": np.empty(0)})
     elif args.dataset in ("deepglobe", "deepglobe_balanced"):  # make_cam.py:83-85
-        np.save(path, {"keys": keys, "cam": strided})
+        save_npy_object(path, {"keys": keys, "cam": strided})
     else:  # make_cam.py:80-82
-        np.save(path, {"keys": keys, "cam": strided, "high_res": highres})
+        save_npy_object(path, {"keys": keys, "cam": strided, "high_res": highres})
 
 
 def _scales_of(v):
