@@ -221,3 +221,28 @@ def test_eval_cam_colour_label_readers(tmp_path):
     assert eval_cam.DeepGlobeSegLabels("train", str(tmp_path), is_balanced=True).ids == ["c"]
     with pytest.raises(ValueError):
         eval_cam.ADPSegLabels("val", str(tmp_path), "func")
+
+
+def test_save_npy_object_loads_like_np_save(tmp_path):
+    """The writer threads' .npy writer (wsscam.step.make_cam.save_npy_object) against np.save on the three dictionaries of
+    make_cam.py:80-88: np.load(..., allow_pickle=True).item() -- what eval_cam.py:48, cam_to_ir_label.py:27 and
+    make_sem_seg_labels.py:61 do -- gives the same keys, dtypes, shapes and values; the extension is appended like np.save does."""
+    from wsscam.step.make_cam import save_npy_object
+
+    rng = np.random.default_rng(3)
+    cases = [
+        {"keys": np.array([3, 7], np.int64), "cam": rng.random((2, 94, 125), dtype=np.float32),
+         "high_res": rng.random((2, 375, 500), dtype=np.float32)},
+        {"keys": np.array([0, 1, 5], np.int64), "cam": rng.random((3, 153, 153), dtype=np.float32)},   # DeepGlobe: no high_res
+        {"keys": np.empty(0), "cam": np.empty(0), "high_res": np.empty(0)},                            # no class present
+        {"keys": np.array([1], np.int64), "cam": rng.random((4, 20, 30), dtype=np.float32)[1:2, ::2]},  # a non-contiguous view
+    ]
+    for i, d in enumerate(cases):
+        a, b = tmp_path / ("a%d" % i), tmp_path / ("b%d.npy" % i)
+        save_npy_object(str(a), d)  # no extension given
+        np.save(str(b), d)
+        got = np.load(str(a) + ".npy", allow_pickle=True).item()
+        ref = np.load(str(b), allow_pickle=True).item()
+        assert list(got.keys()) == list(ref.keys())
+        for k in ref:
+            assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), (i, k)
