@@ -615,3 +615,42 @@ def test_stem_pool_fused_equals_unfused(hw):
             outs.append(ctx.to_host(cd, (3, 20, hh, ww), np.float32))
     assert np.isfinite(outs[0]).all() and outs[0].max() > 0
     assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max() / outs[1].max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [_lib.PREC_F16X3, _lib.PREC_F16])
+def test_stage_entry_fusion_with_extreme_batchnorm_scales(precision):
+    """The first block of a stage runs conv3 and the projection shortcut as one GEMM with both BatchNorm scales folded into the
+    weights relative to sigma_c = max(|s3_c|, |sd_c|) (csrc/net.hip, resnet50.py:44-52).  BatchNorm parameters a real checkpoint
+    can hold: a zero-initialised bn3 (gamma = 0: the residual branch is off), a zero shortcut scale, both zero, negative scales,
+    and scales five orders of magnitude apart in the same channel -- the CAM must stay at the mode's bound against the oracle."""
+    from wsscam.net import resnet50_cam
+
+    sd = cnn_ref.make_resnet50_cam_state_dict(20, seed=4)
+    for li in (1, 2, 3, 4):
+        w3, wd = sd["resnet50.layer%d.0.bn3.weight" % li], sd["resnet50.layer%d.0.downsample.1.weight" % li]
+        n = w3.numel()
+        w3[0:n // 8] = 0.0                      # zero-initialised residual BatchNorm
+        wd[n // 16:n // 8 + n // 16] = 0.0      # ... overlapping a zero shortcut scale: channels with both, and with either
+        w3[n // 4:n // 4 + n // 8] *= -1.0      # negative scales
+        wd[n // 2:n // 2 + n // 8] *= -1.0
+        w3[3 * n // 4:3 * n // 4 + n // 16] *= 1e-5   # tiny next to the shortcut's
+        wd[7 * n // 8:7 * n // 8 + n // 16] *= 1e-5   # and the other way round
+    m = resnet50_cam.CAM(None, "voc12", "", 20, None, precision=precision)
+    m.load_state_dict(sd)
+    m.eval().cuda(0)
+    ctx = m.ctx
+    net = m._ensure_net()
+    rng = np.random.default_rng(11)
+    S = 97
+    img = cnn_ref.synth_image(rng, S, S)
+    xp = cnn_ref.msf_pack(img, None)
+    h = net.cam_size(S)
+    cd = ctx.alloc(20 * h * h * 4)
+    net.forward_cam(ctx.to_device(xp[None]), 1, S, cd)
+    cam = ctx.to_host(cd, (20, h, h), np.float32)
+    with torch.no_grad():
+        ref = cnn_ref.resnet50_cam_forward(torch.from_numpy(xp), sd).numpy()
+    assert np.isfinite(cam).all() and ref.max() > 0
+    tol = 2e-5 if precision == _lib.PREC_F16X3 else 5e-3
+    assert np.abs(cam - ref).max() <= tol * ref.max(), np.abs(cam - ref).max() / ref.max()
