@@ -246,7 +246,18 @@ int build_resnet50_backbone(wsc_net *net, const Dict &d) {
                 if (i != cur) f[nf++] = i;
             // Bottleneck.forward, resnet50.py:34-54; the stride sits on conv2 (resnet50.py:24)
             WSC_TRY(resnet_conv(net, d, pre + ".conv1", pre + ".bn1", 1, 0, 1, 0, cur, f[0], -1));
-            if (has(d, pre + ".downsample.0.weight") && fuse_shortcut) {
+            bool fuse_here = false;
+            if (has(d, pre + ".downsample.0.weight") && has(d, pre + ".conv3.weight") && fuse_shortcut) {
+                // (only for the shapes the concatenated GEMM takes: 1x1 kernels, K1 + K2 a multiple of the 64-channel K chunk;
+                // anything else keeps the separate projection conv + residual)
+                const HostTensor *w3, *wd;
+                WSC_TRY(get(d, pre + ".conv3.weight", 4, &w3));
+                WSC_TRY(get(d, pre + ".downsample.0.weight", 4, &wd));
+                fuse_here = wd->shape[0] == w3->shape[0] && w3->shape[2] == 1 && w3->shape[3] == 1 && wd->shape[2] == 1 &&
+                            wd->shape[3] == 1 && w3->shape[1] % 8 == 0 && wd->shape[1] % 8 == 0 &&
+                            (w3->shape[1] + wd->shape[1]) % 64 == 0;
+            }
+            if (fuse_here) {
                 // out = relu(bn3(conv3(y2)) + bn_d(conv_d(x)))  (resnet50.py:44-52) as ONE 1x1 conv over the concatenated channels
                 // [y2 | x at the block's stride]: conv2 writes its channel range of that tensor, the shortcut input is gathered
                 // beside it, and the two BatchNorm scales go into the weights -- relative to sigma_c = max(|s3_c|, |sd_c|), which
@@ -257,8 +268,6 @@ int build_resnet50_backbone(wsc_net *net, const Dict &d) {
                 WSC_TRY(get(d, pre + ".conv3.weight", 4, &w3));
                 WSC_TRY(get(d, pre + ".downsample.0.weight", 4, &wd));
                 const int Co = (int)w3->shape[0], K1 = (int)w3->shape[1], K2 = (int)wd->shape[1];
-                WSC_CHECK(wd->shape[0] == Co && w3->shape[2] == 1 && w3->shape[3] == 1 && wd->shape[2] == 1 && wd->shape[3] == 1 &&
-                          K1 % 8 == 0 && K2 % 8 == 0, WSC_ERR_SHAPE, "'%s': conv3 / downsample shapes do not match", pre.c_str());
                 std::vector<float> s3, b3, sd, bd;
                 WSC_TRY(fold_bn(d, pre + ".bn3", Co, 1e-5, s3, b3));
                 WSC_TRY(fold_bn(d, pre + ".downsample.1", Co, 1e-5, sd, bd));

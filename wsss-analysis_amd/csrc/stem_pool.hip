@@ -12,11 +12,12 @@
 //     A row pitch of 384 B (a multiple of 128) makes those reads conflict-free without a swizzle;
 //   * the weights ([64][7 K-steps x (32 hi | 32 lo)], the small_cin == 3 packing of net.hip make_conv) stream per kernel
 //     row through a ring of three 8 KB stages by LDS-DMA, swizzled like the B tiles of conv_igemm.hip;
-//   * BN + ReLU + the hi/lo rounding are applied to the accumulators, the tile goes to LDS as fp32 and the 3 x 3 / 2 maximum
-//     is taken there: only the pooled planes (1/4 of the pixels) are written.
-// Arithmetic: the per-accumulator MFMA sequence (kernel row, slice, lo*hi, hi*lo, hi*hi) is the one conv_igemm.hip runs and
-// each conv output is rounded to its hi + lo pair before the maximum, so the pooled planes are BIT-IDENTICAL to
-// conv_igemm + maxpool_f16x2_kernel (tests/test_gpu_conv.py::test_stem_pool_fused_equals_unfused).
+//   * BN + ReLU are applied to the accumulators, the tile goes to LDS as fp32 (nine tile rows at a time: 39 KB, three blocks
+//     per CU) and the 3 x 3 / 2 maximum is taken there: only the pooled planes (1/4 of the pixels) are written.
+// Arithmetic: the per-accumulator MFMA sequence (kernel row, slice, lo*hi, hi*lo, hi*hi) is the one conv_igemm.hip runs; the
+// two-launch form rounds every conv output to its (hi, lo) pair and the pool re-splits the maximum of those values -- the
+// rounding is monotone, so here both roundings are applied to the maximum only and the pooled planes are BIT-IDENTICAL to
+// conv_igemm + maxpool_f16x2_kernel (tests/test_gpu_edge.py::test_stem_pool_fused_equals_unfused).
 #include "common.h"
 #include <type_traits>
 
@@ -32,7 +33,7 @@ constexpr int PROWS = 2 * (TP - 1) + 7;  // 37 patch rows
 constexpr int PPIX = 2 * (TP - 1) + 8;   // 38 patch pixels per row (8-pixel window per kernel row)
 constexpr int PITCH = 384;          // bytes per patch row in LDS (48 pixels x 8 B; 2 * PITCH % 256 == 0: conflict-free reads)
 constexpr int PLANE = 14 * 1024;    // one patch plane = 14 DMA pieces of 1 KiB (37 * 384 = 14208 B used)
-constexpr int B_AT = 2 * PLANE;     // weight stages: NSTB x 8 KiB (the room the fp32 tile of the epilogue needs anyway)
+constexpr int B_AT = 2 * PLANE;     // weight stages: NSTB x 8 KiB
 constexpr int B_BYTES = 8192;
 constexpr int NSTB = 3;
 constexpr int CT_STRIDE = 68;       // fp32 tile rows of 64 + 4
