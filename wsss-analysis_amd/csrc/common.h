@@ -206,6 +206,10 @@ struct ConvLaunch {
     int fmt;       // 16-bit operand format: 0 bf16, 1 f16 (split 1 requires bf16, split 2 f16)
     int generic;   // 1: keep the generic kernel variants (testing: the FAST variants give the same bits)
     int ldy;       // row pitch of y / y_lo in elements; 0 = Cout (wider: the output is a channel range of a concatenated tensor)
+    // optional second input of a 1x1 / stride 1 layer: the last C2 of the Cin input channels of output pixel (n, ho, wo) come from
+    // x2[n][ho * stride2][wo * stride2][0 .. C2) instead of x (which then holds Cin - C2 channels per pixel); null: one input
+    const bf16_t *x2, *x2_lo;
+    int H2, W2, C2, stride2;
 };
 int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p);
 

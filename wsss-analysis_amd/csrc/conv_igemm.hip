@@ -70,6 +70,13 @@ struct ConvKArgs {
     int debug;          // WSC_CONV_DEBUG ablations (timing only, results are wrong): 1 = no DMA after the
                         // first two stages, 2 = no fragment reads / MFMAs
     long long lo_delta; // SPLIT 2: x_lo - x in elements (both planes live in one workspace block)
+    // second A source of a 1 x 1 layer (a ResNet stage's first block: conv3 and the projection shortcut as one GEMM, net.hip):
+    // channel chunks [0, cc2) come from x (dense [M][ldx]), chunks [cc2, cchunks) from x2 = [N][H2][W2][C2] at pixel
+    // (ho * stride2, wo * stride2) of the output pixel.  x2 == nullptr: one source.
+    const bf16_t *x2;
+    long long lo_delta2; // SPLIT 2: x2_lo - x2
+    int cc2, H2, W2, C2, stride2;
+    int ldx;            // pixel pitch of x in elements (Cin; the first source's channel count when there are two)
     int stem_rows;      // host side only: the padded-input stem form (a K-step = one kernel row of 8 pixels x 4 channels)
     int kw_real;        // host side only: kernel width of the layer (FLOP accounting; kw is 1 in the stem form)
 };
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
             const int mc = m < p.m_end ? m : p.m_end - 1;
             hb[i] = 0;
             wb[i] = 0;
-            base[i] = (long long)mc * p.Cin;
+            base[i] = (long long)mc * p.ldx;
         } else if (m < p.m_end) {
             const unsigned t1 = __umulhi(p.div_howo_mul, (unsigned)m);
             const int n = (int)((t1 + (((unsigned)m - t1) >> p.div_howo_s1)) >> p.div_howo_s2);
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
             const int wo = rem - ho * p.Wo;
             hb[i] = ho * p.stride - p.pad;
             wb[i] = wo * p.stride - p.pad;
-            base[i] = (((long long)n * p.H + hb[i]) * p.W + wb[i]) * (long long)p.Cin;
+            base[i] = (((long long)n * p.H + hb[i]) * p.W + wb[i]) * (long long)p.ldx;
         } else {
             hb[i] = -(1 << 28);
             wb[i] = 0;
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
         const int tap = ktl - cc * p.ntaps;
         const int khi = tap / p.kw;
         const int kwi = tap - khi * p.kw;
-        const long long tap_off = ((long long)khi * p.W + kwi) * p.Cin + cc * 64;
+        const long long tap_off = ((long long)khi * p.W + kwi) * p.ldx + cc * 64;
         char *sa = smem + buf * A_BYTES + wv * 4096;
         char *sb = smem + STAGES * A_BYTES + buf * B_BYTES + wv * (NB * 1024);
 #pragma unroll
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
             const int tap = ktl - cc * p.ntaps;
             const int khi = tap / p.kw;
             const int kwi = tap - khi * p.kw;
-            const long long tap_off = ((long long)khi * p.W + kwi) * p.Cin + cc * 64 + slot * 8;
+            const long long tap_off = ((long long)khi * p.W + kwi) * p.ldx + cc * 64 + slot * 8;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hi = hb[i] + khi, wi = wb[i] + kwi;
@@ -407,8 +414,32 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
         int n_wk = 0;
         auto prep = [&]() {
             n_src = (SPLIT == 1 && n_seg == 1) ? p.x_lo : p.x;
-            n_tap = ((long long)n_khi * p.W + n_kwi) * p.Cin + n_cc * CK;
+            n_tap = ((long long)n_khi * p.W + n_kwi) * p.ldx + n_cc * CK;
+            if (SPLIT != 1 && p.x2 != nullptr && n_cc >= p.cc2) { // second source (1 x 1 layers only): its own chunk count
+                n_src = p.x2;
+                n_tap = (n_cc - p.cc2) * CK;
+            }
             n_wk = ((SPLIT == 1 && n_seg == 2) ? p.Kbase : 0) + n_ktl * 64;
+        };
+        // The K loop crosses into the second source once per block: the lanes' row offsets are decoded again for ITS geometry
+        // (same registers -- every piece of the first source has been issued by then)
+        auto second_source = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + lrow + RSTEP * i;
+                const unsigned mc = (unsigned)(m < p.m_end ? m : p.m_end - 1);
+                const unsigned t1 = __umulhi(p.div_howo_mul, mc);
+                const int n = (int)((t1 + ((mc - t1) >> p.div_howo_s1)) >> p.div_howo_s2);
+                const int rem = (int)mc - n * p.HoWo;
+                const unsigned t2 = __umulhi(p.div_wo_mul, (unsigned)rem);
+                const int ho = (int)((t2 + (((unsigned)rem - t2) >> p.div_wo_s1)) >> p.div_wo_s2);
+                const int wo = rem - ho * p.Wo;
+                const long long b2 = (((long long)n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * (long long)p.C2;
+                const int r = lrow + RSTEP * i;
+                const int ks = slot ^ ((r >> 1) & 7);
+                if (SPLIT == 2) aoff[i] = b2 + (ks & 3) * 8 + ((ks & 4) ? p.lo_delta2 : 0ll);
+                else aoff[i] = b2 + ks * 8;
+            }
         };
         auto advance = [&]() {
             // K order (channel chunk, kh, kw): the taps of one 64-channel chunk are consecutive K-steps
@@ -417,6 +448,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                 n_kwi = 0;
                 if (++n_khi == p.kh) {
                     n_khi = 0;
+                    if (SPLIT != 1 && p.x2 != nullptr && n_cc + 1 == p.cc2) second_source();
                     if (++n_cc == p.cchunks) {
                         n_cc = 0;
                         n_ktl = 0;
@@ -1044,6 +1076,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     a.y = p.y; a.y_lo = p.y_lo; a.y_f32 = p.y_f32;
     a.H = p.H; a.W = p.W; a.Cin = p.Cin; a.Ho = p.Ho; a.Wo = p.Wo; a.Cout = p.Cout;
     a.ldy = p.ldy > 0 ? p.ldy : p.Cout;
+    a.ldx = p.Cin; a.x2 = nullptr; a.lo_delta2 = 0; a.cc2 = 0; a.H2 = a.W2 = a.C2 = 0; a.stride2 = 1;
     a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.relu = p.relu;
     a.M = p.N * p.Ho * p.Wo;
     a.m_base = 0;
@@ -1094,6 +1127,18 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     a.Kw = a.Kbase * ((p.split && !single_staged) ? 2 : 1);
     a.nk = a.ksteps_base * ((p.split && !single_staged) ? 3 : 1);
     a.lo_delta = single_staged ? (long long)(p.x_lo - p.x) : 0;
+    if (p.x2 != nullptr) { // two A sources: [x (Cin - C2 channels, dense) | x2 at (ho, wo) * stride2 (C2 channels)]
+        const int K1 = p.Cin - p.C2;
+        WSC_CHECK(p.split != 1 && small_cin_eff == 0 && p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && K1 > 0 &&
+                  K1 % 64 == 0 && p.C2 % 64 == 0 && p.stride2 >= 1 && (p.Ho - 1) * p.stride2 < p.H2 && (p.Wo - 1) * p.stride2 < p.W2 &&
+                  (!single_staged || p.x2_lo != nullptr),
+                  WSC_ERR_INVALID, "conv: a second input needs a 1x1 / stride 1 layer, channel counts in multiples of 64 and no bf16x3");
+        a.x2 = p.x2;
+        a.lo_delta2 = single_staged ? (long long)(p.x2_lo - p.x2) : 0;
+        a.cc2 = K1 / (single_staged ? 32 : 64);
+        a.H2 = p.H2; a.W2 = p.W2; a.C2 = p.C2; a.stride2 = p.stride2;
+        a.ldx = K1;
+    }
     const int BN = p.CoutPad % 128 == 0 ? 128 : 64;
     WSC_CHECK(p.CoutPad % 64 == 0, WSC_ERR_INVALID, "conv: CoutPad=%d not a multiple of 64", p.CoutPad);
     a.ntiles_n = p.CoutPad / BN;
@@ -1143,6 +1188,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     if (force == 512) square = small_cin_eff == 0 && p.CoutPad % 256 == 0;
     if (force != 0 && force != 512) square = false;
     if (p.split == 2) big = false; // (the three-buffer 256 x 128 tile has no single-staged variant)
+    if (p.x2 != nullptr) big = false; // (nor a second A source)
     if (p.split == 2 && !a.fast) square = false; // (its generic epilogue next to 128 accumulators + both planes' fragments spills)
     // f16x3 K-steps are 32 channels: with fewer than 16 of them (K < 512: layer2's 128 -> 512 and 256 -> 512 convs) the 256 x 256
     // block's prologue + two-group epilogue outweigh its smaller staging traffic (sweep: 109 vs 127 us, 149 vs 162 us)

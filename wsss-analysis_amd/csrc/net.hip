@@ -56,6 +56,7 @@ struct Op {
     int pk, ps, pp;   // pool kernel / stride / pad (OP_GATHER: ps = pixel stride)
     int pitch = 0;    // channels per output row when the op writes a channel range of a wider (concatenated) tensor, else 0
     int coff = 0;     // first channel of that range
+    int in2 = -1;     // OP_CONV, 1x1: buffer whose pixels (ho * ps, wo * ps) supply the LAST input channels (ConvLaunch::x2), or -1
 };
 
 } // namespace
@@ -283,15 +284,25 @@ int build_resnet50_backbone(wsc_net *net, const Dict &d) {
                 HostTensor wt;
                 wt.data = wc.data(); wt.ndim = 4; wt.shape[0] = Co; wt.shape[1] = K1 + K2; wt.shape[2] = 1; wt.shape[3] = 1;
                 WSC_TRY(resnet_conv(net, d, pre + ".conv2", pre + ".bn2", s, 1, 1, 0, f[0], f[1], -1));
-                net->ops.back().pitch = K1 + K2;
-                net->ops.back().coff = 0;
-                Op g;
-                g.type = OP_GATHER; g.conv = -1; g.in = cur; g.out = f[1]; g.res = -1; g.pk = 1; g.ps = s; g.pp = 0;
-                g.pitch = K1 + K2; g.coff = K1;
-                net->ops.push_back(g);
                 ConvW c;
                 WSC_TRY(make_conv(net, &wt, 1, 0, 1, 0, sig, sh, nullptr, nullptr, &c));
-                WSC_TRY(add_conv_op(net, c, f[1], f[0], -1));
+                if (net->split != 1) {
+                    // the kernel reads the two inputs where they are: channel chunks [0, K1) from conv2's output, the rest from
+                    // the block input at the block's stride (conv_igemm.hip, second A source)
+                    WSC_TRY(add_conv_op(net, c, f[1], f[0], -1));
+                    net->ops.back().in2 = cur;
+                    net->ops.back().ps = s;
+                } else {
+                    // bf16x3 (three K segments per source): the concatenated tensor is materialised -- conv2 writes its channel
+                    // range, the shortcut input is gathered beside it
+                    net->ops.back().pitch = K1 + K2;
+                    net->ops.back().coff = 0;
+                    Op g;
+                    g.type = OP_GATHER; g.conv = -1; g.in = cur; g.out = f[1]; g.res = -1; g.pk = 1; g.ps = s; g.pp = 0;
+                    g.pitch = K1 + K2; g.coff = K1;
+                    net->ops.push_back(g);
+                    WSC_TRY(add_conv_op(net, c, f[1], f[0], -1));
+                }
                 cur = f[0];
                 continue;
             }
@@ -602,6 +613,11 @@ int plan_dims(const wsc_net *net, int N, int SH, int SW, Plan *pl) {
             Ho = (H + 2 * c.pad - c.kh) / c.stride + 1;
             Wo = (W + 2 * c.pad - c.kw) / c.stride + 1;
             Co = op.pitch ? op.pitch : c.Cout;
+            if (op.in2 >= 0) {
+                WSC_CHECK(c.kh == 1 && c.kw == 1 && c.stride == 1 && (H - 1) * op.ps < bh[op.in2] && (W - 1) * op.ps < bw[op.in2],
+                          WSC_ERR_INVALID, "internal: second input of a %d x %d layer does not cover its %d x %d output", c.kh, c.kw, H, W);
+                C += bc[op.in2];
+            }
             WSC_CHECK(C == c.Cin, WSC_ERR_INVALID, "internal: channel mismatch %d vs %d", C, c.Cin);
         } else if (op.type == OP_GATHER) {
             Ho = (H - 1) / op.ps + 1;
@@ -699,6 +715,10 @@ int run_backbone(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int N, in
             L.res = op.res >= 0 ? buf[op.res] : nullptr;
             L.res_lo = op.res >= 0 ? buf_lo[op.res] : nullptr;
             L.y = buf[op.out]; L.y_lo = buf_lo[op.out]; L.y_f32 = nullptr;
+            if (op.in2 >= 0) {
+                L.x2 = buf[op.in2]; L.x2_lo = buf_lo[op.in2];
+                L.H2 = bh[op.in2]; L.W2 = bw[op.in2]; L.C2 = bc[op.in2]; L.stride2 = op.ps;
+            }
             L.ldy = op.pitch; // (0: dense)
             if (op.pitch) {
                 L.y += op.coff;
