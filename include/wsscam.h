@@ -342,6 +342,16 @@ int wsc_msf_input_u8(wsc_ctx *ctx, const uint8_t *images_dev, int B, const int32
                      const int64_t *offset_host, int S, const float *mean3_host, const float *std3_host,
                      int pre_div255, int pair, float *x_dev);
 
+/* cv2.resize(uint8 HWC image, (OW, OH)) with the default INTER_LINEAR, for a batch of images of different sizes:
+ * read_batch of 02_cues/utilities.py:172-176 and 03c_hsn/utilities.py:170-181 keeps the resized batch as uint8, so the network
+ * input AND the CRF image are OpenCV's 8-bit result.  OpenCV's 8U path is fixed point (11-bit coefficients, two passes, the
+ * vertical pass (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2; exact 2 x 2 decimation = rounded box mean);
+ * restated from the published algorithm, cv2 itself is absent offline (parity vs cv2 unpinned).
+ *   images_dev uint8: image b is the HWC block [H0_b][W0_b][3] at byte offset_host[b];  size_hw_host int32 [B][2];
+ *   out_dev uint8 [B][OH][OW][3]. */
+int wsc_resize_u8(wsc_ctx *ctx, const uint8_t *images_dev, int B, const int32_t *size_hw_host, const int64_t *offset_host,
+                  int OH, int OW, uint8_t *out_dev);
+
 /* F.interpolate(mode='bilinear', align_corners=False) on float32 [C][h][w] -> [C][H][W]
  * (make_cam.py:64-69; also resize_stack 02_cues/utilities.py:20-40 up to the
  * cv2/torch border convention). */

@@ -68,3 +68,87 @@ def get_cs_gradcam(gradcam, classes, htt_class):
 
 def pass_classes(probs_i):
     return np.where(np.sum(np.sum(probs_i, axis=1), axis=1) > 0)[0]
+
+
+def cv2_resize_u8(img, dsize_wh):
+    """cv2.resize(uint8 HWC image, (w, h)) with INTER_LINEAR as OpenCV computes it for 8-bit images (read_batch of
+    02_cues/utilities.py:172-176, 03c_hsn/utilities.py:176-181): OpenCV's published fixed-point algorithm
+    (modules/imgproc/src/resize.cpp: resizeGeneric_ with HResizeLinear<uchar,int,short> + VResizeLinear<uchar,...>,
+    INTER_RESIZE_COEF_BITS = 11), restated as its two passes with explicit loops.  cv2 is not in this image: unpinned
+    against cv2 itself; the product's numpy / HIP versions are checked against THIS statement bit for bit."""
+    import math
+    import struct
+
+    def f32(x):
+        return struct.unpack("f", struct.pack("f", x))[0]
+
+    def rne(x):  # cvRound: nearest, ties to even
+        r = math.floor(x)
+        d = x - r
+        if d > 0.5 or (d == 0.5 and r % 2 == 1):
+            r += 1
+        return int(r)
+
+    img = np.asarray(img, dtype=np.uint8)
+    sh, sw = img.shape[:2]
+    dw, dh = int(dsize_wh[0]), int(dsize_wh[1])
+    if (sh, sw) == (dh, dw):
+        return img.copy()
+    src = img.astype(np.int64)
+    if sw == 2 * dw and sh == 2 * dh:  # INTER_LINEAR with scale exactly 2 x 2 is run as INTER_AREA (fast)
+        out = np.zeros((dh, dw, 3), np.uint8)
+        for y in range(dh):
+            for x in range(dw):
+                out[y, x] = (src[2 * y, 2 * x] + src[2 * y, 2 * x + 1] + src[2 * y + 1, 2 * x] + src[2 * y + 1, 2 * x + 1] + 2) >> 2
+        return out
+    scale_x, scale_y = 1.0 / (dw / sw), 1.0 / (dh / sh)
+    xofs, ialpha = [], []
+    for dx in range(dw):
+        fx = f32((dx + 0.5) * scale_x - 0.5)
+        sx = math.floor(fx)
+        fx = f32(fx - sx)
+        if sx < 0:
+            fx, sx = 0.0, 0
+        if sx >= sw - 1:
+            fx, sx = 0.0, sw - 1
+        xofs.append(sx)
+        ialpha.append((rne(f32(f32(1.0 - fx) * 2048.0)), rne(f32(fx * 2048.0))))
+    out = np.zeros((dh, dw, 3), np.uint8)
+    for dy in range(dh):
+        fy = f32((dy + 0.5) * scale_y - 0.5)
+        sy = math.floor(fy)
+        fy = f32(fy - sy)
+        b0, b1 = rne(f32(f32(1.0 - fy) * 2048.0)), rne(f32(fy * 2048.0))
+        r0, r1 = min(max(sy, 0), sh - 1), min(max(sy + 1, 0), sh - 1)
+        for dx in range(dw):
+            sx = xofs[dx]
+            a0, a1 = ialpha[dx]
+            sx1 = min(sx + 1, sw - 1)
+            S0 = src[r0, sx] * a0 + src[r0, sx1] * a1
+            S1 = src[r1, sx] * a0 + src[r1, sx1] * a1
+            v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
+            out[dy, dx] = np.clip(v, 0, 255)
+    return out
+
+
+def read_batch_u8(images, size_hw):
+    """The uint8 batch of read_batch (02_cues/utilities.py:172-176; 03c_hsn/utilities.py:170-181)."""
+    return np.stack([cv2_resize_u8(im, (size_hw[1], size_hw[0])) for im in images])
+
+
+# ---- ADP class bookkeeping (03c_hsn/adp_cues.py:20-58), restated here so the oracle chain owns its tables ----------------------
+ADP_MORPH = ["E.M.S", "E.M.U", "E.M.O", "E.T.S", "E.T.U", "E.T.O", "E.P", "C.D.I", "C.D.R", "C.L", "H.E", "H.K", "H.Y",
+             "S.M.C", "S.M.S", "S.E", "S.C.H", "S.R", "A.W", "A.B", "A.M", "M.M", "M.K", "N.P", "N.R.B", "N.R.A", "N.G.M",
+             "N.G.W"]
+ADP_FUNC = ["G.O", "G.N", "T"]
+
+
+def adp_class_tables(all_classes=None):
+    """(classes, classinds) dicts of ADPCues.__init__ for the 31-class models."""
+    classes = {"all": list(all_classes) if all_classes is not None else ADP_MORPH + ADP_FUNC, "morph": ADP_MORPH,
+               "func": ADP_FUNC, "valid_morph": ["Background"] + ADP_MORPH, "valid_func": ["Background", "Other"] + ADP_FUNC}
+    inds = {}
+    for htt in ("morph", "func"):
+        inds[htt + "2valid"] = [i for i, x in enumerate(classes["valid_" + htt]) if x in classes[htt]]
+        inds["all2" + htt] = [i for i, x in enumerate(classes["all"]) if x in classes["valid_" + htt]]
+    return classes, inds

@@ -2,6 +2,8 @@
 # Same-box A/B of two builds of the library: put the two .so files under ab_tmp/ (untracked, travels with gpurun) and run
 #   gpurun -- 'bash profiles/lib_ab.sh ab_tmp/lib_base.so ab_tmp/lib_new.so'
 # Alternates base / new twice: pipelined ms per step, then (no pipeline) step, lattice build, mean-field loop, update_splat us, build us.
+cp wsss-analysis_amd/wsscam/libwsscam.so /tmp/lib_ship.so
+trap 'cp /tmp/lib_ship.so wsss-analysis_amd/wsscam/libwsscam.so' EXIT  # the shipped library comes back whatever happens
 for rep in 1 2; do for v in "$1" "$2"; do
   cp "$v" wsss-analysis_amd/wsscam/libwsscam.so
   echo "== $v"

@@ -165,21 +165,26 @@ def label_parity(lab, ref, n_class):
             "images": int(len(ref))}
 
 
-def oracle_chain_hsn_adp(images, sd, alpha, thr, cfgs, all_classes=None):
+def oracle_chain_hsn_adp(images, sd, alpha, thr, cfgs, all_classes=None, size=None, adipose_as_written=True):
     """The reference chain of 03c_hsn/demo.py:271-380 (ADP) for a list of (S, S, 3) uint8 patches, all fp32 / float64 on the
     CPU: VGG16 features (torch) -> sigmoid scores -> Grad-CAM einsum -> bilinear upsample, ReLU, / max, x score x pass ->
     per HTT type: valid-class stack, modify_by_htt (background / other channels, 03c_hsn/utilities.py:306-364),
     get_cs_gradcam (:367-397), dense CRF on the classes with mass (:399-445, oracle/densecrf_ref.c).
-    sd: torch state dict; alpha (F, C); thr: scalar threshold; cfgs {'morph', 'func'} 6-vectors.
+    sd: torch state dict; alpha (F, C); thr: scalar threshold; cfgs {'morph', 'func'} 6-vectors; size: the network size the
+    patches are resized to first (ADPCues.read_batch, adp_cues.py:122-128: cv2.resize into a uint8 batch -- the oracle's own
+    loop statement of OpenCV's 8-bit rule); None = the patches are at the network size.  The class tables are the oracle's
+    own (oracle/hsn_ref.py), not the product's.  adipose_as_written: demo.py:368-369 takes the positions of A.W / A.B / A.M in
+    classes['morph'] and indexes the VALID morph stack with them (channel 0 = Background: the maps picked are S.R, A.W, A.B);
+    False = the evidently intended channels, only to show that a test can tell the two apart.
     Returns {'morph': [label maps], 'func': [label maps]}."""
     import scipy.ndimage
     import scipy.special
     import torch
 
-    from oracle import cnn_ref
-    from wsscam.hsn import demo as hsn_demo
+    from oracle import cnn_ref, hsn_ref
 
-    raw = np.stack(images)
+    raw = np.stack(images) if size is None else hsn_ref.read_batch_u8(images, (size, size))
+    images = list(raw)
     n, S = raw.shape[0], raw.shape[1]
     x = (raw - 193.09203) / 56.450138
     xt = torch.from_numpy(np.transpose(x, (0, 3, 1, 2)).astype(np.float32).copy())
@@ -191,12 +196,12 @@ def oracle_chain_hsn_adp(images, sd, alpha, thr, cfgs, all_classes=None):
     up = np.maximum(torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cams, (0, 3, 1, 2))), (S, S),
                                                     mode="bilinear", align_corners=False).numpy(), 0)
     H = up / np.maximum(up.max(axis=(1, 2, 3), keepdims=True), 1e-7) * (sc * (sc >= thr))[:, :, None, None]
-    ac = hsn_demo.ADPClasses(all_classes)
+    a_classes, a_inds = hsn_ref.adp_class_tables(all_classes)
     Y, out = {}, {"morph": [], "func": []}
     for htt in ("morph", "func"):
-        valid = ac.classes["valid_" + htt]
+        valid = a_classes["valid_" + htt]
         Y[htt] = np.zeros((n, len(valid), S, S))
-        Y[htt][:, ac.classinds[htt + "2valid"]] = H[:, ac.classinds["all2" + htt]]
+        Y[htt][:, a_inds[htt + "2valid"]] = H[:, a_inds["all2" + htt]]
         bgm = np.stack([scipy.ndimage.gaussian_filter(0.75 * scipy.special.expit(4 * (raw[i].mean(-1) - 240)), sigma=2)
                         for i in range(n)])
         if htt == "morph":
@@ -204,7 +209,8 @@ def oracle_chain_hsn_adp(images, sd, alpha, thr, cfgs, all_classes=None):
         else:
             Y[htt][:, 0] = bgm - Y[htt][:, [valid.index(c) for c in ("G.O", "G.N", "T")]].max(1)
             other = 0.05 * (1 - Y[htt].max(1))
-            adi = Y["morph"][:, [ac.classes["morph"].index(c) for c in ("A.W", "A.B", "A.M")]]
+            adi = Y["morph"][:, [(a_classes["morph"] if adipose_as_written else a_classes["valid_morph"]).index(c)
+                                 for c in ("A.W", "A.B", "A.M")]]
             Y[htt][:, 1] = np.maximum(other, adi.max(1))
         srt = np.sort(Y[htt], axis=1)
         cs = (srt[:, -1] - srt[:, -2])[:, None] * (np.arange(len(valid))[None, :, None, None] == Y[htt].argmax(1)[:, None])

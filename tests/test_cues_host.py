@@ -251,3 +251,27 @@ def test_keras_store_settings_sessions_and_csv(tmp_path, monkeypatch):
         ks.Dataset("VOC2012", 321, 4, layout="hsn")  # no default directory in the HSN class
     with pytest.raises(ValueError):
         ks.Dataset("DeepGlobe_train75", 224, 4, database_dir=st["DATA_ROOT"], layout="hsn")  # a 02_cues name
+
+
+def test_adp_adipose_channels_follow_the_reference():
+    """03c_hsn/demo.py:347-371 (twin: 02_cues/demo.py:296-310): the functional 'Other' channel takes
+    `Y_gradcam['morph'][:, adipose_inds]` with adipose_inds = positions of A.W / A.B / A.M in classes['morph'] -- but
+    Y_gradcam['morph'] is the VALID stack (channel 0 = Background), so the maps are S.R, A.W, A.B.  The device driver reads
+    the all-class stack directly: its channel list must select exactly the maps the reference's expression selects."""
+    from oracle import hsn_ref
+    from wsscam.hsn import demo as hsn_demo
+
+    rng = np.random.default_rng(4)
+    for all_classes in (None, list(reversed(hsn_ref.ADP_MORPH + hsn_ref.ADP_FUNC))):
+        classes, inds = hsn_ref.adp_class_tables(all_classes)
+        H = rng.random((2, len(classes["all"]), 3, 3))
+        Y = np.zeros((2, len(classes["valid_morph"]), 3, 3))            # demo.py:353-355
+        Y[:, inds["morph2valid"]] = H[:, inds["all2morph"]]
+        adipose_inds = [i for i, x in enumerate(classes["morph"]) if x in ["A.W", "A.B", "A.M"]]  # demo.py:368
+        ref = Y[:, adipose_inds]                                        # demo.py:369
+        got = H[:, hsn_demo.adipose_source_channels(hsn_demo.ADPClasses(all_classes))]
+        assert np.array_equal(got, ref)
+        if all_classes is None:
+            assert [classes["all"][c] for c in hsn_demo.adipose_source_channels(hsn_demo.ADPClasses())] == ["S.R", "A.W", "A.B"]
+    ac = hsn_demo.ADPClasses()
+    assert (ac.classes, ac.classinds) == hsn_ref.adp_class_tables()

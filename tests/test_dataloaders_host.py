@@ -193,6 +193,48 @@ def test_resize_bilinear_f64_against_cv2_rule():
     assert np.all(voc_dl.resize_bilinear_f64(np.full((9, 7, 3), 4.25), (15, 3)) == 4.25)
 
 
+def test_resize_bilinear_u8_cv2_fixed_point_rule():
+    """read_batch of 02_cues/utilities.py:172-176, 03c_hsn/utilities.py:170-181 and the ADP twins keep the resized batch as
+    uint8: cv2.resize's 8-bit INTER_LINEAR result (11-bit fixed-point coefficients, two passes, truncating shifts).  cv2 is
+    absent offline, so the vectorised host version is checked bit for bit against the oracle's loop statement of OpenCV's
+    published algorithm (oracle/hsn_ref.py::cv2_resize_u8), plus properties the fixed-point rule must have: constants are
+    kept, a same-size call copies, an exact 2 x 2 decimation is the rounded box mean, and the result stays within one
+    level of the float64 bilinear value (the rule TorchvisionResize's float path follows) -- but is NOT its rounding or
+    truncation everywhere, which is why the drivers must not quantise the float path."""
+    from oracle import hsn_ref
+
+    rng = np.random.default_rng(9)
+    n_diff_round = n_diff_trunc = 0
+    for (H, W), out in (((7, 5), (11, 13)), ((20, 31), (9, 8)), ((1, 6), (4, 4)), ((6, 1), (3, 7)), ((12, 12), (12, 12)),
+                        ((37, 50), (64, 64)), ((24, 18), (12, 9)), ((50, 67), (33, 33)), ((33, 50), (65, 65))):
+        img = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        got = voc_dl.resize_bilinear_u8(img, out)
+        ref = hsn_ref.cv2_resize_u8(img, (out[1], out[0]))
+        assert got.dtype == np.uint8 and got.shape == ref.shape == (out[0], out[1], 3)
+        assert np.array_equal(got, ref), ((H, W), out, np.abs(got.astype(int) - ref.astype(int)).max())
+        if (H, W) == (2 * out[0], 2 * out[1]):
+            v = img.astype(np.int64)
+            assert np.array_equal(got, ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+            continue
+        f = voc_dl.resize_bilinear_f64(img, out)
+        assert np.abs(got.astype(np.float64) - f).max() <= 1.0 + 1e-9
+        n_diff_round += int((got != np.clip(np.rint(f), 0, 255).astype(np.uint8)).sum())
+        n_diff_trunc += int((got != f.astype(np.uint8)).sum())
+    assert n_diff_round > 0 and n_diff_trunc > 0
+    for v in (0, 1, 127, 254, 255):
+        assert np.all(voc_dl.resize_bilinear_u8(np.full((9, 7, 3), v, np.uint8), (15, 4)) == v)
+    img = rng.integers(0, 256, (5, 6, 3)).astype(np.uint8)
+    same = voc_dl.resize_bilinear_u8(img, (5, 6))
+    assert np.array_equal(same, img) and same is not img
+    # the drivers' batch reader without a device: uint8 out, normalisation from the uint8 values (02_cues/utilities.py:177-180)
+    from wsscam.cues import demo as cues_demo
+
+    ims = [rng.integers(0, 256, (30, 40, 3)).astype(np.uint8), rng.integers(0, 256, (33, 33, 3)).astype(np.uint8)]
+    norm, raw = cues_demo.read_batch(ims, (33, 33), [104, 117, 123], [255, 255, 255])
+    assert raw.dtype == np.uint8 and np.array_equal(raw, hsn_ref.read_batch_u8(ims, (33, 33)))
+    assert np.array_equal(norm, (raw - np.float64([104, 117, 123])) / 255.0)
+
+
 def test_eval_cam_colour_label_readers(tmp_path):
     """Ground-truth readers of the ADP / DeepGlobe eval_cam branch (adp_semantic_segmentation_dataset.py:33-70,
     deepglobe_semantic_segmentation_dataset.py:21-64): split -> id list, colour PNG -> class index (an unlisted colour

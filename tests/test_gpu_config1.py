@@ -38,7 +38,7 @@ def test_config1_vgg16_val_predicted_labels_to_eval_cam(tmp_path):
     # thresholds (what common_cnn._load_pretrained leaves in the module, max(optimalScoreThresh, 1/3), is a per-class
     # vector): image 0 must fail every class (forced arg-max, vgg16_cam.py:41-42) while other images pass some.  Per
     # class the threshold sits in the middle of the widest gap of the 16 scores above image 0's, so every score keeps
-    # a margin the device precision (bf16x3: <= 1e-4 on a score) respects.
+    # a margin the device precision (f16x3, the headline mode: <= 2e-5 on a score) respects.
     scores = np.stack([r[1] for r in ref])                      # (16, C)
     j_none = 0
     thresholds = np.zeros(C, np.float32)
@@ -60,11 +60,12 @@ def test_config1_vgg16_val_predicted_labels_to_eval_cam(tmp_path):
     args = argparse.Namespace(cam_network="net.vgg16_cam", model_dir=None, dataset="voc12", tag="VOC2012_VGG16", num_classes=C,
                               use_cls=list(range(C)), model_id="vgg16", state_dict=sd_dev, split="val", dataset_obj=packs,
                               cam_out_dir=str(tmp_path / "cam_val"), outsize=(S, S), n_gpus=1, cam_batch_images=8,
-                              cam_precision=_lib.PREC_BF16X3, cam_weights_name=str(tmp_path / "unused"), norm_mode="int",
+                              cam_precision=_lib.PREC_F16X3, cam_weights_name=str(tmp_path / "unused"), norm_mode="int",
                               val_list=None, dev_root=None, cam_scales=(1.0,), class_names={"bg": ["background"], "fg": VOC_FG})
     make_cam.run(args)
 
     n_forced = 0
+    worst = 0.0
     pred_ref, gts = [], []
     for i, p in enumerate(packs):
         cam, score = ref[i]
@@ -78,13 +79,16 @@ def test_config1_vgg16_val_predicted_labels_to_eval_cam(tmp_path):
         assert sorted(d) == ["cam", "high_res", "keys"]
         assert d["keys"].dtype == np.int64 and np.array_equal(d["keys"], valid.numpy())
         assert d["cam"].shape == tuple(strided.shape) and d["high_res"].shape == tuple(hi.shape)
-        # bf16x3 (16-bit effective mantissa per operand) through the 15-conv VGG16 stack at 321^2: 3.0e-4 measured on
-        # the max-normalised maps (ResNet50: 1.2e-4); stated tolerance 5e-4
-        assert np.abs(d["cam"] - strided.numpy()).max() <= 5e-4 and np.abs(d["high_res"] - hi.numpy()).max() <= 5e-4
+        # f16x3 (the headline mode, 22-bit operands) through the 15-conv VGG16 stack at 321^2 on the max-normalised maps:
+        # BASELINE.md section 4's FP32 bar, 1e-4 (bf16x3 measured 3.0e-4 here, which is why it is not the default)
+        err = max(np.abs(d["cam"] - strided.numpy()).max(), np.abs(d["high_res"] - hi.numpy()).max())
+        worst = max(worst, float(err))
+        assert err <= 1e-4, (p["name"], err)
         cams = np.pad(hi.numpy(), ((1, 0), (0, 0), (0, 0)), mode="constant", constant_values=0.15)  # eval_cam.py:50
         keys = np.pad(valid.numpy() + 1, (1, 0), mode="constant")                                   # eval_cam.py:51
         pred_ref.append(keys[np.argmax(cams, axis=0)])
     assert n_forced >= 1 and not (scores[j_none] >= thresholds).any()
+    print("config 1 (VGG16 @321, f16x3): max |cam - oracle| on the normalised maps = %.2e" % worst)
 
     # ---- eval_cam on the files ------------------------------------------------------------------------------
     class Seg:

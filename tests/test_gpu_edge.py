@@ -376,17 +376,28 @@ def test_full_config_batch_properties(ctx):
 
     B, S, C = 32, 321, 20
     sd = cnn_ref.make_resnet50_cam_state_dict(C, seed=0)
-    m = resnet50_cam.CAM(None, "voc12", "", C, None, precision=_lib.PREC_F16)
-    m.load_state_dict(sd)
-    m.eval().cuda(0)
     rng = np.random.default_rng(77)
     imgs = [cnn_ref.synth_image(rng, S, S) for _ in range(B)]
     x = np.stack([cnn_ref.msf_pack(im, (S, S)) for im in imgs])
-    cam = m.forward_batch(x)
-    assert cam.shape == (B, C, 21, 21) and np.isfinite(cam).all() and (cam >= 0).all()
-    for b in (0, 17, 31):
-        assert np.array_equal(m.forward_batch(x[b:b + 1])[0], cam[b])
-    assert np.array_equal(m.forward_batch(x), cam)
+    cams = {}
+    for precision in (_lib.PREC_F16, _lib.PREC_F16X3):  # the fast mode and the headline mode (its 256 x 256 tiles at 64 samples)
+        m = resnet50_cam.CAM(None, "voc12", "", C, None, precision=precision)
+        m.load_state_dict(sd)
+        m.eval().cuda(0)
+        cam = m.forward_batch(x)
+        assert cam.shape == (B, C, 21, 21) and np.isfinite(cam).all() and (cam >= 0).all()
+        for b in (0, 17, 31):
+            assert np.array_equal(m.forward_batch(x[b:b + 1])[0], cam[b]), (precision, b)
+        assert np.array_equal(m.forward_batch(x), cam)
+        cams[precision] = cam
+        del m
+    # the two modes compute the same maps to the fast mode's stated tolerance; the headline mode against the oracle on one image
+    nrm = lambda c: c / (c.max(axis=(2, 3), keepdims=True) + 1e-5)
+    assert np.abs(nrm(cams[_lib.PREC_F16]) - nrm(cams[_lib.PREC_F16X3])).max() <= 2e-2
+    with torch.no_grad():
+        rc = cnn_ref.resnet50_cam_forward(torch.from_numpy(x[5]), sd).numpy()
+    assert np.abs(nrm(cams[_lib.PREC_F16X3][5:6])[0] - rc / (rc.max(axis=(1, 2), keepdims=True) + 1e-5)).max() <= 1e-4
+    cam = cams[_lib.PREC_F16X3]
 
     M = C + 1
     hi = np.stack([np.stack([np.full((S, S), 0.15, np.float32)] + [cnn_ref.resize_bilinear_f64(

@@ -44,6 +44,27 @@ def test_msf_input_bit_identical(ctx, mode):
     assert np.array_equal(ctx.to_host(x_dev, ref.shape, np.float32), ref)
 
 
+def test_resize_u8_device_bit_identical(ctx):
+    """wsc_resize_u8 (cv2.resize on uint8, fixed point: read_batch of 02_cues / 03c_hsn) == the numpy statement == the
+    oracle's loop statement, bit for bit, on VOC-like, ADP-like and degenerate sizes incl. the 2 x 2 decimation shortcut."""
+    from oracle import hsn_ref
+    from wsscam.cues import demo as cues_demo
+
+    rng = np.random.default_rng(11)
+    for (oh, ow), shapes in (((321, 321), [(375, 500), (500, 333), (321, 321), (97, 640), (642, 642)]),
+                             ((224, 224), [(272, 272), (224, 224), (1, 7), (448, 448)]), ((40, 56), [(33, 90), (80, 112)])):
+        imgs = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for h, w in shapes]
+        dev, offs, sizes = _pack_u8(ctx, imgs)
+        out_dev = ctx.alloc(len(imgs) * oh * ow * 3)
+        _lib.resize_u8(ctx, dev, sizes, offs, (oh, ow), out_dev)
+        got = ctx.to_host(out_dev, (len(imgs), oh, ow, 3), np.uint8)
+        ref = np.stack([voc_dl.resize_bilinear_u8(im, (oh, ow)) for im in imgs])
+        assert np.array_equal(got, ref), ((oh, ow), np.abs(got.astype(int) - ref.astype(int)).max())
+        assert np.array_equal(cues_demo.read_batch_u8(imgs, (oh, ow), ctx=ctx), ref)
+    small = [rng.integers(0, 256, (23, 31, 3)).astype(np.uint8), rng.integers(0, 256, (40, 20, 3)).astype(np.uint8)]
+    assert np.array_equal(cues_demo.read_batch_u8(small, (33, 33), ctx=ctx), hsn_ref.read_batch_u8(small, (33, 33)))
+
+
 def test_make_cam_device_transform_same_files(tmp_path):
     rng = np.random.default_rng(6)
     sd = synth.resnet50_cam_state_dict(20, seed=2)

@@ -177,7 +177,7 @@ def test_make_sem_seg_labels_end_to_end(tmp_path):
     a1 = types.SimpleNamespace(cam_network="net.resnet50_cam", model_dir=None, dataset="voc12", tag="", num_classes=20,
                                use_cls=None, model_id="resnet50", cam_weights_name=None, state_dict=cam_sd,
                                dataset_obj=data, split="train_aug", cam_out_dir=str(cam_dir), n_gpus=1,
-                               cam_batch_images=4, cam_precision=_lib.PREC_BF16X3)
+                               cam_batch_images=4, cam_precision=_lib.PREC_F16X3)
     make_cam.run(a1)
     irn_sd = irn_ref.make_vgg16_irn_state_dict(seed=5)
     colours = {"bg": np.array([(0, 0, 0)]), "fg": np.array([(8 * i + 8, 255 - 8 * i, 17 * (i % 15)) for i in range(20)])}
@@ -185,7 +185,7 @@ def test_make_sem_seg_labels_end_to_end(tmp_path):
                                use_cls=None, irn_weights_name=None, state_dict=irn_sd, dataset_obj=data, split="train_aug",
                                cam_out_dir=str(cam_dir), sem_seg_out_dir=str(seg_dir), sem_seg_clr_out_dir=str(clr_dir),
                                beta=10, exp_times=8, sem_seg_bg_thres=0.25, class_colours=colours, overlay_r=0.75,
-                               n_gpus=1, irn_crop_size=96, irn_precision=_lib.PREC_BF16X3)
+                               n_gpus=1, irn_crop_size=96, irn_precision=_lib.PREC_F16X3)
     make_sem_seg_labels.run(a2)
     for d in data:
         png = np.asarray(Image.open(seg_dir / (d["name"] + ".png")))
@@ -220,7 +220,7 @@ def test_sem_seg_other_datasets(dataset):
     from wsscam.step import make_sem_seg_labels as mssl
 
     sd = irn_ref.make_vgg16_irn_state_dict(seed=7, batchnorm=dataset != "adp_func")
-    m = vgg16_irn.EdgeDisplacement(None, dataset, "", 5, None, crop_size=96, stride=4, precision=_lib.PREC_BF16X3)
+    m = vgg16_irn.EdgeDisplacement(None, dataset, "", 5, None, crop_size=96, stride=4, precision=_lib.PREC_F16X3)
     m.load_state_dict(sd)
     m.eval().cuda(0)
     rng = np.random.default_rng(12)

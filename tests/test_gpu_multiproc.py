@@ -19,7 +19,7 @@ def _args(out_dir, packs, sd, n_gpus, ids=None):
     return argparse.Namespace(cam_network="net.resnet50_cam", model_dir=None, dataset="voc12", tag="", num_classes=20,
                               use_cls=list(range(20)), model_id="resnet50", state_dict=sd, split="train_aug", dataset_obj=packs,
                               cam_out_dir=out_dir, outsize=(97, 97), n_gpus=n_gpus, cam_batch_images=3, cam_device_ids=ids,
-                              cam_precision=_lib.PREC_F16, cam_weights_name="unused", norm_mode="int", val_list=None,
+                              cam_precision=_lib.PREC_F16X3, cam_weights_name="unused", norm_mode="int", val_list=None,
                               dev_root=None, cam_scales=(1.0,), class_names={"bg": ["background"], "fg": ["c%d" % i for i in range(20)]})
 
 

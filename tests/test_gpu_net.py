@@ -180,21 +180,22 @@ def test_vgg16_cam(precision, batchnorm):
                                                        _lib.PREC_BF16X3: 1e-4, _lib.PREC_F16X3: 2e-5}[precision]
 
 
-def test_m7_cam():
+@pytest.mark.parametrize("precision,tol", [(_lib.PREC_F16X3, 1e-4), (_lib.PREC_BF16X3, 2e-4)])
+def test_m7_cam(precision, tol):
     C = 20
     sd = cnn_ref.make_plain_state_dict("m7", cnn_ref.M7_CFG, C, True, seed=2)
     alpha = cnn_ref.grad_cam_weights(sd, "m7", cnn_ref.M7_CFG, 32, C)  # (F, C), 02_cues/utilities.py:60-99
     sd_dev = dict(sd)
     sd_dev["gradcam_weights"] = torch.from_numpy(alpha.astype(np.float32))
-    model = _model(m7_cam.CAM, sd_dev, C, _lib.PREC_BF16X3)
+    model = _model(m7_cam.CAM, sd_dev, C, precision)
     rng = np.random.default_rng(5)
     x = cnn_ref.msf_pack(cnn_ref.synth_image(rng, 70, 60), (64, 64))
     cam, score = model.forward_batch(x[None], want_score=True)
     with torch.no_grad():
         rcam, rscore = cnn_ref.m7_cam_forward(torch.from_numpy(x), sd, torch.from_numpy(alpha), C)
     assert cam[0].shape == tuple(rcam.shape) == (C, 16, 16)
-    assert np.abs(cam[0] - rcam.numpy()).max() <= 2e-4 * max(float(rcam.max()), 1e-3)
-    assert np.abs(score[0] - rscore.numpy()).max() <= 1e-4
+    assert np.abs(cam[0] - rcam.numpy()).max() <= tol * max(float(rcam.max()), 1e-3)
+    assert np.abs(score[0] - rscore.numpy()).max() <= tol
 
 
 def test_state_dict_errors(ctx, resnet_sd):
@@ -214,7 +215,7 @@ def test_state_dict_errors(ctx, resnet_sd):
 # ---- 02_cues / 03c_hsn Grad-CAM mirrors -------------------------------------------------------------
 def _vgg_model(C, seed):
     sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, True, seed=seed)
-    return _model(vgg16_cam.CAM, sd, C, _lib.PREC_BF16X3), sd
+    return _model(vgg16_cam.CAM, sd, C, _lib.PREC_F16X3), sd  # the package default / headline mode
 
 
 def test_get_grad_cam_weights_closed_form_vs_autograd():
@@ -236,8 +237,10 @@ def test_cues_grad_cam_and_resize_stack():
     C = 20
     model, sd = _vgg_model(C, seed=4)
     rng = np.random.default_rng(6)
-    imgs = np.stack([cnn_ref.normalize_int(cnn_ref.resize_bilinear_f64(cnn_ref.synth_image(rng, 70, 80), (65, 65)))
-                     for _ in range(3)])                                  # (B, S, S, 3) NHWC as read_batch gives
+    from oracle import hsn_ref
+
+    # (B, S, S, 3) NHWC as read_batch gives it: the uint8 batch of cv2.resize, normalised (02_cues/utilities.py:172-180)
+    imgs = cnn_ref.normalize_int(hsn_ref.read_batch_u8([cnn_ref.synth_image(rng, 70, 80) for _ in range(3)], (65, 65)).astype(np.float64))
     alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 65, C)
     keep = np.array([0, 2, 5, 19])
     is_pass = rng.random((3, len(keep))) > 0.3
@@ -247,7 +250,7 @@ def test_cues_grad_cam_and_resize_stack():
                                       cnn_ref.VGG16_CFG).numpy().astype(np.float64)
     ref = np.maximum(np.einsum("ijkl,lm->ijkm", conv_val, alpha), 0)[:, :, :, keep] * is_pass[:, None, None, :]
     assert out.shape == ref.shape == (3, 8, 8, 4)
-    assert np.abs(out - ref).max() <= 2e-4 * ref.max()
+    assert np.abs(out - ref).max() <= 1e-4 * ref.max()  # f16x3, the package default
     # resize_stack to the 41x41 seed size vs torch bilinear (cv2 INTER_LINEAR has the same half-pixel centres)
     st = np.transpose(ref, (0, 3, 1, 2))
     rs = cues.resize_stack(st, (41, 41), ctx=model.ctx)
@@ -262,8 +265,10 @@ def test_hsn_grad_cam_and_postprocessing():
     C = 20
     model, sd = _vgg_model(C, seed=5)
     rng = np.random.default_rng(7)
+    from oracle import hsn_ref
+
     raw = [cnn_ref.synth_image(rng, 70, 80) for _ in range(2)]
-    imgs = np.stack([cnn_ref.normalize_int(cnn_ref.resize_bilinear_f64(im, (65, 65))) for im in raw])
+    imgs = cnn_ref.normalize_int(hsn_ref.read_batch_u8(raw, (65, 65)).astype(np.float64))
     alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 65, C)
     scores = rng.random((2, C))
     is_pass = scores > 0.4
@@ -276,7 +281,7 @@ def test_hsn_grad_cam_and_postprocessing():
     up = np.maximum(np.transpose(up, (0, 2, 3, 1)), 0)
     ref = up / np.maximum(up.max(axis=(1, 2, 3), keepdims=True), 1e-7) * (scores * is_pass)[:, None, None, :]
     assert out.shape == ref.shape == (2, 65, 65, C)
-    assert np.abs(out - ref).max() <= 5e-4
+    assert np.abs(out - ref).max() <= 1e-4  # maps normalised to a maximum of 1; f16x3
 
     # get_cs_gradcam: margin on the arg-max class only; 'Other' passes through for func
     g = rng.random((2, 4, 5, 6))
@@ -369,7 +374,8 @@ def test_gen_cues_driver(tmp_path):
     fg, sd_fg = _vgg_model(C, seed=8)
     bg, sd_bg = _vgg_model(C, seed=9)
     rng = np.random.default_rng(10)
-    images = [cnn_ref.synth_image(rng, 321, 321) for _ in range(3)]  # already at the network size
+    # two images need resizing (read_batch: cv2.resize to a uint8 batch, 02_cues/utilities.py:172-176), one is at the network size
+    images = [cnn_ref.synth_image(rng, 300, 340), cnn_ref.synth_image(rng, 375, 500), cnn_ref.synth_image(rng, 321, 321)]
     labels = (rng.random((3, C)) < 0.2).astype(np.float64)
     labels[:, 3] = 1
     alphas = {"fg": cnn_ref.grad_cam_weights(sd_fg, "vgg16", cnn_ref.VGG16_CFG, 33, C),
@@ -379,8 +385,14 @@ def test_gen_cues_driver(tmp_path):
                              images=images, labels=labels, out_dir=str(tmp_path), is_verbose=False)
     saved = pickle.load(open(tmp_path / "localization_cues.pickle", "rb"))
     assert sorted(saved) == sorted(out) == sorted(["%d_%s" % (i, k) for i in range(3) for k in ("cues", "labels")])
-    # restatement with the oracle network (batch maxima are per batch of 2: Q7)
-    x = np.stack([cnn_ref.normalize_int(im.astype(np.float64)) for im in images])
+    # restatement with the oracle network (batch maxima are per batch of 2: Q7); the ORACLE quantises the batch itself
+    # (oracle/hsn_ref.py's loop statement of OpenCV's 8-bit resize), so a driver that normalised an un-rounded resize would
+    # feed the network inputs up to 1/255 away and move the thresholded seeds
+    from oracle import hsn_ref
+
+    batch_u8 = hsn_ref.read_batch_u8(images, (321, 321))
+    assert batch_u8.dtype == np.uint8
+    x = np.stack([cnn_ref.normalize_int(im.astype(np.float64)) for im in batch_u8])
     ref = {}
     for lo, hi in ((0, 2), (2, 3)):
         Hm, ip = {}, {}
@@ -406,8 +418,8 @@ def test_gen_cues_driver(tmp_path):
         assert (la == lb).mean() >= 0.995  # thresholded maps: a pixel on the 0.2 x max contour may flip
 
 
-@pytest.mark.parametrize("quirk", [False, True])
-def test_hsn_segment_driver(quirk):
+@pytest.mark.parametrize("quirk,resized", [(False, False), (True, False), (False, True), (True, True)])
+def test_hsn_segment_driver(quirk, resized):
     """03c_hsn/demo.py:18-268 (VOC2012 branch) end to end at the real 321 x 321 size: scores -> 1/3 threshold ->
     HSN Grad-CAM -> batch-max background channel -> dense CRF; labels vs the oracle chain (torch net, numpy
     post-processing, C CRF).  quirk: the reference's actual VOC normalisation (utilities.py:142-146: uint8 wrap-around on
@@ -419,15 +431,22 @@ def test_hsn_segment_driver(quirk):
     C = 5
     sd_fg = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, True, seed=11)
     sd_bg = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, True, seed=12)
-    fg = _model(vgg16_cam.CAM, sd_fg, C, _lib.PREC_BF16X3)
-    bg = _model(vgg16_cam.CAM, sd_bg, C, _lib.PREC_BF16X3)
+    fg = _model(vgg16_cam.CAM, sd_fg, C, _lib.PREC_F16X3)
+    bg = _model(vgg16_cam.CAM, sd_bg, C, _lib.PREC_F16X3)
     rng = np.random.default_rng(13)
-    images = [cnn_ref.synth_image(rng, 321, 321) for _ in range(2)]
+    if resized:  # read_batch's uint8 contract (03c_hsn/utilities.py:170-181): cv2.resize into a uint8 batch, on the path
+        images = [cnn_ref.synth_image(rng, 375, 500), cnn_ref.synth_image(rng, 300, 290)]
+    else:
+        images = [cnn_ref.synth_image(rng, 321, 321) for _ in range(2)]
     alphas = {"fg": cnn_ref.grad_cam_weights(sd_fg, "vgg16", cnn_ref.VGG16_CFG, 33, C),
               "bg": cnn_ref.grad_cam_weights(sd_bg, "vgg16", cnn_ref.VGG16_CFG, 33, C)}
     out = hsn_demo.segment("VOC2012", "VGG16", 2, models={"fg": fg, "bg": bg}, alphas=alphas, images=[im.copy() for im in images],
                            is_verbose=False, reference_normalize_quirk=quirk)
     assert len(out) == 2 and out[0].shape == (321, 321)
+    if resized:  # the oracle chain quantises on its own: the loop statement of OpenCV's 8-bit INTER_LINEAR
+        from oracle import hsn_ref
+
+        images = list(hsn_ref.read_batch_u8(images, (321, 321)))
     if quirk:
         batch = np.stack(images)          # normalize('VOC2012', img_batch) of the reference, verbatim
         batch[:, :, 0] -= 104
@@ -502,6 +521,37 @@ def test_hsn_segment_adp_driver(precision, min_agree):
             assert agree >= min_agree, (htt, b, agree)
 
 
+def test_hsn_adp_driver_resized_patches_and_adipose_indexing():
+    """segment_adp on 272 x 272 patches at a 224 network size: (1) ADPCues.read_batch's uint8 contract (adp_cues.py:122-128:
+    cv2.resize into a uint8 batch -- the oracle quantises with its own loop statement of OpenCV's 8-bit rule); (2) the
+    reference's adipose indexing (demo.py:368-369: positions in classes['morph'] applied to the valid stack = S.R, A.W, A.B;
+    the bookkeeping itself is pinned on the host by tests/test_cues_host.py::test_adp_adipose_channels_follow_the_reference).
+    S.R is forced to pass and the true adipose classes to fail, on patches that are tissue everywhere, so that the functional
+    'Other' channel is where the two indexings differ most (printed)."""
+    from tests.test_gpu_edge import _adp_like_image
+    from wsscam.hsn import demo as hsn_demo
+
+    C, S = 31, 224
+    sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, False, seed=23)
+    model = _model(vgg16_cam.CAM, sd, C, _lib.PREC_F16X3)
+    rng = np.random.default_rng(24)
+    images = [cnn_ref.synth_image(rng, 272, 272), _adp_like_image(rng, 272, 272)]
+    alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 33, C)
+    thr = np.full((1, C), 0.5)
+    thr[0, 17], thr[0, 18:21] = 0.0, 2.0  # S.R always passes, A.W / A.B / A.M never
+    cfgs = {"morph": np.array([3 / 2, 3, 80 / 2, 13, 10, 3]), "func": np.array([3, 3, 50, 5, 10, 3])}
+    out = hsn_demo.segment_adp(model, alpha, thr, images, cfgs, S, 2)
+    ref = helpers.oracle_chain_hsn_adp(images, sd, alpha, thr, cfgs, size=S)
+    other = helpers.oracle_chain_hsn_adp(images, sd, alpha, thr, cfgs, size=S, adipose_as_written=False)
+    for htt in ("morph", "func"):
+        for b in range(2):
+            agree = (out[htt][b] == ref[htt][b]).mean()
+            print("hsn adp resized %s image %d: label agreement %.5f" % (htt, b, agree))
+            assert agree >= 0.99, (htt, b, agree)
+    sep = min((other["func"][b] == ref["func"][b]).mean() for b in range(2))
+    print("hsn adp: reference vs intended adipose indexing agree on %.4f of the func labels" % sep)
+
+
 def test_gen_cues_adp_driver(tmp_path):
     """02_cues/demo.py:224-310: ADP seeds for both HTT types from one 31-class model; checks the cue layout, that
     every cue class is a passing class (plus the synthesised Background / Other), and the restated chain for morph."""
@@ -512,20 +562,21 @@ def test_gen_cues_adp_driver(tmp_path):
 
     from tests.test_gpu_edge import _adp_like_image
     from wsscam.cues import demo as cues_demo
+    from oracle import hsn_ref
     from wsscam.cues import utilities as cues
-    from wsscam.hsn.demo import ADPClasses
 
     C, S = 31, 224
     sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, False, seed=31)
-    model = _model(vgg16_cam.CAM, sd, C, _lib.PREC_BF16X3)
+    model = _model(vgg16_cam.CAM, sd, C, _lib.PREC_F16X3)
     rng = np.random.default_rng(32)
-    images = [_adp_like_image(rng, S, S) for _ in range(3)]
+    # ADP patches are 272 x 272 and the network runs at 224: ADPCues.read_batch resizes into a uint8 batch (adp_cues.py:122-128)
+    images = [_adp_like_image(rng, 272, 272), _adp_like_image(rng, 272, 272), _adp_like_image(rng, S, S)]
     alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 33, C)
     dirs = {"morph": str(tmp_path / "m"), "func": str(tmp_path / "f")}
     out = cues_demo.gen_cues_adp("VGG16", 0.2, 2, S, dirs, "tuning", False, model=model, alpha=alpha,
                                  thresholds=np.full((1, C), 0.5), images=images)
     assert pickle.load(open(tmp_path / "m" / "localization_cues.pickle", "rb")).keys() == out["morph"].keys()
-    raw = np.stack(images)
+    raw = hsn_ref.read_batch_u8(images, (S, S))  # the oracle's own uint8 batch
     xt = torch.from_numpy(np.transpose((raw - 193.09203) / 56.450138, (0, 3, 1, 2)).astype(np.float32).copy())
     with torch.no_grad():
         feat = cnn_ref.plain_features(xt, sd, "vgg16", cnn_ref.VGG16_CFG)
@@ -535,18 +586,18 @@ def test_gen_cues_adp_driver(tmp_path):
     cam = np.maximum(np.einsum("ijkl,lm->ijkm", np.transpose(feat.numpy(), (0, 2, 3, 1)).astype(np.float64), alpha), 0)
     H = torch.nn.functional.interpolate(torch.from_numpy(np.transpose(cam * ip[:, None, None, :], (0, 3, 1, 2))), (41, 41),
                                         mode="bilinear", align_corners=False).numpy()
-    ac = ADPClasses()
-    valid = ac.classes["valid_morph"]
+    a_classes, a_inds = hsn_ref.adp_class_tables()
+    valid = a_classes["valid_morph"]
     ref = {}
     for lo, hi in ((0, 2), (2, 3)):
         seeds = np.zeros((hi - lo, len(valid), 41, 41))
-        seeds[:, ac.classinds["morph2valid"]] = H[lo:hi][:, ac.classinds["all2morph"]]
+        seeds[:, a_inds["morph2valid"]] = H[lo:hi][:, a_inds["all2morph"]]
         bgm = np.stack([scipy.ndimage.gaussian_filter(0.75 * scipy.special.expit(4 * (raw[i].mean(-1) - 240)), sigma=2)
                         for i in range(lo, hi)])
         bgm = torch.nn.functional.interpolate(torch.from_numpy(bgm)[:, None], (41, 41), mode="bilinear",
                                               align_corners=False).numpy()[:, 0]
         seeds[:, 0] = bgm - seeds[:, [valid.index(c) for c in ("A.W", "A.B", "A.M")]].max(1)
-        ci = [np.array(ac.classinds["morph2valid"])[ip[i][:28]] for i in range(lo, hi)]
+        ci = [np.array(a_inds["morph2valid"])[ip[i][:28]] for i in range(lo, hi)]
         cues.update_cues_adp(ref, seeds, ci, list(range(lo, hi)), 0.2)
     for i in range(3):
         assert np.array_equal(out["morph"]["%d_labels" % i], ref["%d_labels" % i])

@@ -532,6 +532,7 @@ int wsc_cam_eval_confusion(wsc_ctx *ctx, const float *highres_dev, int B, const 
                  kb = ((size_t)std::max(nkeys, 1) * sizeof(int32_t) + 15) / 16 * 16;
     char *d = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + kb + 16, (void **)&d));
+    WscCachedGuard d_guard(ctx, d);
     std::vector<char> stage(jb + kb + 16, 0); // the last 16 bytes: out-of-range counter, zeroed
     memcpy(stage.data(), jobs.data(), jobs.size() * sizeof(EvalJob));
     if (nkeys > 0) memcpy(stage.data() + jb, keys_host, (size_t)nkeys * sizeof(int32_t));
@@ -544,7 +545,7 @@ int wsc_cam_eval_confusion(wsc_ctx *ctx, const float *highres_dev, int B, const 
     unsigned n_bad = 0;
     WSC_HIP(hipMemcpyAsync(&n_bad, d + jb + kb, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     WSC_HIP(hipStreamSynchronize(ctx->stream));
-    wsc_ctx_cached_free(ctx, d);
+    d_guard.free_now();
     WSC_CHECK(n_bad == 0, WSC_ERR_INVALID,
               "wsc_cam_eval_confusion: %u pixels carry a ground-truth label outside [0, %d) (and != ignore_label %d)", n_bad,
               n_class, ignore_label);
@@ -585,6 +586,7 @@ int wsc_cam_eval_confusion_nn(wsc_ctx *ctx, const float *maps_dev, int B, const 
     const size_t jb = (jobs.size() * sizeof(EvalNNJob) + 15) / 16 * 16, kb = ((size_t)nkeys * sizeof(int32_t) + 15) / 16 * 16;
     char *d = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + kb + 16, (void **)&d));
+    WscCachedGuard d_guard(ctx, d);
     std::vector<char> stage(jb + kb + 16, 0); // the last 16 bytes: out-of-range counter, zeroed
     memcpy(stage.data(), jobs.data(), jobs.size() * sizeof(EvalNNJob));
     memcpy(stage.data() + jb, keys_host, (size_t)nkeys * sizeof(int32_t));
@@ -597,7 +599,7 @@ int wsc_cam_eval_confusion_nn(wsc_ctx *ctx, const float *maps_dev, int B, const 
     unsigned n_bad = 0;
     WSC_HIP(hipMemcpyAsync(&n_bad, d + jb + kb, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     WSC_HIP(hipStreamSynchronize(ctx->stream));
-    wsc_ctx_cached_free(ctx, d);
+    d_guard.free_now();
     WSC_CHECK(n_bad == 0, WSC_ERR_INVALID,
               "wsc_cam_eval_confusion_nn: %u pixels carry a ground-truth label outside [0, %d) (and != ignore_label %d)", n_bad,
               n_class, ignore_label);
@@ -631,6 +633,7 @@ int wsc_label_confusion_nn(wsc_ctx *ctx, const int32_t *labels_dev, int B, const
     const size_t jb = (jobs.size() * sizeof(EvalNNJob) + 15) / 16 * 16;
     char *d = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + 16, (void **)&d));
+    WscCachedGuard d_guard(ctx, d);
     std::vector<char> stage(jb + 16, 0); // the last 16 bytes: out-of-range counter, zeroed
     memcpy(stage.data(), jobs.data(), jobs.size() * sizeof(EvalNNJob));
     WSC_TRY(wsc_ctx_upload_small(ctx, d, stage.data(), stage.size()));
@@ -642,7 +645,7 @@ int wsc_label_confusion_nn(wsc_ctx *ctx, const int32_t *labels_dev, int B, const
     unsigned n_bad = 0;
     WSC_HIP(hipMemcpyAsync(&n_bad, d + jb, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     WSC_HIP(hipStreamSynchronize(ctx->stream));
-    wsc_ctx_cached_free(ctx, d);
+    d_guard.free_now();
     WSC_CHECK(n_bad == 0, WSC_ERR_INVALID,
               "wsc_label_confusion_nn: %u pixels carry a label or a ground-truth label outside [0, %d) (and != ignore_label %d)", n_bad,
               n_class, ignore_label);
@@ -682,6 +685,7 @@ int wsc_sem_seg_finish(wsc_ctx *ctx, const float *rw_dev, int B, const int64_t *
                  mb = ((size_t)B * sizeof(unsigned) + 15) / 16 * 16;
     char *d = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + kb + mb, (void **)&d));
+    WscCachedGuard d_guard(ctx, d);
     std::vector<char> stage(jb + kb + mb, 0); // the maxima start at code 0 = "below every real number"
     memcpy(stage.data(), jobs.data(), jobs.size() * sizeof(SemSegJob));
     memcpy(stage.data() + jb, keys_host, (size_t)nkeys * sizeof(int32_t));
@@ -693,7 +697,7 @@ int wsc_sem_seg_finish(wsc_ctx *ctx, const float *rw_dev, int B, const int64_t *
     hipLaunchKernelGGL(sem_seg_finish_kernel<true>, grid, dim3(256), 0, ctx->stream, rw_dev, (const SemSegJob *)d,
                        (const int32_t *)(d + jb), has_bg, bg_thres, (unsigned int *)(d + jb + kb), label_dev);
     WSC_HIP(hipGetLastError());
-    wsc_ctx_cached_free(ctx, d); // stream-ordered reuse
+    d_guard.free_now(); // stream-ordered reuse
     return WSC_OK;
 }
 
@@ -765,6 +769,7 @@ static int cam_unary_impl(wsc_ctx *ctx, const float *cam_dev, int B, int C, int 
     const int Hu = ((H0 - 1) / 16 + 1) * 16, Wu = ((W0 - 1) / 16 + 1) * 16;
     unsigned int *mx = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(unsigned int) * (size_t)B * C, (void **)&mx));
+    WscCachedGuard mx_guard(ctx, mx);
     WSC_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned int) * (size_t)B * C, ctx->stream));
     const int n = H0 * W0;
     WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, (double)B * (C + 1) * n * 4);
@@ -785,7 +790,7 @@ static int cam_unary_impl(wsc_ctx *ctx, const float *cam_dev, int B, int C, int 
         hipLaunchKernelGGL((cam_unary_kernel<32, true>), ugrid, dim3(256), lds, ctx->stream, cam_dev, C, h, w, H0, W0, Hu, Wu,
                            (const unsigned int *)mx, bg_value, unary_dev);
     WSC_HIP(hipGetLastError());
-    wsc_ctx_cached_free(ctx, mx); // stream-ordered reuse
+    mx_guard.free_now(); // stream-ordered reuse
     return WSC_OK;
 }
 
@@ -828,6 +833,7 @@ int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h,
     const size_t jb = jobs.size() * sizeof(TailJob), mb = jobs.size() * 2 * sizeof(unsigned int);
     char *d = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, jb + mb, (void **)&d));
+    WscCachedGuard d_guard(ctx, d);
     WSC_TRY(wsc_ctx_upload_small(ctx, d, jobs.data(), jb)); // through pinned staging: no host sync
     WSC_HIP(hipMemsetAsync(d + jb, 0, mb, ctx->stream));
     const dim3 grid((max_pix + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, (unsigned)jobs.size());
@@ -850,7 +856,7 @@ int wsc_cam_postprocess(wsc_ctx *ctx, const float *cam_dev, int B, int C, int h,
     hipLaunchKernelGGL(cam_tail_kernel<true>, grid, dim3(256), lds, ctx->stream, cam_dev, (const TailJob *)d, h, w,
                        (unsigned int *)(d + jb), strided_dev, highres_dev);
     WSC_HIP(hipGetLastError());
-    wsc_ctx_cached_free(ctx, d); // stream-ordered reuse
+    d_guard.free_now(); // stream-ordered reuse
     return WSC_OK;
 }
 

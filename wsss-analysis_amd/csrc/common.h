@@ -182,6 +182,20 @@ struct WscKernelTimer {
 };
 int wsc_ctx_cached_alloc(wsc_ctx *ctx, size_t bytes, void **out);
 void wsc_ctx_cached_free(wsc_ctx *ctx, void *p);
+// Scope guard of a cached block: an early `return` of WSC_TRY / WSC_HIP / WSC_CHECK gives the block back too
+// (free_now() at the usual place keeps the stream-ordered reuse exactly where it was).
+struct WscCachedGuard {
+    wsc_ctx *ctx;
+    void *p;
+    WscCachedGuard(wsc_ctx *c, void *q) : ctx(c), p(q) {}
+    WscCachedGuard(const WscCachedGuard &) = delete;
+    WscCachedGuard &operator=(const WscCachedGuard &) = delete;
+    void free_now() {
+        if (p) wsc_ctx_cached_free(ctx, p);
+        p = nullptr;
+    }
+    ~WscCachedGuard() { free_now(); }
+};
 // copies `bytes` of host data to dst_dev through the ctx's pinned staging buffer, asynchronously
 int wsc_ctx_upload_small(wsc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 

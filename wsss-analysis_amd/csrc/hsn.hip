@@ -302,6 +302,7 @@ int wsc_hsn_gradcam_post(wsc_ctx *ctx, const float *cams_nhwc_dev, int B, int h,
     WSC_HIP(hipSetDevice(ctx->device));
     unsigned int *mx = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(unsigned int) * (size_t)B, (void **)&mx));
+    WscCachedGuard mx_guard(ctx, mx);
     WSC_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned int) * (size_t)B, ctx->stream));
     // bands of output rows: a few blocks per CU over the B * C maps
     int nb = std::max(1, std::min(S, (4 * ctx->num_cus + B * C - 1) / (B * C)));
@@ -314,7 +315,7 @@ int wsc_hsn_gradcam_post(wsc_ctx *ctx, const float *cams_nhwc_dev, int B, int h,
     hipLaunchKernelGGL(hsn_gradcam_post_kernel<true>, grid, dim3(256), lds, ctx->stream, cams_nhwc_dev, h, w, C, S, gate_dev, mx,
                        out_dev, out_channels, out_first, band);
     WSC_HIP(hipGetLastError());
-    wsc_ctx_cached_free(ctx, mx); // stream-ordered reuse
+    mx_guard.free_now(); // stream-ordered reuse
     return WSC_OK;
 }
 
@@ -327,7 +328,9 @@ int wsc_hsn_background(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W
     const bool resize = Ho != H || Wo != W;
     double *t1 = nullptr, *t2 = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(double) * (size_t)total, (void **)&t1));
+    WscCachedGuard t1_guard(ctx, t1);
     WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(double) * (size_t)total, (void **)&t2));
+    WscCachedGuard t2_guard(ctx, t2);
     GaussTaps t; // scipy.ndimage._filters._gaussian_kernel1d(sigma = 2, order = 0, radius = 8)
     double ws[17], sum = 0.0;
     for (int k = -8; k <= 8; ++k) {
@@ -346,8 +349,8 @@ int wsc_hsn_background(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W
                            bg_dev);
     }
     WSC_HIP(hipGetLastError());
-    wsc_ctx_cached_free(ctx, t1);
-    wsc_ctx_cached_free(ctx, t2);
+    t1_guard.free_now();
+    t2_guard.free_now();
     return WSC_OK;
 }
 
@@ -396,13 +399,14 @@ int wsc_hsn_voc_background(wsc_ctx *ctx, const float *Hbg_dev, int B, int Cb, in
     const long long total = (long long)B * N;
     float *xbg = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(float) * (size_t)total + 256, (void **)&xbg));
+    WscCachedGuard xbg_guard(ctx, xbg);
     unsigned int *mx = reinterpret_cast<unsigned int *>(xbg + total);
     WSC_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(hsn_sum_max_kernel, dim3(grid_for(total, 2048)), dim3(256), 0, ctx->stream, Hbg_dev, Cb, N, total, xbg, mx);
     hipLaunchKernelGGL(hsn_voc_bg_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float *)xbg,
                        (const unsigned int *)mx, Ctot, N, total, y_dev);
     WSC_HIP(hipGetLastError());
-    wsc_ctx_cached_free(ctx, xbg);
+    xbg_guard.free_now();
     return WSC_OK;
 }
 
@@ -423,13 +427,14 @@ int wsc_hsn_gather_unary(wsc_ctx *ctx, const float *maps_dev, const int64_t *cha
     WSC_HIP(hipSetDevice(ctx->device));
     long long *d = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(long long) * (size_t)n_chan, (void **)&d));
+    WscCachedGuard d_guard(ctx, d);
     WSC_TRY(wsc_ctx_upload_small(ctx, d, chan_off_host, sizeof(long long) * (size_t)n_chan));
     const long long total = (long long)n_chan * N;
     WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, (double)total * 8);
     hipLaunchKernelGGL(hsn_gather_unary_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, maps_dev, (const long long *)d, N,
                        total, unary_dev);
     WSC_HIP(hipGetLastError());
-    wsc_ctx_cached_free(ctx, d);
+    d_guard.free_now();
     return WSC_OK;
 }
 

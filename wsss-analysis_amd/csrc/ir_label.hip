@@ -84,12 +84,13 @@ int wsc_ir_label_combine(wsc_ctx *ctx, const int32_t *fg_pred_dev, const int32_t
     WSC_HIP(hipSetDevice(ctx->device));
     int32_t *k = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(int32_t) * (size_t)B * M, (void **)&k));
+    WscCachedGuard k_guard(ctx, k);
     WSC_TRY(wsc_ctx_upload_small(ctx, k, keys_host, sizeof(int32_t) * (size_t)B * M));
     const long long total = (long long)B * N;
     hipLaunchKernelGGL(ir_combine_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, fg_pred_dev, bg_pred_dev,
                        (const int32_t *)k, M, N, total, bg_pred_dev != nullptr ? 1 : 0, conf_dev);
     WSC_HIP(hipGetLastError());
-    wsc_ctx_cached_free(ctx, k);
+    k_guard.free_now();
     return WSC_OK;
 }
 

@@ -416,12 +416,13 @@ int launch_gap_linear_sigmoid(wsc_ctx *ctx, const bf16_t *feat, const bf16_t *fe
                               const float *Wc, const float *bias, int C, float *score, int fmt, int sample_stride) {
     float *gapbuf = nullptr;
     WSC_TRY(wsc_ctx_cached_alloc(ctx, sizeof(float) * (size_t)B * F, (void **)&gapbuf));
+    WscCachedGuard gapbuf_guard(ctx, gapbuf);
     hipLaunchKernelGGL(gap_kernel, dim3((unsigned)((F + 63) / 64), (unsigned)B), dim3(64 * GAP_WAVES), 0, ctx->stream, feat, feat_lo, hw, F, gapbuf,
                        fmt, sample_stride);
     hipLaunchKernelGGL(linear_sigmoid_kernel, dim3(B), dim3(256), F * sizeof(float), ctx->stream, (const float *)gapbuf, F, Wc, bias, C,
                        score);
     WSC_HIP(hipGetLastError());
-    wsc_ctx_cached_free(ctx, gapbuf); // stream-ordered reuse
+    gapbuf_guard.free_now(); // stream-ordered reuse
     return WSC_OK;
 }
 

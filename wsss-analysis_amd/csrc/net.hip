@@ -157,9 +157,31 @@ int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, 
     // (conv_igemm.hip, SPLIT 2); everything else: [hi K | lo K]
     const bool interleaved = net->split == 2 && (small_cin == 0 || small_cin == 3);
     std::vector<bf16_t> wp((size_t)c.CoutPad * Kw, 0);
+    // IEEE-half modes (f16, f16x3): every output channel's weights are stored times a power of two that puts the channel's
+    // largest |w| into [2^12, 2^13), and the epilogue scale s1 takes the inverse -- exact in fp32, the accumulators are fp32.
+    // Half has 5 exponent bits: a checkpoint's late-layer weights (|w| ~ 1e-4 ... 1e-3, below half's smallest normal
+    // 6.1e-5 for many of them) would lose their `hi` bits and all of `lo` (the split's lo = half(w - hi) is ~2^-11 |w|);
+    // scaled, every weight within 2^-15 of its channel's maximum keeps the full 22-bit hi + lo pair and smaller ones an
+    // absolute error of 2^-25 against a maximum of >= 2^12 (bfloat16 has fp32's exponent range).
+    std::vector<float> s1v(s1);
+    std::vector<float> wscale(Cout, 1.f);
+    if (net->fmt == 1) {
+        const size_t per = (size_t)Cin * kh * kw;
+        for (int co = 0; co < Cout; ++co) {
+            float mx = 0.f;
+            for (size_t i = 0; i < per; ++i) mx = std::max(mx, std::fabs(w->data[(size_t)co * per + i]));
+            if (!(mx > 0.f) || !std::isfinite(mx)) continue;
+            int e;
+            std::frexp(mx, &e); // mx = m * 2^e, m in [0.5, 1)
+            wscale[co] = std::ldexp(1.f, 13 - e);
+            s1v[co] = s1[co] * std::ldexp(1.f, e - 13);
+        }
+    }
     for (int co = 0; co < Cout; ++co) {
         bf16_t *row = wp.data() + (size_t)co * Kw;
+        const float wsc = wscale[co];
         auto put = [&](int k, float v) {
+            v *= wsc;
             const bf16_t h = f32_to_h16(v, net->fmt);
             const int lo_at = interleaved ? 32 : Kbase;
             row[k] = h;
@@ -187,7 +209,7 @@ int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, 
         for (int i = 0; i < Cout; ++i) p[i] = v[i];
         return upload(net, p.data(), p.size() * sizeof(float), (void **)dst);
     };
-    WSC_TRY(up_vec(s1, &c.s1));
+    WSC_TRY(up_vec(s1v, &c.s1));
     WSC_TRY(up_vec(b1, &c.b1));
     if (s2) {
         WSC_TRY(up_vec(*s2, &c.s2));

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "wsc_sem_seg_finish": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
     "wsc_bilinear_resize": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     "wsc_msf_input_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "wsc_resize_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "wsc_label_unary_from_cam": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
     "wsc_ir_label_combine": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "wsc_hsn_gradcam_post": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i]),
@@ -201,6 +202,7 @@ class Context:
         self.h = h
         self.device = device
         self._lib = lib
+        self._options = {}  # selectors set through set_option (the library has no getter; option() restores from here)
 
     def close(self):
         if getattr(self, "h", None):
@@ -275,18 +277,25 @@ class Context:
     def set_option(self, option, value):
         """A path selector of this context (OPT_*): forces a fallback path that gives the same bits (testing / debugging)."""
         check(self._lib.wsc_ctx_set_option(self.h, int(option), int(value)))
+        self._options[int(option)] = int(value)
+
+    def get_option(self, option):
+        """The selector's current value (what set_option last stored; OPT_DEFAULTS before that)."""
+        return self._options.get(int(option), OPT_DEFAULTS[int(option)])
 
     def option(self, option, value):
-        """Context manager: the selector is set inside the block and back to its default afterwards."""
+        """Context manager: the selector is set inside the block and back to the value it HAD afterwards (an earlier
+        set_option or an enclosing option() block stays in force)."""
         import contextlib
 
         @contextlib.contextmanager
         def _cm():
+            before = self.get_option(option)
             self.set_option(option, value)
             try:
                 yield self
             finally:
-                self.set_option(option, OPT_DEFAULTS[option])
+                self.set_option(option, before)
 
         return _cm()
 
@@ -757,6 +766,15 @@ def msf_input_u8(ctx, images_dev, sizes, offsets, S, mean, std, x_dev, pre_div25
     sd = np.ascontiguousarray(std, dtype=np.float32)
     check(ctx._lib.wsc_msf_input_u8(ctx.h, _ptr(images_dev), B, size_hw.ctypes.data, off.ctypes.data, int(S), m.ctypes.data,
                                     sd.ctypes.data, int(bool(pre_div255)), int(bool(pair)), _ptr(x_dev)))
+
+
+def resize_u8(ctx, images_dev, sizes, offsets, out_hw, out_dev):
+    """wsc_resize_u8: cv2.resize (INTER_LINEAR, 8-bit fixed point) of packed uint8 HWC images -> uint8 [B][OH][OW][3]."""
+    B = len(sizes)
+    size_hw = np.ascontiguousarray(sizes, dtype=np.int32).reshape(B, 2)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    check(ctx._lib.wsc_resize_u8(ctx.h, _ptr(images_dev), B, size_hw.ctypes.data, off.ctypes.data, int(out_hw[0]), int(out_hw[1]),
+                                 _ptr(out_dev)))
 
 
 def label_unary_from_cam(ctx, highres_dev, B, K, N, thres, gt_prob, unary_dev, labels_dev=None):

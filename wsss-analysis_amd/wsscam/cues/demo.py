@@ -19,7 +19,6 @@ import pickle
 
 import numpy as np
 
-from ..voc12.dataloader import resize_bilinear_f64
 from . import utilities as cu
 
 SEED_SIZE = 41
@@ -40,15 +39,33 @@ class _LazyImages:
         return self.set_list.images(sl, sl + 1)[0]
 
 
-def read_batch(images, size, img_mean, img_std):
-    """02_cues/utilities.py:146-181 on in-memory images: (normalised float (B,S,S,3), original (B,S,S,3))."""
-    B = len(images)
-    norm = np.empty((B, size[0], size[1], 3))
-    raw = np.empty((B, size[0], size[1], 3))
-    for i, im in enumerate(images):
-        r = resize_bilinear_f64(np.asarray(im), size)  # the reference leaves same-size images uninitialised (Q4)
-        raw[i] = r
-        norm[i] = (r - np.asarray(img_mean, np.float64)) / np.asarray(img_std, np.float64)
+def read_batch_u8(images, size, ctx=None):
+    """The uint8 batch of read_batch: `img_batch = np.empty(..., dtype='uint8'); img_batch[i] = cv2.resize(tmp, size)`
+    (02_cues/utilities.py:172-176, 02_cues/adp_cues.py / 03c_hsn/adp_cues.py:122-128, 03c_hsn/utilities.py:170-181) -- OpenCV's
+    8-bit INTER_LINEAR result, which the network input AND the CRF image are made of.  With `ctx` the resize runs on the
+    device (wsc_resize_u8: the decoded images travel once, packed), else in numpy (voc12.dataloader.resize_bilinear_u8);
+    the two are bit-identical.  Images already at `size` are copied (the reference's ADP twin does that, :127-128; its
+    VOC / DeepGlobe twin leaves them uninitialised)."""
+    from ..voc12.dataloader import resize_bilinear_u8
+
+    ims = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+    B, (oh, ow) = len(ims), (int(size[0]), int(size[1]))
+    if ctx is None or all(im.shape[:2] == (oh, ow) for im in ims):
+        return np.stack([resize_bilinear_u8(im, (oh, ow)) for im in ims]) if B else np.empty((0, oh, ow, 3), np.uint8)
+    from .. import _lib
+
+    offs = np.concatenate(([0], np.cumsum([im.size for im in ims]))).astype(np.int64)
+    packed = np.concatenate([im.reshape(-1) for im in ims])
+    src_dev, out_dev = ctx.to_device(packed, pooled=True), ctx.alloc(B * oh * ow * 3, pooled=True)
+    _lib.resize_u8(ctx, src_dev, [im.shape[:2] for im in ims], offs[:-1], (oh, ow), out_dev)
+    return ctx.to_host(out_dev, (B, oh, ow, 3), np.uint8)
+
+
+def read_batch(images, size, img_mean, img_std, ctx=None):
+    """02_cues/utilities.py:146-181 on in-memory images: (normalised float64 (B,S,S,3), uint8 batch (B,S,S,3)); the
+    normalisation starts from the uint8 batch like the reference's (:177-180)."""
+    raw = read_batch_u8(images, size, ctx=ctx)
+    norm = (raw - np.asarray(img_mean, np.float64)) / np.asarray(img_std, np.float64)
     return norm, raw
 
 
@@ -99,7 +116,7 @@ def gen_cues(dataset, model_type, thresh, batch_size, set_name=None, run_train=T
         lo, hi = ib * batch_size, min((ib + 1) * batch_size, len(images))
         if is_verbose:
             print("\tBatch #%d of %d" % (ib + 1, n_batches))
-        norm, _ = read_batch(images[lo:hi], (img_size, img_size), mean, std)
+        norm, _ = read_batch(images[lo:hi], (img_size, img_size), mean, std, ctx=models["fg"].ctx)
         H, is_pass = {}, {}
         for m in fgbg_modes:
             cams, scores = cu.conv_and_cams(models[m], np.asarray(alphas[m]), norm, relu=True, want_scores=True)
@@ -138,8 +155,7 @@ def gen_cues_adp(model_type, thresh, batch_size, size, cues_dir, set_name, is_ve
     thr = np.asarray(thresholds).reshape(1, -1)
     for lo in range(0, len(images), batch_size):
         hi = min(lo + batch_size, len(images))
-        _, raw = read_batch(images[lo:hi], (size, size), [0, 0, 0], [1, 1, 1])
-        raw = np.clip(np.rint(raw), 0, 255).astype(np.uint8)  # ADPCues.read_batch keeps the batch as uint8
+        raw = read_batch_u8(images[lo:hi], (size, size), ctx=model.ctx)  # ADPCues.read_batch keeps the batch as uint8
         norm = (raw - 193.09203) / 56.450138
         cams, scores = cu.conv_and_cams(model, np.asarray(alpha), norm, relu=True, want_scores=True)
         is_pass = np.greater_equal(scores, thr)

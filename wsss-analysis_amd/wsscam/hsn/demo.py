@@ -12,7 +12,7 @@ import numpy as np
 import scipy.special
 
 from ..cues import utilities as cu
-from ..cues.demo import read_batch
+from ..cues.demo import read_batch_u8
 from . import utilities as hu
 
 
@@ -43,7 +43,8 @@ def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True,
     assert dataset in ["VOC2012", "DeepGlobe", "DeepGlobe_balanced"], "ADP: segment_adp"
     assert model_type in ["VGG16", "M7"]
     img_size = 321 if model_type == "VGG16" else 224
-    if models is None or images is None:
+    from_settings = models is None or images is None
+    if from_settings:
         # the reference's own call form segment(dataset, model_type, batch_size, ...): models, thresholds and the evaluation
         # image list come from settings.ini and the files under it (03c_hsn/demo.py:46-90), through keras_store
         from .. import keras_store as ks
@@ -61,13 +62,16 @@ def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True,
                 models[m], alphas[m], _, _ = ks.load_model(model_dir, sess_id, model_type, dataset)
     voc = dataset == "VOC2012"
     if reference_normalize_quirk is None:
+        # a settings file is consulted only when one is in play (passed, or the models / images were loaded through it above):
+        # a call with everything in memory must not depend on a settings.ini relative to the working directory
         reference_normalize_quirk = True
-        try:
+        if settings is not None or from_settings:
             from .. import keras_store as ks
 
             reference_normalize_quirk = ks.read_option(settings, "hsn_voc_normalize", "reference") != "intended"
-        except FileNotFoundError:
-            pass
+    if voc and is_verbose:
+        print("\tVOC2012 normalisation: %s" % ("the reference's uint8 / column arithmetic (03c_hsn/utilities.py:142-146)"
+                                              if reference_normalize_quirk else "per channel (x - [104, 117, 123]) / 255"))
     mean, std = ([104, 117, 123], [255, 255, 255]) if voc else ([0, 0, 0], [255, 255, 255])
     cfg = dcrf_config_for(dataset, model_type)
     out = []
@@ -79,33 +83,31 @@ def segment(dataset, model_type, batch_size, set_name=None, should_saveimg=True,
         lo, hi = ib * batch_size, min((ib + 1) * batch_size, len(images))
         B = hi - lo
         chunk = images[lo:hi]
-        if all(np.asarray(im).shape == (img_size, img_size, 3) and np.asarray(im).dtype == np.uint8 for im in chunk):
-            norm, raw, raw_u8 = None, None, np.ascontiguousarray(np.stack(chunk))
-        else:  # the resize of read_batch stays on the host (float64, kept un-rounded like the reference's batch)
-            norm, raw = read_batch(chunk, (img_size, img_size), mean, std)
-            raw_u8 = raw.astype(np.uint8)
+        # read_batch (03c_hsn/utilities.py:170-181): the batch is uint8 -- cv2.resize's 8-bit result -- and both the
+        # normalised network input and the CRF image are made from it; resize on the device, normalisation too
+        raw_u8 = read_batch_u8(chunk, (img_size, img_size), ctx=ctx)
         b_mean = mean  # per batch: the quirk path normalises the modified uint8 batch with a zero mean
         if voc and reference_normalize_quirk:
             raw_u8 = np.ascontiguousarray(raw_u8)
             raw_u8[:, :, 0] -= 104  # (B, H, 3): image column 0 of every row and channel, uint8 wrap-around, in place
             raw_u8[:, :, 1] -= 117
             raw_u8[:, :, 2] -= 123
-            norm, b_mean = None, [0, 0, 0]
+            b_mean = [0, 0, 0]
         C = np.asarray(alphas["fg"]).shape[1]
         if voc:
             Cv = n_seg_classes or C + 1
             y_dev = ctx.alloc(B * Cv * N * 4, pooled=True)
-            kw = dict(raw_u8=raw_u8, mean_std=(b_mean, std)) if norm is None else {}
-            hu.grad_cam_device(models["fg"], alphas["fg"], norm, thr_of(alphas["fg"]), [img_size, img_size], out=(y_dev, Cv, 1),
+            kw = dict(raw_u8=raw_u8, mean_std=(b_mean, std))
+            hu.grad_cam_device(models["fg"], alphas["fg"], None, thr_of(alphas["fg"]), [img_size, img_size], out=(y_dev, Cv, 1),
                                ctx=ctx, **kw)
             Cb = np.asarray(alphas["bg"]).shape[1]
-            hb = hu.grad_cam_device(models["bg"], alphas["bg"], norm, thr_of(alphas["bg"]), [img_size, img_size], ctx=ctx, **kw)
+            hb = hu.grad_cam_device(models["bg"], alphas["bg"], None, thr_of(alphas["bg"]), [img_size, img_size], ctx=ctx, **kw)
             _lib.hsn_voc_background(ctx, hb[0], B, Cb, N, y_dev, Cv)
             valid = list(range(Cv))
         else:
             Cv = C
-            kw = dict(raw_u8=raw_u8, mean_std=(b_mean, std)) if norm is None else {}
-            y_dev = hu.grad_cam_device(models["fg"], alphas["fg"], norm, thr_of(alphas["fg"]), [img_size, img_size], ctx=ctx,
+            kw = dict(raw_u8=raw_u8, mean_std=(b_mean, std))
+            y_dev = hu.grad_cam_device(models["fg"], alphas["fg"], None, thr_of(alphas["fg"]), [img_size, img_size], ctx=ctx,
                                        **kw)[0]
             valid = list(range(C - 1))  # Y = H_fg[:, :-1]: the 'unknown' class is dropped (demo.py:153)
         mass_dev = ctx.alloc(B * Cv * 4, pooled=True)
@@ -141,6 +143,14 @@ class ADPClasses:
         }
 
 
+def adipose_source_channels(ac):
+    """Channels of the all-class Grad-CAM stack that the reference's `Y_gradcam['morph'][:, adipose_inds]` reads
+    (demo.py:368-369; 02_cues/demo.py:307-308): positions of A.W / A.B / A.M in classes['morph'], used as channel numbers of the
+    valid morph stack, traced back through morph2valid / all2morph."""
+    morph_src = dict(zip(ac.classinds["morph2valid"], ac.classinds["all2morph"]))
+    return [morph_src[i] for i, x in enumerate(ac.classes["morph"]) if x in ["A.W", "A.B", "A.M"]]
+
+
 def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size, is_verbose=False, all_classes=None, stats=None):
     """demo.py:271-380 for one ADP model: per batch scores >= thresholds -> HSN Grad-CAM at (size, size) -> per
     HTT type {morph, func}: scatter into the valid-class stack, modify_by_htt (background / other channels),
@@ -158,16 +168,16 @@ def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size
     out = {"morph": [], "func": []}
     N = size * size
     C_all = len(ac.classes["all"])
-    adipose_all = [i for i, x in enumerate(ac.classes["all"]) if x in ["A.W", "A.B", "A.M"]]
+    # demo.py:368-369: `adipose_inds` are positions of A.W / A.B / A.M in classes['morph'] (18, 19, 20) but index
+    # Y_gradcam['morph'], the VALID stack whose channel 0 is 'Background' -- so the reference's "adipose" maps are the valid
+    # stack's channels 18..20 = S.R, A.W, A.B (off by one; the 02_cues twin has the same line, demo.py:307-308).  Reproduced:
+    # those channels of the valid stack, traced back to their source channels of the all-class stack (a quirk found in round 5).
+    adipose_all = adipose_source_channels(ac)
     for lo in range(0, len(images), batch_size):
         hi = min(lo + batch_size, len(images))
         B = hi - lo
         chunk = images[lo:hi]
-        if all(np.asarray(im).shape == (size, size, 3) and np.asarray(im).dtype == np.uint8 for im in chunk):
-            raw = np.ascontiguousarray(np.stack(chunk))       # already at the network size: nothing to resize
-        else:
-            _, raw = read_batch(chunk, (size, size), [0, 0, 0], [1, 1, 1])
-            raw = np.clip(np.rint(raw), 0, 255).astype(np.uint8)  # ADPCues.read_batch keeps the resized batch as uint8
+        raw = read_batch_u8(chunk, (size, size), ctx=model.ctx)  # ADPCues.read_batch: cv2.resize's uint8 batch (adp_cues.py:122-128)
         # (raw - 193.09203) / 56.450138 (adp_cues.py:130) and the NHWC -> NCHW layout on the device
         H_dev, scores, is_pass, ctx, raw_dev = hu.grad_cam_device(model, alpha, None, thresholds, [size, size], raw_u8=raw,
                                                                   mean_std=(193.09203, 56.450138))

@@ -24,13 +24,13 @@ GT_PROB = 0.7
 
 
 def _nearest_resize_cv2(img, out_wh):
-    """cv2.resize(img, (w, h)) with the default INTER_LINEAR is what :63 calls on the uint8 DeepGlobe image; the mirror
-    resizes in float64 with the same coordinate rule and rounds back to uint8 (OpenCV's fixed-point path is unpinned
-    offline)."""
-    from ..voc12.dataloader import resize_bilinear_f64
+    """cv2.resize(img, (w, h)) with the default INTER_LINEAR is what :61 calls on the uint8 DeepGlobe image (the name is
+    historical): OpenCV's 8-bit fixed-point result, voc12.dataloader.resize_bilinear_u8 (an exact /2 decimation is its
+    INTER_AREA shortcut; restated from the published algorithm, cv2 absent offline -- SURVEY Q10)."""
+    from ..voc12.dataloader import resize_bilinear_u8
 
     w, h = int(out_wh[0]), int(out_wh[1])
-    return np.clip(np.rint(resize_bilinear_f64(img, (h, w))), 0, 255).astype(np.uint8)
+    return resize_bilinear_u8(img, (h, w))
 
 
 def ir_label_batch(ctx, imgs, maps, keys_list, mode, conf_fg_thres, conf_bg_thres):

@@ -269,7 +269,7 @@ def _run_resized(args, labels, ctx, batch_images, field, drop_last_class):
         if clr_dir:
             from PIL import Image
 
-            from ..voc12.dataloader import resize_bilinear_f64
+            from ..voc12.dataloader import resize_bilinear_u8
 
             flat = ctx.to_host(pred_dev, (sum(g.size for g in gts),), np.uint8)
             o = 0
@@ -282,8 +282,8 @@ def _run_resized(args, labels, ctx, batch_images, field, drop_last_class):
                 if img_path is not None:
                     orig = np.asarray(Image.open(img_path(ids[i])).convert("RGB"))
 
-                    def _bil(a, hw):  # cv2.resize(..., INTER_LINEAR) on uint8: float64 mirror, rounded (OpenCV's fixed point unpinned)
-                        return a if a.shape[:2] == tuple(hw) else np.clip(np.rint(resize_bilinear_f64(a, hw)), 0, 255).astype(np.uint8)
+                    def _bil(a, hw):  # cv2.resize(..., INTER_LINEAR) on uint8: OpenCV's 8-bit fixed-point rule
+                        return a if a.shape[:2] == tuple(hw) else resize_bilinear_u8(a, hw)
 
                     if drop_last_class:   # DeepGlobe (:79): the image is resized to the prediction
                         orig = _bil(orig, clr.shape[:2])

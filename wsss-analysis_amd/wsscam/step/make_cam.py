@@ -78,6 +78,18 @@ def process_batch(model, packs, args, save=True):
     """One device batch: list of dataset items -> list of result dicts (and .npy files)."""
     ctx = model.ctx
     B = len(packs)
+    if B and "img" not in packs[0]:
+        # items of a dataset built with device_transform=True (decoded uint8 images) on the SERIAL path (cam_pipeline off):
+        # the same transform on the host -- msf_pack is what wsc_msf_input_u8 reproduces bit for bit (tests/test_gpu_input.py)
+        from ..voc12.dataloader import TorchvisionNormalize, msf_pack
+
+        norm = TorchvisionNormalize(getattr(args, "norm_mode", "int"))
+        outsize = getattr(args, "outsize", (321, 321))
+        conv = []
+        for p in packs:
+            ms = [msf_pack(np.asarray(si), outsize, norm) for si in _scales_of(p["img_u8"])]
+            conv.append(dict(p, img=ms[0] if len(ms) == 1 else ms))
+        packs = conv
     # multi-scale items carry a list of (2,3,S,S) pairs (one per args.cam_scales entry, all resized to the same S): the scales
     # of an image run as consecutive "images" of one device batch and their CAMs are summed before the tail
     n_sc = len(_scales_of(packs[0]["img"]))
@@ -217,7 +229,11 @@ def _device_transform_default(args):
     v = getattr(args, "cam_device_transform", None)
     if v is not None:
         return bool(v)
-    n = int(getattr(args, "n_gpus", 0))
+    # only where the overlapped pipeline (the consumer of "img_u8" items on the device) will run: voc12 with a fixed network
+    # size; the worker count is derived exactly as run() derives it (args.n_gpus, else every visible device)
+    if not getattr(args, "cam_pipeline", True) or getattr(args, "outsize", (321, 321)) is None:
+        return False
+    n = int(getattr(args, "n_gpus", 0) or 0) or _device_count()
     return n > 1
 
 

@@ -48,6 +48,44 @@ def resize_bilinear_f64(img, out_hw):
     return top * (1 - wy) + bot * wy
 
 
+def _cv2_linear_taps_u8(src, dst, clamp_taps):
+    """Source index and the two 11-bit fixed-point coefficients of OpenCV's 8-bit INTER_LINEAR along one axis."""
+    scale = 1.0 / (np.float64(dst) / np.float64(src))
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    if clamp_taps:  # columns: the window is moved inside and the fraction dropped
+        lo, hi = s < 0, s >= src - 1
+        s = np.where(lo, 0, np.where(hi, src - 1, s))
+        f = np.where(lo | hi, np.float32(0), f)
+    c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)  # saturate_cast<short>: round half to even
+    c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+    return s, c0, c1
+
+
+def resize_bilinear_u8(img, out_hw):
+    """cv2.resize(uint8 image, (w, h)) with the default INTER_LINEAR, as read_batch of 02_cues/utilities.py:172-176 and
+    03c_hsn/utilities.py:176-181 get it (the batch array is uint8).  OpenCV's 8-bit path is fixed point -- 11-bit
+    coefficients, an int horizontal pass, the vertical pass (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 --
+    and an exact 2 x 2 decimation is the rounded box mean (INTER_AREA shortcut); restated from the published algorithm
+    (cv2 is absent offline: parity against cv2 itself unpinned).  Bit-identical to wsc_resize_u8 (csrc/input.hip)."""
+    im = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W = im.shape[:2]
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    if (H, W) == (oh, ow):
+        return im.copy()
+    v = im.astype(np.int64)
+    if (H, W) == (2 * oh, 2 * ow):
+        return ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    sx, a0, a1 = _cv2_linear_taps_u8(W, ow, True)
+    sy, b0, b1 = _cv2_linear_taps_u8(H, oh, False)
+    x1 = np.minimum(sx + 1, W - 1)
+    y0, y1 = np.clip(sy, 0, H - 1), np.clip(sy + 1, 0, H - 1)
+    hor = v[:, sx] * a0[None, :, None] + v[:, x1] * a1[None, :, None]  # (H, ow, 3) int
+    out = (((b0[:, None, None] * (hor[y0] >> 4)) >> 16) + ((b1[:, None, None] * (hor[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 class TorchvisionNormalize:
     def __init__(self, norm_mode="int"):
         self.norm_mode = norm_mode
