@@ -102,6 +102,23 @@ def crf_bytes_per_image(N, M, T, vg, vb):
     return T * per_it
 
 
+def cu_masked_stream(device, lo, hi):
+    """A HIP stream whose kernels run on compute units [lo, hi) only (A/B experiments; ctypes on the HIP runtime the
+    library itself is linked against)."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipSetDevice(int(device))
+    words = (ctypes.c_uint32 * 8)()
+    for i in range(lo, hi):
+        words[i // 32] |= 1 << (i % 32)
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    return st.value
+
+
 class Workload:
     def __init__(self, device, batch, precision, workload, seed, arch="resnet50", share=None):
         import numpy as np
@@ -114,13 +131,24 @@ class Workload:
 
         self.np, self._lib = np, _lib
         self.B, self.workload, self.device = batch, workload, device
-        self.ctx = _lib.Context(device)
+        # A/B: WSC_BENCH_CUMASK="a[,b]" gives the conv stream compute units [0, a) and the lattice-build / mean-field streams
+        # [b, 256) (b = a when omitted) through hipExtStreamCreateWithCUMask -- mask bits interleave over the 8 XCDs, so a
+        # prefix is balanced.  Unset (default): ordinary streams, every kernel may use every CU.
+        sA = sB = sC = None
+        cm = os.environ.get("WSC_BENCH_CUMASK")
+        if cm:
+            a = int(cm.split(",")[0])
+            b = int(cm.split(",")[1]) if "," in cm else a
+            sA = cu_masked_stream(device, 0, a)
+            sB = cu_masked_stream(device, b, 256)
+            sC = cu_masked_stream(device, b, 256)
+        self.ctx = _lib.Context(device, stream=sA)
         # second context (own stream) for the lattice build: it needs only the RGB images, so it runs
         # concurrently with the CNN forward pass of the same batch and joins before the inference
-        self.ctx_build = _lib.Context(device)
+        self.ctx_build = _lib.Context(device, stream=sB)
         # third context: the mean-field loop.  With --pipeline (default) step i's loop runs here while
         # step i+1's conv stack (self.ctx) and lattice build (self.ctx_build) are already under way.
-        self.ctx_crf = _lib.Context(device)
+        self.ctx_crf = _lib.Context(device, stream=sC)
         self.pending = None  # lattices of the step whose mean-field loop is still in flight
         # step_pipelined(): the loops of the last TWO steps may be in flight.  done[p] is a stream that only ever waits for the
         # loop that last used parity p's buffers, so the host can wait for exactly that loop (two steps old: normally finished)
@@ -620,8 +648,12 @@ def build_roofline(prof, n_steps, precision, traffic_classes=None, loop_gbps=Non
 
     roofline["avg_launch_us"] = round(ms / calls * 1e3, 2)
     roofline["launches_per_step"] = calls // n_steps
-    if roofline["bound"] == "hbm":
-        add_traffic(roofline, dom, ms / calls * 1e3)
+    add_traffic(roofline, dom, ms / calls * 1e3)  # (conv: HBM bytes per launch averaged over every instantiation's launches)
+    for name, k in kernels.items():               # every class the PMC passes cover: measured HBM bytes per launch beside its time
+        cls = traffic_classes.get(name)
+        if cls:
+            k["traffic_bytes_per_launch"] = cls["bytes_per_launch"]
+            k["traffic_GBps"] = round(cls["bytes_per_launch"] / (k["avg_us"] * 1e-6) / 1e9, 1) if k["avg_us"] > 0 else None
     conv = [(c, m, w) for n, (c, m, w) in prof.items() if n.startswith("conv_igemm")]
     if conv:
         c_ms, c_fl = sum(m for _, m, _ in conv), sum(w for _, _, w in conv)
@@ -644,7 +676,7 @@ def build_roofline(prof, n_steps, precision, traffic_classes=None, loop_gbps=Non
     return kernels, roofline
 
 
-def run_hsn(args, device):
+def hsn_measure(args, device):
     """BASELINE config 5 on one GPU: `segment_adp` (03c_hsn/demo.py:271-380) on batches of ADP-like patches, device
     resident from the batch upload to the label maps.  One step = one batch of --batch images (reference: 16)."""
     import numpy as np
@@ -719,7 +751,7 @@ def run_hsn(args, device):
             par[h] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in pp.items()}
         par["against"] = "all-fp32 oracle chain (tests/helpers.py::oracle_chain_hsn_adp) on the first %d patches" % n_cpu
         extra["parity"] = par
-    print(json.dumps({
+    return {
         "metric": "images/sec HistoSegNet CAM+CRF (BASELINE config 5, ADP-like 321x321 patches, morph + func label maps)",
         "value": round(args.batch * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -731,7 +763,54 @@ def run_hsn(args, device):
                    "effective_M_note": "classes with mass per image = the M its dense CRF runs with (dcrf_process keeps the classes "
                                        "whose class-specific Grad-CAM is not all zero, 03c_hsn/utilities.py:425); classifier head "
                                        "calibrated to the random features (wsscam.synth.specialise_classifier)"},
-        "roofline": roofline, "stages": {"kernels": kernels}, **extra}))
+        "roofline": roofline, "stages": {"kernels": kernels}, **extra}
+
+
+def run_hsn(args, device):
+    print(json.dumps(hsn_measure(args, device)))
+
+
+def irn_measure(device, precision, arch="resnet50", n_images=16, reps=3):
+    """BASELINE config 4 (IRNet inference) at VOC size on one GPU: the make_sem_seg_labels driver (03b_irn/step/
+    make_sem_seg_labels.py:22-143) on `n_images` 375 x 500 images -- EdgeDisplacement on the [orig, flip] pair zero-padded to
+    512 x 512 (:46), boundary maps to the CAM size, the random walk of K = 2 strided CAMs at 94 x 125 (beta 10, 2^8 steps), x4
+    upsample, / max, background channel, arg-max: host arrays in, label maps out, no file I/O.  Seeded random weights
+    (wsscam.synth.irn_state_dict: no trained IRNet weights offline)."""
+    import types
+
+    import numpy as np
+
+    from wsscam import _lib, synth
+    from wsscam.step import make_sem_seg_labels as mssl
+
+    prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "f16x3": _lib.PREC_F16X3}[precision]
+    sd = synth.irn_state_dict(arch, seed=0)
+    if arch == "vgg16":
+        from wsscam.net import vgg16_irn as irn_mod
+
+        model = irn_mod.EdgeDisplacement(None, "voc12", "", 20, None, precision=prec)
+    else:
+        from wsscam.net import resnet50_irn as irn_mod
+
+        model = irn_mod.EdgeDisplacement(None, 20, precision=prec)
+    model.load_state_dict(sd, strict=False)
+    model.cuda(device)
+    rng = np.random.default_rng(0)
+    h, w, K = 94, 125, 2
+    packs = [{"name": "i%d" % i, "img": rng.normal(0, 1, (2, 3, 375, 500)).astype(np.float32), "size": (375, 500)} for i in range(n_images)]
+    cam_dicts = [{"keys": np.array([3, 11]), "cam": rng.random((K, h, w)).astype(np.float32)} for _ in range(n_images)]
+    dargs = types.SimpleNamespace(dataset="voc12", beta=10, exp_times=8, sem_seg_bg_thres=0.25)
+    mssl.sem_seg_batch(model, packs, cam_dicts, dargs)
+    model.ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mssl.sem_seg_batch(model, packs, cam_dicts, dargs)
+    model.ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(n_images / dt, 2), "unit": "images/s", "ms_per_image": round(dt / n_images * 1e3, 3), "dtype": precision,
+            "workload": "IRNet inference (BASELINE config 4): %s EdgeDisplacement @512 pad -> random walk K=%d at %dx%d, 2^8 steps -> "
+                        "label map at 375x500; make_sem_seg_labels driver, %d images per call, host arrays in / label maps out"
+                        % (arch, K, h, w, n_images)}
 
 
 def main():
@@ -871,34 +950,50 @@ def main():
                                        stages.get("crf_loop_algorithmic_GBps") if args.workload == "cam_crf" else None)
     stages["kernels"] = kernels
 
-    # ---- the other numbers SURVEY 8(d) asks for, same images (rank 0 of a 1-GPU run) ---------------------------
-    if world == 1 and args.workload == "cam_crf" and args.arch == "resnet50" and not args.quick:
+    # ---- the other numbers SURVEY 8(d) asks for, same images ----------------------------------------------------------------
+    if args.workload == "cam_crf" and args.arch == "resnet50" and not args.quick:
         k_extra = max(3, min(args.steps, 10))
-        if args.precision != "f16":  # the fast mode: half operands, one MFMA product per term (1.5e-2 on the CAM maps)
-            w3 = Workload(device, args.batch, "f16", args.workload, seed=rank, arch=args.arch, share=wl)
-            t3 = timed_run(w3, w3.step_pipelined if pipelined else w3.step, k_extra, 2, w3.drain)
-            stages["value_f16"] = round(args.batch * k_extra / t3, 3)
-            stages["cnn_ms_f16"] = round(w3.timed(w3.run_cnn, 3), 4)
-            w3.close()
-            del w3
-        wl.setup_kplus1()
-        tk = timed_run(wl, wl.step_kplus1, k_extra, 2, wl.drain)
-        stages["value_M_eq_Kplus1"] = round(args.batch * k_extra / tk, 3)
-        stages["M_eq_Kplus1_groups"] = ["K=%d x %d images" % (K, nb) for (_, nb, K) in wl.kp_groups]
+        if world == 1:
+            if args.precision != "f16":  # the fast mode: half operands, one MFMA product per term (1.5e-2 on the CAM maps)
+                w3 = Workload(device, args.batch, "f16", args.workload, seed=rank, arch=args.arch, share=wl)
+                t3 = timed_run(w3, w3.step_pipelined if pipelined else w3.step, k_extra, 2, w3.drain)
+                stages["value_f16"] = round(args.batch * k_extra / t3, 3)
+                stages["cnn_ms_f16"] = round(w3.timed(w3.run_cnn, 3), 4)
+                w3.close()
+                del w3
+            wl.setup_kplus1()
+            tk = timed_run(wl, wl.step_kplus1, k_extra, 2, wl.drain)
+            stages["value_M_eq_Kplus1"] = round(args.batch * k_extra / tk, 3)
+            stages["M_eq_Kplus1_groups"] = ["K=%d x %d images" % (K, nb) for (_, nb, K) in wl.kp_groups]
+        # End to end (host batch in, .npy files out) on EVERY rank at once: N workers share the host's cores, PCIe root and
+        # page cache, so the aggregate is what a make_cam run over N GPUs sees.  Writers go to a tmpfs when
+        # there is one (WSC_BENCH_TMP overrides): the measurement is the host pipeline, not a disk.
         import shutil
         import tempfile
 
-        tmp = tempfile.mkdtemp(prefix="wsc_bench_", dir=os.environ.get("WSC_BENCH_TMP", None))
+        def agg(seconds):
+            if dist is None:
+                return seconds
+            t = torch.tensor([seconds], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        tmp_root = os.environ.get("WSC_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
+        tmp = tempfile.mkdtemp(prefix="wsc_bench_r%d_" % rank, dir=tmp_root)
         try:
-            wl.setup_e2e(tmp)
-            te = timed_run(wl, wl.step_e2e, k_extra, 2, wl.drain_e2e)
-            stages["value_end_to_end"] = round(args.batch * k_extra / te, 3)
-            stages["end_to_end"] = ("per step: 79 MB pageable float32 batch -> pinned -> H2D; D2H of cam + high_res (%.1f MB) and "
-                                    "label maps (%.1f MB); %d .npy files through 8 writer threads; overlapped with the next step, whose staging copy the same threads make ahead of time"
-                                    % ((wl.s_tot + wl.h_tot) * 4 / 1e6, args.batch * S * S * 4 / 1e6, 2 * args.batch))
-            wl.setup_e2e(tmp, u8=True)
-            te = timed_run(wl, wl.step_e2e, k_extra, 2, wl.drain_e2e)
-            stages["value_end_to_end_u8_input"] = round(args.batch * k_extra / te, 3)
+            from wsscam.step.pipeline import host_thread_budget
+
+            n_wr = 8 if world == 1 else max(2, host_thread_budget(world)["n_writers"])
+            wl.setup_e2e(tmp, n_writers=n_wr)
+            te = agg(timed_run(wl, wl.step_e2e, k_extra, 2, wl.drain_e2e))
+            stages["value_end_to_end"] = round(world * args.batch * k_extra / te, 3)
+            stages["end_to_end"] = ("per step and rank: 79 MB pageable float32 batch -> pinned -> H2D; D2H of cam + high_res (%.1f MB) and "
+                                    "label maps (%.1f MB); %d .npy files through %d writer threads (%s); overlapped with the next step, whose staging copy the same threads make ahead of time; %d rank(s) at once, max over ranks"
+                                    % ((wl.s_tot + wl.h_tot) * 4 / 1e6, args.batch * S * S * 4 / 1e6, 2 * args.batch, n_wr,
+                                       "tmpfs" if tmp_root == "/dev/shm" else (tmp_root or "system temp dir"), world))
+            wl.setup_e2e(tmp, n_writers=n_wr, u8=True)
+            te = agg(timed_run(wl, wl.step_e2e, k_extra, 2, wl.drain_e2e))
+            stages["value_end_to_end_u8_input"] = round(world * args.batch * k_extra / te, 3)
             stages["end_to_end_u8_input"] = ("as value_end_to_end, but the host hands over the DECODED native-size images (%.1f MB "
                                              "per step); float64 resize + normalise + flip pair on the device, bit-identical"
                                              % (wl.u8_offs[-1] / 1e6))
@@ -906,6 +1001,23 @@ def main():
             wl.e2e["finisher"].shutdown(wait=True)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+        if world == 1:
+            # BASELINE configs 5 and 4 timed by the same default command: HistoSegNet on ADP-like patches and
+            # IRNet inference at VOC size, each through its driver; full detail: --workload hsn / profiles/bench_irn.py
+            wl.drain()
+            try:
+                ha = argparse.Namespace(**vars(args))
+                ha.batch, ha.steps, ha.warmup, ha.no_cpu_baseline = 16, 5, 1, True
+                hs = hsn_measure(ha, device)
+                stages["value_hsn"] = {"value": hs["value"], "unit": "images/s", "ms_per_step": hs["ms_per_step"], "dtype": hs["dtype"],
+                                       "batch_images": 16, "workload": hs["config"]["workload"],
+                                       "effective_M": hs["config"]["effective_M"]}
+            except Exception as e:  # an extra leg must not lose the headline line
+                stages["value_hsn"] = {"error": repr(e)}
+            try:
+                stages["value_irn"] = irn_measure(device, args.precision)
+            except Exception as e:
+                stages["value_irn"] = {"error": repr(e)}
 
     if rank == 0:
         images = args.batch * (steps if args.scaling == "strong" else steps * world)

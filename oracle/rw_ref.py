@@ -65,3 +65,37 @@ def propagate_to_edge(x, edge, radius=5, beta=10, exp_times=8, dtype=torch.float
     xm = x.view(-1, height, width) * (1 - edge)
     rw = torch.matmul(xm.view(-1, height * width), trans)
     return rw.view(rw.size(0), 1, height, width)
+
+
+def propagate_to_edge_sparse(x, edge, radius=5, beta=10, exp_times=8):
+    """The same expression at sizes where the dense (hw x hw) matrix does not fit a test (94 x 125: 11 750^2 entries, 26 TFLOP
+    of squarings): the transition matrix built as a SPARSE float64 matrix from the very same affinities, index tables, padding
+    and crop -- dense[ind_from, ind_to] += a; dense[ind_to, ind_from] += a; + I; crop; pow beta; column-normalise -- and
+    x (1 - edge) @ T^(2^exp_times) evaluated as 2^exp_times vector-matrix products (matrix powers commute with the product;
+    float64 makes the evaluation order immaterial at the tolerances used: equal to the dense float64 form to 1e-12 on small
+    grids, tests/test_irn_oracle.py).  x (K,h,w), edge (1,h,w) torch or numpy -> numpy float64 (K,1,h,w)."""
+    import scipy.sparse as sp
+
+    x = torch.as_tensor(np.asarray(x)).to(torch.float64)
+    edge = torch.as_tensor(np.asarray(edge)).to(torch.float64)
+    height, width = x.shape[-2:]
+    hor_padded, vert_padded = width + radius * 2, height + radius
+    pi = PathIndex(radius=radius, default_size=(vert_padded, hor_padded))
+    edge_padded = F.pad(edge, (radius, radius, 0, radius), mode="constant", value=1.0)
+    aff = edge_to_affinity(torch.unsqueeze(edge_padded, 0), pi.path_indices).reshape(-1).numpy()
+    n = vert_padded * hor_padded
+    ind_to = np.asarray(pi.dst_indices).reshape(-1)
+    ind_from = np.tile(np.asarray(pi.src_indices), np.asarray(pi.dst_indices).shape[0])
+    assert ind_from.shape == ind_to.shape == aff.shape
+    dense = sp.coo_matrix((aff, (ind_from, ind_to)), shape=(n, n)).tocsr()
+    dense = dense + dense.T + sp.identity(n, format="csr")
+    keep = np.arange(n).reshape(vert_padded, hor_padded)[:-radius, radius:-radius].reshape(-1)  # dense[:-r, r:-r, :-r, r:-r]
+    dense = dense[keep][:, keep].tocsc()
+    dense.data = dense.data ** beta
+    col = np.asarray(dense.sum(axis=0)).reshape(-1)
+    trans = (dense @ sp.diags(1.0 / col)).tocsr()
+    v = (x.reshape(-1, height, width) * (1 - edge)).reshape(-1, height * width).numpy()
+    tt = trans.T.tocsr()
+    for _ in range(2 ** exp_times):
+        v = (tt @ v.T).T
+    return v.reshape(v.shape[0], 1, height, width)

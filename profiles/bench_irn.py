@@ -20,22 +20,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--arch", default="vgg16", choices=["vgg16", "resnet50"])
-    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "bf16x3"])
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16", "bf16", "bf16x3"])
     ap.add_argument("--steps", type=int, default=5)
     args = ap.parse_args()
     import numpy as np
 
-    from oracle import irn_ref  # synthetic weights only
-    from wsscam import _lib
+    from wsscam import _lib, synth
     from wsscam.misc.indexing import PathIndex
 
     ctx = _lib.Context(0)
-    prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3}[args.precision]
-    if args.arch == "vgg16":
-        sd, arch = irn_ref.make_vgg16_irn_state_dict(0), _lib.ARCH_VGG16_IRN
-    else:
-        sd, arch = irn_ref.make_resnet50_irn_state_dict(0), _lib.ARCH_RESNET50_IRN
-    net = _lib.Net(ctx, arch, {k: v.numpy() for k, v in sd.items()}, 20, prec)
+    prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "f16x3": _lib.PREC_F16X3}[args.precision]
+    sd = synth.irn_state_dict(args.arch, 0)  # seeded random weights (no trained IRNet weights offline)
+    arch = _lib.ARCH_VGG16_IRN if args.arch == "vgg16" else _lib.ARCH_RESNET50_IRN
+    net = _lib.Net(ctx, arch, sd, 20, prec)
     B, S, fh, fw = args.batch, 512, 81, 81  # 321x321 network input -> (321-1)//4+1 = 81
     rng = np.random.default_rng(0)
     x = np.zeros((B, 2, 3, S, S), np.float32)
@@ -82,7 +79,7 @@ def main():
         from wsscam.net import resnet50_irn as irn_mod
 
         model = irn_mod.EdgeDisplacement(None, 20, precision=prec)
-    model.load_state_dict({k: v.numpy() for k, v in sd.items()}, strict=False)
+    model.load_state_dict(sd, strict=False)
     model.cuda(0)
     DB = 16
     packs = [{"name": "i%d" % i, "img": rng.normal(0, 1, (2, 3, 375, 500)).astype(np.float32), "size": (375, 500)} for i in range(DB)]

@@ -136,6 +136,49 @@ def test_propagate_tiled_step_is_bit_identical(ctx):
         assert r.shape == o.shape and np.array_equal(r, o)
 
 
+def test_config4_real_size_walk_and_edge_net(ctx):
+    """BASELINE config 4 at its REAL size: a 375 x 500 VOC image -- the random walk of K = 2 strided CAMs on
+    94 x 125 (exp_times 8 = 256 stencil steps, beta 10) through wsc_rw_propagate_batch's TILED path (32 images per pass: the
+    batch fills the chip with 16 x 16 tiles, csrc/rw.hip) against the float64 sparse statement of the reference's dense
+    matrix-power form (oracle/rw_ref.py::propagate_to_edge_sparse; the 11 750^2 matrix itself is never built), and
+    wsc_net_forward_edge on the [orig, flip] pair zero-padded to crop 512 in the headline mode f16x3 against oracle/irn_ref.py
+    (03b_irn/step/make_sem_seg_labels.py:46-110, net/resnet50_irn.py:210-232)."""
+    from oracle import rw_ref
+    from wsscam.misc import indexing
+
+    rng = np.random.default_rng(31)
+    K, h, w, n_img = 2, 94, 125, 32
+    xs = [rng.random((K, h, w)).astype(np.float32) for _ in range(n_img)]
+    es = [(rng.random((1, h, w)) ** 2).astype(np.float32) for _ in range(n_img)]
+    with ctx.option(_lib.OPT_RW_TILED, 1):  # (the default picks it for this batch as well; forced so the test says what it covers)
+        outs = indexing.propagate_to_edge_batch(xs, es, beta=10, exp_times=8, ctx=ctx)
+    worst = 0.0
+    for i in (0, 13, 31):
+        exact = rw_ref.propagate_to_edge_sparse(xs[i], es[i], radius=5, beta=10, exp_times=8)
+        assert outs[i].shape == exact.shape == (K, 1, h, w)
+        scale = max(1.0, float(np.abs(exact).max()))
+        err = float(np.abs(outs[i] - exact).max()) / scale
+        worst = max(worst, err)
+        assert err <= 1e-5, (i, err)  # the bound of the small-grid test against the exact value of the reference's expression
+        assert float(np.abs(exact).max()) > 1e-3  # (the walk has not collapsed to zero: the comparison is not vacuous)
+    print("config 4 walk at 94 x 125, 256 steps, tiled path: max |device - float64 oracle| = %.2e x scale" % worst)
+
+    sd = irn_ref.make_resnet50_irn_state_dict(seed=3)
+    m = resnet50_irn.EdgeDisplacement(None, 20, crop_size=512, stride=4, precision=_lib.PREC_F16X3)
+    m.load_state_dict(sd)
+    m.eval().cuda(0)
+    x = cnn_ref.msf_pack(cnn_ref.synth_image(rng, 375, 500), None)  # (2, 3, 375, 500): make_sem_seg_labels feeds the native size
+    assert x.shape == (2, 3, 375, 500)
+    edge, dp = m.forward(x)
+    with torch.no_grad():
+        e, d = irn_ref.edge_displacement_forward(torch.from_numpy(x), sd, "resnet50", crop_size=512, stride=4)
+    assert edge.shape == tuple(e.shape) == (1, h, w) and dp.shape == tuple(d.shape) == (2, h, w)
+    te, td = TOL[_lib.PREC_F16X3]
+    ee, ed = float(np.abs(edge - e.numpy()).max()), float(np.abs(dp - d.numpy()).max()) / max(1.0, float(d.abs().max()))
+    print("config 4 edge net at crop 512 (f16x3): edge %.2e, displacement %.2e" % (ee, ed))
+    assert ee <= te and ed <= td, (ee, ed)
+
+
 def test_path_index_tables():
     """PathIndex(radius=5): 34 directions in the upper half plane, paths include both end points, destinations
     first; radius 10 (cam_to_ir_label / train_irn) also builds."""

@@ -31,3 +31,18 @@ def test_vgg16_irn_restatement_shapes():
     assert e.shape == (2, 1, 16, 16) and d.shape == (2, 2, 16, 16)
     assert edge.shape == (1, 13, 16) and dp.shape == (2, 13, 16)
     assert float(edge.min()) > 0 and float(edge.max()) < 1
+
+
+def test_sparse_random_walk_oracle_equals_dense_form():
+    """oracle/rw_ref.py::propagate_to_edge_sparse (what the VOC-size GPU test checks the tiled random-walk path against)
+    is the dense matrix-power form of the same file, evaluated in float64, on grids the dense form still fits."""
+    from oracle import rw_ref
+
+    for (K, h, w, radius, beta, exp_times) in ((2, 13, 17, 5, 10, 4), (3, 9, 22, 5, 8, 6), (1, 6, 7, 3, 10, 3)):
+        g = torch.Generator().manual_seed(h * 100 + w)
+        x = torch.rand(K, h, w, generator=g)
+        edge = torch.rand(1, h, w, generator=g) ** 2
+        dense = rw_ref.propagate_to_edge(x, edge, radius=radius, beta=beta, exp_times=exp_times, dtype=torch.float64).numpy()
+        sparse = rw_ref.propagate_to_edge_sparse(x, edge, radius=radius, beta=beta, exp_times=exp_times)
+        assert sparse.shape == dense.shape and sparse.dtype == np.float64
+        assert np.abs(sparse - dense).max() <= 1e-12 * max(1.0, float(np.abs(dense).max())), np.abs(sparse - dense).max()

@@ -222,14 +222,32 @@ class _HostWorkDataset:
                 "label": np.eye(20, dtype=np.float32)[i % 20]}
 
 
-def _host_rank_main(rank, world, port, out_dir, n_items, S, result_file):
+class _StubDecodeDataset:
+    """Decode STUBBED (one precomputed network input handed out for every item: no host arithmetic per image), outputs at
+    the VOC size with K = 2 classes: what is left is the pipeline's own host work -- staging copies, views, the .npy writer."""
+
+    def __init__(self, n, S):
+        self.n = n
+        x = np.zeros((3, S, S), np.float32)
+        self.pair = np.stack([x, x])
+        self.label = np.zeros(20, np.float32)
+        self.label[[3, 11]] = 1
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return {"name": "w%03d" % i, "img": self.pair, "size": (375, 500), "label": self.label}
+
+
+def _host_rank_main(rank, world, port, out_dir, n_items, S, result_file, stub_decode=False):
     import time
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        shards = torchutils.split_dataset(_HostWorkDataset(n_items, S, 7), world)
+        shards = torchutils.split_dataset(_StubDecodeDataset(n_items, S) if stub_decode else _HostWorkDataset(n_items, S, 7), world)
         pipe = _stub_pipeline(world, out_dir, S)
         dist.barrier()
         t0 = time.perf_counter()
@@ -274,3 +292,22 @@ def test_eight_rank_host_budget(tmp_path):
         assert (int(nl), int(nw)) == ((b1 if world == 1 else b8)["n_loaders"], (b1 if world == 1 else b8)["n_writers"])
     # same images, same cores: eight sharded workers must not be slower than one worker by more than process start-up noise
     assert n_items / times[8] >= 0.6 * n_items / times[1], times
+    # What 8 GPUs at ~2000 images/s each ask of the host: 16 000 images/s through loaders -> lanes -> finishers
+    # -> the REAL .npy writer at the VOC size (K = 2: 1.6 MB per file), decode stubbed.  A GPU node has >= 64 cores for its 8
+    # GPUs, i.e. the requirement is 250 images/s per core.  The figure is PRINTED next to the requirement; the assertion only
+    # catches a collapse (a twentieth of the requirement): on the 8-core build container the same run measured 175 ... 1500
+    # images/s from one minute to the next (shared cores, page cache), so a tight bound here would be a flaky test, not
+    # evidence.  No scaling curve exists on hardware yet -- this pins the host side's bookkeeping and order of magnitude only.
+    n_big = int(os.environ.get("WSC_TEST_HOST_ITEMS", 32 * max(8, cores)))
+    out = tmp_path / "voc8"
+    out.mkdir()
+    res = str(tmp_path / "res_voc8.txt")
+    mp.spawn(_host_rank_main, nprocs=8, args=(8, _free_port(), str(out), n_big, S, res, True), join=True)
+    assert len(os.listdir(out)) == n_big
+    rec = np.load(str(out / "w000.npy"), allow_pickle=True).item()
+    assert rec["high_res"].shape == (2, 375, 500) and rec["cam"].shape == (2, 94, 125)
+    rate = n_big / float(open(res).read().split()[0])
+    need = 8 * 2000.0 * cores / 64.0
+    print("8-rank host pipeline, decode stubbed, real .npy writer at VOC size: %.0f images/s on %d cores "
+          "(8 x 2000 images/s on a 64-core node = %.0f on this many cores)" % (rate, cores, need))
+    assert rate >= 0.05 * need, (rate, need)

@@ -98,6 +98,46 @@ def plain_state_dict(root, num_classes=20, batchnorm=True, seed=0):
     return sd
 
 
+# IRNet EdgeDisplacement heads (03b_irn/net/resnet50_irn.py:24-77, vgg16_irn.py:30-98 with ds_fac = 0.25):
+# (name, backbone stage feeding it, output channels)
+IRN_HEADS = {
+    "resnet50": {"stage_channels": (64, 256, 512, 1024, 2048),
+                 "heads": [("fc_edge1", 1, 32), ("fc_edge2", 2, 32), ("fc_edge3", 3, 32), ("fc_edge4", 4, 32), ("fc_edge5", 5, 32),
+                           ("fc_dp1", 1, 64), ("fc_dp2", 2, 128), ("fc_dp3", 3, 256), ("fc_dp4", 4, 256), ("fc_dp5", 5, 256)]},
+    "vgg16": {"stage_channels": (64, 128, 256, 512, 1024),
+              "heads": [("fc_edge1", 1, 32), ("fc_edge2", 2, 32), ("fc_edge3", 3, 32), ("fc_edge4", 4, 32), ("fc_edge5", 5, 32),
+                        ("fc_dp1", 1, 64), ("fc_dp2", 2, 128), ("fc_dp3", 3, 256), ("fc_dp4", 4, 256), ("fc_dp5", 5, 256)]},
+}
+
+
+def irn_state_dict(arch="resnet50", seed=0):
+    """Seeded random weights of an IRNet EdgeDisplacement network (there are no trained IRNet weights offline): the CAM
+    backbone's state dict without its classifier + the Conv1x1 / GroupNorm heads of both branches, the final edge conv
+    (with bias), the final displacement conv and the mean-shift buffer.  Keys as the reference's state dict has them."""
+    rng = np.random.default_rng(3000 + seed)
+    if arch == "resnet50":
+        sd = resnet50_cam_state_dict(20, seed=seed)
+        del sd["classifier.weight"]
+    else:
+        sd = plain_state_dict("vgg16", 20, True, seed=seed)
+    cs = IRN_HEADS[arch]["stage_channels"]
+
+    def head(name, cin, cout):
+        sd[name + ".0.weight"] = _conv(rng, cout, cin, 1)
+        sd[name + ".1.weight"] = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        sd[name + ".1.bias"] = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+
+    for name, src, cout in IRN_HEADS[arch]["heads"]:
+        head(name, cs[src - 1], cout)
+    head("fc_dp6", 768, 256)
+    head("fc_dp7", 448, 256)
+    sd["fc_edge6.weight"] = (rng.standard_normal((1, 160, 1, 1)) * 0.1).astype(np.float32)
+    sd["fc_edge6.bias"] = (rng.standard_normal(1) * 0.1).astype(np.float32)
+    sd["fc_dp7.3.weight"] = _conv(rng, 2, 256, 1)
+    sd["mean_shift.running_mean"] = (rng.standard_normal(2) * 0.1).astype(np.float32)
+    return sd
+
+
 def image_batch(batch, S, seed=0, with_native=False):
     """-> (x float32 (B,2,3,S,S) MSF items, rgb uint8 (B,S,S,3) resized images, native sizes [(H0,W0)]
     [, the native-size uint8 images])."""
