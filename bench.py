@@ -149,6 +149,11 @@ class Workload:
         # third context: the mean-field loop.  With --pipeline (default) step i's loop runs here while
         # step i+1's conv stack (self.ctx) and lattice build (self.ctx_build) are already under way.
         self.ctx_crf = _lib.Context(device, stream=sC)
+        # A/B: WSC_BENCH_OPT="7=0,..." sets path selectors (include/wsscam.h wsc_option) on the three contexts
+        for kv in filter(None, os.environ.get("WSC_BENCH_OPT", "").split(",")):
+            o, v = kv.split("=")
+            for c in (self.ctx, self.ctx_build, self.ctx_crf):
+                c.set_option(int(o), int(v))
         self.pending = None  # lattices of the step whose mean-field loop is still in flight
         # step_pipelined(): the loops of the last TWO steps may be in flight.  done[p] is a stream that only ever waits for the
         # loop that last used parity p's buffers, so the host can wait for exactly that loop (two steps old: normally finished)

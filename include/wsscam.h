@@ -80,7 +80,8 @@ typedef enum {
     WSC_OPT_CRF_EMBED_FULL = 4,    /* default 0; 1: the 2048-slot LDS table for every tile of the lattice build */
     WSC_OPT_RW_TILED = 5,          /* default -1 (by batch size); 0: flat random-walk step; 1: tiled step */
     WSC_OPT_STEM_POOL_FUSED = 6,   /* default 1; 0: the f16x3 ResNet stem as conv_igemm + max-pool launches instead of stem_pool_kernel */
-    WSC_OPT_COUNT = 7
+    WSC_OPT_CONV_WINDOW = 7,       /* default 1; 0: per-tap A tiles instead of the LDS input window of the f16x3 3x3 / stride 1 layers (same bits) */
+    WSC_OPT_COUNT = 8
 } wsc_option;
 
 typedef struct wsc_crf wsc_crf; /* lattices (Gaussian + bilateral) of a batch of images */

@@ -21,6 +21,8 @@ def main():
     reps = int(a[10]) if len(a) > 10 else 5
     rng = np.random.default_rng(0)
     ctx = _lib.Context(0)
+    for kv in filter(None, os.environ.get("WSC_BENCH_OPT", "").split(",")):  # A/B: path selectors, e.g. 7=0 (no LDS window)
+        ctx.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
     x = ctx.to_device(rng.normal(0, 1, (N, Cin, H, W)).astype(np.float32))
     w = (rng.normal(0, 1, (Cout, Cin, k, k)) * np.sqrt(2.0 / (Cin * k * k))).astype(np.float32)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1

@@ -181,3 +181,30 @@ def test_conv_fast_variants_equal_generic_path(ctx, shape, precision):
         # (f16x3: hi saturates at 65504 and lo adds what is left of the clamped value: 65504 again)
         assert np.isfinite(y).all() and np.abs(y).max() == 65504.0
         assert np.array_equal(y, y_ref), (shape, use_res, relu, np.abs(y - y_ref).max())
+
+
+@pytest.mark.parametrize("shape", [(3, 128, 41, 41, 128), (2, 256, 21, 21, 256), (5, 64, 7, 9, 128), (1, 64, 40, 33, 128),
+                                   (7, 128, 5, 5, 256), (2, 64, 1, 1, 128), (2, 64, 3, 50, 128), (64, 256, 21, 21, 256)])
+def test_conv_lds_window_equals_per_tap_staging(ctx, shape):
+    """The LDS input window of the f16x3 3 x 3 / stride 1 layers (conv_igemm.hip, WPT > 0: all nine taps of a 32-channel
+    chunk read ONE window of the zero-padded input raster, staged once per chunk) against the per-tap A tiles of the same
+    kernel (ctx option OPT_CONV_WINDOW = 0): the same MFMA sequence on the same operands -- identical bits -- with and
+    without residual, on tiles that cross image rows, images and the end of the batch, 1 x 1 and 3 x 50 maps, and the
+    ResNet50 layer3 shape at the bench's 64 samples; and against the float64 oracle at the f16x3 bound."""
+    N, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(N * 131 + Cin + H * 7 + W)
+    x = rng.normal(0, 1, (N, Cin, H, W)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    w *= (1.0 + 0.5 * np.arange(Cout, dtype=np.float32) / Cout)[:, None, None, None]
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.normal(0, 0.2, Cout).astype(np.float32)
+    res = rng.normal(0, 1, (N, Cout, H, W)).astype(np.float32)
+    for use_res, relu in [(False, True), (True, False)]:
+        with ctx.option(_lib.OPT_CONV_WINDOW, 0):
+            y_tap = _run(ctx, x, w, 1, 1, scale, shift, res if use_res else None, relu, _lib.PREC_F16X3)
+        y_win = _run(ctx, x, w, 1, 1, scale, shift, res if use_res else None, relu, _lib.PREC_F16X3)
+        assert np.array_equal(y_win, y_tap), (shape, use_res, np.abs(y_win - y_tap).max())
+    if N <= 8:
+        ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), padding=1).numpy()
+        ref = ref * scale[None, :, None, None] + shift[None, :, None, None] + res
+        assert np.abs(y_win - ref).max() <= 4e-6 * np.abs(ref).max()  # the f16x3 bound of this file

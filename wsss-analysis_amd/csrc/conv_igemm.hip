@@ -77,6 +77,10 @@ struct ConvKArgs {
     long long lo_delta2; // SPLIT 2: x2_lo - x2
     int cc2, H2, W2, C2, stride2;
     int ldx;            // pixel pitch of x in elements (Cin; the first source's channel count when there are two)
+    // LDS input window of a 3 x 3 / stride 1 / pad 1 layer (WPT > 0 variants): positions of the zero-padded raster
+    // [N][H + 2][W + 2]; the block's window starts at the padded position of (its first output pixel's row - 1, column - 1)
+    int win_Wp, win_HpWp, win_N;
+    unsigned div_hpwp_mul, div_hpwp_s1, div_hpwp_s2, div_wp_mul, div_wp_s1, div_wp_s2;
     int stem_rows;      // host side only: the padded-input stem form (a K-step = one kernel row of 8 pixels x 4 channels)
     int kw_real;        // host side only: kernel width of the layer (FLOP accounting; kw is 1 in the stem form)
 };
@@ -105,9 +109,20 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 // a K-step is one (tap, 32-channel chunk); its 128-byte LDS row holds the chunk's 32 hi values in 16-byte slots 0-3 and
 // its 32 lo values in slots 4-7 (weights packed the same way), so one K-step's 4 + NB DMA pieces feed 2 k-slices x 3
 // MFMA products: 1.5x the matrix work per LDS byte of the one-plane kernel instead of 3x its staging.
-template <int BM, int BN, int MODE, int SPLIT, int ET, bool GLDS, int STAGES, int WMT = 64, int FAST = 0>
+//
+// WPT > 0 (LDS input WINDOW, f16x3 single-staged 128-row tiles, 3 x 3 / stride 1 / pad 1): the A operand of all nine taps of a
+// 32-channel chunk is ONE window of the zero-padded input raster -- the block's 128 output pixels are consecutive in (n, ho, wo)
+// order, so their input pixels for tap (r, s) are the window positions q(m) - q(m0) + r (W + 2) + s -- staged once per chunk
+// (WPT x 32 positions x [32 hi | 32 lo], same 128-byte rows and XOR swizzle as an A tile, so the fragment reads only change
+// their base address per tap) instead of nine per-tap A tiles: 2.4-4.9x fewer A bytes through L2 -> LDS.  The next chunk's
+// window travels in registers (WPT 16-byte loads per thread, issued at the chunk's first tap) and is written to LDS between
+// the chunk's last tap and the next one's first; the weight tiles keep their per-K-step LDS-DMA double buffer.  Same MFMA
+// sequence on the same operands as the per-tap kernel: bit-identical results (tests/test_gpu_conv.py).
+template <int BM, int BN, int MODE, int SPLIT, int ET, bool GLDS, int STAGES, int WMT = 64, int FAST = 0, int WPT = 0>
 __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void conv_igemm_kernel(ConvKArgs p) {
     constexpr bool FEPI = (FAST & 1) != 0, PW = (FAST & 2) != 0;
+    constexpr bool WIN = WPT > 0;
+    static_assert(!WIN || (SPLIT == 2 && BM == 128 && WMT == 64 && STAGES == 2 && FAST == 1), "LDS window: single-staged split, 128-row tile");
     static_assert(FAST == 0 || (SPLIT != 1 && ET == 1 && ((GLDS && MODE == 0) || FAST == 1)),
                   "FAST paths: f16, one plane or the single-staged split; the pointwise prologue belongs to the LDS-DMA layers");
     static_assert(SPLIT != 2 || (GLDS && MODE == 0 && STAGES == 2), "single-staged split: LDS-DMA layers, two LDS buffers");
@@ -126,6 +141,8 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
     constexpr int NB = BN * 8 / NT; // B 16-byte slots per thread per K-step
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int B_BYTES = BN * BK * 2;
+    constexpr int WIN_BYTES = WPT * 4096;                           // WPT x 32 window positions of 128 bytes
+    constexpr int A_REGION = WIN ? WIN_BYTES : STAGES * A_BYTES;    // bytes in front of the B buffers (two-buffer LDS-DMA path)
     constexpr int CT_STRIDE = BN + 4;
     static_assert(GLDS || (BM == 128 && STAGES <= 2), "register staging exists for the 128-row tile only");
     static_assert(STAGES >= 1 && STAGES <= 3, "1 (single K-step layers), 2 or 3 LDS buffers");
@@ -467,17 +484,77 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
         };
         auto issue_b = [&](int i, int buf) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wrow[i] + n_wk),
-                                             (__attribute__((address_space(3))) void *)(smem + STAGES * A_BYTES + buf * B_BYTES + wv * (NB * 1024) + i * 1024),
+                                             (__attribute__((address_space(3))) void *)(smem + A_REGION + buf * B_BYTES + wv * (NB * 1024) + i * 1024),
                                              16, 0, 0);
         };
         // ROLL (single-staged split on the 256 x 256 block): the fragment reads roll across the K-steps, see below
         constexpr bool ROLL = SPLIT == 2 && WMT == 128;
-        prep();
+        // ---- LDS window (WIN) state -----------------------------------------------------------------------------------------
+        constexpr int WP = WIN ? WPT : 1;
+        int woff[WP];          // per thread and piece: source offset in 16-byte units (plane and 8-channel group included)
+        unsigned wvalid = 0;   // bit i: piece i is a pixel of the image (else halo / outside: zeros)
+        u32x4_t wreg[WP];      // the next chunk's window pieces on their way to LDS
+        int qm[MI];            // window position of the lane's rows for tap (0, 0)
+        int c_khi = 0, c_kwi = 0, c_cc = 0; // decode of the K-step being computed
+        auto win_load = [&](int cc) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) issue_a(i, 0);
+            for (int i = 0; i < WP; ++i) {
+                const u32x4_t *g = reinterpret_cast<const u32x4_t *>(p.x + ((long long)woff[i] * 8 + cc * 32));
+                wreg[i] = ((wvalid >> i) & 1u) ? *g : u32x4_t{0u, 0u, 0u, 0u};
+            }
+        };
+        auto win_store = [&]() {
+#pragma unroll
+            for (int i = 0; i < WP; ++i) {
+                const int g = i * NT + t;
+                *reinterpret_cast<u32x4_t *>(smem + lds_off(g >> 3, g & 7)) = wreg[i];
+            }
+        };
+        if constexpr (WIN) {
+            auto q_of = [&](int m) {
+                const unsigned t1 = __umulhi(p.div_howo_mul, (unsigned)m);
+                const int n = (int)((t1 + (((unsigned)m - t1) >> p.div_howo_s1)) >> p.div_howo_s2);
+                const int rem = m - n * p.HoWo;
+                const unsigned t2 = __umulhi(p.div_wo_mul, (unsigned)rem);
+                const int ho = (int)((t2 + (((unsigned)rem - t2) >> p.div_wo_s1)) >> p.div_wo_s2);
+                const int wo = rem - ho * p.Wo;
+                return n * p.win_HpWp + (ho + 1) * p.win_Wp + wo + 1;
+            };
+            const int qm0 = q_of(m0);
+            const int q0 = qm0 - p.win_Wp - 1; // window position 0: the padded pixel above-left of the first output pixel
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = m0 + wm * WMT + mi * 32 + l31;
+                qm[mi] = q_of(m < p.m_end ? m : p.m_end - 1) - qm0; // (rows past the end: a valid position, results never stored)
+            }
+#pragma unroll
+            for (int i = 0; i < WP; ++i) {
+                const int g = i * NT + t;
+                const unsigned Q = (unsigned)(q0 + (g >> 3));
+                const int sl = g & 7;
+                const unsigned t1 = __umulhi(p.div_hpwp_mul, Q);
+                const int n = (int)((t1 + ((Q - t1) >> p.div_hpwp_s1)) >> p.div_hpwp_s2);
+                const unsigned rr = Q - (unsigned)n * (unsigned)p.win_HpWp;
+                const unsigned t2 = __umulhi(p.div_wp_mul, rr);
+                const int hp = (int)((t2 + ((rr - t2) >> p.div_wp_s1)) >> p.div_wp_s2);
+                const int wp = (int)rr - hp * p.win_Wp;
+                const bool ok = n < p.win_N && hp >= 1 && hp <= p.H && wp >= 1 && wp <= p.W;
+                const long long e = (((long long)n * p.H + (hp - 1)) * p.W + (wp - 1)) * (long long)p.ldx + (sl & 3) * 8 +
+                                    ((sl & 4) ? p.lo_delta : 0ll);
+                woff[i] = ok ? (int)(e >> 3) : 0;
+                wvalid |= ok ? (1u << i) : 0u;
+            }
+            win_load(0);
+        }
+        prep();
+        if constexpr (!WIN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_a(i, 0);
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i) issue_b(i, 0);
         advance();
+        if constexpr (WIN) win_store();
         if (ROLL && nk > 1) { // two stages ahead; the first one has landed when all but the newest 4 + NB pieces have
             prep();
 #pragma unroll
@@ -498,7 +575,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             offA[ks] = lds0 + lds_off(wm * WMT + l31, ks * 2 + kgrp);
-            offB[ks] = lds0 + STAGES * A_BYTES + lds_off(wn * WN + l31, ks * 2 + kgrp);
+            offB[ks] = lds0 + A_REGION + lds_off(wn * WN + l31, ks * 2 + kgrp);
         }
         auto kstep = [&](auto cur_c, int kt) __attribute__((always_inline)) {
             constexpr int cur = decltype(cur_c)::value;
@@ -519,21 +596,41 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                 u32x4_t fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];
                 // the next K-step's 4 + NB DMA pieces go out one at a time between this K-step's 6 MI NI MFMAs (issued back to
                 // back at the top of the step they queue in front of the texture addresser and hold the wave in its issue stage)
-                constexpr int EVERY = (6 * MI * NI) / (4 + NB);
+                constexpr int NAP = WIN ? 0 : 4; // per-K-step A pieces (none with the LDS window)
+                constexpr int EVERY = (6 * MI * NI) / (NAP + NB);
                 static_assert(EVERY >= 1, "a K-step has room for every DMA piece");
                 auto piece = [&](int j) {
                     if (!more || j % EVERY != 0) return;
                     const int q = j / EVERY;
-                    if (q < 4) {
+                    if (q < NAP) {
                         if (!(WSC_DBG(p, 32) && (n_khi | n_kwi) != 0)) issue_a(q, cur ^ 1); // (ablation 32: A staged for the first tap of a chunk only)
-                    } else if (q < 4 + NB) issue_b(q - 4, cur ^ 1);
+                    } else if (q < NAP + NB) issue_b(q - NAP, cur ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 };
+                // LDS window: the first tap of a chunk sends for the NEXT chunk's window (it has the whole chunk to arrive); the
+                // fragment addresses of this tap are the lane's window positions + r (W + 2) + s, swizzled by the position
+                unsigned aw[MI][4];
+                if constexpr (WIN) {
+                    if ((c_khi | c_kwi) == 0 && c_cc + 1 < p.cchunks) win_load(c_cc + 1);
+                    const int toff = c_khi * p.win_Wp + c_kwi;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int pos = qm[mi] + toff;
+                        const unsigned b0 = lds0 + (unsigned)pos * 128u, sw = (unsigned)(pos >> 1) & 7u;
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr) aw[mi][pr] = b0 + ((((unsigned)(pr * 2 + kgrp)) ^ sw) << 4);
+                    }
+                }
                 auto rd = [&](int set, int sl) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fah[set][mi]) : "v"(oA[sl]), "n"(cur * A_BYTES + mi * 4096) : "memory");
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fal[set][mi]) : "v"(oA[2 + sl]), "n"(cur * A_BYTES + mi * 4096) : "memory");
+                        if constexpr (WIN) {
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(fah[set][mi]) : "v"(aw[mi][sl]) : "memory");
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(fal[set][mi]) : "v"(aw[mi][2 + sl]) : "memory");
+                        } else {
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fah[set][mi]) : "v"(oA[sl]), "n"(cur * A_BYTES + mi * 4096) : "memory");
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fal[set][mi]) : "v"(oA[2 + sl]), "n"(cur * A_BYTES + mi * 4096) : "memory");
+                        }
                     }
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
@@ -609,6 +706,21 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
             }
             if (more) advance();
             __syncthreads();
+            if constexpr (WIN) {
+                // every read of the window has landed (barrier above).  Was this the chunk's last tap?  Then the next chunk's
+                // window, which has been travelling in registers since the chunk's first tap, replaces it.
+                if (++c_kwi == p.kw) {
+                    c_kwi = 0;
+                    if (++c_khi == p.kh) {
+                        c_khi = 0;
+                        ++c_cc;
+                        if (more) {
+                            win_store();
+                            __syncthreads();
+                        }
+                    }
+                }
+            }
         };
         static_assert(A_BYTES + (MI - 1) * 4096 < 65536 && B_BYTES + (NI - 1) * 4096 < 65536, "ds_read immediate offset range");
         if constexpr (ROLL) {
@@ -964,18 +1076,18 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
     }
 }
 
-template <int BM, int BN, int MODE, int SPLIT, int ET, int STAGES, int WMT = 64, int FAST = 0>
+template <int BM, int BN, int MODE, int SPLIT, int ET, int STAGES, int WMT = 64, int FAST = 0, int WPT = 0>
 int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     constexpr bool GLDS = MODE == 0; // LDS-DMA staging for every generic layer; small-Cin layers stage via registers
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    constexpr int PIPE = STAGES * (A_BYTES + B_BYTES);
+    constexpr int PIPE = WPT > 0 ? WPT * 4096 + STAGES * B_BYTES : STAGES * (A_BYTES + B_BYTES);
     // fp32 transpose: 64-row groups in the single-buffer variant, 128-row groups in the 256 x 256 tile
     constexpr int EPI = (STAGES == 1 ? 64 : (WMT == 128 ? 128 : BM)) * (BN + 4) * 4;
     constexpr int LDS = PIPE > EPI ? PIPE : EPI;
     static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
     // the attribute belongs to the (function, device) pair: a process may hold contexts on several GPUs
     static bool attr_set[64] = {};
-    auto kern = conv_igemm_kernel<BM, BN, MODE, SPLIT, ET, GLDS, STAGES, WMT, FAST>;
+    auto kern = conv_igemm_kernel<BM, BN, MODE, SPLIT, ET, GLDS, STAGES, WMT, FAST, WPT>;
     const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
     int lds_req = LDS;
 #ifdef WSC_AB_KNOBS
@@ -995,6 +1107,12 @@ int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
     hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(BM * 2), lds_req, ctx->stream, a);
     WSC_HIP(hipGetLastError());
     return WSC_OK;
+}
+
+// 3 x 3 / stride 1 / pad 1 layer of the f16x3 mode on the LDS-window variant (WPT x 32 window positions)
+template <int WPT>
+int launch_window(wsc_ctx *ctx, const ConvKArgs &a) {
+    return launch_stages<128, 128, 0, 2, 1, 2, 64, 1, WPT>(ctx, a);
 }
 
 template <int BM, int BN, int MODE, int SPLIT, int ET, int FAST = 0>
@@ -1076,6 +1194,8 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     a.y = p.y; a.y_lo = p.y_lo; a.y_f32 = p.y_f32;
     a.H = p.H; a.W = p.W; a.Cin = p.Cin; a.Ho = p.Ho; a.Wo = p.Wo; a.Cout = p.Cout;
     a.ldy = p.ldy > 0 ? p.ldy : p.Cout;
+    a.win_Wp = a.win_HpWp = a.win_N = 0;
+    a.div_hpwp_mul = a.div_hpwp_s1 = a.div_hpwp_s2 = a.div_wp_mul = a.div_wp_s1 = a.div_wp_s2 = 0;
     a.ldx = p.Cin; a.x2 = nullptr; a.lo_delta2 = 0; a.cc2 = 0; a.H2 = a.W2 = a.C2 = 0; a.stride2 = 1;
     a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.relu = p.relu;
     a.M = p.N * p.Ho * p.Wo;
@@ -1222,6 +1342,31 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     }
     const int BMsel = big ? 256 : 128;
     a.nblocks = ((a.M + BMsel - 1) / BMsel) * a.ntiles_n;
+    // LDS input window (north star: "3x3 convolutions as MFMA-tiled direct convs with LDS-staged input windows"): the f16x3
+    // 3 x 3 / stride 1 / pad 1 layers on 128 x 128 tiles whose window -- the padded-raster positions from (first output pixel's
+    // row - 1, column - 1) to (last output pixel's row + 1, column + 1) -- fits 256 or 320 positions (32 / 40 KB next to the
+    // weight tiles' 32 KB: two blocks per CU stay): ResNet50 @321 layer2 / layer3 conv2 (41 x 41: 312, 21 x 21: 236 positions).
+    // Larger maps keep the per-tap A tiles (81 x 81 would need 468 positions = 60 KB, one block per CU).
+    if (!big && BN == 128 && single_staged && a.fast == 1 && p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad == 1 && p.x2 == nullptr &&
+        p.Ho == p.H && p.Wo == p.W && ctx->opt[WSC_OPT_CONV_WINDOW] != 0) {
+        const int Wp = p.W + 2, HpWp = (p.H + 2) * Wp;
+        auto q_of = [&](long long m) {
+            const long long n = m / a.HoWo, rem = m - n * a.HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            return n * HpWp + (ho + 1) * Wp + wo + 1;
+        };
+        long long need = 0;
+        for (long long m0 = a.m_base; m0 < a.m_end; m0 += 128) {
+            const long long ml = std::min<long long>(m0 + 127, a.m_end - 1);
+            need = std::max(need, q_of(ml) - q_of(m0) + 2 * Wp + 3);
+        }
+        const long long last_pos = q_of(a.m_end - 1) + Wp + 1 + 320; // (padded positions are decoded with 32-bit arithmetic)
+        if (need <= 320 && last_pos < (1ll << 31) && (long long)p.N * p.H * p.W * p.Cin < (1ll << 33)) {
+            a.win_Wp = Wp; a.win_HpWp = HpWp; a.win_N = p.N;
+            fastdiv((unsigned)HpWp, a.div_hpwp_mul, a.div_hpwp_s1, a.div_hpwp_s2);
+            fastdiv((unsigned)Wp, a.div_wp_mul, a.div_wp_s1, a.div_wp_s2);
+            return need <= 256 ? launch_window<8>(ctx, a) : launch_window<10>(ctx, a);
+        }
+    }
     if (big) return launch_big(ctx, a, p.split, p.fmt);
     if (BN == 128) return launch_bn<128>(ctx, a, small_cin_eff, p.split, p.fmt);
     return launch_bn<64>(ctx, a, small_cin_eff, p.split, p.fmt);
