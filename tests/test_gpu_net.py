@@ -689,3 +689,33 @@ def test_gen_cues_reference_call_form(tmp_path, monkeypatch):
     for k in ref:
         assert np.array_equal(np.asarray(ref[k]), np.asarray(out[k])), k
     assert any(np.asarray(out["%d_cues" % i]).size for i in range(3))
+
+
+@pytest.mark.parametrize("precision", [_lib.PREC_F16X3, _lib.PREC_F16])
+def test_cam_head_stream_equals_tiled_head(resnet_sd, precision):
+    """The 1x1 CAM head as a streaming GEMM (csrc/cam_head.hip: operands straight from memory into the MFMA, K in four
+    quarters added in a fixed order) against the same head through the tiled conv kernel (ctx option OPT_CAM_HEAD_STREAM = 0):
+    the same products, a different fp32 summation order -- equal to fp32 round-off; ResNet50 (K = 2048, C = 20, ragged last
+    block: 2 x 2 x 5 x 5 rows), VGG16 Grad-CAM with 31 classes, ReLU and scores, and the batch-independence of a row."""
+    model = _model(resnet50_cam.CAM, resnet_sd, 20, precision)
+    rng = np.random.default_rng(51)
+    x = np.stack([cnn_ref.msf_pack(cnn_ref.synth_image(rng, 70, 90), (65, 65)) for _ in range(2)])
+    cam = model.forward_batch(x)
+    with model.ctx.option(_lib.OPT_CAM_HEAD_STREAM, 0):
+        cam_t = model.forward_batch(x)
+    tol = 2e-6 if precision == _lib.PREC_F16X3 else 2e-6
+    assert cam.shape == cam_t.shape == (2, 20, 5, 5)
+    assert np.abs(cam - cam_t).max() <= tol * cam_t.max(), np.abs(cam - cam_t).max() / cam_t.max()
+    assert np.array_equal(model.forward_batch(x[1:])[0], cam[1])  # a row's sum does not depend on the rest of the batch
+    C = 31
+    sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, False, seed=8)
+    m = _model(vgg16_cam.CAM, sd, C, precision)
+    alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 33, C)
+    from wsscam.cues import utilities as cues
+
+    imgs = cnn_ref.normalize_int(np.stack([cnn_ref.synth_image(rng, 65, 65) for _ in range(3)]).astype(np.float64))
+    a, sa = cues.conv_and_cams(m, alpha, imgs, relu=True, want_scores=True)
+    with m.ctx.option(_lib.OPT_CAM_HEAD_STREAM, 0):
+        b, sb = cues.conv_and_cams(m, alpha, imgs, relu=True, want_scores=True)
+    assert a.shape == b.shape == (3, 8, 8, C) and (a >= 0).all()
+    assert np.abs(a - b).max() <= 2e-6 * b.max() and np.array_equal(sa, sb)

@@ -147,7 +147,7 @@ struct wsc_ctx {
     int pin_next = 0;
     // path selectors (wsc_ctx_set_option): every one picks between two paths that both exist for some inputs and give the
     // same bits -- the tests hold them to that.  Defaults: wsc_option in include/wsscam.h.
-    int opt[WSC_OPT_COUNT] = {1, 1, 1, 0, 0, -1, 1, 1};
+    int opt[WSC_OPT_COUNT] = {1, 1, 1, 0, 0, -1, 1, 1, 1};
     void *pinned = nullptr; // (legacy single buffer: unused)
     size_t pinned_bytes = 0;
     void *zero_page = nullptr; // 256 bytes of zeros in HBM (source of padded conv taps)
@@ -226,6 +226,9 @@ struct ConvLaunch {
     int H2, W2, C2, stride2;
 };
 int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p);
+// cam_head.hip: the 1x1 head with <= 32 output channels as a streaming GEMM (IEEE-half planes, fp32 [M][C] output)
+int launch_cam_head(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int M, int K, const bf16_t *w, int Kw, const float *s1,
+                    const float *b1, int C, int relu, float *y);
 
 // ---- misc kernels ---------------------------------------------------------------------
 int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo, int fmt);

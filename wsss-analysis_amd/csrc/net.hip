@@ -862,6 +862,17 @@ int wsc_net_cam_size_hw(const wsc_net *net, int H, int W, int *h_out, int *w_out
     return WSC_OK;
 }
 
+// The 1x1 head (CAM classifier weights / Grad-CAM alpha) with an fp32 NHWC output: in the IEEE-half modes (f16, f16x3) with at
+// most 32 classes it is the streaming kernel of cam_head.hip (an HBM stream, not a tile problem); else the tiled kernel.
+static int run_head(wsc_ctx *ctx, const wsc_net *net, const ConvLaunch &L) {
+    if (L.fmt == 1 && L.split != 1 && L.Cout <= 32 && L.CoutPad >= 32 && L.Cin % 64 == 0 && L.y_f32 != nullptr &&
+        ctx->opt[WSC_OPT_CAM_HEAD_STREAM] != 0)
+        return launch_cam_head(ctx, L.x, L.split == 2 ? L.x_lo : nullptr, L.N * L.Ho * L.Wo, L.Cin, L.w, L.Cin * (L.split == 2 ? 2 : 1),
+                               L.s1, L.b1, L.Cout, L.relu, L.y_f32);
+    (void)net;
+    return conv_igemm_launch(ctx, L);
+}
+
 int wsc_net_forward_cam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev, int B, int S, float *cam_dev,
                         float *score_dev) {
     return wsc_net_forward_cam_hw(ctx, net, x_dev, B, S, S, cam_dev, score_dev);
@@ -890,7 +901,7 @@ int wsc_net_forward_cam_hw(wsc_ctx *ctx, const wsc_net *net, const float *x_dev,
     L.y_f32 = head_out;
     L.N = N; L.H = hf; L.W = wf; L.Cin = c.Cin; L.Ho = hf; L.Wo = wf; L.Cout = c.Cout; L.CoutPad = c.CoutPad;
     L.kh = 1; L.kw = 1; L.stride = 1; L.pad = 0; L.relu = 0; L.small_cin = 0; L.split = net->split; L.fmt = net->fmt;
-    WSC_TRY(conv_igemm_launch(ctx, L));
+    WSC_TRY(run_head(ctx, net, L));
     WSC_TRY(launch_flip_add(ctx, head_out, B, hf, wf, net->C, net->C, cam_dev));
     if (score_dev != nullptr)
         WSC_TRY(launch_gap_linear_sigmoid(ctx, feat, feat_lo, B, net->cls_max ? -(hf * wf) : hf * wf, net->F,
@@ -917,7 +928,7 @@ int wsc_net_forward_gradcam(wsc_ctx *ctx, const wsc_net *net, const float *x_dev
     L.N = N; L.H = hf; L.W = wf; L.Cin = c.Cin; L.Ho = hf; L.Wo = wf; L.Cout = c.Cout; L.CoutPad = c.CoutPad;
     L.kh = 1; L.kw = 1; L.stride = 1; L.pad = 0; L.relu = relu ? 1 : 0; L.small_cin = 0; L.split = net->split;
     L.fmt = net->fmt;
-    WSC_TRY(conv_igemm_launch(ctx, L));
+    WSC_TRY(run_head(ctx, net, L));
     if (score_dev != nullptr)
         WSC_TRY(launch_gap_linear_sigmoid(ctx, feat, feat_lo, N, net->cls_max ? -(hf * wf) : hf * wf, net->F,
                                           net->cls_w, net->cls_b, net->Ccls, score_dev, net->fmt, 1));

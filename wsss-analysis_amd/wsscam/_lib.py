@@ -36,9 +36,9 @@ PREC_F16 = 2
 PREC_F16X3 = 3  # split-half operands and activations (hi + lo), three MFMA products: the fp32-class mode
 # path selectors of a context (include/wsscam.h wsc_option; Context.set_option / Context.option)
 OPT_CRF_GAUSS_ON_CHIP, OPT_CRF_FUSED_BLUR, OPT_CRF_BLUR_ON_CHIP, OPT_CRF_RANK_BALLOT, OPT_CRF_EMBED_FULL, OPT_RW_TILED, \
-    OPT_STEM_POOL_FUSED, OPT_CONV_WINDOW = range(8)
+    OPT_STEM_POOL_FUSED, OPT_CONV_WINDOW, OPT_CAM_HEAD_STREAM = range(9)
 OPT_DEFAULTS = {OPT_CRF_GAUSS_ON_CHIP: 1, OPT_CRF_FUSED_BLUR: 1, OPT_CRF_BLUR_ON_CHIP: 1, OPT_CRF_RANK_BALLOT: 0,
-                OPT_CRF_EMBED_FULL: 0, OPT_RW_TILED: -1, OPT_STEM_POOL_FUSED: 1, OPT_CONV_WINDOW: 1}
+                OPT_CRF_EMBED_FULL: 0, OPT_RW_TILED: -1, OPT_STEM_POOL_FUSED: 1, OPT_CONV_WINDOW: 1, OPT_CAM_HEAD_STREAM: 1}
 CONV_GENERIC = 0x100  # conv2d_nchw only: OR into precision to keep the kernel's generic variants (testing)
 
 
