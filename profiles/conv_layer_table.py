@@ -59,7 +59,7 @@ def main(db, N=64, S=321, planes=1):
     rows = c.execute("select s.kernel_name, d.start, d.end, d.grid_size_x / d.workgroup_size_x, d.group_segment_size "
                      "from %s d join %s s on d.kernel_id = s.id order by d.start" % (kd, ks)).fetchall()
     start = [i for i, r in enumerate(rows) if "nchw_to_nhwc4" in r[0]][-1]
-    convs = [r for r in rows[start:] if "conv_igemm_kernel" in r[0] or "stem_pool_kernel" in r[0]]
+    convs = [r for r in rows[start:] if "conv_igemm_kernel" in r[0] or "stem_pool_kernel" in r[0] or "cam_head_kernel" in r[0]]
     layers = resnet50_layers(S)
     if "stem_pool_kernel" in convs[0][0]:  # f16x3: conv 7x7 + BN + ReLU + the 3x3/2 max-pool in one launch (csrc/stem_pool.hip)
         layers[0] = ("stem 7x7 s2 3->64 + maxpool (fused)",) + layers[0][1:]

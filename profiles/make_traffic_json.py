@@ -20,10 +20,10 @@ CLASSES = {  # bench.py kernel-class label -> (kernel-name substrings, substring
     "update_splat_kernel<true, true, true, true>": (("update_splat_kernel<true, true, true, true>",), "update_splat_kernel<true, true, true, true>"),
     # the conv stack: every instantiation together (bench.py's top-level roofline kernel), then per tile
     # shape -- the labels are bench.py's profile classes -- and the fused stem + max-pool kernel
-    "conv_igemm_kernel": (("conv_igemm_kernel", "conv_win_kernel"), ("conv_igemm_kernel", "conv_win_kernel")),
-    "conv_igemm_kernel<256-row tiles,glds>": (("conv_igemm_kernel<256, ", "conv_win_kernel"), ("conv_igemm_kernel<256, ", "conv_win_kernel")),
+    "conv_igemm_kernel": (("conv_igemm_kernel", "cam_head_kernel"), ("conv_igemm_kernel", "cam_head_kernel")),
+    "conv_igemm_kernel<256-row tiles,glds>": (("conv_igemm_kernel<256, ",), "conv_igemm_kernel<256, "),
     "conv_igemm_kernel<128x128,glds>": (("conv_igemm_kernel<128, 128, ",), "conv_igemm_kernel<128, 128, "),
-    "conv_igemm_kernel<128x64,glds>": (("conv_igemm_kernel<128, 64, ",), "conv_igemm_kernel<128, 64, "),
+    "conv_igemm_kernel<128x64,glds>": (("conv_igemm_kernel<128, 64, ", "cam_head_kernel"), ("conv_igemm_kernel<128, 64, ", "cam_head_kernel")),
     "conv_igemm_kernel<small-Cin> / stem_pool_kernel": (("stem_pool_kernel",), "stem_pool_kernel"),
     "crf_build(all)": (("tile_embed", "slice_norm_tile", "tile_slots", "neighbors_kernel", "slot_dest", "scan_", "slot_ones", "assign_rows",
                         "first_bits", "combine1_kernel", "blur1_kernel", "fill_tables", "pack_pixels", "tile_build"), "tile_embed_kernel<5>"),
