@@ -152,3 +152,53 @@ def test_hsn_evaluation_tail_1088(ctx):
         assert np.array_equal(m["confusion_matrix"], conf) and np.array_equal(m["intersects"], inter)
         assert np.array_equal(m["unions"], union) and np.array_equal(m["gt_count"], gtc)
         assert m["mIoU"] == float(np.mean(inter / (union + 1e-7)))
+
+
+@pytest.mark.parametrize("dataset", ["VOC2012", "DeepGlobe"])
+def test_eval_cues_vs_reference_loop(ctx, tmp_path, dataset):
+    """02_cues/demo.py:323-484 (eval_cues): cues -> 41 x 41 arg-max map -> cv2 nearest resize to each ground truth's own size
+    -> per-class intersections / unions over the set -> IoU, mIoU, metrics file.  The device counters (wsc_label_confusion_nn)
+    against the reference's loop restated line by line in numpy: exact (integer counts), incl. VOC's void label 255, images
+    without any cue and DeepGlobe's 'no class claims the pixel' label."""
+    from tests.test_gpu_edge import _cv2_nearest
+    from wsscam.cues import demo as cues_demo
+    from wsscam.step.eval_cam import DEEPGLOBE_CLS_COLOURS
+
+    rng = np.random.default_rng(61)
+    voc = dataset == "VOC2012"
+    n_cls = 21 if voc else 6
+    sizes = [(50, 70), (41, 41), (120, 95), (33, 200), (64, 64)]
+    cues, gts = {}, []
+    for i, (H, W) in enumerate(sizes):
+        one = np.zeros((n_cls, 41, 41), np.int64)
+        if i != 3:  # image 3 has no cue at all
+            lab = rng.integers(0, n_cls, (41, 41))
+            keep = rng.random((41, 41)) < 0.6
+            one[lab[keep], np.nonzero(keep)[0], np.nonzero(keep)[1]] = 1
+        cues["%d_cues" % i] = np.array(np.where(one))
+        cues["%d_labels" % i] = np.unique(cues["%d_cues" % i][0])
+        if voc:
+            g = rng.integers(0, n_cls, (H, W)).astype(np.uint8)
+            g[rng.random((H, W)) < 0.1] = 255
+            gts.append(g)
+        else:
+            cols = np.asarray(list(DEEPGLOBE_CLS_COLOURS) + [(0, 0, 0)], np.uint8)  # + the 'unknown' colour, which is not scored
+            gts.append(cols[rng.integers(0, n_cls + 1, (H, W))])
+    out = cues_demo.eval_cues(dataset, "VGG16", 0.2, 2, cues=cues, gts=gts, out_dir=str(tmp_path), ctx=ctx, is_verbose=False)
+    inter, union = np.zeros(n_cls), np.zeros(n_cls)
+    for i, g in enumerate(gts):
+        ci = cues["%d_cues" % i]
+        pred = np.zeros((41, 41, n_cls))
+        pred[ci[1], ci[2], ci[0]] = 1.0
+        pm = np.argmax(pred, axis=-1)
+        if not voc:
+            pm[np.sum(pred, axis=-1) == 0] = 6
+        pidx = _cv2_nearest(np.uint8(pm), g.shape[:2])
+        for k in range(n_cls):
+            gm = (g == k) if voc else np.all(g == np.asarray(DEEPGLOBE_CLS_COLOURS[k], np.uint8)[None, None, :], axis=2)
+            inter[k] += np.sum(gm & (pidx == k))
+            union[k] += np.sum(gm | (pidx == k))
+    assert np.array_equal(out["intersects"], inter) and np.array_equal(out["unions"], union)
+    assert np.allclose(out["IoU"], inter / (union + 1e-7), rtol=0, atol=0) and out["mIoU"] == float(np.mean(inter / (union + 1e-7)))
+    rows = open(tmp_path / ("metrics_%s_VGG16_%s.csv" % (dataset, "val" if voc else "test"))).read().strip().splitlines()
+    assert rows[0] == ",Class,IoU" and len(rows) == n_cls + 2 and rows[-1].split(",")[1] == "Mean"

@@ -183,3 +183,120 @@ def gen_cues_adp(model_type, thresh, batch_size, size, cues_dir, set_name, is_ve
             with open(os.path.join(cues_dir[htt], "localization_cues.pickle"), "wb") as f:
                 pickle.dump(cues[htt], f)
     return cues
+
+
+# ---- evaluation of the cues (02_cues/demo.py:323-484) -------------------------------------------------------------------------
+VOC_SEG_CLASS_NAMES = ["__background__", "aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow",
+                       "diningtable", "dog", "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]
+
+
+def cue_label_map(cues_i, n_classes, seed_size=SEED_SIZE, empty_label=0):
+    """demo.py:423-427 / :446-451: `cues_pred[cues_i[1], cues_i[2], cues_i[0]] = 1; argmax(cues_pred, -1)` -- the class of every
+    seed pixel, `empty_label` where no class claims it (VOC2012: arg-max of an all-zero vector = 0, the background; DeepGlobe:
+    `ignore_ind`, a class outside the scored ones)."""
+    cues_i = np.asarray(cues_i)
+    pred = np.zeros((seed_size, seed_size, n_classes))
+    if cues_i.size:
+        pred[cues_i[1], cues_i[2], cues_i[0]] = 1.0
+    lab = np.argmax(pred, axis=-1).astype(np.int32)
+    lab[np.sum(pred, axis=-1) == 0] = empty_label
+    return lab
+
+
+def eval_cues(dataset, model_type, thresh, batch_size, set_name=None, run_train=False, should_saveimg=False, is_verbose=True, *,
+              cues=None, gts=None, colours=None, class_names=None, out_dir=None, ctx=None, settings=None):
+    """02_cues/demo.py:323-484 for VOC2012 / DeepGlobe: every image's cues -> 41 x 41 class map -> cv2 nearest-neighbour
+    resize to the ground truth's size -> per-class intersections and unions over the whole set -> IoU = I / (U + 1e-7), mIoU
+    = their mean; written as `metrics_<sess_id>_<set>.csv` (and `.xlsx` when openpyxl is installed, the reference's format).
+    The resize and the counting run on the device (wsc_label_confusion_nn, the kernel of the HistoSegNet evaluation tail).
+      cues     the dict gen_cues(..., run_train=False) returns / pickles (`'%d_cues'` -> int64 (3, n) rows class, row, col)
+      gts      per image: VOC2012 the class-index map (H, W) uint8 (what `cv2.imread(png)[:, :, 0]` of the reference reads);
+               DeepGlobe the colour-coded (H, W, 3) RGB map, matched against `colours`
+    Both default to what the reference reads from disk: ./eval/<sess_id>/localization_cues_val.pickle and the PNGs under
+    SegmentationClassAug next to the evaluation images (wsscam.keras_store).  Debug images (`should_saveimg`) are not
+    rendered.  Returns {'intersects', 'unions', 'IoU', 'mIoU', 'classes'}."""
+    from .. import _lib
+    from ..misc.imutils import default_context
+
+    assert dataset in ["VOC2012", "DeepGlobe", "DeepGlobe_balanced"], "ADP: eval_cues_adp is not mirrored"
+    assert batch_size > 0 and set_name in [None, "tuning", "segtest"]
+    sess_id = dataset + "_" + model_type if set_name is None else dataset + "_" + set_name + "_" + model_type
+    if thresh != 0.2:
+        sess_id += "_" + str(thresh)
+    eval_dir = out_dir or os.path.join("./eval", sess_id)
+    eval_set = "val" if dataset == "VOC2012" else "test"
+    if cues is None or gts is None:
+        from PIL import Image
+
+        from .. import keras_store as ks
+
+        st = ks.read_settings(settings)
+        img_size = 321 if model_type in ["VGG16", "VGG16bg"] else 224
+        ds = ks.Dataset(data_type=dataset, size=img_size, batch_size=batch_size,
+                        database_dir=st["DATA_ROOT"] if settings is not None else None)
+        eval_set = ds.sets[ds.is_evals.index(True)]
+        gen_eval = ds.set_gens[eval_set]
+        if cues is None:
+            path = os.path.join(eval_dir, "localization_cues_val.pickle")
+            if not os.path.exists(path):  # generate first if not already existing (demo.py:398-400)
+                gen_cues(dataset, model_type, thresh, batch_size, run_train=False, is_verbose=is_verbose, settings=settings,
+                         out_dir=eval_dir)
+            with open(path, "rb") as f:
+                cues = pickle.load(f, encoding="iso-8859-1")
+        if gts is None:
+            gt_dir = os.path.join(os.path.dirname(gen_eval.directory), "SegmentationClassAug")
+            names = [os.path.splitext(f)[0] + ".png" for f in gen_eval.filenames]
+            if dataset == "VOC2012":  # palette PNG: the index IS the class (cv2.imread(...)[:, :, 0] after the colour swap)
+                gts = [np.asarray(Image.open(os.path.join(gt_dir, n))) for n in names]
+            else:
+                gts = [np.asarray(Image.open(os.path.join(gt_dir, n)).convert("RGB")) for n in names]
+    if dataset == "VOC2012":
+        names_c = list(class_names or VOC_SEG_CLASS_NAMES)
+        n, empty = len(names_c), 0
+    else:
+        from ..step.eval_cam import DEEPGLOBE_CLS_COLOURS
+
+        colours = list(colours or DEEPGLOBE_CLS_COLOURS)  # get_colours(dataset)[:-1]: the 'unknown' class is not scored
+        names_c = list(class_names or ["class%d" % k for k in range(len(colours))])
+        n, empty = len(colours), len(colours)
+    ctx = ctx or default_context()
+    conf_dev = ctx.alloc((n + 1) * (n + 1) * 8)
+    _lib.check(ctx._lib.wsc_memset(ctx.h, conf_dev.ptr, 0, (n + 1) * (n + 1) * 8))
+    n_img = len(gts)
+    for lo in range(0, n_img, batch_size):
+        hi = min(lo + batch_size, n_img)
+        labs, gidx = [], []
+        for i in range(lo, hi):
+            labs.append(cue_label_map(cues["%d_cues" % i], n, empty_label=empty))
+            g = np.asarray(gts[i])
+            if dataset == "VOC2012":
+                gi = np.where(g < n, g, n).astype(np.uint8)  # 255 (void border) is no class's ground truth (gt_idx == k never holds)
+            else:
+                from ..hsn.demo import gt_index_from_colours
+
+                gi = gt_index_from_colours(g, colours)
+            gidx.append(np.ascontiguousarray(gi))
+        lab_dev = ctx.to_device(np.ascontiguousarray(np.stack(labs)), pooled=True)
+        gt_dev = ctx.to_device(np.concatenate([g.reshape(-1) for g in gidx]), pooled=True)
+        _lib.label_confusion_nn(ctx, lab_dev, [(SEED_SIZE, SEED_SIZE)] * (hi - lo), [g.shape for g in gidx],
+                                [b * SEED_SIZE * SEED_SIZE for b in range(hi - lo)], gt_dev, n + 1, conf_dev, ignore_label=-1)
+        if is_verbose:
+            print("\tImages %d-%d of %d" % (lo + 1, hi, n_img))
+    conf = ctx.to_host(conf_dev, (n + 1, n + 1), np.int64)
+    inter = np.diag(conf)[:n].astype(np.float64)
+    union = conf[:n, :].sum(1) + conf[:, :n].sum(0) - inter  # (gt == k) | (pred == k) over every pixel
+    iou = inter / (union + 1e-7)
+    out = {"intersects": inter, "unions": union.astype(np.float64), "IoU": iou, "mIoU": float(np.mean(iou)), "classes": names_c}
+    os.makedirs(eval_dir, exist_ok=True)
+    base = os.path.join(eval_dir, "metrics_" + sess_id + "_" + eval_set)
+    with open(base + ".csv", "w") as f:
+        f.write(",Class,IoU\n")
+        for k, (c, v) in enumerate(zip(names_c + ["Mean"], list(iou) + [out["mIoU"]])):
+            f.write("%d,%s,%r\n" % (k, c, float(v)))
+    try:  # the reference writes df.to_excel (demo.py:481-484); pandas needs openpyxl for that
+        import pandas as pd
+
+        pd.DataFrame({"Class": names_c + ["Mean"], "IoU": list(iou) + [out["mIoU"]]}, columns=["Class", "IoU"]).to_excel(base + ".xlsx")
+    except Exception:
+        pass
+    return out
