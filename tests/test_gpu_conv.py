@@ -184,7 +184,8 @@ def test_conv_fast_variants_equal_generic_path(ctx, shape, precision):
 
 
 @pytest.mark.parametrize("shape", [(3, 128, 41, 41, 128), (2, 256, 21, 21, 256), (5, 64, 7, 9, 128), (1, 64, 40, 33, 128),
-                                   (7, 128, 5, 5, 256), (2, 64, 1, 1, 128), (2, 64, 3, 50, 128), (64, 256, 21, 21, 256)])
+                                   (7, 128, 5, 5, 256), (2, 64, 1, 1, 128), (2, 64, 3, 50, 128), (64, 256, 21, 21, 256),
+                                   (4, 64, 19, 23, 64), (2, 128, 40, 40, 64)])
 def test_conv_lds_window_equals_per_tap_staging(ctx, shape):
     """The LDS input window of the f16x3 3 x 3 / stride 1 layers (conv_igemm.hip, WPT > 0: all nine taps of a 32-channel
     chunk read ONE window of the zero-padded input raster, staged once per chunk) against the per-tap A tiles of the same

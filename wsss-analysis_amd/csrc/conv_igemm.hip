@@ -1110,9 +1110,9 @@ int launch_stages(wsc_ctx *ctx, const ConvKArgs &a) {
 }
 
 // 3 x 3 / stride 1 / pad 1 layer of the f16x3 mode on the LDS-window variant (WPT x 32 window positions)
-template <int WPT>
+template <int WPT, int BN = 128>
 int launch_window(wsc_ctx *ctx, const ConvKArgs &a) {
-    return launch_stages<128, 128, 0, 2, 1, 2, 64, 1, WPT>(ctx, a);
+    return launch_stages<128, BN, 0, 2, 1, 2, 64, 1, WPT>(ctx, a);
 }
 
 template <int BM, int BN, int MODE, int SPLIT, int ET, int FAST = 0>
@@ -1347,7 +1347,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     // row - 1, column - 1) to (last output pixel's row + 1, column + 1) -- fits 256 or 320 positions (32 / 40 KB next to the
     // weight tiles' 32 KB: two blocks per CU stay): ResNet50 @321 layer2 / layer3 conv2 (41 x 41: 312, 21 x 21: 236 positions).
     // Larger maps keep the per-tap A tiles (81 x 81 would need 468 positions = 60 KB, one block per CU).
-    if (!big && BN == 128 && single_staged && a.fast == 1 && p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad == 1 && p.x2 == nullptr &&
+    if (!big && single_staged && a.fast == 1 && p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad == 1 && p.x2 == nullptr &&
         p.Ho == p.H && p.Wo == p.W && ctx->opt[WSC_OPT_CONV_WINDOW] != 0) {
         const int Wp = p.W + 2, HpWp = (p.H + 2) * Wp;
         auto q_of = [&](long long m) {
@@ -1360,11 +1360,14 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
             need = std::max(need, q_of(ml) - q_of(m0) + 2 * Wp + 3);
         }
         const long long last_pos = q_of(a.m_end - 1) + Wp + 1 + 320; // (padded positions are decoded with 32-bit arithmetic)
+        // (64-column tiles -- Cout = 64: ResNet50 layer1 conv2 at 81 x 81 -- would fit a 480-position window (60 KB + 16 KB of weight
+        // tiles, two blocks per CU instead of three): measured 129.2 -> 138.4 us, rejected; they take the window up to 320 positions too)
         if (need <= 320 && last_pos < (1ll << 31) && (long long)p.N * p.H * p.W * p.Cin < (1ll << 33)) {
             a.win_Wp = Wp; a.win_HpWp = HpWp; a.win_N = p.N;
             fastdiv((unsigned)HpWp, a.div_hpwp_mul, a.div_hpwp_s1, a.div_hpwp_s2);
             fastdiv((unsigned)Wp, a.div_wp_mul, a.div_wp_s1, a.div_wp_s2);
-            return need <= 256 ? launch_window<8>(ctx, a) : launch_window<10>(ctx, a);
+            if (BN == 128) return need <= 256 ? launch_window<8>(ctx, a) : launch_window<10>(ctx, a);
+            return need <= 256 ? launch_window<8, 64>(ctx, a) : launch_window<10, 64>(ctx, a);
         }
     }
     if (big) return launch_big(ctx, a, p.split, p.fmt);
