@@ -209,3 +209,20 @@ def test_conv_lds_window_equals_per_tap_staging(ctx, shape):
         ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), padding=1).numpy()
         ref = ref * scale[None, :, None, None] + shift[None, :, None, None] + res
         assert np.abs(y_win - ref).max() <= 4e-6 * np.abs(ref).max()  # the f16x3 bound of this file
+
+
+def test_context_option_restores_the_previous_value(ctx):
+    """Context.option(): the block ends with the value the selector HAD, not with the library default -- an
+    earlier set_option or an enclosing option() block stays in force, so an A/B test cannot silently compare default vs default."""
+    o = _lib.OPT_CONV_WINDOW
+    assert ctx.get_option(o) == _lib.OPT_DEFAULTS[o] == 1
+    ctx.set_option(o, 0)
+    try:
+        with ctx.option(o, 1):
+            assert ctx.get_option(o) == 1
+            with ctx.option(o, 0):
+                assert ctx.get_option(o) == 0
+            assert ctx.get_option(o) == 1
+        assert ctx.get_option(o) == 0
+    finally:
+        ctx.set_option(o, _lib.OPT_DEFAULTS[o])

@@ -86,11 +86,26 @@ def test_make_cam_device_transform_same_files(tmp_path):
                                   cam_weights_name="unused", norm_mode="int", val_list=None, dev_root=None, cam_scales=(1.0,),
                                   class_names={"bg": ["background"], "fg": ["c%d" % i for i in range(20)]})
 
-    d1, d2 = str(tmp_path / "host"), str(tmp_path / "dev")
+    d1, d2, d3 = str(tmp_path / "host"), str(tmp_path / "dev"), str(tmp_path / "serial")
     make_cam.run(args(d1, a))
     make_cam.run(args(d2, b))
+    # the SERIAL path (cam_pipeline off: the documented one-batch-at-a-time path, also what a multi-GPU run with the pipeline
+    # disabled takes) must accept the decoded-image items too (it raised KeyError 'img'): same files again
+    a3 = args(d3, b)
+    a3.cam_pipeline = False
+    make_cam.run(a3)
     for f in sorted(os.listdir(d1)):
         x = np.load(os.path.join(d1, f), allow_pickle=True).item()
         y = np.load(os.path.join(d2, f), allow_pickle=True).item()
+        z = np.load(os.path.join(d3, f), allow_pickle=True).item()
         for k in x:
             assert np.array_equal(x[k], y[k]), (f, k)
+            assert np.array_equal(x[k], z[k]), (f, k, "serial path")
+    # the default of the device-side transform follows the worker count run() will use and the path that will consume the items
+    ns = argparse.Namespace(n_gpus=2, outsize=(S, S), dataset="voc12")
+    assert make_cam._device_transform_default(ns) is True
+    ns.cam_pipeline = False
+    assert make_cam._device_transform_default(ns) is False
+    assert make_cam._device_transform_default(argparse.Namespace(n_gpus=2, outsize=None)) is False
+    assert make_cam._device_transform_default(argparse.Namespace(n_gpus=1, outsize=(S, S))) is False
+    assert make_cam._device_transform_default(argparse.Namespace(n_gpus=1, outsize=(S, S), cam_device_transform=True)) is True

@@ -719,3 +719,51 @@ def test_cam_head_stream_equals_tiled_head(resnet_sd, precision):
         b, sb = cues.conv_and_cams(m, alpha, imgs, relu=True, want_scores=True)
     assert a.shape == b.shape == (3, 8, 8, C) and (a >= 0).all()
     assert np.abs(a - b).max() <= 2e-6 * b.max() and np.array_equal(sa, sb)
+
+
+def test_eval_cues_adp_vs_reference_loop(tmp_path):
+    """02_cues/demo.py:487-640 (eval_cues_adp): the ADP seeds of both HTT types scored against colour-coded ground truth --
+    per class `cv2.resize(cues[:, :, k], (size, size), INTER_NEAREST) == 1` vs the ground-truth colour mask: intersects, unions,
+    predicted / gt totals, IoU (no epsilon), the reference's 'precision' / 'recall' ratios and the metrics file.  The device
+    counters against the reference's loop restated in numpy on the SAME cues: exact."""
+    from tests.test_gpu_edge import _adp_like_image, _cv2_nearest
+    from wsscam.cues import demo as cues_demo
+    from wsscam.step.eval_cam import ADP_CLS_COLOURS
+
+    C, S = 31, 224
+    sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, False, seed=33)
+    model = _model(vgg16_cam.CAM, sd, C, _lib.PREC_F16X3)
+    rng = np.random.default_rng(34)
+    images = [_adp_like_image(rng, S, S) for _ in range(3)]
+    alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 33, C)
+    gts = {h: [np.asarray(ADP_CLS_COLOURS[h], np.uint8)[rng.integers(0, len(ADP_CLS_COLOURS[h]), (S, S))] for _ in images]
+           for h in ("morph", "func")}
+    for h in gts:
+        gts[h][0][:5, :7] = (1, 2, 3)  # pixels of no class colour
+    out, cues = cues_demo.eval_cues_adp("VGG16", "ADP_tuning_VGG16", 2, S, "tuning", False, False, model=model, alpha=alpha,
+                                        thresholds=np.full((1, C), 0.5), images=images, gts=gts, out_dir=str(tmp_path))
+    for h in ("morph", "func"):
+        cols = ADP_CLS_COLOURS[h]
+        n = len(cols)
+        inter, union, ptot, gtot = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+        for j in range(3):
+            ci = cues[h]["%d_cues" % j]
+            cu = np.zeros((41, 41, n))
+            cu[ci[1], ci[2], ci[0]] = 1.0
+            g = gts[h][j]
+            for k, col in enumerate(cols):
+                gm = (g[:, :, 0] == col[0]) & (g[:, :, 1] == col[1]) & (g[:, :, 2] == col[2])
+                pm = _cv2_nearest(cu[:, :, k], (S, S)) == 1.0
+                inter[k] += np.sum(gm & pm)
+                union[k] += np.sum(gm | pm)
+                ptot[k] += np.sum(pm)
+                gtot[k] += np.sum(gm)
+        o = out[h]
+        assert np.array_equal(o["intersects"], inter) and np.array_equal(o["unions"], union)
+        assert np.array_equal(o["predicted_totals"], ptot) and np.array_equal(o["gt_totals"], gtot)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            assert np.array_equal(o["IoU"], inter / union, equal_nan=True)
+        assert np.array_equal(o["Precision"], inter / (gtot + 1e-5)) and np.array_equal(o["Recall"], inter / (ptot + 1e-5))
+        assert ptot.sum() > 0  # some seeds exist: the comparison is not vacuous
+        rows = open(tmp_path / ("metrics_ADP-%s_tuning_VGG16.csv" % h)).read().strip().splitlines()
+        assert rows[0] == ",Class,IoU,Precision,Recall" and len(rows) == n + 2

@@ -203,6 +203,28 @@ def cue_label_map(cues_i, n_classes, seed_size=SEED_SIZE, empty_label=0):
     return lab
 
 
+def cue_confusion(ctx, cues, gt_index_maps, n, empty_label, batch_size, is_verbose=False, first_index=0):
+    """Confusion counts [gt][pred] of (n + 1) x (n + 1) classes (index n: 'no class') between the cue label maps -- arg-max of
+    the one-hot seeds, cv2 nearest-neighbour resized to each ground truth's own size -- and the ground-truth index maps, on the
+    device (wsc_label_confusion_nn).  Every quantity of 02_cues/demo.py:428-433 / :586-597 is a sum over this matrix."""
+    from .. import _lib
+
+    conf_dev = ctx.alloc((n + 1) * (n + 1) * 8)
+    _lib.check(ctx._lib.wsc_memset(ctx.h, conf_dev.ptr, 0, (n + 1) * (n + 1) * 8))
+    n_img = len(gt_index_maps)
+    for lo in range(0, n_img, batch_size):
+        hi = min(lo + batch_size, n_img)
+        labs = [cue_label_map(cues["%d_cues" % (first_index + i)], n, empty_label=empty_label) for i in range(lo, hi)]
+        gidx = [np.ascontiguousarray(gt_index_maps[i], dtype=np.uint8) for i in range(lo, hi)]
+        lab_dev = ctx.to_device(np.ascontiguousarray(np.stack(labs)), pooled=True)
+        gt_dev = ctx.to_device(np.concatenate([g.reshape(-1) for g in gidx]), pooled=True)
+        _lib.label_confusion_nn(ctx, lab_dev, [(SEED_SIZE, SEED_SIZE)] * (hi - lo), [g.shape for g in gidx],
+                                [b * SEED_SIZE * SEED_SIZE for b in range(hi - lo)], gt_dev, n + 1, conf_dev, ignore_label=-1)
+        if is_verbose:
+            print("\tImages %d-%d of %d" % (lo + 1, hi, n_img))
+    return ctx.to_host(conf_dev, (n + 1, n + 1), np.int64)
+
+
 def eval_cues(dataset, model_type, thresh, batch_size, set_name=None, run_train=False, should_saveimg=False, is_verbose=True, *,
               cues=None, gts=None, colours=None, class_names=None, out_dir=None, ctx=None, settings=None):
     """02_cues/demo.py:323-484 for VOC2012 / DeepGlobe: every image's cues -> 41 x 41 class map -> cv2 nearest-neighbour
@@ -260,29 +282,15 @@ def eval_cues(dataset, model_type, thresh, batch_size, set_name=None, run_train=
         names_c = list(class_names or ["class%d" % k for k in range(len(colours))])
         n, empty = len(colours), len(colours)
     ctx = ctx or default_context()
-    conf_dev = ctx.alloc((n + 1) * (n + 1) * 8)
-    _lib.check(ctx._lib.wsc_memset(ctx.h, conf_dev.ptr, 0, (n + 1) * (n + 1) * 8))
-    n_img = len(gts)
-    for lo in range(0, n_img, batch_size):
-        hi = min(lo + batch_size, n_img)
-        labs, gidx = [], []
-        for i in range(lo, hi):
-            labs.append(cue_label_map(cues["%d_cues" % i], n, empty_label=empty))
-            g = np.asarray(gts[i])
-            if dataset == "VOC2012":
-                gi = np.where(g < n, g, n).astype(np.uint8)  # 255 (void border) is no class's ground truth (gt_idx == k never holds)
-            else:
-                from ..hsn.demo import gt_index_from_colours
 
-                gi = gt_index_from_colours(g, colours)
-            gidx.append(np.ascontiguousarray(gi))
-        lab_dev = ctx.to_device(np.ascontiguousarray(np.stack(labs)), pooled=True)
-        gt_dev = ctx.to_device(np.concatenate([g.reshape(-1) for g in gidx]), pooled=True)
-        _lib.label_confusion_nn(ctx, lab_dev, [(SEED_SIZE, SEED_SIZE)] * (hi - lo), [g.shape for g in gidx],
-                                [b * SEED_SIZE * SEED_SIZE for b in range(hi - lo)], gt_dev, n + 1, conf_dev, ignore_label=-1)
-        if is_verbose:
-            print("\tImages %d-%d of %d" % (lo + 1, hi, n_img))
-    conf = ctx.to_host(conf_dev, (n + 1, n + 1), np.int64)
+    def gt_index(g):
+        if dataset == "VOC2012":
+            return np.where(g < n, g, n).astype(np.uint8)  # 255 (void border) is no class's ground truth (gt_idx == k never holds)
+        from ..hsn.demo import gt_index_from_colours
+
+        return gt_index_from_colours(g, colours)
+
+    conf = cue_confusion(ctx, cues, [gt_index(np.asarray(g)) for g in gts], n, empty, batch_size, is_verbose)
     inter = np.diag(conf)[:n].astype(np.float64)
     union = conf[:n, :].sum(1) + conf[:, :n].sum(0) - inter  # (gt == k) | (pred == k) over every pixel
     iou = inter / (union + 1e-7)
@@ -300,3 +308,55 @@ def eval_cues(dataset, model_type, thresh, batch_size, set_name=None, run_train=
     except Exception:
         pass
     return out
+
+
+def eval_cues_adp(model_type, sess_id, batch_size, size, set_name, should_saveimg=False, is_verbose=True, *, model, alpha,
+                  thresholds, images, gts, thresh=0.2, all_classes=None, out_dir=None):
+    """02_cues/demo.py:487-640 (ADP): the seeds of gen_cues_adp for both HTT types, then per type and class
+    `pred_mask = cv2.resize(cues[:, :, k], (size, size), INTER_NEAREST) == 1` against the colour-coded ground truth:
+    intersects, unions, predicted_totals, gt_totals over the set; IoU = I / U (no epsilon: NaN for a class that never occurs,
+    as in the reference), 'precision' = I / (gt_totals + 1e-5) and 'recall' = I / (predicted_totals + 1e-5) -- the reference's
+    names for these two ratios, kept -- and their means; `metrics_ADP-<htt>_<set>_<model>.csv` (+ `.xlsx` with openpyxl).
+    `gts` {'morph': [...], 'func': [...]}: (size, size, 3) RGB ground-truth maps (ADPCues.read_gt_batch).  The one-hot seeds are
+    exclusive after the overlap resolution, so the per-class masks are one label map and all four sums come from one confusion
+    matrix on the device.  Debug images are not rendered."""
+    from ..hsn.demo import ADPClasses, gt_index_from_colours
+    from ..step.eval_cam import ADP_CLS_COLOURS
+
+    cues = gen_cues_adp(model_type, thresh, batch_size, size, None, set_name, is_verbose, model=model, alpha=alpha,
+                        thresholds=thresholds, images=images, all_classes=all_classes)
+    ac = ADPClasses(all_classes)
+    eval_dir = out_dir or os.path.join("./eval", sess_id)
+    os.makedirs(eval_dir, exist_ok=True)
+    out = {}
+    for htt in ("morph", "func"):
+        colours = [tuple(int(v) for v in c) for c in ADP_CLS_COLOURS[htt]]
+        names = ac.classes["valid_" + htt]
+        n = len(colours)
+        assert n == len(names)
+        gidx = [gt_index_from_colours(np.asarray(g), colours) for g in gts[htt]]
+        conf = cue_confusion(model.ctx, cues[htt], gidx, n, n, batch_size)
+        inter = np.diag(conf)[:n].astype(np.float64)
+        gt_tot, pred_tot = conf[:n, :].sum(1).astype(np.float64), conf[:, :n].sum(0).astype(np.float64)
+        union = gt_tot + pred_tot - inter
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = inter / union
+        prec, rec = inter / (gt_tot + 1e-5), inter / (pred_tot + 1e-5)
+        out[htt] = {"intersects": inter, "unions": union, "gt_totals": gt_tot, "predicted_totals": pred_tot, "IoU": iou,
+                    "Precision": prec, "Recall": rec, "mIoU": float(np.mean(iou)), "classes": list(names)}
+        if is_verbose:
+            print("\tmIoU (%s): %s" % (htt, out[htt]["mIoU"]))
+        base = os.path.join(eval_dir, "metrics_ADP-" + htt + "_" + str(set_name) + "_" + model_type)
+        with open(base + ".csv", "w") as f:
+            f.write(",Class,IoU,Precision,Recall\n")
+            rows = zip(list(names) + ["Mean"], list(iou) + [np.mean(iou)], list(prec) + [np.mean(prec)], list(rec) + [np.mean(rec)])
+            for k, (c, a, b, d) in enumerate(rows):
+                f.write("%d,%s,%r,%r,%r\n" % (k, c, float(a), float(b), float(d)))
+        try:
+            import pandas as pd
+
+            pd.DataFrame({"Class": list(names) + ["Mean"], "IoU": list(iou) + [np.mean(iou)], "Precision": list(prec) + [np.mean(prec)],
+                          "Recall": list(rec) + [np.mean(rec)]}, columns=["Class", "IoU", "Precision", "Recall"]).to_excel(base + ".xlsx")
+        except Exception:
+            pass
+    return out, cues
