@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void cam_head_kernel(HeadArgs p) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int l31 = lane & 31, kgrp = lane >> 5;
     const int m0 = blockIdx.x * 64;
-    const int kq = p.K >> 2;           // the wave's quarter of K (a multiple of 16: K % 64 == 0)
+    const int kq = p.K >> 2;           // the wave's quarter of K (a multiple of 64: K % 256 == 0 -- whole trips of U slices)
     const int k_begin = wv * kq;
     const int nsl = kq >> 4;           // k-slices of 16
     // A rows of the lane: m0 + l31 and m0 + 32 + l31 (clamped: rows past the end are computed and never stored)
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void cam_head_kernel(HeadArgs p) {
 // Returns WSC_ERR_INVALID for shapes the streaming form does not take (the caller keeps the tiled kernel for those).
 int launch_cam_head(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int M, int K, const bf16_t *w, int Kw, const float *s1,
                     const float *b1, int C, int relu, float *y) {
-    WSC_CHECK(M > 0 && K > 0 && K % 64 == 0 && C > 0 && C <= 32, WSC_ERR_INVALID, "cam head: M=%d K=%d C=%d", M, K, C);
+    WSC_CHECK(M > 0 && K > 0 && K % 256 == 0 && C > 0 && C <= 32, WSC_ERR_INVALID, "cam head: M=%d K=%d C=%d (K in multiples of 256)", M, K, C);
     HeadArgs a;
     a.x = x; a.x_lo = x_lo; a.w = w; a.s1 = s1; a.b1 = b1; a.y = y;
     a.M = M; a.K = K; a.C = C; a.Kw = Kw; a.relu = relu;

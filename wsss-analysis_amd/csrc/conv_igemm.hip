@@ -1362,7 +1362,9 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
         const long long last_pos = q_of(a.m_end - 1) + Wp + 1 + 320; // (padded positions are decoded with 32-bit arithmetic)
         // (64-column tiles -- Cout = 64: ResNet50 layer1 conv2 at 81 x 81 -- would fit a 480-position window (60 KB + 16 KB of weight
         // tiles, two blocks per CU instead of three): measured 129.2 -> 138.4 us, rejected; they take the window up to 320 positions too)
-        if (need <= 320 && last_pos < (1ll << 31) && (long long)p.N * p.H * p.W * p.Cin < (1ll << 33)) {
+        // (window source offsets are 32-bit counts of 16-byte units, the lo plane's distance included)
+        const long long lo_d = a.lo_delta < 0 ? -a.lo_delta : a.lo_delta;
+        if (need <= 320 && last_pos < (1ll << 31) && (long long)p.N * p.H * p.W * p.Cin + lo_d < (1ll << 33) && (a.lo_delta & 7) == 0) {
             a.win_Wp = Wp; a.win_HpWp = HpWp; a.win_N = p.N;
             fastdiv((unsigned)HpWp, a.div_hpwp_mul, a.div_hpwp_s1, a.div_hpwp_s2);
             fastdiv((unsigned)Wp, a.div_wp_mul, a.div_wp_s1, a.div_wp_s2);

@@ -865,7 +865,8 @@ int wsc_net_cam_size_hw(const wsc_net *net, int H, int W, int *h_out, int *w_out
 // The 1x1 head (CAM classifier weights / Grad-CAM alpha) with an fp32 NHWC output: in the IEEE-half modes (f16, f16x3) with at
 // most 32 classes it is the streaming kernel of cam_head.hip (an HBM stream, not a tile problem); else the tiled kernel.
 static int run_head(wsc_ctx *ctx, const wsc_net *net, const ConvLaunch &L) {
-    if (L.fmt == 1 && L.split != 1 && L.Cout <= 32 && L.CoutPad >= 32 && L.Cin % 64 == 0 && L.y_f32 != nullptr &&
+    // (K % 256: each wave's quarter of K is whole trips of four 16-channel slices)
+    if (L.fmt == 1 && L.split != 1 && L.Cout <= 32 && L.CoutPad >= 32 && L.Cin % 256 == 0 && L.y_f32 != nullptr &&
         ctx->opt[WSC_OPT_CAM_HEAD_STREAM] != 0)
         return launch_cam_head(ctx, L.x, L.split == 2 ? L.x_lo : nullptr, L.N * L.Ho * L.Wo, L.Cin, L.w, L.Cin * (L.split == 2 ? 2 : 1),
                                L.s1, L.b1, L.Cout, L.relu, L.y_f32);
