@@ -276,6 +276,14 @@ __device__ __forceinline__ void xcd_range(long long total, long long &begin, lon
     end = begin + per < total ? begin + per : total;
 }
 
+// logical block id that puts the blocks of one XCD next to each other (see xcd_range): for kernels with one block per pixel
+// tile, the tiles of an image -- which share its lattice rows, hash table and slot -> row map -- then run on one XCD's L2
+__device__ __forceinline__ int xcd_block_id() {
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nb >> 3, r = nb & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 // Replicated form: the grid is `rep` equal groups of blocks (gridDim.x % rep == 0); group k works on
 // replica k's [0, n_local) items.  The replica is uniform over the block, so its pointer offsets are
 // scalar and the loop bodies are the same as in the unreplicated case (rep = 1 reduces to xcd_range).
@@ -882,7 +890,7 @@ __global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restri
     __shared__ unsigned short seg[SORT_MAX];
     __shared__ unsigned short pos[SORT_MAX + 2];
     __shared__ int wtot[4];
-    const int tile = blockIdx.x;
+    const int tile = xcd_block_id(); // (round 5: an image's tiles on one XCD -- its slot -> row map is read once, not by all eight L2s)
     const int b = tile / tg.tpi, j = tile - b * tg.tpi;
     const TileBox tb = tile_box(tg, j);
     const int N = tg.H * tg.W;
@@ -998,7 +1006,13 @@ __global__ void neighbors_kernel(const unsigned long long *__restrict__ rowkey, 
                                  const unsigned long long *__restrict__ table, const int32_t *__restrict__ slot2row,
                                  long long cap, unsigned cap_mask, int rows, int2 *__restrict__ nbr) {
     const int j = blockIdx.y; // blur axis
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+    // XCD-contiguous row ranges (round 5): rows are numbered image by image, and a row's lookups go to ITS image's hash table
+    // (1 MB at 321 x 321) and slot -> row map; with a plain grid-stride loop every XCD probed every image's table -- 417 MB
+    // fetched per build for 42 MB of neighbour ids (r05_pmc_hbm_traffic.txt) -- now an XCD's blocks sweep a contiguous window
+    // of rows, i.e. a few images whose tables stay in that XCD's 4 MB L2.  Any placement writes the same ids.
+    long long rbeg, rend;
+    xcd_range(rows, rbeg, rend);
+    for (int row = (int)rbeg + (int)threadIdx.x; row < (int)rend; row += (int)blockDim.x) {
         const long long i = (long long)j * rows + row;
         int *nb = reinterpret_cast<int *>(nbr);
         if (row == 0) {
@@ -1713,7 +1727,7 @@ __global__ __launch_bounds__(256) void slice_norm_tile_kernel(const int32_t *__r
                                                                float *__restrict__ tent_w, const uint8_t *__restrict__ tent_p) {
     __shared__ uint32_t lrec[256 * 13];
     __shared__ float lnorm[256];
-    const int tile = blockIdx.x;
+    const int tile = xcd_block_id();
     const int b = tile / tg.tpi, j = tile - b * tg.tpi;
     const TileBox tb = tile_box(tg, j);
     const int N = tg.H * tg.W;
