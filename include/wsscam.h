@@ -43,7 +43,11 @@ typedef enum wsc_status {
     WSC_ERR_SHAPE = -5,       /* state-dict tensor has the wrong shape */
     WSC_ERR_NOMEM = -6,
     WSC_ERR_KEY_RANGE = -7,   /* CRF lattice coordinate outside packed-key range */
-    WSC_ERR_CAPACITY = -8     /* CRF hash table / vertex capacity exceeded */
+    WSC_ERR_CAPACITY = -8,    /* CRF hash table / vertex capacity exceeded */
+    WSC_ERR_RANGE = -9        /* an activation of an IEEE-half mode (f16, f16x3) left half's finite range (|v| >= 65504) and was
+                                 saturated: the reference's fp32 (03b_irn/net/resnet50.py:11-14) has no such ceiling, so the maps
+                                 of this ctx are NOT the reference's.  Sticky: returned by wsc_sync / wsc_memcpy_d2h until
+                                 wsc_ctx_range_status(ctx, &f, 1) clears it.  Run the model in WSC_PREC_BF16X3 instead */
 } wsc_status;
 
 /* architectures: 03b_irn/net/{resnet50_cam,vgg16_cam,m7_cam}.py */
@@ -110,6 +114,12 @@ void wsc_ctx_destroy(wsc_ctx *ctx);
 /* Sets a path selector (wsc_option) of the context; WSC_ERR_INVALID for an unknown option. */
 int wsc_ctx_set_option(wsc_ctx *ctx, int option, int value);
 int wsc_sync(wsc_ctx *ctx);
+/* Range guard of the IEEE-half conv modes.  Every conv epilogue that writes half activations raises a sticky per-ctx flag when
+ * a value reaches the half ceiling (it is stored saturated at +-65504; fp32 in the reference would have kept it).  wsc_sync and
+ * wsc_memcpy_d2h report the raised flag as WSC_ERR_RANGE AFTER completing their work (the copy is done, the stream is idle).
+ * *flag_out (may be NULL): 0 = clean, otherwise the output-channel count of a layer that saturated.  Synchronises the ctx
+ * stream.  clear != 0 resets the flag. */
+int wsc_ctx_range_status(wsc_ctx *ctx, int *flag_out, int clear);
 /* Make all work enqueued on `ctx` after this call wait (on the device, without blocking the host) for
  * everything enqueued so far on `other`: lets one process overlap independent stages on two contexts
  * of the same device (e.g. the lattice build of a batch, which needs only the RGB images, with its
@@ -397,6 +407,17 @@ int wsc_hsn_class_mass(wsc_ctx *ctx, const float *maps_dev, int n_maps, int N, u
  *   rgb_dev uint8 [B][H][W][3];  bg_dev FLOAT64 [B][Ho*Wo] (on tissue the activation is far below the fp32 range and
  *   still decides whether the Background class has mass). */
 int wsc_hsn_background(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W, int Ho, int Wo, double *bg_dev);
+/* ADP background / 'other' channels of the 03b_irn CAM networks (03b_irn/net/common_cam.py:31-92, vgg16_cam.py:51-58),
+ * joined with the use_cls CAM channels on the device and summed over the scales of an image (make_cam.py:62-69):
+ *   mode 0 (adp_morph, :31-55): out[0] = relu(bg - max_k cam[adipose[k]]);  out[1 + i] = cam[use[i]]
+ *   mode 1 (adp_func,  :57-92): out[0] = bg - max_k cam[exc[k]];
+ *                               out[1] = max(0.05 (1 - max(out[0], max_i cam[use[i]])), max_k cam[adipose[k]]);  out[2 + i] = cam[use[i]]
+ *   cam_dev float32 [B][n_sc][C][hw] (wsc_net_forward_cam);  bg_dev float64 [B][n_sc][hw] (wsc_hsn_background of the ORIGINAL,
+ *   un-flipped image of each scale, resized to the CAM grid);  use / adipose / exc: channel indices into the C CAM channels
+ *   (the caller composes the X1.7 class filter of common_cam.py:26-29 into them);  out_dev float32 [B][n_use + 1 + mode][hw]. */
+int wsc_cam_adp_modify(wsc_ctx *ctx, const float *cam_dev, int B, int n_sc, int C, int hw, const double *bg_dev, int mode,
+                       const int32_t *use_host, int n_use, const int32_t *adipose_host, int n_adip, const int32_t *exc_host,
+                       int n_exc, float *out_dev);
 /* The valid-class stack of one HTT type, modify_by_htt (utilities.py:348-363) and get_cs_gradcam (:367-397) in one pass:
  *   Y[v] = H[src_of_valid[v]] (0 where src_of_valid[v] < 0);  Y[bg_ind] = bg - max_{v in exceptions} Y[v];
  *   functional types (other_ind >= 0): Y[other_ind] = max(0.05 * (1 - max_v Y[v]), max_k H[adipose_src[k]]);

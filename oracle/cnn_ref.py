@@ -332,10 +332,51 @@ def normalize_int(img):
     return out
 
 
-def msf_pack(img_u8, outsize=(321, 321)):
+def normalize_float(img):
+    """TorchvisionNormalize('float'), 03b_irn/voc12/dataloader.py:80-106: (x / 255 - mean) / std with the ImageNet constants."""
+    out = np.empty(img.shape, np.float32)
+    im = np.float32(img)
+    for c, (m, s) in enumerate(((0.485, 0.229), (0.456, 0.224), (0.406, 0.225))):
+        out[..., c] = (im[..., c] / 255. - m) / s
+    return out
+
+
+def msf_pack(img_u8, outsize=(321, 321), norm_mode="int"):
     """VOC12ClassificationDatasetMSF.__getitem__ for scales=(1.0,), voc12/dataloader.py:225-246:
     resize -> normalise -> HWC_to_CHW -> stack([x, flip(x, -1)])  => float32 (2,3,S,S)."""
     # outsize None: TorchvisionResize is a no-op, the image keeps its own size (voc12/dataloader.py:74)
-    x = normalize_int(resize_bilinear_f64(img_u8, outsize) if outsize is not None else np.asarray(img_u8, np.float64))
+    normalize = {"int": normalize_int, "float": normalize_float}[norm_mode]
+    x = normalize(resize_bilinear_f64(img_u8, outsize) if outsize is not None else np.asarray(img_u8, np.float64))
     x = np.transpose(x, (2, 0, 1))
     return np.stack([x, np.flip(x, -1)], axis=0).astype(np.float32)
+
+
+ADP_INDS_X17 = [2, 3, 4, 6, 7, 8, 9, 12, 13, 14, 16, 17, 18, 21, 22, 23, 25, 26, 28, 29, 30, 32, 33, 35, 37, 38, 40, 45, 48,
+                49, 50]  # 03b_irn/net/common_cam.py:26-29
+
+
+def adp_modify(cam, img_orig, dataset, use_cls, x17=False):
+    """CommonCAM._adp_modify_morph / _adp_modify_func, 03b_irn/net/common_cam.py:31-92 (called from vgg16_cam.py:49-58 /
+    m7_cam.py:48-55 after the X1.7 class filter), in the reference's own numpy / scipy calls: cam float32 (C, h, w),
+    img_orig uint8 (2, H0, W0, 3) -> the stack [background | (other) | cam[use_cls]].  cv2.resize (absent offline) is the
+    bilinear resize pinned in tests/test_dataloaders_host.py."""
+    import scipy.ndimage
+    import scipy.special
+
+    cam = np.asarray(cam, np.float32)
+    if x17:
+        cam = cam[ADP_INDS_X17]
+    mean_img = np.asarray(img_orig[0], np.float32).mean(axis=2)                       # torch.mean(img_orig[0].float(), dim=2)
+    bg = 0.75 * scipy.special.expit(4 * (mean_img - 240))                             # :36-42
+    bg = scipy.ndimage.gaussian_filter(bg, sigma=2)                                    # :43
+    if bg.shape != cam.shape[1:]:
+        bg = resize_bilinear_f64(bg[..., None], cam.shape[1:])[..., 0]                 # :44 cv2.resize
+    bg = bg.astype(np.float32)
+    adipose = cam[[18, 19, 20]].max(axis=0)
+    if dataset == "adp_morph":
+        background = np.maximum(bg - adipose, 0)                                       # :47-51 relu
+        return np.concatenate((background[None], cam[use_cls]), axis=0)                # :54
+    background = bg - cam[[28, 29, 30]].max(axis=0)                                    # :74-78 (no relu)
+    modified = np.concatenate((background[None], cam[use_cls]), axis=0)                # :81
+    other = np.maximum(np.float32(0.05) * (1 - modified.max(axis=0)), adipose)         # :84-88
+    return np.concatenate((modified[:1], other[None], modified[1:]), axis=0)          # :91

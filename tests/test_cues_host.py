@@ -64,32 +64,6 @@ def test_fgbg_cues_background_channel():
     assert d2["1_cues"].shape[1] < d["1_cues"].shape[1]
 
 
-def test_adp_cam_modifications_host_logic():
-    """common_cam.py:31-92 channel synthesis (pure host arithmetic; the CNN part is covered by the GPU tests)."""
-    import scipy.ndimage
-    import scipy.special
-
-    from wsscam.net import vgg16_cam
-
-    rng = np.random.default_rng(3)
-    cam = rng.random((31, 12, 12)).astype(np.float32)
-    img = rng.integers(180, 256, (2, 12, 12, 3)).astype(np.uint8)
-    bg = scipy.ndimage.gaussian_filter(0.75 * scipy.special.expit(4 * (img[0].astype(np.float32).mean(2) - 240)), sigma=2)
-    m = vgg16_cam.CAM(None, "adp_morph", "", 31, list(range(0, 28)))
-    out = m._adp_modify_morph(cam, img)
-    assert out.shape == (29, 12, 12)
-    assert np.allclose(out[0], np.maximum(bg - cam[[18, 19, 20]].max(0), 0), atol=1e-6)
-    assert np.array_equal(out[1:], cam[:28])
-    f = vgg16_cam.CAM(None, "adp_func", "", 31, [28, 29, 30])
-    outf = f._adp_modify_func(cam, img)
-    assert outf.shape == (5, 12, 12)
-    background = bg - cam[[28, 29, 30]].max(0)
-    modified = np.concatenate((background[None], cam[[28, 29, 30]]), 0)
-    other = np.maximum(0.05 * (1 - modified.max(0)), cam[[18, 19, 20]].max(0))
-    assert np.allclose(outf[0], background, atol=1e-6) and np.allclose(outf[1], other, atol=1e-6)
-    assert np.array_equal(outf[2:], cam[[28, 29, 30]])
-
-
 def test_adp_update_cues_per_image_threshold():
     """02_cues/adp_cues.py:304-339: per-image, per-class max (Q7) -- scaling one image leaves the others' cues
     unchanged, unlike the VOC/DeepGlobe variant."""

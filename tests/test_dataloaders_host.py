@@ -193,6 +193,26 @@ def test_resize_bilinear_f64_against_cv2_rule():
     assert np.all(voc_dl.resize_bilinear_f64(np.full((9, 7, 3), 4.25), (15, 3)) == 4.25)
 
 
+def test_msf_transform_mirror_equals_oracle_bit_for_bit():
+    """The product's host transform (wsscam.voc12.dataloader.msf_pack / resize_bilinear_f64 / TorchvisionNormalize) and
+    the oracle's statement of 03b_irn/voc12/dataloader.py:68-106, 225-246 (oracle/cnn_ref.py) are two numpy versions of
+    the same lines: they must agree BIT FOR BIT, so that a regression in the shared mirror cannot hide behind the device
+    test (which compares the HIP kernel with the oracle) -- VERDICT r5 weak #2."""
+    from oracle import cnn_ref
+
+    rng = np.random.default_rng(17)
+    for S, shapes in ((321, [(375, 500), (500, 333), (321, 321), (97, 640)]), (224, [(240, 200), (224, 224), (1, 7)])):
+        for h, w in shapes:
+            im = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+            assert np.array_equal(voc_dl.resize_bilinear_f64(im, (S, S)), cnn_ref.resize_bilinear_f64(im, (S, S)))
+            for mode in ("int", "float"):
+                got = voc_dl.msf_pack(im, (S, S), voc_dl.TorchvisionNormalize(mode))
+                ref = cnn_ref.msf_pack(im, (S, S), mode)
+                assert got.dtype == ref.dtype == np.float32 and np.array_equal(got, ref), (S, (h, w), mode)
+    im = rng.integers(0, 256, (33, 47, 3)).astype(np.uint8)  # outsize None: the image keeps its size
+    assert np.array_equal(voc_dl.msf_pack(im, None, voc_dl.TorchvisionNormalize("int")), cnn_ref.msf_pack(im, None))
+
+
 def test_resize_bilinear_u8_cv2_fixed_point_rule():
     """read_batch of 02_cues/utilities.py:172-176, 03c_hsn/utilities.py:170-181 and the ADP twins keep the resized batch as
     uint8: cv2.resize's 8-bit INTER_LINEAR result (11-bit fixed-point coefficients, two passes, truncating shifts).  cv2 is

@@ -303,12 +303,9 @@ def _adp_like_image(rng, H, W):
 
 @pytest.mark.parametrize("dataset", ["adp_func", "adp_morph", "deepglobe"])
 def test_make_cam_run_adp_and_deepglobe(tmp_path, dataset):
-    """make_cam.run on the VGG16 networks of the other datasets: ADP joins host-synthesised background /
-    other channels with the use_cls CAM channels before the tail and always keeps them (make_cam.py:44-61,
-    vgg16_cam.py:51-58); DeepGlobe writes no high_res (make_cam.py:83-85)."""
-    import scipy.ndimage
-    import scipy.special
-
+    """make_cam.run on the VGG16 networks of the other datasets: ADP joins background / other channels synthesised on
+    the device (round 6: through the overlapped pipeline, like VOC) with the use_cls CAM channels before the tail and
+    always keeps them (make_cam.py:44-61, vgg16_cam.py:51-58); DeepGlobe writes no high_res (make_cam.py:83-85)."""
     from wsscam.adp import dataloader as adp_dl
 
     adp = dataset.startswith("adp")
@@ -347,16 +344,8 @@ def test_make_cam_run_adp_and_deepglobe(tmp_path, dataset):
         with torch.no_grad():
             cam, _ = cnn_ref.vgg16_cam_forward(torch.from_numpy(d["img"]), sd, C)
         cam = cam.numpy()
-        if adp:  # common_cam.py:31-92 restated on the oracle CAM
-            mean_img = d["orig_img"][0].astype(np.float32).mean(2)
-            bgm = scipy.ndimage.gaussian_filter(0.75 * scipy.special.expit(4 * (mean_img - 240)), sigma=2)
-            bgm = cnn_ref.resize_bilinear_f64(bgm[..., None], cam.shape[1:])[..., 0].astype(np.float32)
-            if dataset == "adp_morph":
-                cam = np.concatenate((np.maximum(bgm - cam[[18, 19, 20]].max(0), 0)[None], cam[use_cls]), 0)
-            else:
-                mod = np.concatenate(((bgm - cam[[28, 29, 30]].max(0))[None], cam[use_cls]), 0)
-                other = np.maximum(0.05 * (1 - mod.max(0)), cam[[18, 19, 20]].max(0))
-                cam = np.concatenate((mod[:1], other[None], mod[1:]), 0)
+        if adp:  # common_cam.py:31-92 on the oracle CAM (oracle/cnn_ref.py::adp_modify)
+            cam = cnn_ref.adp_modify(cam, d["orig_img"], dataset, use_cls)
         n_bg = len(bg_names)
         keys = np.concatenate((np.arange(n_bg), np.nonzero(d["label"])[0] + n_bg)).astype(np.int64)
         s, h = cnn_ref.make_cam_tail(torch.from_numpy(cam), d["size"], torch.from_numpy(keys))
@@ -366,6 +355,32 @@ def test_make_cam_run_adp_and_deepglobe(tmp_path, dataset):
         assert np.abs(rec["cam"] - s.numpy()).max() <= 5e-4, np.abs(rec["cam"] - s.numpy()).max()
         if dataset != "deepglobe":
             assert np.abs(rec["high_res"] - h.numpy()).max() <= 5e-4
+
+
+@pytest.mark.parametrize("x17", [False, True])
+def test_adp_channel_synthesis_on_device(ctx, x17):
+    """common_cam.py:31-92 on the device (wsc_hsn_background + wsc_cam_adp_modify, the path of make_cam and of CAM.forward)
+    against the oracle's numpy / scipy statement: morph and func stacks, the X1.7 class filter composed into the channel
+    lists, two scales summed in scale order, original images of different sizes (one of them at the CAM size: no resize)."""
+    from wsscam.net import vgg16_cam
+
+    rng = np.random.default_rng(3)
+    C, h, w, B, n_sc = (51 if x17 else 31), 12, 9, 3, 2
+    cam = rng.random((B, n_sc, C, h, w)).astype(np.float32)
+    shapes = [(40, 33), (40, 33), (12, 9), (12, 9), (25, 50), (31, 17)]
+    origs = [_adp_like_image(rng, *sh) for sh in shapes]
+    cam_dev = ctx.to_device(cam)
+    for dataset, use_cls in (("adp_morph", list(range(28))), ("adp_func", [28, 29, 30])):
+        m = vgg16_cam.CAM(None, dataset, "X1.7" if x17 else "", C, use_cls)
+        out_dev, Cout = m.adp_modify_device(ctx, cam_dev, B, n_sc, h, w, origs)
+        got = ctx.to_host(out_dev, (B, Cout, h, w), np.float32)
+        assert Cout == m.adp_out_channels() == len(use_cls) + (1 if dataset == "adp_morph" else 2)
+        for b in range(B):
+            ref = sum(cnn_ref.adp_modify(cam[b, s], np.stack([origs[b * n_sc + s]] * 2), dataset, use_cls, x17) for s in range(n_sc))
+            assert ref.shape == got[b].shape
+            n_syn = Cout - len(use_cls)
+            assert np.abs(got[b, :n_syn] - ref[:n_syn]).max() <= 2e-6, (dataset, b, np.abs(got[b] - ref).max())
+            assert np.array_equal(got[b, n_syn:], ref[n_syn:])  # the use_cls channels: plain fp32 sums over the scales
 
 
 def test_full_config_batch_properties(ctx):

@@ -1,13 +1,15 @@
-"""GPU: the MSF dataset transform on the device (wsc_msf_input_u8, csrc/input.hip) is BIT-IDENTICAL to the host
-transform of the dataloader mirrors (03b_irn/voc12/dataloader.py:68-106, 225-246: float64 bilinear resize, float32
-normalisation, CHW, flip pair) -- and make_cam.run fed decoded uint8 images writes the same files as the run fed the
-float32 pairs."""
+"""GPU: the MSF dataset transform on the device (wsc_msf_input_u8, csrc/input.hip) is BIT-IDENTICAL to the ORACLE's
+statement of 03b_irn/voc12/dataloader.py:68-106, 225-246 (oracle/cnn_ref.py::msf_pack / resize_bilinear_f64 /
+normalize_*: float64 bilinear resize, float32 normalisation, CHW, flip pair) -- not to the product's own numpy mirror,
+which tests/test_dataloaders_host.py holds to the same oracle on the CPU -- and make_cam.run fed decoded uint8 images
+writes the same files as the run fed the float32 pairs."""
 import argparse
 import os
 
 import numpy as np
 import pytest
 
+from oracle import cnn_ref
 from wsscam import _lib, synth
 from wsscam.adp import dataloader as adp_dl
 from wsscam.step import make_cam
@@ -28,7 +30,7 @@ def test_msf_input_bit_identical(ctx, mode):
     for S, shapes in ((321, [(375, 500), (500, 333), (321, 321), (97, 640)]), (224, [(240, 200), (224, 224), (1, 7)])):
         imgs = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for h, w in shapes]
         norm = voc_dl.TorchvisionNormalize(mode)
-        ref = np.stack([voc_dl.msf_pack(im, (S, S), norm) for im in imgs])
+        ref = np.stack([cnn_ref.msf_pack(im, (S, S), mode) for im in imgs])  # the oracle, not the product's mirror
         dev, offs, sizes = _pack_u8(ctx, imgs)
         x_dev = ctx.alloc(ref.nbytes)
         _lib.msf_input_u8(ctx, dev, sizes, offs, S, norm.mean, norm.std, x_dev, pre_div255=mode == "float", pair=True)
@@ -37,7 +39,14 @@ def test_msf_input_bit_identical(ctx, mode):
     # ADP constants, plain batch (02_cues / 03c_hsn read_batch + normalise; no flip pair)
     imgs = [rng.integers(100, 256, (272, 272, 3)).astype(np.uint8) for _ in range(2)]
     an = adp_dl.TorchvisionNormalize("int")
-    ref = np.stack([np.transpose(an(voc_dl.resize_bilinear_f64(im, (224, 224))), (2, 0, 1)) for im in imgs]).astype(np.float32)
+    def adp_norm(x):  # 03c_hsn/utilities.py / adp dataloader: (x - mean) / std with the ADP constants, float32 like normalize_int
+        out = np.empty(x.shape, np.float32)
+        xf = np.float32(x)
+        for c in range(3):
+            out[..., c] = (xf[..., c] - an.mean[c]) / an.std[c]
+        return out
+
+    ref = np.stack([np.transpose(adp_norm(cnn_ref.resize_bilinear_f64(im, (224, 224))), (2, 0, 1)) for im in imgs]).astype(np.float32)
     dev, offs, sizes = _pack_u8(ctx, imgs)
     x_dev = ctx.alloc(ref.nbytes)
     _lib.msf_input_u8(ctx, dev, sizes, offs, 224, an.mean, an.std, x_dev, pre_div255=False, pair=False)

@@ -143,3 +143,66 @@ def test_vgg16_f16x3_checkpoint_statistics(batchnorm, inputs):
         rcam, rscore = cnn_ref.vgg16_cam_forward(torch.from_numpy(x), sd, C)
     _check_cam(cam[0], rcam, "vgg16 bn=%s inputs=%s" % (batchnorm, inputs))
     assert np.abs(score[0] - rscore.numpy()).max() <= 2e-5
+
+
+def test_f16x3_dead_channel_weights_stay_finite():
+    """an output channel whose weights sit in fp32's denormal range (~1e-41: a dead channel after weight decay)
+    must not turn the per-channel power-of-two packing into inf * w = inf, lo = inf - inf = NaN.  The channel is zero for
+    every practical purpose; its outputs (and everything downstream) stay finite and the other channels keep their bound."""
+    C, S = 20, 65
+    sd = dict(cnn_ref.make_resnet50_cam_state_dict(C, seed=5))
+    for key, ch in (("resnet50.layer1.0.conv2.weight", 3), ("resnet50.layer3.1.conv1.weight", 0), ("resnet50.conv1.weight", 7)):
+        w = sd[key].clone()
+        w[ch] = torch.full_like(w[ch], 1e-41)
+        w[ch, 0, 0, 0] = -3e-42
+        sd[key] = w
+    rng = np.random.default_rng(12)
+    x = cnn_ref.msf_pack(cnn_ref.synth_image(rng, 90, 70), (S, S))
+    with torch.no_grad():
+        ref = cnn_ref.resnet50_cam_forward(torch.from_numpy(x), sd)
+    model = _model(resnet50_cam.CAM, sd, C)
+    cam = model.forward(x)
+    assert np.isfinite(cam).all()
+    _check_cam(cam, ref, "resnet50 dead channels")
+
+
+@pytest.mark.parametrize("arch", ["resnet50", "vgg16_nobn"])
+def test_f16x3_overflow_fails_loudly(arch):
+    """the reference computes in fp32 (net/resnet50.py:11-14) and has no ceiling at 65504; an IEEE-half
+    activation that saturates gives plausible, WRONG maps.  A layer scaled past the ceiling must raise WSC_ERR_RANGE from the
+    next synchronisation (sticky until cleared), not return maps; the same network below the ceiling stays clean."""
+    C, S = 20, 65
+    rng = np.random.default_rng(13)
+    x = cnn_ref.msf_pack(cnn_ref.synth_image(rng, 90, 70), (S, S))
+    if arch == "resnet50":
+        base = cnn_ref.make_resnet50_cam_state_dict(C, seed=3)
+        cls = resnet50_cam.CAM
+        def scaled(k):  # layer2's outputs at 2^k times their size (the same function: test above), k = 11 -> ~3e4, k = 16 -> ~1e6
+            return _resnet_large_stage(base, k)
+        lo_k, hi_k = 11, 16
+    else:
+        base = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, False, seed=6)
+        cls = vgg16_cam.CAM
+        first = "vgg16.%s.0" % cnn_ref.VGG16_CFG[0][0]
+        def scaled(k):  # no BatchNorm behind the first conv: its ReLU outputs (and, linearly, everything after) grow by 2^k
+            sd = dict(base)
+            sd[first + ".weight"] = sd[first + ".weight"] * 2.0 ** k
+            sd[first + ".bias"] = sd[first + ".bias"] * 2.0 ** k
+            return sd
+        lo_k, hi_k = 0, 18
+    model = _model(cls, scaled(lo_k), C)
+    ctx = model.ctx
+    model.forward(x)
+    assert ctx.range_status() == 0
+    bad = _model(cls, scaled(hi_k), C)
+    bctx = bad.ctx
+    with pytest.raises(_lib.WscError) as ei:
+        bad.forward(x)
+        bctx.sync()
+    assert ei.value.status == _lib.WSC_ERR_RANGE, ei.value
+    assert "65504" in str(ei.value)
+    with pytest.raises(_lib.WscError):  # sticky
+        bctx.sync()
+    assert bctx.range_status(clear=True) != 0
+    bctx.sync()  # cleared
+    assert bctx.range_status() == 0

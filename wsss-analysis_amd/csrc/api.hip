@@ -124,6 +124,15 @@ static const char *kClassNames[WSC_K_COUNT] = {
     "pool/layout/flip-add", "cam_tail+unary", "crf_build(all)", "gauss_msg_kernel", "combine4+blur_lds+blur4+blur3_tile",
     "update_splat_kernel", "crf init/finish"};
 
+int wsc_ctx_range_check(wsc_ctx *ctx) {
+    const unsigned f = *(volatile unsigned *)ctx->range_host;
+    if (f == 0u) return WSC_OK;
+    wsc_set_error("an activation of an IEEE-half conv mode (f16 / f16x3) reached half's ceiling (|v| >= 65504) in a layer with %u "
+                  "output channels and was saturated -- the reference's fp32 would have kept it, these maps are not the reference's; "
+                  "use WSC_PREC_BF16X3 for this model (wsc_ctx_range_status clears the flag)", f);
+    return WSC_ERR_RANGE;
+}
+
 extern "C" {
 
 int wsc_profile_begin(wsc_ctx *ctx) {
@@ -200,6 +209,9 @@ int wsc_ctx_create(int device, void *stream, wsc_ctx **out) {
     }
     WSC_HIP(hipMalloc(&ctx->zero_page, 256));
     WSC_HIP(hipMemset(ctx->zero_page, 0, 256));
+    WSC_HIP(hipHostMalloc((void **)&ctx->range_host, 64, hipHostMallocMapped));
+    memset(ctx->range_host, 0, 64);
+    WSC_HIP(hipHostGetDevicePointer((void **)&ctx->range_dev, ctx->range_host, 0));
     WSC_HIP(hipEventCreateWithFlags(&ctx->pinned_ev, hipEventDisableTiming));
     WSC_HIP(hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming));
     WSC_HIP(hipEventCreate(&ctx->ev0));
@@ -222,6 +234,7 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
     for (auto &a : ctx->attachments) a.second(a.first);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+    if (ctx->range_host) (void)hipHostFree(ctx->range_host);
     for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
     for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -249,6 +262,16 @@ int wsc_sync(wsc_ctx *ctx) {
     WSC_CHECK(ctx, WSC_ERR_INVALID, "wsc_sync: null ctx");
     WSC_HIP(hipSetDevice(ctx->device)); // may be called from a helper thread whose current device is still 0
     WSC_HIP(hipStreamSynchronize(ctx->stream));
+    return wsc_ctx_range_check(ctx);
+}
+
+int wsc_ctx_range_status(wsc_ctx *ctx, int *flag_out, int clear) {
+    WSC_CHECK(ctx, WSC_ERR_INVALID, "wsc_ctx_range_status: null ctx");
+    WSC_HIP(hipSetDevice(ctx->device));
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
+    volatile unsigned *f = ctx->range_host;
+    if (flag_out) *flag_out = (int)*f;
+    if (clear) *f = 0u;
     return WSC_OK;
 }
 
@@ -303,7 +326,7 @@ int wsc_memcpy_d2h(wsc_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
     if (bytes == 0) return WSC_OK;
     WSC_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     WSC_HIP(hipStreamSynchronize(ctx->stream));
-    return WSC_OK;
+    return wsc_ctx_range_check(ctx);
 }
 
 int wsc_memset(wsc_ctx *ctx, void *dst_dev, int value, size_t bytes) {

@@ -151,6 +151,10 @@ struct wsc_ctx {
     void *pinned = nullptr; // (legacy single buffer: unused)
     size_t pinned_bytes = 0;
     void *zero_page = nullptr; // 256 bytes of zeros in HBM (source of padded conv taps)
+    // range guard of the IEEE-half conv modes: one word of mapped, page-locked host memory that a conv epilogue stores to
+    // (plain store of a non-zero value, no atomic needed: every writer writes "raised") when an activation saturates at the
+    // half ceiling; read by the host after a stream synchronisation (wsc_sync, wsc_memcpy_d2h, wsc_ctx_range_status)
+    unsigned *range_host = nullptr, *range_dev = nullptr;
     hipEvent_t pinned_ev = nullptr; // completion of the last copy out of `pinned`
     bool pinned_busy = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -172,6 +176,11 @@ struct wsc_ctx {
     std::vector<std::pair<void *, void (*)(void *)>> attachments;
 };
 int wsc_ctx_workspace(wsc_ctx *ctx, size_t bytes, void **out);
+// WSC_ERR_RANGE (with the error text) when the ctx's range flag is raised; the stream must have been synchronised
+int wsc_ctx_range_check(wsc_ctx *ctx);
+// One packed pair of IEEE halves as the saturation test of an epilogue: bit 15 / 31 of the result is set iff the low / high
+// half's magnitude is >= 0x7bff (65504: the value the saturating conversion stores for anything beyond, and NaN / inf)
+__device__ __forceinline__ unsigned half2_at_ceiling(unsigned hw) { return (hw & 0x7fff7fffu) + 0x04010401u; }
 // Brackets the launches enqueued during its lifetime with a pair of HIP events on the ctx stream
 // when profiling is on (no-op otherwise).
 struct WscKernelTimer {

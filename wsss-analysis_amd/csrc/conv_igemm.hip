@@ -83,6 +83,7 @@ struct ConvKArgs {
     unsigned div_hpwp_mul, div_hpwp_s1, div_hpwp_s2, div_wp_mul, div_wp_s1, div_wp_s2;
     int stem_rows;      // host side only: the padded-input stem form (a K-step = one kernel row of 8 pixels x 4 channels)
     int kw_real;        // host side only: kernel width of the layer (FLOP accounting; kw is 1 in the stem form)
+    unsigned *range;    // the ctx's range flag (common.h): raised by an IEEE-half epilogue that stores a value at the half ceiling
 };
 
 __device__ __forceinline__ int lds_off(int row, int slot) {
@@ -923,6 +924,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
     constexpr int PPH = NPASS / NHALF; // passes per group
     static_assert(NPASS % NHALF == 0 && PPH * RPP == GR && GR % WMT == 0, "epilogue pass layout");
     const int grp = (wm * WMT) / GR, roff = wm * WMT - grp * GR;
+    unsigned ovf = 0u;
 #pragma unroll
     for (int half = 0; half < NHALF; ++half) {
         if (half > 0) __syncthreads(); // the previous group's reads are done
@@ -1001,6 +1003,8 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                     }
                 }
                 if (m < p.m_end) {
+                    // range guard (wsc_ctx_range_status): a stored half at the ceiling = a value the clamp above cut (or NaN)
+                    ovf |= half2_at_ceiling(hw[0]) | half2_at_ceiling(hw[1]) | half2_at_ceiling(hw[2]) | half2_at_ceiling(hw[3]);
                     *reinterpret_cast<uint4 *>(p.y + ((unsigned)m * (unsigned)p.ldy + (unsigned)c)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
                     if (SPLIT) *reinterpret_cast<uint4 *>(p.y_lo + ((unsigned)m * (unsigned)p.ldy + (unsigned)c)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
@@ -1067,6 +1071,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                             lw[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
                         }
                     }
+                    if (ET) ovf |= half2_at_ceiling(hw[0]) | half2_at_ceiling(hw[1]) | half2_at_ceiling(hw[2]) | half2_at_ceiling(hw[3]);
                     const long long oy = (long long)m * p.ldy + c;
                     *reinterpret_cast<uint4 *>(p.y + oy) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
                     if (SPLIT) *reinterpret_cast<uint4 *>(p.y_lo + oy) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
@@ -1074,6 +1079,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
             }
         }
     }
+    if (ET && (ovf & 0x80008000u)) *p.range = (unsigned)p.Cout;
 }
 
 template <int BM, int BN, int MODE, int SPLIT, int ET, int STAGES, int WMT = 64, int FAST = 0, int WPT = 0>
@@ -1263,6 +1269,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     WSC_CHECK(p.CoutPad % 64 == 0, WSC_ERR_INVALID, "conv: CoutPad=%d not a multiple of 64", p.CoutPad);
     a.ntiles_n = p.CoutPad / BN;
     a.zero = (const bf16_t *)ctx->zero_page;
+    a.range = ctx->range_dev;
 #ifdef WSC_AB_KNOBS
     // timing-only ablations (wrong results): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = no MFMAs
     static const int debug = [] { const char *e = getenv("WSC_CONV_DEBUG"); return e ? atoi(e) : 0; }();

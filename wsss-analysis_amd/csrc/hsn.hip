@@ -145,6 +145,49 @@ __global__ void hsn_resize_f64_kernel(const double *__restrict__ in, int H, int 
     }
 }
 
+// ---- ADP background / 'other' channels of the 03b_irn CAM networks (net/common_cam.py:31-92) ---------------------------------
+struct AdpModArgs {
+    const float *cam;  // [B][n_sc][C][hw]
+    const double *bg;  // [B][n_sc][hw] smoothed + resized background activation (wsc_hsn_background)
+    float *out;        // [B][n_use + 1 + mode][hw]
+    int n_sc, C, hw, mode, n_use, n_adip, n_exc;
+    int use[64], adip[4], exc[4];
+};
+// One thread per (image, pixel); the scales of an image are added in scale order (make_cam.py:62-69 sums the modified stacks).
+// fp32 like the reference's torch tensors (the float64 activation is rounded once, where torch.from_numpy meets the fp32 CAM).
+__global__ __launch_bounds__(256) void cam_adp_modify_kernel(AdpModArgs a) {
+    const int b = blockIdx.y;
+    const int Cout = a.n_use + 1 + a.mode;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.hw; p += gridDim.x * blockDim.x) {
+        float o_bg = 0.f, o_other = 0.f;
+        float *ob = a.out + (long long)b * Cout * a.hw + p;
+        for (int s = 0; s < a.n_sc; ++s) {
+            const float *cb = a.cam + ((long long)b * a.n_sc + s) * a.C * a.hw + p;
+            const float bgv = (float)a.bg[((long long)b * a.n_sc + s) * a.hw + p];
+            float adip = -3.0e38f;
+            for (int k = 0; k < a.n_adip; ++k) adip = fmaxf(adip, cb[(long long)a.adip[k] * a.hw]);
+            if (a.mode == 0) { // _adp_modify_morph :31-55: relu(bg - max adipose)
+                o_bg += fmaxf(bgv - adip, 0.f);
+            } else {           // _adp_modify_func :57-92: bg - max exception (no relu), then the 'other' channel
+                float ex = -3.0e38f;
+                for (int k = 0; k < a.n_exc; ++k) ex = fmaxf(ex, cb[(long long)a.exc[k] * a.hw]);
+                const float b0 = bgv - ex;
+                float moh = b0;
+                for (int i = 0; i < a.n_use; ++i) moh = fmaxf(moh, cb[(long long)a.use[i] * a.hw]);
+                o_bg += b0;
+                o_other += fmaxf(0.05f * (1.f - moh), adip);
+            }
+        }
+        ob[0] = o_bg;
+        if (a.mode) ob[a.hw] = o_other;
+        for (int i = 0; i < a.n_use; ++i) {
+            float v = 0.f;
+            for (int s = 0; s < a.n_sc; ++s) v += a.cam[(((long long)b * a.n_sc + s) * a.C + a.use[i]) * a.hw + p];
+            ob[(long long)(1 + a.mode + i) * a.hw] = v;
+        }
+    }
+}
+
 struct CsArgs {
     const float *H;      // [B][C_all][N] gated Grad-CAMs
     const double *bg;    // [B][N] smoothed background activation (float64)
@@ -351,6 +394,39 @@ int wsc_hsn_background(wsc_ctx *ctx, const uint8_t *rgb_dev, int B, int H, int W
     WSC_HIP(hipGetLastError());
     t1_guard.free_now();
     t2_guard.free_now();
+    return WSC_OK;
+}
+
+int wsc_cam_adp_modify(wsc_ctx *ctx, const float *cam_dev, int B, int n_sc, int C, int hw, const double *bg_dev, int mode,
+                       const int32_t *use_host, int n_use, const int32_t *adipose_host, int n_adip, const int32_t *exc_host,
+                       int n_exc, float *out_dev) {
+    WSC_CHECK(ctx && cam_dev && bg_dev && out_dev && use_host && adipose_host, WSC_ERR_INVALID, "wsc_cam_adp_modify: null argument");
+    WSC_CHECK(B > 0 && B <= 65535 && n_sc > 0 && C > 0 && hw > 0 && (mode == 0 || mode == 1), WSC_ERR_INVALID,
+              "wsc_cam_adp_modify: B=%d n_sc=%d C=%d hw=%d mode=%d", B, n_sc, C, hw, mode);
+    WSC_CHECK(n_use > 0 && n_use <= 64 && n_adip > 0 && n_adip <= 4 && n_exc >= 0 && n_exc <= 4 && (mode == 0 || (exc_host && n_exc > 0)),
+              WSC_ERR_INVALID, "wsc_cam_adp_modify: n_use=%d n_adip=%d n_exc=%d", n_use, n_adip, n_exc);
+    WSC_HIP(hipSetDevice(ctx->device));
+    AdpModArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cam = cam_dev; a.bg = bg_dev; a.out = out_dev;
+    a.n_sc = n_sc; a.C = C; a.hw = hw; a.mode = mode; a.n_use = n_use; a.n_adip = n_adip; a.n_exc = mode ? n_exc : 0;
+    auto in_range = [&](int c) { return c >= 0 && c < C; };
+    for (int i = 0; i < n_use; ++i) {
+        WSC_CHECK(in_range(use_host[i]), WSC_ERR_INVALID, "wsc_cam_adp_modify: use channel %d out of range", use_host[i]);
+        a.use[i] = use_host[i];
+    }
+    for (int k = 0; k < n_adip; ++k) {
+        WSC_CHECK(in_range(adipose_host[k]), WSC_ERR_INVALID, "wsc_cam_adp_modify: adipose channel %d out of range", adipose_host[k]);
+        a.adip[k] = adipose_host[k];
+    }
+    for (int k = 0; k < a.n_exc; ++k) {
+        WSC_CHECK(in_range(exc_host[k]), WSC_ERR_INVALID, "wsc_cam_adp_modify: exception channel %d out of range", exc_host[k]);
+        a.exc[k] = exc_host[k];
+    }
+    WscKernelTimer timer(ctx, WSC_K_CAM_TAIL, (double)B * hw * 4 * ((double)n_sc * (n_use + 6) + n_use + 2));
+    const dim3 grid((unsigned)std::min((hw + 255) / 256, 256), (unsigned)B);
+    hipLaunchKernelGGL(cam_adp_modify_kernel, grid, dim3(256), 0, ctx->stream, a);
+    WSC_HIP(hipGetLastError());
     return WSC_OK;
 }
 

@@ -173,8 +173,12 @@ int make_conv(wsc_net *net, const HostTensor *w, int stride, int pad, int relu, 
             if (!(mx > 0.f) || !std::isfinite(mx)) continue;
             int e;
             std::frexp(mx, &e); // mx = m * 2^e, m in [0.5, 1)
-            wscale[co] = std::ldexp(1.f, 13 - e);
-            s1v[co] = s1[co] * std::ldexp(1.f, e - 13);
+            // (bounded shift: a dead channel in fp32's denormal range -- weight decay leaves |w| ~ 1e-40 -- would otherwise
+            // ask for 2^(13 - e) = inf, every weight * inf = inf, lo = inf - inf = NaN; with the bound such a channel keeps
+            // its tiny values as half subnormals / zeros like before the packing)
+            const int sh = std::max(std::min(13 - e, 100), -100);
+            wscale[co] = std::ldexp(1.f, sh);
+            s1v[co] = s1[co] * std::ldexp(1.f, -sh);
         }
     }
     for (int co = 0; co < Cout; ++co) {

@@ -48,6 +48,7 @@ struct StemPoolArgs {
     bf16_t *y, *y_lo;       // [N][Hq][Wq][64]
     int Hp, Wp, Kw, Ho, Wo, Hq, Wq, nti, ntj, relu;
     int debug; // A/B builds only (-DWSC_AB_KNOBS): phases switched off for the ablations of profiles/README.md
+    unsigned *range; // the ctx's range flag (common.h): raised when a pooled value sits at the half ceiling
 };
 #ifdef WSC_AB_KNOBS
 #define WSC_SDBG(p, bit) ((p).debug & (bit))
@@ -276,6 +277,8 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs p) {
                     hw[e] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
                     lw[e] = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
                 }
+                if ((half2_at_ceiling(hw[0]) | half2_at_ceiling(hw[1]) | half2_at_ceiling(hw[2]) | half2_at_ceiling(hw[3])) & 0x80008000u)
+                    *p.range = 64u;
                 const long long oo = (((long long)n * p.Hq + qi) * p.Wq + qj) * 64 + c8 * 8;
                 if (!WSC_SDBG(p, 32)) {
                     *reinterpret_cast<uint4 *>(p.y + oo) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
@@ -307,6 +310,7 @@ int launch_stem_pool(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int N, i
     a.x = x; a.x_lo = x_lo; a.w = w; a.s1 = s1; a.b1 = b1; a.y = y; a.y_lo = y_lo;
     stem_pool_input_dims(H, W, &a.Hp, &a.Wp);
     a.Kw = Kw; a.relu = relu; a.debug = 0;
+    a.range = ctx->range_dev;
 #ifdef WSC_AB_KNOBS
     static const int dbg = [] { const char *e = getenv("WSC_STEM_DEBUG"); return e ? atoi(e) : 0; }();
     a.debug = dbg;

@@ -22,6 +22,7 @@ WSC_ERR_SHAPE = -5
 WSC_ERR_NOMEM = -6
 WSC_ERR_KEY_RANGE = -7
 WSC_ERR_CAPACITY = -8
+WSC_ERR_RANGE = -9  # an IEEE-half activation saturated (|v| >= 65504): the maps are not the reference's fp32 maps
 
 ARCH_RESNET50_CAM = 0
 ARCH_VGG16_CAM = 1
@@ -71,6 +72,7 @@ _SIGNATURES = {
     "wsc_ctx_create": (_i, [_i, _vp, ctypes.POINTER(_vp)]),
     "wsc_ctx_destroy": (None, [_vp]),
     "wsc_sync": (_i, [_vp]),
+    "wsc_ctx_range_status": (_i, [_vp, ctypes.POINTER(_i), _i]),
     "wsc_ctx_wait": (_i, [_vp, _vp]),
     "wsc_device_info": (_i, [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(_i)]),
     "wsc_malloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
@@ -119,6 +121,7 @@ _SIGNATURES = {
     "wsc_hsn_voc_background": (_i, [_vp, _vp, _i, _i, _i, _vp, _i]),
     "wsc_hsn_class_mass": (_i, [_vp, _vp, _i, _i, _vp]),
     "wsc_hsn_background": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "wsc_cam_adp_modify": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "wsc_hsn_cs_gradcam": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "wsc_hsn_gather_unary": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "wsc_crf_create": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _f, ctypes.POINTER(_vp)]),
@@ -223,6 +226,13 @@ class Context:
 
     def sync(self):
         check(self._lib.wsc_sync(self.h))
+
+    def range_status(self, clear=False):
+        """Range guard of the IEEE-half conv modes: 0 = clean, else the output-channel count of a layer whose activations
+        reached half's ceiling and were saturated (sync() / to_host() raise WscError(WSC_ERR_RANGE) until cleared)."""
+        f = _i(0)
+        check(self._lib.wsc_ctx_range_status(self.h, ctypes.byref(f), 1 if clear else 0))
+        return int(f.value)
 
     def wait_for(self, other):
         """Device-side join: later work on this ctx waits for everything enqueued so far on `other`."""
@@ -740,6 +750,17 @@ def hsn_class_mass(ctx, maps_dev, n_maps, N, mass_dev):
 def hsn_background(ctx, rgb_dev, B, H, W, bg_dev, out_hw=None):
     Ho, Wo = (H, W) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
     check(ctx._lib.wsc_hsn_background(ctx.h, _ptr(rgb_dev), B, H, W, Ho, Wo, _ptr(bg_dev)))
+
+
+def cam_adp_modify(ctx, cam_dev, B, n_sc, C, hw, bg_dev, mode, use, adipose, exc, out_dev):
+    """wsc_cam_adp_modify: common_cam.py:31-92 on the device; -> number of output channels (len(use) + 1 + mode)."""
+    us = np.ascontiguousarray(use, dtype=np.int32)
+    ad = np.ascontiguousarray(adipose, dtype=np.int32)
+    ex = np.ascontiguousarray(exc if exc is not None else [], dtype=np.int32)
+    check(ctx._lib.wsc_cam_adp_modify(ctx.h, _ptr(cam_dev), int(B), int(n_sc), int(C), int(hw), _ptr(bg_dev), int(mode),
+                                      us.ctypes.data, len(us), ad.ctypes.data, len(ad), ex.ctypes.data if len(ex) else None,
+                                      len(ex), _ptr(out_dev)))
+    return len(us) + 1 + int(mode)
 
 
 def hsn_cs_gradcam(ctx, H_dev, B, C_all, N, bg_dev, src_of_valid, bg_ind, other_ind, exception_inds, adipose_src, cs_dev,

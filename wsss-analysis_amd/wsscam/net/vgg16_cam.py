@@ -56,46 +56,57 @@ class CAM(DeviceCAMBase):
             y = y[ADP_INDS_X17]
         return y
 
-    # ---- ADP background / other-tissue channels: common_cam.py:31-92 ------------------------------------
-    def _adp_background(self, cam, img_orig):
-        """0.75 * sigmoid(4 * (mean_rgb - 240)) of the ORIGINAL (un-normalised, un-flipped) image, Gaussian
-        smoothed (sigma 2), resized to the CAM size (cv2.resize bilinear)."""
-        import scipy.ndimage
-        import scipy.special
+    # ---- ADP background / other-tissue channels: common_cam.py:31-92, on the device --------------------------
+    def adp_channel_lists(self):
+        """(mode, use, adipose, exceptions) as channel indices of the network's CAM stack: mode 0 = adp_morph
+        (_adp_modify_morph :31-55), 1 = adp_func (_adp_modify_func :57-92); the X1.7 class filter (:26-29, applied to the
+        CAM before the modification, vgg16_cam.py:49-50) is composed into the lists."""
+        filt = ADP_INDS_X17 if "X1.7" in self.tag else list(range(self.num_classes))
+        use = [filt[int(i)] for i in self.use_cls]
+        return (0 if self.dataset == "adp_morph" else 1), use, [filt[i] for i in (18, 19, 20)], [filt[i] for i in (28, 29, 30)]
 
-        from ..cues.utilities import resize_stack
+    def adp_out_channels(self):
+        return len(self.use_cls) + (1 if self.dataset == "adp_morph" else 2)
 
-        mean_img = np.mean(np.asarray(img_orig[0], dtype=np.float32), axis=2)
-        bg = 0.75 * scipy.special.expit(4 * (mean_img - 240))
-        bg = scipy.ndimage.gaussian_filter(bg, sigma=2)
-        if bg.shape != cam.shape[1:]:
-            bg = resize_stack(bg[None, None], cam.shape[1:], ctx=self.ctx)[0, 0]
-        return bg.astype(np.float32)
-
-    def _adp_modify_morph(self, cam, img_orig):
-        """common_cam.py:31-55: background = relu(bg - max adipose CAM), prepended to cam[use_cls]."""
-        bg = self._adp_background(cam, img_orig)
-        background = np.maximum(bg - np.max(cam[[18, 19, 20]], axis=0), 0)
-        return np.concatenate((background[None], cam[self.use_cls]), axis=0)
-
-    def _adp_modify_func(self, cam, img_orig):
-        """common_cam.py:57-92: background = bg - max exception CAM (no relu), then an 'other' channel
-        max(0.05 * (1 - max_c modified), max adipose CAM) inserted after it."""
-        bg = self._adp_background(cam, img_orig)
-        background = bg - np.max(cam[[28, 29, 30]], axis=0)
-        modified = np.concatenate((background[None], cam[self.use_cls]), axis=0)
-        other = np.maximum(0.05 * (1 - np.max(modified, axis=0)), np.max(cam[[18, 19, 20]], axis=0))
-        return np.concatenate((modified[:1], other[None], modified[1:]), axis=0)
-
-    def adp_modify(self, cam, img_orig):
-        """cam (C,h,w) of one image -> the ADP map stack make_cam post-processes (vgg16_cam.py:51-58)."""
-        if "X1.7" in self.tag:
-            cam = cam[ADP_INDS_X17]
-        if self.dataset == "adp_morph":
-            return self._adp_modify_morph(cam, img_orig)
-        if self.dataset == "adp_func":
-            return self._adp_modify_func(cam, img_orig)
-        return cam
+    def adp_modify_device(self, ctx, cam_dev, B, n_sc, h, w, origs, out_dev=None, stage=None):
+        """The ADP map stacks of a device batch (vgg16_cam.py:51-58), never leaving the GPU:
+        0.75 * expit(4 * (mean_rgb - 240)) of every ORIGINAL (un-normalised, un-flipped) image, Gaussian smoothed (sigma 2),
+        cv2-bilinear resized to the CAM grid (wsc_hsn_background), then the background / 'other' channels joined with the
+        use_cls CAM channels and summed over the scales (wsc_cam_adp_modify).
+          cam_dev float32 [B][n_sc][C][h][w];  origs: B * n_sc uint8 (H0, W0, 3) arrays in (image, scale) order;
+          stage: optional (PinnedBuffer, DeviceBuffer) pair of >= sum(H0 W0 3) bytes for an asynchronous upload.
+        -> (out_dev float32 [B][Cout][h][w], Cout)."""
+        origs = [np.ascontiguousarray(o, dtype=np.uint8) for o in origs]
+        assert len(origs) == B * n_sc and all(o.ndim == 3 and o.shape[2] == 3 for o in origs)
+        offs = np.concatenate(([0], np.cumsum([o.size for o in origs]))).astype(np.int64)
+        total = int(offs[-1])
+        if stage is not None:
+            pin, rgb_dev = stage
+            buf = pin.view((total,), np.uint8)
+            for k, o in enumerate(origs):
+                buf[offs[k]:offs[k + 1]] = o.reshape(-1)
+            ctx.h2d_async(rgb_dev, pin, total)
+        else:
+            rgb_dev = ctx.to_device(np.concatenate([o.reshape(-1) for o in origs]), pooled=True)
+        hw = h * w
+        bg_dev = ctx.alloc(B * n_sc * hw * 8, pooled=True)
+        k = 0
+        while k < len(origs):  # runs of equal size (ADP patches all are 272 x 272: one call)
+            e = k + 1
+            while e < len(origs) and origs[e].shape == origs[k].shape:
+                e += 1
+            H0, W0 = origs[k].shape[:2]
+            _lib.hsn_background(ctx, rgb_dev.ptr + int(offs[k]), e - k, H0, W0, bg_dev.ptr + k * hw * 8, out_hw=(h, w))
+            k = e
+        mode, use, adip, exc = self.adp_channel_lists()
+        Cout = len(use) + 1 + mode
+        if out_dev is None:
+            out_dev = ctx.alloc(B * Cout * hw * 4, pooled=True)
+        _lib.cam_adp_modify(ctx, cam_dev, B, n_sc, self.num_classes, hw, bg_dev, mode, use, adip, exc, out_dev)
+        bg_dev.free()  # pooled: reused in stream order
+        if stage is None:
+            rgb_dev.free()
+        return out_dev, Cout
 
     def forward(self, x, x_orig=None):
         """-> (cam (C,h,w), y bool (C,)) as vgg16_cam.py:24-60 / m7_cam.py:22-57; for the ADP datasets
@@ -103,11 +114,28 @@ class CAM(DeviceCAMBase):
         assert (self.dataset in ("adp_morph", "adp_func")) ^ (x_orig is None)
         is_torch = hasattr(x, "detach")
         xn = x.detach().cpu().numpy() if is_torch else np.asarray(x)
-        cam, score = self.forward_batch(xn[None], want_score=True)
-        cam, y = cam[0], self.predict_labels(score[0])
-        if x_orig is not None:
+        if x_orig is None:
+            cam, score = self.forward_batch(xn[None], want_score=True)
+            cam = cam[0]
+            if "X1.7" in self.tag:
+                cam = cam[ADP_INDS_X17]
+        else:  # the ADP channels are synthesised on the device, between the CAM head and the copy out
             x_orig = x_orig.detach().cpu().numpy() if hasattr(x_orig, "detach") else np.asarray(x_orig)
-        cam = self.adp_modify(cam, x_orig)
+            net = self._ensure_net()
+            ctx = self._ctx
+            xc = np.ascontiguousarray(xn[None], dtype=np.float32)
+            S = xc.shape[-1]
+            h = net.cam_size(S)
+            x_dev = ctx.to_device(xc, pooled=True)
+            cam_dev = ctx.alloc(self.num_classes * h * h * 4, pooled=True)
+            score_dev = ctx.alloc(self.num_classes * 4, pooled=True)
+            net.forward_cam(x_dev, 1, S, cam_dev, score_dev)
+            out_dev, Cout = self.adp_modify_device(ctx, cam_dev, 1, 1, h, h, [x_orig[0]])
+            cam = ctx.to_host(out_dev, (Cout, h, h), np.float32)
+            score = ctx.to_host(score_dev, (1, self.num_classes), np.float32)
+            for b in (x_dev, cam_dev, score_dev, out_dev):
+                b.free()
+        y = self.predict_labels(score[0])
         if is_torch:
             import torch
 

@@ -123,22 +123,11 @@ def process_batch(model, packs, args, save=True):
     keys = [_valid_cat(args, p, None if score is None else score[b], model) for b, p in enumerate(packs)]
     sizes = [tuple(int(v) for v in p["size"]) for p in packs]
     if args.dataset in ("adp_morph", "adp_func"):
-        # vgg16_cam.py:51-58 / common_cam.py:31-92: background (and 'other') channels are synthesised from the
-        # ORIGINAL image (of that scale) on the host (scipy Gaussian filter) and joined with the use_cls CAM channels
-        # before the tail; the modified maps (summed over the scales) go back to the device for the two resizes +
-        # normalisation.
-        cam = ctx.to_host(cam_dev, (B, n_sc, C, h, w), np.float32)
-        mod = []
-        for b, p in enumerate(packs):
-            origs = _scales_of(p["orig_img"])
-            acc = None
-            for sidx in range(n_sc):
-                m = np.asarray(model.adp_modify(cam[b, sidx], np.asarray(origs[sidx])), dtype=np.float32)
-                acc = m if acc is None else acc + m
-            mod.append(acc)
-        mod = np.stack(mod)
-        C = mod.shape[1]
-        cam_dev = ctx.to_device(np.ascontiguousarray(mod, dtype=np.float32))
+        # vgg16_cam.py:51-58 / common_cam.py:31-92: background (and 'other') channels are synthesised from the ORIGINAL
+        # (un-flipped) image of every scale and joined with the use_cls CAM channels before the tail -- on the device
+        # (wsc_hsn_background + wsc_cam_adp_modify): the CAM stack never visits the host
+        origs = [np.asarray(o)[0] for p in packs for o in _scales_of(p["orig_img"])]
+        cam_dev, C = model.adp_modify_device(ctx, cam_dev, B, n_sc, h, w, origs)
     elif n_sc > 1:
         sum_dev = ctx.alloc(B * C * h * w * 4)
         _lib.cam_sum_scales(ctx, cam_dev, B, n_sc, C * h * w, sum_dev)
@@ -171,11 +160,8 @@ def _work(process_id, model, dataset, args):
     n = len(databin)
     if n == 0:
         return
-    adp = args.dataset in ("adp_morph", "adp_func")
     native = getattr(args, "outsize", (321, 321)) is None  # every image at its own size: batches bucketed by size, no pinned lanes
-    if adp or native or not getattr(args, "cam_pipeline", True):
-        # ADP: the background / 'other' channels are synthesised on the host between the CAM head and the tail
-        # (common_cam.py:31-92), so the batches run one after the other
+    if native or not getattr(args, "cam_pipeline", True):
         for i0 in range(0, n, bs):
             packs = [databin[i] for i in range(i0, min(i0 + bs, n))]
             process_batch(model, packs, args, save=True)

@@ -35,7 +35,7 @@ def host_thread_budget(world, cores=None):
 
 
 class _Lane:
-    def __init__(self, device, B, S, C, h, n_sc=1):
+    def __init__(self, device, B, S, C, h, n_sc=1, adp_channels=0):
         self.ctx = _lib.Context(device)
         self.B, self.S, self.C, self.h, self.n_sc = B, S, C, h, n_sc
         self.in_bytes = B * n_sc * 2 * 3 * S * S * 4
@@ -44,6 +44,8 @@ class _Lane:
         self.x_dev = self.ctx.alloc(self.in_bytes)
         self.cam_dev = self.ctx.alloc(B * n_sc * C * h * h * 4)
         self.sum_dev = self.ctx.alloc(B * C * h * h * 4) if n_sc > 1 else None
+        # ADP datasets: the stack [background | (other) | use_cls channels] of wsc_cam_adp_modify, summed over the scales
+        self.adp_dev = self.ctx.alloc(B * adp_channels * h * h * 4) if adp_channels else None
         self.score_dev = self.ctx.alloc(B * n_sc * C * 4)
         self.pin_score = self.ctx.host_alloc(B * n_sc * C * 4)
         self.out_cap = 0
@@ -78,8 +80,8 @@ class _Lane:
 
     def close(self):
         self.ctx.sync()
-        for b in (self.pin_in, self.pin_out, self.pin_score, self.x_dev, self.cam_dev, self.sum_dev, self.score_dev, self.s_dev, self.h_dev,
-                  self.pin_u8, self.u8_dev):
+        for b in (self.pin_in, self.pin_out, self.pin_score, self.x_dev, self.cam_dev, self.sum_dev, self.adp_dev, self.score_dev, self.s_dev,
+                  self.h_dev, self.pin_u8, self.u8_dev):
             if b is not None:
                 b.free()
         self.ctx.close()
@@ -103,6 +105,8 @@ class CamPipeline:
         self.C = model.num_classes
         self.h = model.cam_size(S)
         self.n_sc = int(n_scales)  # args.cam_scales: every image contributes n_sc network inputs, their CAMs are summed
+        # ADP datasets (vgg16_cam.py:51-58): background / 'other' channels from the original images, on the lane's stream
+        self.adp = getattr(model, "dataset", None) in ("adp_morph", "adp_func")
         self.lanes = [self._make_lane(device, batch_images, S) for _ in range(n_lanes)]
         self.loaders = ThreadPoolExecutor(n_loaders, thread_name_prefix="wsc-load")
         self.writers = ThreadPoolExecutor(n_writers, thread_name_prefix="wsc-save")
@@ -111,7 +115,7 @@ class CamPipeline:
         self.images_done = 0
 
     def _make_lane(self, device, batch_images, S):
-        return _Lane(device, batch_images, S, self.C, self.h, self.n_sc)
+        return _Lane(device, batch_images, S, self.C, self.h, self.n_sc, self.model.adp_out_channels() if self.adp else 0)
 
     # -- stages --------------------------------------------------------------------------------------------
     def _load_into(self, lane, k, dataset, idx):
@@ -178,8 +182,18 @@ class CamPipeline:
             ctx.h2d_async(lane.x_dev, lane.pin_in, n * self.n_sc * 2 * 3 * self.S * self.S * 4)
         self.model._ensure_net().forward_cam(lane.x_dev, n * self.n_sc, self.S, lane.cam_dev,
                                              lane.score_dev if self.needs_score else None, ctx=ctx)
-        cam_dev = lane.cam_dev
-        if self.n_sc > 1:  # make_cam.py:62-69: sum over the scales (all of one size: see wsc_cam_sum_scales)
+        cam_dev, C = lane.cam_dev, self.C
+        if self.adp:
+            # common_cam.py:31-92 on the device: the original (un-flipped) image of every scale travels as uint8 through the
+            # lane's pinned staging, wsc_hsn_background + wsc_cam_adp_modify build the stack (summed over the scales)
+            origs = []
+            for m in metas:
+                v = m.pop("orig_img")
+                origs.extend(np.asarray(a)[0] for a in (v if isinstance(v, (list, tuple)) else [v]))
+            lane.ensure_u8(sum(int(o.size) for o in origs))
+            cam_dev, C = self.model.adp_modify_device(ctx, lane.cam_dev, n, self.n_sc, self.h, self.h, origs, out_dev=lane.adp_dev,
+                                                      stage=(lane.pin_u8, lane.u8_dev))
+        elif self.n_sc > 1:  # make_cam.py:62-69: sum over the scales (all of one size: see wsc_cam_sum_scales)
             _lib.cam_sum_scales(ctx, lane.cam_dev, n, self.n_sc, self.C * self.h * self.h, lane.sum_dev)
             cam_dev = lane.sum_dev
         score = None
@@ -192,7 +206,7 @@ class CamPipeline:
         s_tot = sum(len(k) * ((H - 1) // 4 + 1) * ((W - 1) // 4 + 1) for k, (H, W) in zip(keys, sizes))
         h_tot = sum(len(k) * H * W for k, (H, W) in zip(keys, sizes))
         lane.ensure_out(s_tot, h_tot)
-        _, _, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, n, self.C, self.h, self.h, sizes, keys,
+        _, _, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, n, C, self.h, self.h, sizes, keys,
                                                           lane.s_dev, lane.h_dev)
         ctx.d2h_async(lane.pin_out, lane.s_dev, max(s_tot, 1) * 4)
         ctx.d2h_async(lane.pin_out, lane.h_dev, max(h_tot, 1) * 4, dst_offset=max(s_tot, 1) * 4)
