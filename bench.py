@@ -721,11 +721,13 @@ def hsn_measure(args, device):
     for _ in range(max(args.warmup, 1)):
         eff_m = {}
         out = step(eff_m)
+    # The timed region is ONE driver call over steps x batch patches (the reference's dataset loop, 03c_hsn/demo.py:318-380):
+    # the driver keeps two batches in flight on two streams, so a batch's host decisions hide behind the other's kernels
+    hsn_demo.segment_adp(model, alpha, thr, images * 2, cfgs, S_, args.batch)  # (untimed: the second lane's context and workspace)
     model.ctx.sync()
     ctx = model.ctx
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    hsn_demo.segment_adp(model, alpha, thr, images * args.steps, cfgs, S_, args.batch)
     ctx.sync()
     elapsed = time.perf_counter() - t0
     ctx.profile_begin()
@@ -762,7 +764,8 @@ def hsn_measure(args, device):
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "vgg16 (31 classes, no BN) HSN Grad-CAM + modify_by_htt + cs-gradcam + dense-CRF x2 (morph 29 / "
-                               "func 5 classes, 10 iters), 321x321, batch %d" % args.batch, "batch_images": args.batch,
+                               "func 5 classes, 10 iters), 321x321, batch %d; one segment_adp call over steps x batch patches, two batches in "
+                               "flight (two streams)" % args.batch, "batch_images": args.batch,
                    "distinct_labels_per_image": m_classes,
                    "effective_M": {h: {"min": int(min(v)), "mean": round(float(np.mean(v)), 2), "max": int(max(v))} for h, v in eff_m.items()},
                    "effective_M_note": "classes with mass per image = the M its dense CRF runs with (dcrf_process keeps the classes "
@@ -775,7 +778,7 @@ def run_hsn(args, device):
     print(json.dumps(hsn_measure(args, device)))
 
 
-def irn_measure(device, precision, arch="resnet50", n_images=16, reps=3):
+def irn_measure(device, precision, arch="resnet50", n_images=32, reps=3):
     """BASELINE config 4 (IRNet inference) at VOC size on one GPU: the make_sem_seg_labels driver (03b_irn/step/
     make_sem_seg_labels.py:22-143) on `n_images` 375 x 500 images -- EdgeDisplacement on the [orig, flip] pair zero-padded to
     512 x 512 (:46), boundary maps to the CAM size, the random walk of K = 2 strided CAMs at 94 x 125 (beta 10, 2^8 steps), x4
@@ -802,19 +805,21 @@ def irn_measure(device, precision, arch="resnet50", n_images=16, reps=3):
     model.cuda(device)
     rng = np.random.default_rng(0)
     h, w, K = 94, 125, 2
+    n_images = int(os.environ.get("WSC_BENCH_IRN_BATCH", n_images))
     packs = [{"name": "i%d" % i, "img": rng.normal(0, 1, (2, 3, 375, 500)).astype(np.float32), "size": (375, 500)} for i in range(n_images)]
     cam_dicts = [{"keys": np.array([3, 11]), "cam": rng.random((K, h, w)).astype(np.float32)} for _ in range(n_images)]
     dargs = types.SimpleNamespace(dataset="voc12", beta=10, exp_times=8, sem_seg_bg_thres=0.25)
-    mssl.sem_seg_batch(model, packs, cam_dicts, dargs)
+    # the driver's dataset loop (make_sem_seg_labels._work) over `reps` batches: two batches in flight on two streams
+    n_lanes = int(os.environ.get("WSC_BENCH_IRN_LANES", "3"))  # (the driver's default, make_sem_seg_labels._work)
+    mssl.sem_seg_batches(model, [(packs, cam_dicts)] * n_lanes, dargs, n_lanes=n_lanes)
     model.ctx.sync()
     t0 = time.perf_counter()
-    for _ in range(reps):
-        mssl.sem_seg_batch(model, packs, cam_dicts, dargs)
+    mssl.sem_seg_batches(model, [(packs, cam_dicts)] * reps, dargs, n_lanes=n_lanes)
     model.ctx.sync()
     dt = (time.perf_counter() - t0) / reps
     return {"value": round(n_images / dt, 2), "unit": "images/s", "ms_per_image": round(dt / n_images * 1e3, 3), "dtype": precision,
             "workload": "IRNet inference (BASELINE config 4): %s EdgeDisplacement @512 pad -> random walk K=%d at %dx%d, 2^8 steps -> "
-                        "label map at 375x500; make_sem_seg_labels driver, %d images per call, host arrays in / label maps out"
+                        "label map at 375x500; make_sem_seg_labels driver loop, %d images per batch, three batches in flight, host arrays in / label maps out"
                         % (arch, K, h, w, n_images)}
 
 
@@ -889,10 +894,28 @@ def main():
     # strong scaling: the K steps are one fixed image set, sharded -- rank g owns ceil(K / N) of them
     my_steps = (steps + world - 1) // world if args.scaling == "strong" else steps
     elapsed = timed_run(wl, do_step, my_steps, args.warmup, wl.drain)
+    # what the line says about the ranks behind it: who contributed, each rank's own time (the value is computed from the MAX)
+    ranks_info = {"ranks_seen": 1, "barrier_world_size": 1, "backend": None, "launch": "single process",
+                  "per_rank_ms_per_step": [round(elapsed / my_steps * 1e3, 4)],
+                  "per_rank_value": [round(args.batch * my_steps / elapsed, 3)], "devices": [device]}
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dev_t = "cuda" if args.dist_backend == "nccl" else "cpu"
+        mine = torch.tensor([elapsed, float(device), float(my_steps), float(rank)], dtype=torch.float64, device=dev_t)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = [[float(v) for v in e.cpu()] for e in every]
+        assert sorted(int(e[3]) for e in every) == list(range(world)), "a rank is missing from the gather"
+        ranks_info = {"ranks_seen": len(every), "barrier_world_size": dist.get_world_size(),
+                      "backend": "%s (%s)" % (args.dist_backend, "RCCL over xGMI: timing barrier + max only, no data-path collective"
+                                              if args.dist_backend == "nccl" else "CPU dry run"),
+                      "launch": "torch.distributed.run, one process per GPU",
+                      "per_rank_ms_per_step": [round(e[0] / e[2] * 1e3, 4) for e in every],
+                      "per_rank_value": [round(args.batch * e[2] / e[0], 3) for e in every],
+                      "devices": [int(e[1]) for e in every]}
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        assert abs(elapsed - max(e[0] for e in every)) < 1e-9
         dist.barrier()
 
     # ---- steady state: >= --steady-seconds of steps cycling over four distinct resident batches (rank 0 of a 1-GPU run) ----
@@ -1051,6 +1074,8 @@ def main():
                                        "(3 HIP streams)" if pipelined else "none"},
             "roofline": roofline,
             "stages": stages,
+            # N = 1 (also `--gpus 1` of a scaling run) is this very path with ranks_seen = 1: no launcher, no process group
+            "ranks": ranks_info,
         }
         if steady is not None:
             out["value_steady"] = steady["value"]

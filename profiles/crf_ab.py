@@ -11,9 +11,14 @@ rng = np.random.default_rng(7)
 imgs = np.stack([synth.synth_image(rng, H, W) for _ in range(B)])
 U = (-np.log(np.clip(rng.dirichlet(np.ones(M) * 0.3, size=(B, H * W)).transpose(0, 2, 1), 1e-5, 1))).astype(np.float32)
 ctx = _lib.Context(0)
+for kv in os.environ.get("AB_OPTS", "").split(","):  # e.g. AB_OPTS=9:0 -> ctx.set_option(9, 0)
+    if kv:
+        o, v = kv.split(":")
+        ctx.set_option(int(o), int(v))
 rgb = ctx.to_device(imgs)
 u = ctx.to_device(U)
 a = ctx.alloc(B * H * W * 4)
+_lib.Crf(ctx, rgb, B, H, W, cfg[0], cfg[2], cfg[3]).close()  # (a size's tile vertex sets -- the on-chip Gaussian message -- come with its second use)
 crf = _lib.Crf(ctx, rgb, B, H, W, cfg[0], cfg[2], cfg[3])
 for _ in range(3):
     crf.inference(u, M, cfg[1], cfg[4], cfg[5], None, a)

@@ -36,12 +36,21 @@ SHAPES = [
 ]
 
 
-def _run(ctx, x, w, stride, pad, scale, shift, res, relu, precision):
+def _run(ctx, x, w, stride, pad, scale, shift, res, relu, precision, expect_range=False):
     N, Cin, H, W = x.shape
     x_dev = ctx.to_device(x)
     r_dev = ctx.to_device(res) if res is not None else None
     y_dev, shp = _lib.conv2d_nchw(ctx, x_dev, N, Cin, H, W, w, stride, pad, scale, shift, r_dev, relu, precision)
-    return ctx.to_host(y_dev, shp, np.float32)
+    if not expect_range:
+        return ctx.to_host(y_dev, shp, np.float32)
+    # a layer that saturates on purpose: the copy completes, reports WSC_ERR_RANGE (the range guard of the IEEE-half modes,
+    # include/wsscam.h) with the saturating layer's channel count, and the flag stays up until it is cleared
+    out = np.empty(shp, np.float32)
+    st = ctx._lib.wsc_memcpy_d2h(ctx.h, out.ctypes.data, y_dev.ptr, out.nbytes)
+    assert st == _lib.WSC_ERR_RANGE, st
+    assert ctx.range_status(clear=True) == w.shape[0]
+    assert ctx.range_status() == 0
+    return out
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -176,8 +185,9 @@ def test_conv_fast_variants_equal_generic_path(ctx, shape, precision):
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     res = rng.normal(0, 1, (N, Cout, Ho, Wo)).astype(np.float32)
     for use_res, relu in [(False, True), (True, True), (True, False)]:
-        y_ref = _run(ctx, x, w, stride, pad, scale, shift, res if use_res else None, relu, precision | _lib.CONV_GENERIC)
-        y = _run(ctx, x, w, stride, pad, scale, shift, res if use_res else None, relu, precision)
+        # (both epilogues must also raise the range flag: the generic one and the FAST one)
+        y_ref = _run(ctx, x, w, stride, pad, scale, shift, res if use_res else None, relu, precision | _lib.CONV_GENERIC, expect_range=True)
+        y = _run(ctx, x, w, stride, pad, scale, shift, res if use_res else None, relu, precision, expect_range=True)
         # (f16x3: hi saturates at 65504 and lo adds what is left of the clamped value: 65504 again)
         assert np.isfinite(y).all() and np.abs(y).max() == 65504.0
         assert np.array_equal(y, y_ref), (shape, use_res, relu, np.abs(y - y_ref).max())

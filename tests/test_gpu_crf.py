@@ -260,6 +260,11 @@ def test_crf_gaussian_blur_inside_update_is_bit_identical(ctx, case):
     print("gaussian on chip:", case, _gpu_crf.on_chip)
     assert list(vg) == list(vg2) and list(vb) == list(vb2)
     assert np.array_equal(q, q_ref) and np.array_equal(a, a_ref)
+    # round 6: the default path forms the message INSIDE the update kernel (E = -U + message never leaves the Q stage);
+    # OPT_CRF_MSG_IN_UPDATE = 0 is round 3's two-launch form (gauss_msg_kernel writes E, the update reads it): identical bits
+    with ctx.option(_lib.OPT_CRF_MSG_IN_UPDATE, 0):
+        q2, a2, _, _ = _gpu_crf(ctx, rgbs, Us, cfg)
+    assert np.array_equal(q2, q_ref) and np.array_equal(a2, a_ref)
 
 
 @pytest.mark.parametrize("case", [(321, 321, 21, 8, (1.5, 3, 40, 13, 10, 4)), (47, 61, 5, 1, (1.5, 3, 40, 13, 10, 3)),

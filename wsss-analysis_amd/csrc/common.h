@@ -147,7 +147,7 @@ struct wsc_ctx {
     int pin_next = 0;
     // path selectors (wsc_ctx_set_option): every one picks between two paths that both exist for some inputs and give the
     // same bits -- the tests hold them to that.  Defaults: wsc_option in include/wsscam.h.
-    int opt[WSC_OPT_COUNT] = {1, 1, 1, 0, 0, -1, 1, 1, 1};
+    int opt[WSC_OPT_COUNT] = {1, 1, 1, 0, 0, -1, 1, 1, 1, 1};
     void *pinned = nullptr; // (legacy single buffer: unused)
     size_t pinned_bytes = 0;
     void *zero_page = nullptr; // 256 bytes of zeros in HBM (source of padded conv taps)

@@ -1236,6 +1236,103 @@ __global__ __launch_bounds__(256) void combine4_balanced_kernel(const f32x4_t *_
     }
 }
 
+// Round 6: the same rows from the same partials with CHUNKS of consecutive partial rows per lane group.  In the kernel above
+// the lane groups of a wave hold CONSECUTIVE partial rows -- ~5 of which belong to one lattice row -- and add them into that
+// row's LDS accumulators at once: same-address 64-bit atomics, serialised by the LDS (SQ_LDS_BANK_CONFLICT 0.75 of its
+// LDS-active cycles, r05_pmc_crf.txt).  Here a lane group owns CB_CHUNK consecutive partial rows: it sums the partials of a
+// lattice row in registers (64-bit fixed point, as everywhere: order-independent, identical bits), stores a row whose
+// partials all lie inside its chunk directly, and only a row that straddles two chunks goes through the LDS accumulators --
+// a third of the atomics, and neighbouring lane groups now hold different rows.
+#ifndef WSC_CB_CHUNK
+#define WSC_CB_CHUNK 8
+#endif
+constexpr int CB_CHUNK = WSC_CB_CHUNK;
+__global__ __launch_bounds__(256) void combine4_chunk_kernel(const f32x4_t *__restrict__ part, const int32_t *__restrict__ row_slot_start,
+                                                             const uint32_t *__restrict__ part_row, int LP, int rows,
+                                                             f32x4_t *__restrict__ val) {
+    __shared__ int rss_l[CB_ROWS + 1];
+    __shared__ unsigned long long acc[CB_ROWS * 32];
+    const int r0 = blockIdx.x * CB_ROWS;
+    const int nr = min(CB_ROWS, rows - r0);
+    const int P0 = row_slot_start[r0], P1 = row_slot_start[r0 + nr]; // (uniform: scalar loads)
+    for (int i = threadIdx.x; i <= nr; i += 256) rss_l[i] = row_slot_start[r0 + i];
+    for (int i = threadIdx.x; i < CB_ROWS * 32; i += 256) acc[i] = 0ull;
+    const int gpb = 256 / LP;
+    const int tr = threadIdx.x / LP, l = threadIdx.x - tr * LP;
+    constexpr int U = CB_CHUNK;
+    f32x4_t v[U];
+    uint32_t pr[U];
+    auto fetch = [&](int p) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pp = p + u;
+            v[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            pr[u] = 0u;
+            if (tr < gpb && pp < P1) {
+                v[u] = part[(unsigned)pp * (unsigned)LP + l];
+                pr[u] = part_row[pp];
+            }
+        }
+    };
+    fetch(P0 + tr * U);
+    __syncthreads();
+    if (tr < gpb) {
+        for (int p = P0 + tr * U; p < P1; p += U * gpb) {
+            if (p != P0 + tr * U) fetch(p);
+            const int pe = min(p + U, P1); // the chunk is [p, pe)
+            long long a4[4] = {0, 0, 0, 0};
+            int cur = -1;
+            auto flush = [&]() {
+                if (cur < 0) return;
+                // all partials of the row inside this chunk: the row is final
+                if (rss_l[cur] >= p && rss_l[cur + 1] <= pe) {
+                    const f32x4_t o = {(float)a4[0] * PFIX_INV, (float)a4[1] * PFIX_INV, (float)a4[2] * PFIX_INV, (float)a4[3] * PFIX_INV};
+                    val[(unsigned)(r0 + cur) * (unsigned)LP + l] = o;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) atomicAdd(&acc[cur * 32 + 4 * l + k], (unsigned long long)a4[k]);
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (p + u < pe) {
+                    const int lo = (int)(pr[u] & 0xffffffu) - r0;
+                    if ((pr[u] >> 24) == 1u) { // the row's only partial: passed through unconverted, as everywhere
+                        flush();
+                        cur = -1;
+                        val[(unsigned)(r0 + lo) * (unsigned)LP + l] = v[u];
+                    } else {
+                        if (lo != cur) {
+                            flush();
+                            cur = lo;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) a4[k] = 0;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a4[k] += (long long)__float2int_rn(v[u][k] * PFIX_SCALE);
+                    }
+                }
+            }
+            flush();
+        }
+    }
+    __syncthreads();
+    if (tr < gpb) {
+        for (int row = tr; row < nr; row += gpb) {
+            const int b = rss_l[row], e = rss_l[row + 1], n = e - b;
+            if (n == 1) continue; // written above
+            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+            if (n > 1) {
+                // (chunks are aligned to P0 in steps of U: a row inside one chunk was stored by its lane group)
+                if ((b - P0) / U == (e - 1 - P0) / U) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (float)(long long)acc[row * 32 + 4 * l + k] * PFIX_INV;
+            }
+            val[(unsigned)(r0 + row) * (unsigned)LP + l] = o;
+        }
+    }
+}
+
 // One blur pass along one lattice axis: out[row] = in[row] + 0.5*(in[n1] + in[n2]).
 // Scalar form for the normalisation pass (one value per row).
 __global__ __launch_bounds__(256) void blur1_kernel(const float *__restrict__ in, const int2 *__restrict__ nbr,
@@ -1803,6 +1900,7 @@ __global__ void pack_pixels_b_kernel(const int32_t *__restrict__ off_b, const fl
     }
 }
 
+constexpr int GM_THREADS = 512; // block size of gauss_msg_kernel and of the update kernel's FG variants
 struct SplatTab { // splat tables of one lattice as the update kernel sees them
     const int32_t *tslot_start;
     const int2 *slot_desc;
@@ -1827,7 +1925,28 @@ struct UpdateArgs {
     TileGeom tg;
     unsigned g_pix, g_rows; // shared Gaussian lattice: pixels / rows per replica (g_rows = 0: not shared)
     SplatTab sg, sb;
+    // FG variants (the Gaussian message formed inside this kernel, E never in HBM): the tile vertex sets of gauss_fuse_tables
+    // and the Gaussian slot partials of the PREVIOUS splat (a different array from sg.part, which this launch writes: a
+    // neighbouring tile's block may already be splatting while this one still sums its closed vertex set)
+    const int4 *gt_cnt;
+    const int2 *gt_rows;
+    const uint4 *gt_nbr;
+    const uint4 *gt_pix;
+    const float *part_g_in;
+    int gt_stride;
+    unsigned long long *tl; // A/B builds: per block 8 shader-clock stamps at the phase boundaries (null: off)
 };
+#ifdef WSC_AB_KNOBS
+#define WSC_TL(a, i)                                                                                    \
+    do {                                                                                                \
+        if ((a).tl != nullptr && threadIdx.x == 0) (a).tl[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define WSC_TL(a, i) \
+    do {             \
+    } while (0)
+#endif
+constexpr int SPLAT_TAB_BYTES = (int)(sizeof(uint2) * TILE_PIX * 6 + sizeof(int2) * 256); // entries + slot descriptors
 
 // load through a uniform base + 32-bit byte offset: the compiler can use the SGPR-base addressing form and the
 // per-lane address arithmetic stays 32-bit (the 64-bit pointer adds were a fifth of the update loop's VALU work)
@@ -1970,9 +2089,10 @@ __device__ __forceinline__ void tile_gather(const SplatTab &T, int s_beg, int s_
 // for its record from HBM before it can request its rows, and the kernel is bound by that latency at 4 waves per SIMD.
 constexpr int REC_LDS_BYTES = 56; // 13 dwords + 1 pad: 8-byte aligned records, TILE_PIX of them fit the splat-table region
 static_assert(TILE_PIX * REC_LDS_BYTES <= (int)(sizeof(uint2) * GATHER_ENT + sizeof(int2) * GATHER_SB), "record stage");
-template <bool SLICE, bool SPLAT, bool GF = false, bool DMA = false>
+template <bool SLICE, bool SPLAT, bool GF = false, bool DMA = false, int FG = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void update_splat_kernel(UpdateArgs a) {
     static_assert(!DMA || (SLICE && GF) || (!SLICE && SPLAT), "the LDS-DMA staging belongs to the GF updates and the first update");
+    static_assert(FG == 0 || (SLICE && GF && DMA), "the in-kernel Gaussian message belongs to the DMA-staged GF updates");
     extern __shared__ f32x4_t stage[]; // [TILE_PIX][LP]
     const int LP = a.LP;
     const int gpw = 64 / LP;
@@ -2106,7 +2226,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
     // splat tables of the Gaussian lattice: requested now, used after the trips (8 registers across the loop)
     constexpr int EN_G = (TILE_PIX * 3 + 255) / 256, EN_B = (TILE_PIX * 6 + 255) / 256; // blocks of >= 256 threads (update_threads)
     SplatRegs<EN_G> rg;
-    if (SPLAT) splat_fetch<EN_G>(a.sg, a.sg.shared ? j : lb, (a.sg.shared ? 0ll : (long long)k * N) + tb.ebase, np, rg);
+    WSC_TL(a, 0); // block start
+    if (SPLAT && FG == 0) splat_fetch<EN_G>(a.sg, a.sg.shared ? j : lb, (a.sg.shared ? 0ll : (long long)k * N) + tb.ebase, np, rg);
+    // FG: the descriptors of the tile's closed vertex set {first partial row, count} are requested before the LDS-DMA pieces
+    // (loads return in order: behind them the first wait of the Gaussian phase would sit behind the whole tile's stream)
+    int4 cnt = make_int4(0, 0, 0, 0);
+    int2 ps[FG > 0 ? FG : 1];
+    uint4 tn0 = make_uint4(0, 0, 0, 0);
+    if (FG > 0) {
+        cnt = a.gt_cnt[j];
+        const unsigned lpm = (65536u + (unsigned)LP - 1u) / (unsigned)LP;
+        const int2 *trow = a.gt_rows + (size_t)j * a.gt_stride;
+#pragma unroll
+        for (int it = 0; it < (FG > 0 ? FG : 1); ++it) {
+            const int i = (int)threadIdx.x + it * GM_THREADS;
+            ps[it] = make_int2(0, 0);
+            if (i < a.gt_stride * LP) ps[it] = trow[((unsigned)i * lpm) >> 16];
+        }
+        if ((int)threadIdx.x < a.gt_stride) tn0 = a.gt_nbr[(size_t)j * a.gt_stride + threadIdx.x]; // (neighbour words: to LDS below)
+    }
     if (DMA) {
         // E rows -> stage[t][l] (16-byte units u = t * LP + l), records -> lrec[t][14 dwords] (dword units d = t * 14 + k);
         // a wave instruction fills 64 consecutive units from per-lane source addresses (units past the tile re-read its
@@ -2134,38 +2272,132 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(const_cast<char *>(lrec) + d0 * 4), 4, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FG == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    WSC_TL(a, 1); // DMA issued (FG) / landed (two-launch form)
+    if constexpr (FG > 0) {
+        // ---- Gaussian message of the tile, on chip (round 6): the body of gauss_msg_kernel with E = -U + message left in the
+        // Q stage instead of HBM.  blockDim.x == GM_THREADS.  The U rows and the records are already travelling (LDS-DMA above);
+        // this phase sums the Gaussian slot partials of the tile's closed vertex set into LDS, blurs them in place and slices
+        // them into the staged U rows -- the same loads, the same FMAs in the same order as the two-kernel form: identical bits.
+        constexpr int NIT = FG, NPI = FG == 4 ? 3 : 4;
+        f32x4_t *gl = reinterpret_cast<f32x4_t *>(reinterpret_cast<char *>(stage + TILE_PIX * LP) + SPLAT_TAB_BYTES);
+        const int stride = a.gt_stride, tid = (int)threadIdx.x;
+        unsigned *lnb = reinterpret_cast<unsigned *>(gl + (size_t)stride * (size_t)LP);
+        const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4_t *partg = reinterpret_cast<const f32x4_t *>(a.part_g_in) + (a.sg.shared ? (size_t)k * a.sg.n_slots * LP : (size_t)0);
+        const int nitems_all = stride * LP;
+        const unsigned lp_magic = (65536u + (unsigned)LP - 1u) / (unsigned)LP;
+        const uint4 *tn = a.gt_nbr + (size_t)j * stride;
+        const unsigned gpix0 = (unsigned)tb.y0 * (unsigned)a.tg.W + (unsigned)tb.x0;
+        {
+            f32x4_t val[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * GM_THREADS;
+                const unsigned v = ((unsigned)i * lp_magic) >> 16, ll = (unsigned)i - v * (unsigned)LP;
+                val[it] = zero;
+                if (ps[it].y > 0) val[it] = partg[(unsigned)ps[it].x * (unsigned)LP + ll];
+            }
+            WSC_TL(a, 2); // descriptors arrived, first partials requested
+            if (tid < stride) reinterpret_cast<uint4 *>(lnb)[tid] = tn0;
+            for (int v = tid + GM_THREADS; v < stride; v += GM_THREADS) reinterpret_cast<uint4 *>(lnb)[v] = tn[v];
+            int maxc = 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) maxc = max(maxc, ps[it].y);
+            for (int c = 1; c < maxc; ++c) {
+                f32x4_t more[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int i = tid + it * GM_THREADS;
+                    const unsigned v = ((unsigned)i * lp_magic) >> 16, ll = (unsigned)i - v * (unsigned)LP;
+                    more[it] = zero;
+                    if (c < ps[it].y) more[it] = partg[(unsigned)(ps[it].x + c) * (unsigned)LP + ll];
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if (c < ps[it].y) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) val[it][q] += more[it][q];
+                    }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * GM_THREADS;
+                if (i < nitems_all) gl[i] = val[it];
+            }
+        }
+        WSC_TL(a, 3); // all partial rows summed into LDS
+        // the pixels' Gaussian records (L2: one table for all images) travel under the blur passes
+        uint4 gpx[NPI];
+#pragma unroll
+        for (int it = 0; it < NPI; ++it) {
+            const int i = tid + it * GM_THREADS;
+            gpx[it] = make_uint4(0, 0, 0, 0);
+            if (i < np * LP) {
+                const unsigned t = ((unsigned)i * lp_magic) >> 16;
+                const unsigned ty = (t * cw_magic) >> 16, tx = t - ty * (unsigned)tb.cw;
+                gpx[it] = a.gt_pix[gpix0 + ty * (unsigned)a.tg.W + tx];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int axis = 0; axis < 3; ++axis) {
+            const int nitems = (axis == 0 ? cnt.z : (axis == 1 ? cnt.y : cnt.x)) * LP;
+            f32x4_t o[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * GM_THREADS;
+                o[it] = zero;
+                if (i < nitems) {
+                    const unsigned v = ((unsigned)i * lp_magic) >> 16, ll = (unsigned)i - v * (unsigned)LP;
+                    const unsigned w = lnb[v * 4 + axis];
+                    const f32x4_t c = gl[i], x1 = gl[(w & 0xffffu) * (unsigned)LP + ll], x2 = gl[(w >> 16) * (unsigned)LP + ll];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[it][q] = c[q] + 0.5f * (x1[q] + x2[q]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * GM_THREADS;
+                if (i < nitems) gl[i] = o[it];
+            }
+            if (axis == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the wave's LDS-DMA pieces (U rows, records) have landed
+            __syncthreads();
+        }
+        // slice into the staged U rows: E = -U, then the three FMAs (weights (bary * norm) * (compat * alpha)), in place
+#pragma unroll
+        for (int it = 0; it < NPI; ++it) {
+            const int i = tid + it * GM_THREADS;
+            if (i < np * LP) {
+                const unsigned t = ((unsigned)i * lp_magic) >> 16, ll = (unsigned)i - t * (unsigned)LP;
+                const uint4 gp = gpx[it];
+                const f32x4_t uu = stage[i];
+                f32x2_t o01 = {-uu[0], -uu[1]}, o23 = {-uu[2], -uu[3]};
+                const float wr[3] = {__uint_as_float(gp.y) * cag, __uint_as_float(gp.z) * cag, __uint_as_float(gp.w) * cag};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const f32x4_t row = gl[((gp.x >> (10 * r)) & 1023u) * (unsigned)LP + ll];
+                    const f32x2_t w2 = {wr[r], wr[r]}, lo = {row[0], row[1]}, hi = {row[2], row[3]};
+                    o01 = __builtin_elementwise_fma(w2, lo, o01);
+                    o23 = __builtin_elementwise_fma(w2, hi, o23);
+                }
+                stage[i] = f32x4_t{o01[0], o01[1], o23[0], o23[1]};
+            }
+        }
+        if (SPLAT) splat_fetch<EN_G>(a.sg, a.sg.shared ? j : lb, (a.sg.shared ? 0ll : (long long)k * N) + tb.ebase, np, rg);
         __syncthreads();
     }
-    {
-        const f32x4_t u0 = load_u(t_first);
-        f32x4_t g3[3], b6[6];
-        float w9[9];
-        if (SLICE) {
-            load_rec(t_first, rq);
-            issue_rows(rq, g3, b6, w9);
-        }
-        unn = u0;
-        if (t_first + ppt < np) {
-            if (SLICE) load_rec(t_first + ppt, rq);
-            unn = load_u(t_first + ppt);
-        }
-        fold(u0, g3, b6, w9, e01, e23);
-    }
-    for (int t0 = t_first; t0 < np; t0 += ppt) {
+    WSC_TL(a, 4); // E in the Q stage: the trips start
+    // softmax of the current trip's energy (e01, e23) -> Q into the tile's stage (and to memory / the arg-max in the last update)
+    auto emit = [&](int t0) {
         const int t = t0 + g;
         const bool ok = act && t < np;
         const unsigned p = pixel_of(t0);
-        // next trip's rows (its record was requested one trip ago), then the record + unary of the trip after it
-        const bool has_next = t0 + ppt < np;
-        f32x4_t vgn[3], vbn[6];
-        float wrn[9];
-        const f32x4_t un1 = unn;
-        if (SLICE && has_next) issue_rows(rq, vgn, vbn, wrn);
-        if (t0 + 2 * ppt < np) {
-            if (SLICE) load_rec(t0 + 2 * ppt, rq);
-            unn = load_u(t0 + 2 * ppt);
-        }
         float e[4] = {e01[0], e01[1], e23[0], e23[1]};
         float mx = -3.0e38f;
 #pragma unroll
@@ -2217,8 +2449,96 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
             }
             if (ok && l == 0) a.argmax[pix0 + p] = bi;
         }
-        if (has_next) fold(un1, vgn, vbn, wrn, e01, e23); // the next trip's energy: its rows have had this trip to arrive
+    };
+#ifndef WSC_UPD_DEEP
+#define WSC_UPD_DEEP 1 // 0: rows requested one trip before they are folded (rounds 2-5)
+#endif
+    if constexpr (DMA && SLICE && GF && WSC_UPD_DEEP) {
+        // Round 6: the six bilateral rows of a trip are requested TWO trips before they are folded (two sets of row registers,
+        // the loop unrolled by two so that both are static).  The records and E rows of every trip are in LDS (DMA), so a
+        // request needs nothing from memory; with one trip of lead the L2 gather (~1 us under load) was exposed in every
+        // trip -- the phase timeline (profiles/upd_timeline.py) shows 1.25 us per trip against ~0.3 us of issue work.
+        // Same FMAs in the same order per pixel: bit-identical.
+        // (a request reads only the six row ids from the LDS record; the fold re-reads the trip's E row and its weights from
+        // LDS -- both stay valid until the trip's own Q overwrites the E row / the splat tables replace the records -- so
+        // nothing but the 2 x 6 row registers lives across a trip: 128 registers without spills)
+        f32x4_t rA[6], rB[6];
+        auto req_rows = [&](int t0, f32x4_t(&r)[6]) {
+            const char *q = lrec + tile_idx(t0) * (unsigned)REC_LDS_BYTES;
+            uint2 w[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w[i] = *reinterpret_cast<const uint2 *>(q + 8 * i);
+            const unsigned id[6] = {w[0].x, w[0].y, w[1].x, w[1].y, w[2].x, w[2].y};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) r[i] = ld_off<f32x4_t>(vb_b, __umul24(id[i], LP16) + l16);
+        };
+        auto fold_rows = [&](int t0, const f32x4_t(&r)[6]) {
+            const unsigned ti = tile_idx(t0);
+            const char *q = lrec + ti * (unsigned)REC_LDS_BYTES;
+            const f32x4_t u = stage[ti * (unsigned)LP + (unsigned)l]; // E = -U + Gaussian message
+            uint2 w[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w[i] = *reinterpret_cast<const uint2 *>(q + 24 + 8 * i);
+            const float wb = cab * __uint_as_float(*reinterpret_cast<const uint32_t *>(q + 48));
+            const float bw[6] = {__uint_as_float(w[0].x) * wb, __uint_as_float(w[0].y) * wb, __uint_as_float(w[1].x) * wb,
+                                 __uint_as_float(w[1].y) * wb, __uint_as_float(w[2].x) * wb, __uint_as_float(w[2].y) * wb};
+            e01 = f32x2_t{u[0], u[1]};
+            e23 = f32x2_t{u[2], u[3]};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const f32x2_t w2 = {bw[i], bw[i]}, lo = {r[i][0], r[i][1]}, hi = {r[i][2], r[i][3]};
+                e01 = __builtin_elementwise_fma(w2, lo, e01);
+                e23 = __builtin_elementwise_fma(w2, hi, e23);
+            }
+        };
+        {
+            f32x4_t r0[6];
+            req_rows(t_first, r0);
+            if (t_first + ppt < np) req_rows(t_first + ppt, rA);
+            fold_rows(t_first, r0);
+        }
+        auto step = [&](int t0, const f32x4_t(&r_nx)[6], f32x4_t(&r_new)[6]) {
+            if (t0 + 2 * ppt < np) req_rows(t0 + 2 * ppt, r_new); // the trip after the next one: two trips to arrive
+            emit(t0);
+            if (t0 + ppt < np) fold_rows(t0 + ppt, r_nx);
+        };
+        for (int t0 = t_first; t0 < np; t0 += 2 * ppt) {
+            step(t0, rA, rB);
+            if (t0 + ppt >= np) break;
+            step(t0 + ppt, rB, rA);
+        }
+    } else {
+        {
+            const f32x4_t u0 = load_u(t_first);
+            f32x4_t g3[3], b6[6];
+            float w9[9];
+            if (SLICE) {
+                load_rec(t_first, rq);
+                issue_rows(rq, g3, b6, w9);
+            }
+            unn = u0;
+            if (t_first + ppt < np) {
+                if (SLICE) load_rec(t_first + ppt, rq);
+                unn = load_u(t_first + ppt);
+            }
+            fold(u0, g3, b6, w9, e01, e23);
+        }
+        for (int t0 = t_first; t0 < np; t0 += ppt) {
+            // next trip's rows (its record was requested one trip ago), then the record + unary of the trip after it
+            const bool has_next = t0 + ppt < np;
+            f32x4_t vgn[3], vbn[6];
+            float wrn[9];
+            const f32x4_t un1 = unn;
+            if (SLICE && has_next) issue_rows(rq, vgn, vbn, wrn);
+            if (t0 + 2 * ppt < np) {
+                if (SLICE) load_rec(t0 + 2 * ppt, rq);
+                unn = load_u(t0 + 2 * ppt);
+            }
+            emit(t0);
+            if (has_next) fold(un1, vgn, vbn, wrn, e01, e23); // the next trip's energy: its rows have had this trip to arrive
+        }
     }
+    WSC_TL(a, 5); // this wave's trips done
     if (SPLAT) {
         uint2 *lent = reinterpret_cast<uint2 *>(stage + TILE_PIX * LP);
         int2 *ldesc = reinterpret_cast<int2 *>(lent + GATHER_ENT);
@@ -2229,10 +2549,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
         splat_fetch<EN_B>(a.sb, a.sb.shared ? j : lb, (a.sb.shared ? 0ll : (long long)k * N) + tb.ebase, np, rb);
         __syncthreads(); // Q stage + Gaussian tables complete
         tile_gather(a.sg, rg.s_beg, rg.s_end, k, stage, lent, ldesc, LP, l, g, gpw, act); // (ends with a barrier)
+        WSC_TL(a, 6); // Gaussian slots written
         splat_commit<EN_B>(a.sb, np, rb, lent, ldesc, LP);
         __syncthreads();
         tile_gather(a.sb, rb.s_beg, rb.s_end, k, stage, lent, ldesc, LP, l, g, gpw, act);
     }
+    WSC_TL(a, 7); // block end
 }
 
 // ---- Gaussian message of a pixel tile, on chip ------------------------------------------------------------------------
@@ -2257,7 +2579,6 @@ struct GaussMsgArgs {
     float cag;         // compat * alpha
     TileGeom tg;
 };
-constexpr int GM_THREADS = 512;
 // NIT: (vertex, float4) items per thread in a blur pass; NPI: (pixel, float4) items per thread in the slice
 template <int NIT, int NPI>
 __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void gauss_msg_kernel(GaussMsgArgs a) {
@@ -2571,6 +2892,9 @@ void combine4(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, const float *pa
     if (L.sorted_dest)
         hipLaunchKernelGGL(combine4_kernel<true>, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
                            st, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
+    else if (L.rep == 1 && L.part_row && CB_CHUNK > 0 && !(be && atoi(be) != 2))
+        hipLaunchKernelGGL(combine4_chunk_kernel, dim3((unsigned)((L.rows + CB_ROWS - 1) / CB_ROWS)), dim3(256), 0, st,
+                           (const f32x4_t *)part, L.row_slot_start, (const uint32_t *)L.part_row, LP, L.rows, (f32x4_t *)val);
     else if (L.rep == 1 && !(be && atoi(be) == 0))
         hipLaunchKernelGGL(combine4_balanced_kernel, dim3((unsigned)((L.rows + CB_ROWS - 1) / CB_ROWS)), dim3(256), 0, st,
                            (const f32x4_t *)part, L.row_slot_start, (const uint32_t *)L.part_row, LP, L.rows, (f32x4_t *)val);
@@ -3107,7 +3431,15 @@ int launch_gauss_msg(wsc_ctx *ctx, hipStream_t st, const GaussMsgArgs &g, double
 }
 
 // gf: the energy starts from the E buffer of gauss_msg_kernel (a.u points at it), no Gaussian rows are gathered
-int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat, bool gf) {
+// LDS of the FG variants: Q stage + splat tables / records + the tile's closed vertex set (rows + neighbour words)
+size_t update_fg_lds(int LP, int gt_stride) { return update_splat_lds(LP) + gauss_msg_lds(LP, gt_stride); }
+// can the Gaussian message be formed INSIDE the update kernel?  Two blocks of GM_THREADS threads per CU must fit
+bool update_fg_ok(const wsc_ctx *ctx, const LatticeDev &G, int LP) {
+    if (!ctx->opt[WSC_OPT_CRF_MSG_IN_UPDATE] || !update_gf_ok(ctx, G, LP)) return false;
+    return update_fg_lds(LP, G.gt_stride) <= 80 * 1024;
+}
+// fg: the Gaussian message is formed inside the kernel (a.u = U, a.part_g_in = the previous splat's Gaussian partials)
+int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat, bool gf, bool fg = false, double fg_bytes = 0.0) {
     const double npix = (double)a.B * a.tg.H * a.tg.W;
     // algorithmic bytes: read U, write Q; slice: index+weight of both lattices (9 entries of 8 bytes) and the
     // two messages the reference materialises (N*M*4 each); splat: read Q for both lattices + index+weight
@@ -3115,9 +3447,40 @@ int launch_update(wsc_ctx *ctx, const UpdateArgs &a, bool slice, bool splat, boo
     // is accounted there)
     const double by = npix * (2.0 * a.M * 4 + (slice ? (gf ? 6 * 8 + 1.0 * a.M * 4 : 9 * 8 + 2.0 * a.M * 4) : 0.0) +
                               (splat ? 9 * 8 + 2.0 * a.M * 4 : 0.0));
-    WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, by);
+    WscKernelTimer timer(ctx, WSC_K_SLICE_UPDATE, by + (fg ? fg_bytes : 0.0));
     const dim3 grid((unsigned)(a.B * a.tg.tpi)), block(update_threads());
     size_t lds = splat ? update_splat_lds(a.LP) : 0;
+    if (fg) {
+        const size_t l = update_fg_lds(a.LP, a.gt_stride);
+        const bool small = (long long)a.gt_stride * a.LP <= 4ll * GM_THREADS && a.LP <= 6;
+        auto set_lds = [&](const void *fn) {
+            static bool done[64][4] = {};
+            const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0, vi = (small ? 0 : 2) + (splat ? 0 : 1);
+            if (!done[dev][vi] && l > 48 * 1024) {
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                done[dev][vi] = true;
+            }
+        };
+        if (small) {
+            if (splat) {
+                set_lds(reinterpret_cast<const void *>(update_splat_kernel<true, true, true, true, 4>));
+                hipLaunchKernelGGL((update_splat_kernel<true, true, true, true, 4>), grid, dim3(GM_THREADS), l, ctx->stream, a);
+            } else {
+                set_lds(reinterpret_cast<const void *>(update_splat_kernel<true, false, true, true, 4>));
+                hipLaunchKernelGGL((update_splat_kernel<true, false, true, true, 4>), grid, dim3(GM_THREADS), l, ctx->stream, a);
+            }
+        } else {
+            if (splat) {
+                set_lds(reinterpret_cast<const void *>(update_splat_kernel<true, true, true, true, 6>));
+                hipLaunchKernelGGL((update_splat_kernel<true, true, true, true, 6>), grid, dim3(GM_THREADS), l, ctx->stream, a);
+            } else {
+                set_lds(reinterpret_cast<const void *>(update_splat_kernel<true, false, true, true, 6>));
+                hipLaunchKernelGGL((update_splat_kernel<true, false, true, true, 6>), grid, dim3(GM_THREADS), l, ctx->stream, a);
+            }
+        }
+        WSC_HIP(hipGetLastError());
+        return WSC_OK;
+    }
 #ifdef WSC_AB_KNOBS
     const char *de = getenv("WSC_CRF_UPD_DMA"); // A/B: 0 keeps the register loads of E and the records
 #else
@@ -3334,7 +3697,7 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     const size_t pg = al(sizeof(float) * (size_t)g_slots * Mp), pb = al(sizeof(float) * (size_t)Bl.n_slots * Mp);
     const size_t vg = al(sizeof(float) * (size_t)g_rows * Mp), vb = al(sizeof(float) * (size_t)Bl.rows * Mp);
     void *ws;
-    WSC_TRY(wsc_ctx_workspace(ctx, 2 * qb + 2 * vg + 2 * vb + pg + pb, &ws));
+    WSC_TRY(wsc_ctx_workspace(ctx, 2 * qb + 2 * vg + 2 * vb + 2 * pg + pb, &ws));
     char *p = (char *)ws;
     float *u = (float *)p; p += qb;
     float *q = (float *)p; p += qb;
@@ -3343,6 +3706,7 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     float *vb0 = (float *)p; p += vb;
     float *vb1 = (float *)p; p += vb;
     float *partg = (float *)p; p += pg;
+    float *partg2 = (float *)p; p += pg; // FG updates: the splat writes one array while the blocks still read the other
     float *partb = (float *)p; p += pb;
 
     crf->lat[0].M_cur = M;
@@ -3388,6 +3752,26 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
     // gauss_msg_kernel turns the Gaussian slot partials into E = -U + message (in the Q buffer: an update reads its slot of
     // E before it writes Q there) beside the bilateral lattice's combine + six passes, and the update starts from E
     const bool gf = update_gf_ok(ctx, G, LP);
+    const bool fg = gf && update_fg_ok(ctx, G, LP);
+    a.gt_cnt = G.gt_cnt; a.gt_rows = G.gt_rows; a.gt_nbr = G.gt_nbr; a.gt_pix = G.gt_pix; a.gt_stride = G.gt_stride;
+    a.part_g_in = nullptr;
+    a.tl = nullptr;
+#ifdef WSC_AB_KNOBS
+    if (const char *te = getenv("WSC_CRF_UPD_TIMELINE")) { // A/B: file the stamps of the LAST splatting update of this call go to
+        static unsigned long long *tl_dev = nullptr;
+        static size_t tl_cap = 0;
+        const size_t need = (size_t)B * a.tg.tpi * 8;
+        if (need > tl_cap) {
+            if (tl_dev) (void)hipFree(tl_dev);
+            WSC_HIP(hipMalloc((void **)&tl_dev, need * sizeof(unsigned long long)));
+            tl_cap = need;
+        }
+        WSC_HIP(hipMemsetAsync(tl_dev, 0, need * sizeof(unsigned long long), ctx->stream));
+        a.tl = tl_dev;
+        (void)te;
+    }
+    unsigned long long *const tl_keep = a.tl;
+#endif
     if (gf && n_iters > 0) { // (built by wsc_crf_create whenever the lattice has its tile vertex sets; here for completeness)
         WSC_TRY(crf_bilateral_records(crf, ctx->stream));
         a.pix_rec_b = crf->pix_rec_b;
@@ -3414,8 +3798,16 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
         const bool labels_only = last && q_dev == nullptr && argmax_dev != nullptr;
         a.q = last && !labels_only ? q : nullptr;
         a.argmax = labels_only ? argmax_dev : nullptr;
-        a.u = (gf && it > 0) ? q : u;
-        WSC_TRY(launch_update(ctx, a, it > 0, !last, gf));
+        a.u = (gf && !fg && it > 0) ? q : u;
+#ifdef WSC_AB_KNOBS
+        if (last || it == 0) a.tl = nullptr; // (the stamps are those of the last SPLATTING update with messages)
+        else a.tl = tl_keep;
+#endif
+        if (fg) { // iteration `it` reads the Gaussian partials of splat it - 1 and writes those of splat `it`
+            a.part_g_in = (it & 1) ? partg : partg2;
+            a.sg.part = (it & 1) ? partg2 : partg;
+        }
+        WSC_TRY(launch_update(ctx, a, it > 0, !last, gf, fg && it > 0, gf_bytes));
         if (last) break;
         // The two lattices are independent until the next update: the bilateral one (seven short launches on ~1 MB per
         // image) runs on the ctx's side stream beside the Gaussian lattice's fused blur.
@@ -3427,7 +3819,8 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
         }
         a.val_b = combine_blur_all4(ctx, fork ? ctx->aux_stream : main_stream, Bl, LP, partb, vb0, vb1);
         if (fork) WSC_HIP(hipEventRecord(ctx->aux_done_ev, ctx->aux_stream));
-        if (gf) WSC_TRY(launch_gauss_msg(ctx, main_stream, gm, gf_bytes));
+        if (fg) {
+        } else if (gf) WSC_TRY(launch_gauss_msg(ctx, main_stream, gm, gf_bytes));
         else a.val_g = combine_blur_all4(ctx, main_stream, G, LP, partg, vg0, vg1);
         if (fork) WSC_HIP(hipStreamWaitEvent(main_stream, ctx->aux_done_ev, 0));
     }
@@ -3438,6 +3831,18 @@ static int crf_inference_impl(wsc_ctx *ctx, wsc_crf *crf, const float *unary_dev
                                N, q_dev, argmax_dev);
     }
     WSC_HIP(hipGetLastError());
+#ifdef WSC_AB_KNOBS
+    if (tl_keep != nullptr) {
+        const size_t need = (size_t)B * a.tg.tpi * 8;
+        std::vector<unsigned long long> h(need);
+        WSC_HIP(hipMemcpyAsync(h.data(), tl_keep, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        WSC_HIP(hipStreamSynchronize(ctx->stream));
+        if (FILE *f = fopen(getenv("WSC_CRF_UPD_TIMELINE"), "wb")) {
+            fwrite(h.data(), sizeof(unsigned long long), need, f);
+            fclose(f);
+        }
+    }
+#endif
     if (ctx != crf->ctx) { // destroy must not hand the lattices back to the build ctx's cache before this loop is done
         if (!crf->use_ev) WSC_HIP(hipEventCreateWithFlags(&crf->use_ev, hipEventDisableTiming));
         WSC_HIP(hipEventRecord(crf->use_ev, ctx->stream));

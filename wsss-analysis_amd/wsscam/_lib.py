@@ -37,9 +37,10 @@ PREC_F16 = 2
 PREC_F16X3 = 3  # split-half operands and activations (hi + lo), three MFMA products: the fp32-class mode
 # path selectors of a context (include/wsscam.h wsc_option; Context.set_option / Context.option)
 OPT_CRF_GAUSS_ON_CHIP, OPT_CRF_FUSED_BLUR, OPT_CRF_BLUR_ON_CHIP, OPT_CRF_RANK_BALLOT, OPT_CRF_EMBED_FULL, OPT_RW_TILED, \
-    OPT_STEM_POOL_FUSED, OPT_CONV_WINDOW, OPT_CAM_HEAD_STREAM = range(9)
+    OPT_STEM_POOL_FUSED, OPT_CONV_WINDOW, OPT_CAM_HEAD_STREAM, OPT_CRF_MSG_IN_UPDATE = range(10)
 OPT_DEFAULTS = {OPT_CRF_GAUSS_ON_CHIP: 1, OPT_CRF_FUSED_BLUR: 1, OPT_CRF_BLUR_ON_CHIP: 1, OPT_CRF_RANK_BALLOT: 0,
-                OPT_CRF_EMBED_FULL: 0, OPT_RW_TILED: -1, OPT_STEM_POOL_FUSED: 1, OPT_CONV_WINDOW: 1, OPT_CAM_HEAD_STREAM: 1}
+                OPT_CRF_EMBED_FULL: 0, OPT_RW_TILED: -1, OPT_STEM_POOL_FUSED: 1, OPT_CONV_WINDOW: 1, OPT_CAM_HEAD_STREAM: 1,
+                OPT_CRF_MSG_IN_UPDATE: 1}
 CONV_GENERIC = 0x100  # conv2d_nchw only: OR into precision to keep the kernel's generic variants (testing)
 
 
@@ -469,8 +470,9 @@ class Net:
     def forward_features(self, x_dev, N, S, feat_dev):
         check(self.ctx._lib.wsc_net_forward_features(self.ctx.h, self.h, _ptr(x_dev), N, S, _ptr(feat_dev)))
 
-    def forward_edge(self, x_dev, B, S, feat_h, feat_w, edge_dev, dp_dev):
-        check(self.ctx._lib.wsc_net_forward_edge(self.ctx.h, self.h, _ptr(x_dev), B, S, feat_h, feat_w,
+    def forward_edge(self, x_dev, B, S, feat_h, feat_w, edge_dev, dp_dev, ctx=None):
+        run = ctx or self.ctx
+        check(self.ctx._lib.wsc_net_forward_edge(run.h, self.h, _ptr(x_dev), B, S, feat_h, feat_w,
                                                  _ptr(edge_dev), _ptr(dp_dev)))
 
 

@@ -22,10 +22,11 @@ class EdgeDisplacementBase(DeviceCAMBase):
         ctx = self._ctx
         return ctx.to_host(edge_dev, (B, 1, fh, fw), np.float32), ctx.to_host(dp_dev, (B, 2, fh, fw), np.float32)
 
-    def forward_batch_device(self, x):
+    def forward_batch_device(self, x, ctx=None):
         """forward_batch with the outputs left in HBM: (edge_dev float32 [B][fh][fw], dp_dev [B][2][fh][fw], (B, fh, fw)).
         x: (B,2,3,h,w) array / tensor, or a list of B (2,3,h,w) arrays of one size (copied straight into the page-locked,
-        zero-padded staging batch: no stacked temporary, no pageable upload)."""
+        zero-padded staging batch: no stacked temporary, no pageable upload).  `ctx`: run on this context (a lane of the
+        make_sem_seg_labels driver: its own stream, staging batch and workspace) instead of the model's own."""
         net = self._ensure_net()
         if isinstance(x, (list, tuple)):
             items = [np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32) for v in x]
@@ -41,8 +42,8 @@ class EdgeDisplacementBase(DeviceCAMBase):
         if h > S or w > S:
             raise ValueError("input %dx%d is larger than crop_size %d" % (h, w, S))
         fh, fw = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
-        ctx = self._ctx
-        st = self.__dict__.setdefault("_stage", {})
+        ctx = ctx or self._ctx
+        st = self.__dict__.setdefault("_stage", {}).setdefault(id(ctx), {})
         if st.get("key") != (B, S):  # page-locked (B,2,3,S,S) staging batch + its device twin, kept across calls
             for k in ("pin", "dev"):
                 if st.get(k) is not None:
@@ -56,9 +57,9 @@ class EdgeDisplacementBase(DeviceCAMBase):
         for i, v in enumerate(items):
             xp[i, :, :, :h, :w] = v
         ctx.h2d_async(st["dev"], st["pin"], B * 2 * 3 * S * S * 4)
-        edge_dev = ctx.alloc(B * fh * fw * 4)
-        dp_dev = ctx.alloc(B * 2 * fh * fw * 4)
-        net.forward_edge(st["dev"], B, S, fh, fw, edge_dev, dp_dev)
+        edge_dev = ctx.alloc(B * fh * fw * 4, pooled=True)
+        dp_dev = ctx.alloc(B * 2 * fh * fw * 4, pooled=True)
+        net.forward_edge(st["dev"], B, S, fh, fw, edge_dev, dp_dev, ctx=ctx)
         return edge_dev, dp_dev, (B, fh, fw)
 
     def forward(self, x):
