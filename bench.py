@@ -391,13 +391,13 @@ class Workload:
         K, h4, w4, H0, W0 = shapes[b]
         st = e["pin_out"][p].view((max(self.s_tot, 1),), np.float32)
         hi = e["pin_out"][p].view((max(self.h_tot, 1),), np.float32, offset_bytes=max(self.s_tot, 1) * 4)
-        from wsscam.step.make_cam import save_npy_object  # np.load-compatible, writer threads do not serialise on the GIL
+        from wsscam.step.make_cam import save_npy_array, save_npy_object  # np.load-compatible; one C call per file, no GIL
 
         save_npy_object(os.path.join(e["dir"], "img%03d.npy" % b),
                 {"keys": self.keys[b].astype(np.int64), "cam": st[s_off[b]:s_off[b] + K * h4 * w4].reshape(K, h4, w4),
                  "high_res": hi[h_off[b]:h_off[b] + K * H0 * W0].reshape(K, H0, W0)})  # make_cam.py:80-82
         lab = e["pin_lab"][p].view((self.B, S, S), np.int32)[b]
-        np.save(os.path.join(e["dir"], "img%03d_crf.npy" % b), lab.astype(np.uint8))
+        save_npy_array(os.path.join(e["dir"], "img%03d_crf.npy" % b), lab.astype(np.uint8))
 
     def _e2e_finish(self, p, s_off, h_off, shapes):
         """Finisher thread: sleeps until the outputs of the step that used parity p are in page-locked memory (its own stream
@@ -438,6 +438,9 @@ class Workload:
         self.ctx.wait_for(e["io"])       # batch i is on the device
         self._e2e_feed(p ^ 1)            # batch i + 1 follows while step i computes
         x_keep, self.x_dev = self.x_dev, e["x"][p]
+        if e["u8"]:
+            self._lib.msf_input_u8(self.ctx, e["u8d"][p], [im.shape[:2] for im in self.native], self.u8_offs[:-1], S,
+                                   (104.0, 117.0, 123.0), (255.0, 255.0, 255.0), e["x"][p], pre_div255=False, pair=True)
         self.run_cnn()
         self.x_dev = x_keep
         crf = self.crf_create()
@@ -470,10 +473,12 @@ class Workload:
         e["stage"][q] = None
         io = e["io"]
         io.wait_for(self.ctx)  # the conv stack that read buffer q (two steps ago) has been enqueued before this point
-        if e["u8"]:  # decoded images in: the dataset transform (resize, normalise, flip pair) runs on the device
+        if e["u8"]:
+            # decoded images in: only the copy runs on the input stream; the dataset transform (resize, normalise, flip pair:
+            # a 45 us kernel) is the first launch of the step's conv stream (step_e2e).  On the input stream it had to find
+            # free compute units between the conv stack's workgroups, and the host's wait for "the staging buffer is free
+            # again" waited for it: the u8 leg, which moves 6x fewer bytes, was the slower one
             io.h2d_async(e["u8d"][q], e["pin_u8"][q], int(self.u8_offs[-1]))
-            self._lib.msf_input_u8(io, e["u8d"][q], [im.shape[:2] for im in self.native], self.u8_offs[:-1], S,
-                                   (104.0, 117.0, 123.0), (255.0, 255.0, 255.0), e["x"][q], pre_div255=False, pair=True)
         else:
             io.h2d_async(e["x"][q], e["pin_in"][q], self.x_host.nbytes)
 

@@ -142,6 +142,11 @@ int wsc_memset(wsc_ctx *ctx, void *dst_dev, int value, size_t bytes);
  * asynchronous on the ctx stream; the host buffer must stay untouched until a later wsc_sync(ctx) returns. */
 int wsc_host_alloc(wsc_ctx *ctx, size_t bytes, void **host_out);
 int wsc_host_free(wsc_ctx *ctx, void *host);
+/* Host I/O helper of the writer threads (03b_irn/step/make_cam.py:80-88 np.save per image): creates / truncates `path` and
+ * writes the n byte segments one after the other (open + writev + close; no GPU involved, any thread).  A caller that holds
+ * the bytes of an .npy container as [header | metadata | array | metadata | array ...] writes the arrays straight from where
+ * they are (e.g. the page-locked staging buffer of a D2H copy) without the interpreter lock: wsscam.step.make_cam.save_npy_object. */
+int wsc_host_write_segments(const char *path, int n, const void *const *ptrs, const size_t *sizes);
 int wsc_memcpy_h2d_async(wsc_ctx *ctx, void *dst_dev, const void *src_pinned_host, size_t bytes);
 int wsc_memcpy_d2h_async(wsc_ctx *ctx, void *dst_pinned_host, const void *src_dev, size_t bytes);
 

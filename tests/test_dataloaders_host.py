@@ -308,3 +308,24 @@ def test_save_npy_object_loads_like_np_save(tmp_path):
         assert list(got.keys()) == list(ref.keys())
         for k in ref:
             assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), (i, k)
+    # round 6: dicts of one signature share the container's cached metadata pieces, written around the arrays by one C call
+    # (wsc_host_write_segments).  A second dict of the same shapes -- other values, keys that are all zero bytes, a read-only
+    # view like the ones cut out of a page-locked staging buffer -- must give the very bytes of the pickle.dump path.
+    from wsscam.step import make_cam as mc
+
+    for trial in range(3):
+        hr = rng.random((2, 375, 500), dtype=np.float32)
+        hr.flags.writeable = trial != 2
+        d = {"keys": np.array([0, 0] if trial == 1 else [5, 19], np.int64), "cam": rng.random((2, 94, 125), dtype=np.float32),
+             "high_res": hr}
+        pth = tmp_path / ("c%d.npy" % trial)
+        save_npy_object(str(pth), d)
+        assert pth.read_bytes() == mc._npy_object_bytes(d), trial
+        got = np.load(str(pth), allow_pickle=True).item()
+        assert all(np.array_equal(got[k], d[k]) and got[k].dtype == d[k].dtype for k in d)
+    lab = rng.integers(0, 21, (321, 321)).astype(np.uint8)
+    mc.save_npy_array(str(tmp_path / "lab"), lab)
+    np.save(str(tmp_path / "lab_ref.npy"), lab)
+    assert (tmp_path / "lab.npy").read_bytes() == (tmp_path / "lab_ref.npy").read_bytes()
+    sig = (("keys", "<i8", (2,), True), ("cam", "<f4", (2, 94, 125), True), ("high_res", "<f4", (2, 375, 500), True))
+    assert mc._NPY_TEMPLATES.get(sig) is not None  # (the fast path was the one that ran)

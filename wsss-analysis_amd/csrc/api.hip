@@ -1,7 +1,12 @@
 // api.hip -- context, error plumbing, memory helpers and timers of the C ABI (include/wsscam.h).
 #include "common.h"
 
+#include <cerrno>
 #include <cstdarg>
+#include <fcntl.h>
+#include <sys/uio.h>
+#include <unistd.h>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 
@@ -353,6 +358,45 @@ int wsc_host_free(wsc_ctx *ctx, void *host) {
     WSC_HIP(hipStreamSynchronize(ctx->stream));
     WSC_HIP(hipHostFree(host));
     return WSC_OK;
+}
+
+int wsc_host_write_segments(const char *path, int n, const void *const *ptrs, const size_t *sizes) {
+    WSC_CHECK(path && n >= 0 && (n == 0 || (ptrs && sizes)), WSC_ERR_INVALID, "wsc_host_write_segments: null argument");
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) {
+        wsc_set_error("wsc_host_write_segments: cannot open %s: %s", path, strerror(errno));
+        return WSC_ERR_INVALID;
+    }
+    int st = WSC_OK;
+    std::vector<struct iovec> iov;
+    for (int i = 0; i < n; ++i)
+        if (sizes[i] > 0) iov.push_back({const_cast<void *>(ptrs[i]), sizes[i]});
+    size_t at = 0;
+    while (at < iov.size() && st == WSC_OK) {
+        const int cnt = (int)std::min<size_t>(iov.size() - at, 64);
+        ssize_t w = writev(fd, iov.data() + at, cnt);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            wsc_set_error("wsc_host_write_segments: write to %s failed: %s", path, strerror(errno));
+            st = WSC_ERR_INVALID;
+            break;
+        }
+        while (w > 0 && at < iov.size()) { // advance past what was written (short writes leave a partial segment)
+            if ((size_t)w >= iov[at].iov_len) {
+                w -= (ssize_t)iov[at].iov_len;
+                ++at;
+            } else {
+                iov[at].iov_base = (char *)iov[at].iov_base + w;
+                iov[at].iov_len -= (size_t)w;
+                w = 0;
+            }
+        }
+    }
+    if (close(fd) != 0 && st == WSC_OK) {
+        wsc_set_error("wsc_host_write_segments: close of %s failed: %s", path, strerror(errno));
+        st = WSC_ERR_INVALID;
+    }
+    return st;
 }
 
 int wsc_memcpy_h2d_async(wsc_ctx *ctx, void *dst_dev, const void *src_pinned_host, size_t bytes) {

@@ -84,6 +84,7 @@ _SIGNATURES = {
     "wsc_ctx_set_option": (_i, [_vp, _i, _i]),
     "wsc_host_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     "wsc_host_free": (_i, [_vp, _vp]),
+    "wsc_host_write_segments": (_i, [ctypes.c_char_p, _i, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
     "wsc_memcpy_h2d_async": (_i, [_vp, _vp, _vp, _sz]),
     "wsc_memcpy_d2h_async": (_i, [_vp, _vp, _vp, _sz]),
     "wsc_profile_begin": (_i, [_vp]),
@@ -388,6 +389,24 @@ class PinnedBuffer:
             self.free()
         except Exception:
             pass
+
+
+def host_write_segments(path, segments):
+    """wsc_host_write_segments: `segments` = bytes objects / C-contiguous numpy arrays, written to `path` one after the other by
+    one C call (open + writev + close) -- the interpreter lock is released for its whole duration."""
+    n = len(segments)
+    ptrs = (_vp * max(n, 1))()
+    sizes = (_sz * max(n, 1))()
+    keep = []
+    for i, sgm in enumerate(segments):
+        if isinstance(sgm, np.ndarray):
+            assert sgm.flags["C_CONTIGUOUS"]
+            ptrs[i], sizes[i] = sgm.ctypes.data, sgm.nbytes
+        else:
+            sgm = bytes(sgm)
+            keep.append(sgm)  # (the pointer below is the bytes object's own buffer)
+            ptrs[i], sizes[i] = ctypes.cast(ctypes.c_char_p(sgm), _vp).value, len(sgm)
+    check(load().wsc_host_write_segments(os.fsencode(path), n, ptrs, sizes))
 
 
 def make_tensor_descs(state_dict):

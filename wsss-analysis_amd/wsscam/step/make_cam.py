@@ -40,23 +40,118 @@ def _valid_cat(args, pack, score, model):
     return cat
 
 
-def save_npy_object(path, obj):
-    """`np.save(path, obj)` for a Python object (the reference stores a dict of arrays that way, make_cam.py:80-88), written so
-    that writer THREADS scale: same .npy container (0-d object array, `np.load(path, allow_pickle=True).item()` gives the same
-    dict, dtypes and shapes), but the pickle inside uses protocol 5, whose in-band buffers go from the arrays straight to the
-    file -- np.save's protocol 3 first copies every array into a bytes object with the GIL held, which serialised eight
-    writer threads (0.3 ms per image alone, 1.3 ms under contention: 85 thread-ms per 32-image step)."""
+def _npy_object_bytes(obj):
+    """The bytes `np.save(path, obj)`-compatible container of a Python object: .npy header of a 0-d object array + a protocol-5
+    pickle (in-band buffers)."""
+    import io
     import pickle
 
     from numpy.lib import format as npy_format
 
     arr = np.empty((), dtype=object)
     arr[()] = obj
+    bio = io.BytesIO()
+    npy_format.write_array_header_1_0(bio, npy_format.header_data_from_array_1_0(arr))
+    pickle.dump(arr, bio, protocol=5)
+    return bio.getvalue()
+
+
+_NPY_TEMPLATES = {}   # signature of a dict of arrays -> (metadata pieces, patched small arrays) of its .npy container
+_NPY_TEMPLATES_MAX = 8192
+
+
+def _npy_template(obj, sig):
+    """Cuts the container of `obj` (a dict of C-contiguous arrays) into [piece 0 | array 0 | piece 1 | array 1 | ... | piece n]:
+    the pieces (headers, pickle opcodes, frame lengths, dtype / shape tuples) depend on the dtypes, shapes and flags only, so
+    the next dict of the same signature is written as the cached pieces around ITS arrays.  None when the cut cannot be
+    verified (the caller then writes the plain pickle)."""
+    import struct
+
+    full = _npy_object_bytes(obj)
+    pieces, at = [], 0
+    for v in obj.values():
+        raw = v.tobytes()
+        n = len(raw)
+        pos = at
+        while True:
+            pos = full.find(raw, pos) if n else -1
+            if pos < 0:
+                return None
+            # an in-band buffer is preceded by its opcode and length: BYTEARRAY8 / BINBYTES8 (8-byte length), BINBYTES (4),
+            # SHORT_BINBYTES (1) -- anything else is a chance match inside the metadata
+            if (full[pos - 9:pos - 8] in (b"\x96", b"\x8e") and full[pos - 8:pos] == struct.pack("<Q", n)) or \
+                    (full[pos - 5:pos - 4] == b"B" and full[pos - 4:pos] == struct.pack("<I", n)) or \
+                    (full[pos - 2:pos - 1] == b"C" and full[pos - 1:pos] == struct.pack("<B", n & 0xff) and n < 256):
+                break
+            pos += 1
+        pieces.append(full[at:pos])
+        at = pos + n
+    pieces.append(full[at:])
+    # verification: the pieces around the arrays reproduce the container
+    chk = b"".join(p + v.tobytes() for p, v in zip(pieces, obj.values())) + pieces[-1]
+    return pieces if chk == full else None
+
+
+def save_npy_object(path, obj):
+    """`np.save(path, obj)` for a Python object (the reference stores a dict of arrays that way, make_cam.py:80-88), written so
+    that writer THREADS scale: same .npy container (0-d object array, `np.load(path, allow_pickle=True).item()` gives the same
+    dict, dtypes and shapes) with a protocol-5 pickle inside, whose in-band buffers are the arrays' own bytes.
+    Round 4: pickle.dump straight to the file (np.save's protocol 3 copies every array into a bytes object with the interpreter
+    lock held: 0.3 ms per image alone, 1.3 ms under contention).  Round 6: for a dict of non-empty C-contiguous arrays the
+    metadata pieces of the container are cached per (keys, dtypes, shapes) signature and ONE C call (wsc_host_write_segments:
+    open + writev + close, no interpreter lock) writes them around the arrays where they lie -- e.g. in the page-locked staging
+    buffer of the D2H copy.  64 files per 32-image step held the lock for most of a step before (profiles/README.md, round 6).
+    Anything else (other objects, empty arrays, a cut that does not verify) takes the pickle.dump path: same bytes."""
     if not str(path).endswith(".npy"):
         path = str(path) + ".npy"  # np.save appends the extension
+    if isinstance(obj, dict) and obj and all(isinstance(v, np.ndarray) and v.flags["C_CONTIGUOUS"] and v.size > 0 and
+                                             v.dtype.kind in "fiub" for v in obj.values()):
+        sig = tuple((k, v.dtype.str, v.shape, bool(v.flags["WRITEABLE"])) for k, v in obj.items())
+        pieces = _NPY_TEMPLATES.get(sig, False)
+        if pieces is False:
+            pieces = _npy_template(obj, sig)
+            if len(_NPY_TEMPLATES) < _NPY_TEMPLATES_MAX:
+                _NPY_TEMPLATES[sig] = pieces
+        if pieces is not None:
+            segs = []
+            for pc, v in zip(pieces, obj.values()):
+                segs.append(pc)
+                segs.append(v)
+            segs.append(pieces[-1])
+            _lib.host_write_segments(path, segs)
+            return
     with open(path, "wb") as fp:
+        import pickle
+
+        from numpy.lib import format as npy_format
+
+        arr = np.empty((), dtype=object)
+        arr[()] = obj
         npy_format.write_array_header_1_0(fp, npy_format.header_data_from_array_1_0(arr))
         pickle.dump(arr, fp, protocol=5)
+
+
+_NPY_HEADERS = {}
+
+
+def save_npy_array(path, arr):
+    """`np.save(path, arr)` of a plain C-contiguous array as one C call (cached .npy header + the array's bytes)."""
+    import io
+
+    from numpy.lib import format as npy_format
+
+    arr = np.ascontiguousarray(arr)
+    if not str(path).endswith(".npy"):
+        path = str(path) + ".npy"
+    key = (arr.dtype.str, arr.shape)
+    hdr = _NPY_HEADERS.get(key)
+    if hdr is None:
+        bio = io.BytesIO()
+        npy_format.write_array_header_1_0(bio, npy_format.header_data_from_array_1_0(arr))
+        hdr = bio.getvalue()
+        if len(_NPY_HEADERS) < _NPY_TEMPLATES_MAX:
+            _NPY_HEADERS[key] = hdr
+    _lib.host_write_segments(path, [hdr, arr])
 
 
 def _save(args, name, keys, strided, highres):
