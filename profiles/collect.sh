@@ -2,7 +2,7 @@
 # Collects every round artifact under profiles/ in ONE gpurun call:
 #   gpurun --timeout 2400 -- 'bash profiles/collect.sh r04'
 # Outputs land in gpurun_out/<tag>_* (merged back by gpurun); copy the ones to keep into profiles/.
-tag=${1:-r05}
+tag=${1:-r06}
 out=gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -10,7 +10,10 @@ export WSC_PROFILE_ROUND=$tag
 timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/${tag}_pytest_gpu.txt
 timeout 300 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 python bench.py --no-cpu-baseline --no-pipeline --quick > $out/${tag}_bench_nopipeline.json 2>> $out/${tag}_bench.err
-timeout 300 python profiles/bench_irn.py > $out/${tag}_bench_irn.json 2>> $out/${tag}_bench.err
+timeout 300 python profiles/bench_irn.py > $out/${tag}_bench_irn_stages.json 2>> $out/${tag}_bench.err
+# round 6: the same step with round 5's two-launch mean-field iteration (gauss_msg_kernel writes E, the update reads it)
+WSC_BENCH_OPT=9=0 timeout 300 python bench.py --no-cpu-baseline --quick --steps 30 --warmup 4 > $out/${tag}_bench_two_launch.json 2>> $out/${tag}_bench.err
+timeout 300 python bench.py --no-cpu-baseline --quick --steps 30 --warmup 4 > $out/${tag}_bench_msg_in_update.json 2>> $out/${tag}_bench.err
 timeout 400 python bench.py --workload hsn --arch vgg16 --batch 16 --steps 10 --warmup 2 > $out/${tag}_bench_hsn.json 2>> $out/${tag}_bench.err
 timeout 600 python bench.py --no-cpu-baseline --quick --seconds 30 > $out/${tag}_bench_30s.json 2>> $out/${tag}_bench.err
 rm -rf $out/prof_stats $out/pmc_f $out/pmc_w
@@ -44,4 +47,7 @@ rm -rf $out/prof_pipe
 timeout 300 rocprofv3 --kernel-trace -d $out/prof_pipe -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --quick > $out/${tag}_prof_pipe.log 2>&1
 { echo "# rocprofv3 --kernel-trace -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --quick  (the PIPELINED step: three streams)"; python profiles/busy_timeline.py $out/prof_pipe/*/*_results.db; } > $out/${tag}_busy_timeline.txt 2>&1
 python profiles/make_traffic_json.py $out/pmc_f/*/*_results.db $out/pmc_w/*/*_results.db > $out/${tag}_hbm_traffic.json 2>> $out/${tag}_bench.err
+# round 6: configs 4 and 5 through their drivers under the kernel trace (busy timelines + per-kernel stats), VGG16 counter table
+bash profiles/r06_cfg54_prof.sh > $out/${tag}_cfg54_prof.log 2>&1
+bash profiles/r06_conv_probe.sh > $out/${tag}_conv_probe.log 2>&1
 ls -la $out | grep ${tag}_

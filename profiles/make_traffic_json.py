@@ -17,7 +17,9 @@ CLASSES = {  # bench.py kernel-class label -> (kernel-name substrings, substring
                                   ("combine4_kernel", "combine4_balanced_kernel", "blur_lds_kernel", "blur4_kernel", "blur3_tile_kernel")),
     "gauss_msg_kernel": (("gauss_msg_kernel",), "gauss_msg_kernel"),
     "blur3_tile_kernel": (("blur3_tile_kernel",), "blur3_tile_kernel"),
-    "update_splat_kernel<true, true, true, true>": (("update_splat_kernel<true, true, true, true>",), "update_splat_kernel<true, true, true, true>"),
+    # the splatting update with messages: round 6's message-in-update form (template argument FG = 4 / 6) and the two-launch form (0)
+    "update_splat_kernel<true, true, true, true, 4>": (("update_splat_kernel<true, true, true, true, 4>",), "update_splat_kernel<true, true, true, true, 4>"),
+    "update_splat_kernel<true, true, true, true, 0>": (("update_splat_kernel<true, true, true, true, 0>",), "update_splat_kernel<true, true, true, true, 0>"),
     # the conv stack: every instantiation together (bench.py's top-level roofline kernel), then per tile
     # shape -- the labels are bench.py's profile classes -- and the fused stem + max-pool kernel
     "conv_igemm_kernel": (("conv_igemm_kernel", "cam_head_kernel"), ("conv_igemm_kernel", "cam_head_kernel")),

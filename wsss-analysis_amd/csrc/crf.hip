@@ -1236,102 +1236,10 @@ __global__ __launch_bounds__(256) void combine4_balanced_kernel(const f32x4_t *_
     }
 }
 
-// Round 6: the same rows from the same partials with CHUNKS of consecutive partial rows per lane group.  In the kernel above
-// the lane groups of a wave hold CONSECUTIVE partial rows -- ~5 of which belong to one lattice row -- and add them into that
-// row's LDS accumulators at once: same-address 64-bit atomics, serialised by the LDS (SQ_LDS_BANK_CONFLICT 0.75 of its
-// LDS-active cycles, r05_pmc_crf.txt).  Here a lane group owns CB_CHUNK consecutive partial rows: it sums the partials of a
-// lattice row in registers (64-bit fixed point, as everywhere: order-independent, identical bits), stores a row whose
-// partials all lie inside its chunk directly, and only a row that straddles two chunks goes through the LDS accumulators --
-// a third of the atomics, and neighbouring lane groups now hold different rows.
-#ifndef WSC_CB_CHUNK
-#define WSC_CB_CHUNK 8
-#endif
-constexpr int CB_CHUNK = WSC_CB_CHUNK;
-__global__ __launch_bounds__(256) void combine4_chunk_kernel(const f32x4_t *__restrict__ part, const int32_t *__restrict__ row_slot_start,
-                                                             const uint32_t *__restrict__ part_row, int LP, int rows,
-                                                             f32x4_t *__restrict__ val) {
-    __shared__ int rss_l[CB_ROWS + 1];
-    __shared__ unsigned long long acc[CB_ROWS * 32];
-    const int r0 = blockIdx.x * CB_ROWS;
-    const int nr = min(CB_ROWS, rows - r0);
-    const int P0 = row_slot_start[r0], P1 = row_slot_start[r0 + nr]; // (uniform: scalar loads)
-    for (int i = threadIdx.x; i <= nr; i += 256) rss_l[i] = row_slot_start[r0 + i];
-    for (int i = threadIdx.x; i < CB_ROWS * 32; i += 256) acc[i] = 0ull;
-    const int gpb = 256 / LP;
-    const int tr = threadIdx.x / LP, l = threadIdx.x - tr * LP;
-    constexpr int U = CB_CHUNK;
-    f32x4_t v[U];
-    uint32_t pr[U];
-    auto fetch = [&](int p) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int pp = p + u;
-            v[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            pr[u] = 0u;
-            if (tr < gpb && pp < P1) {
-                v[u] = part[(unsigned)pp * (unsigned)LP + l];
-                pr[u] = part_row[pp];
-            }
-        }
-    };
-    fetch(P0 + tr * U);
-    __syncthreads();
-    if (tr < gpb) {
-        for (int p = P0 + tr * U; p < P1; p += U * gpb) {
-            if (p != P0 + tr * U) fetch(p);
-            const int pe = min(p + U, P1); // the chunk is [p, pe)
-            long long a4[4] = {0, 0, 0, 0};
-            int cur = -1;
-            auto flush = [&]() {
-                if (cur < 0) return;
-                // all partials of the row inside this chunk: the row is final
-                if (rss_l[cur] >= p && rss_l[cur + 1] <= pe) {
-                    const f32x4_t o = {(float)a4[0] * PFIX_INV, (float)a4[1] * PFIX_INV, (float)a4[2] * PFIX_INV, (float)a4[3] * PFIX_INV};
-                    val[(unsigned)(r0 + cur) * (unsigned)LP + l] = o;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) atomicAdd(&acc[cur * 32 + 4 * l + k], (unsigned long long)a4[k]);
-                }
-            };
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (p + u < pe) {
-                    const int lo = (int)(pr[u] & 0xffffffu) - r0;
-                    if ((pr[u] >> 24) == 1u) { // the row's only partial: passed through unconverted, as everywhere
-                        flush();
-                        cur = -1;
-                        val[(unsigned)(r0 + lo) * (unsigned)LP + l] = v[u];
-                    } else {
-                        if (lo != cur) {
-                            flush();
-                            cur = lo;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) a4[k] = 0;
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) a4[k] += (long long)__float2int_rn(v[u][k] * PFIX_SCALE);
-                    }
-                }
-            }
-            flush();
-        }
-    }
-    __syncthreads();
-    if (tr < gpb) {
-        for (int row = tr; row < nr; row += gpb) {
-            const int b = rss_l[row], e = rss_l[row + 1], n = e - b;
-            if (n == 1) continue; // written above
-            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-            if (n > 1) {
-                // (chunks are aligned to P0 in steps of U: a row inside one chunk was stored by its lane group)
-                if ((b - P0) / U == (e - 1 - P0) / U) continue;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = (float)(long long)acc[row * 32 + 4 * l + k] * PFIX_INV;
-            }
-            val[(unsigned)(r0 + row) * (unsigned)LP + l] = o;
-        }
-    }
-}
+// (Round 6, measured and removed: CHUNKS of 4 / 8 / 16 consecutive partial rows per lane group, summed in registers, a row whose
+// partials lie inside one chunk stored directly -- a third of the LDS atomics and no same-address conflicts between
+// neighbouring lane groups: 126.8 / 130.7 / 138.9 us against 127.0 us for this kernel + the on-chip blur on the A/B batch
+// (profiles/README.md).  The same-address atomics that SQ_LDS_BANK_CONFLICT counts here are not what bounds the kernel.)
 
 // One blur pass along one lattice axis: out[row] = in[row] + 0.5*(in[n1] + in[n2]).
 // Scalar form for the normalisation pass (one value per row).
@@ -2305,10 +2213,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
             WSC_TL(a, 2); // descriptors arrived, first partials requested
             if (tid < stride) reinterpret_cast<uint4 *>(lnb)[tid] = tn0;
             for (int v = tid + GM_THREADS; v < stride; v += GM_THREADS) reinterpret_cast<uint4 *>(lnb)[v] = tn[v];
+            // further partials of the rows that have them (tile-border vertices: up to four tiles touch one): the second, third
+            // and fourth partial of every item are requested TOGETHER (round 6: one memory round trip instead of one per
+            // partial -- the phase timeline showed 2.4 us here) and added in index order as before: first + second + ...
             int maxc = 0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) maxc = max(maxc, ps[it].y);
-            for (int c = 1; c < maxc; ++c) {
+            constexpr int UN = NIT <= 4 ? 3 : 2;
+            if (maxc > 1) {
+                f32x4_t more[UN][NIT];
+#pragma unroll
+                for (int c = 1; c <= UN; ++c)
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int i = tid + it * GM_THREADS;
+                        const unsigned v = ((unsigned)i * lp_magic) >> 16, ll = (unsigned)i - v * (unsigned)LP;
+                        more[c - 1][it] = zero;
+                        if (c < ps[it].y) more[c - 1][it] = partg[(unsigned)(ps[it].x + c) * (unsigned)LP + ll];
+                    }
+#pragma unroll
+                for (int c = 1; c <= UN; ++c)
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it)
+                        if (c < ps[it].y) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) val[it][q] += more[c - 1][it][q];
+                        }
+            }
+            for (int c = UN + 1; c < maxc; ++c) {
                 f32x4_t more[NIT];
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
@@ -2330,6 +2262,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
                 if (i < nitems_all) gl[i] = val[it];
             }
         }
+        // every load of this wave so far has been consumed -- the partial rows were requested after the LDS-DMA pieces and
+        // loads return in order, so the wave's pieces (U rows, records) have landed too; the barrier below publishes them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WSC_TL(a, 3); // all partial rows summed into LDS
         // the pixels' Gaussian records (L2: one table for all images) travel under the blur passes
         uint4 gpx[NPI];
@@ -2344,8 +2279,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
             }
         }
         __syncthreads();
+        // (Round 6, measured and removed: the six bilateral rows of the wave's first trip requested here, under the blur passes:
+        // trips 3.54 -> 2.89 us, blur + slice 4.30 -> 4.75 us, Gaussian splat 2.59 -> 2.84 us -- the block's lifetime did not
+        // move (18.4 -> 18.6 us).  What one phase gives up another takes: the kernel is bound by throughput, not by a latency.)
 #pragma unroll
         for (int axis = 0; axis < 3; ++axis) {
+            // (Round 6, measured and removed: an item's own value carried through the passes in registers instead of re-read
+            // from LDS -- a quarter of the blur's LDS reads less, 118 registers, no spills: 463.6 -> 505.7 us per launch, the
+            // blur + slice phase 4.33 -> 5.00 us.)
             const int nitems = (axis == 0 ? cnt.z : (axis == 1 ? cnt.y : cnt.x)) * LP;
             f32x4_t o[NIT];
 #pragma unroll
@@ -2366,7 +2307,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
                 const int i = tid + it * GM_THREADS;
                 if (i < nitems) gl[i] = o[it];
             }
-            if (axis == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the wave's LDS-DMA pieces (U rows, records) have landed
             __syncthreads();
         }
         // slice into the staged U rows: E = -U, then the three FMAs (weights (bary * norm) * (compat * alpha)), in place
@@ -2450,64 +2390,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void u
             if (ok && l == 0) a.argmax[pix0 + p] = bi;
         }
     };
-#ifndef WSC_UPD_DEEP
-#define WSC_UPD_DEEP 1 // 0: rows requested one trip before they are folded (rounds 2-5)
-#endif
-    if constexpr (DMA && SLICE && GF && WSC_UPD_DEEP) {
-        // Round 6: the six bilateral rows of a trip are requested TWO trips before they are folded (two sets of row registers,
-        // the loop unrolled by two so that both are static).  The records and E rows of every trip are in LDS (DMA), so a
-        // request needs nothing from memory; with one trip of lead the L2 gather (~1 us under load) was exposed in every
-        // trip -- the phase timeline (profiles/upd_timeline.py) shows 1.25 us per trip against ~0.3 us of issue work.
-        // Same FMAs in the same order per pixel: bit-identical.
-        // (a request reads only the six row ids from the LDS record; the fold re-reads the trip's E row and its weights from
-        // LDS -- both stay valid until the trip's own Q overwrites the E row / the splat tables replace the records -- so
-        // nothing but the 2 x 6 row registers lives across a trip: 128 registers without spills)
-        f32x4_t rA[6], rB[6];
-        auto req_rows = [&](int t0, f32x4_t(&r)[6]) {
-            const char *q = lrec + tile_idx(t0) * (unsigned)REC_LDS_BYTES;
-            uint2 w[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) w[i] = *reinterpret_cast<const uint2 *>(q + 8 * i);
-            const unsigned id[6] = {w[0].x, w[0].y, w[1].x, w[1].y, w[2].x, w[2].y};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) r[i] = ld_off<f32x4_t>(vb_b, __umul24(id[i], LP16) + l16);
-        };
-        auto fold_rows = [&](int t0, const f32x4_t(&r)[6]) {
-            const unsigned ti = tile_idx(t0);
-            const char *q = lrec + ti * (unsigned)REC_LDS_BYTES;
-            const f32x4_t u = stage[ti * (unsigned)LP + (unsigned)l]; // E = -U + Gaussian message
-            uint2 w[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) w[i] = *reinterpret_cast<const uint2 *>(q + 24 + 8 * i);
-            const float wb = cab * __uint_as_float(*reinterpret_cast<const uint32_t *>(q + 48));
-            const float bw[6] = {__uint_as_float(w[0].x) * wb, __uint_as_float(w[0].y) * wb, __uint_as_float(w[1].x) * wb,
-                                 __uint_as_float(w[1].y) * wb, __uint_as_float(w[2].x) * wb, __uint_as_float(w[2].y) * wb};
-            e01 = f32x2_t{u[0], u[1]};
-            e23 = f32x2_t{u[2], u[3]};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const f32x2_t w2 = {bw[i], bw[i]}, lo = {r[i][0], r[i][1]}, hi = {r[i][2], r[i][3]};
-                e01 = __builtin_elementwise_fma(w2, lo, e01);
-                e23 = __builtin_elementwise_fma(w2, hi, e23);
-            }
-        };
-        {
-            f32x4_t r0[6];
-            req_rows(t_first, r0);
-            if (t_first + ppt < np) req_rows(t_first + ppt, rA);
-            fold_rows(t_first, r0);
-        }
-        auto step = [&](int t0, const f32x4_t(&r_nx)[6], f32x4_t(&r_new)[6]) {
-            if (t0 + 2 * ppt < np) req_rows(t0 + 2 * ppt, r_new); // the trip after the next one: two trips to arrive
-            emit(t0);
-            if (t0 + ppt < np) fold_rows(t0 + ppt, r_nx);
-        };
-        for (int t0 = t_first; t0 < np; t0 += 2 * ppt) {
-            step(t0, rA, rB);
-            if (t0 + ppt >= np) break;
-            step(t0 + ppt, rB, rA);
-        }
-    } else {
+    // (Round 6, measured and removed: the six bilateral rows of a trip requested TWO trips before they are folded -- two sets of
+    // row registers, the loop unrolled by two, records and E rows re-read from LDS at fold time: 128 registers, no spills,
+    // identical bits.  The trips of a block got 0.55 us shorter (8.41 -> 7.86 us, profiles/upd_timeline.py) and the wait at the
+    // next barrier as much longer: 302.0 -> 301.1 us per launch.  The trips are not bound by the L2 gather latency.)
+    {
         {
             const f32x4_t u0 = load_u(t_first);
             f32x4_t g3[3], b6[6];
@@ -2657,6 +2544,8 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
         for (int it = 0; it < NIT; ++it) maxc = max(maxc, ps[it].y);
         if (WSC_GF_ABL & 2) maxc = 0;
+        // (round 6: requesting the second ... fourth partials of every item together -- what the FG variants of
+        // update_splat_kernel do -- costs this kernel 32 registers and a block per CU: 186 -> 220 us; one partial per step stays)
         for (int c = 1; c < maxc; ++c) {
             f32x4_t more[NIT];
 #pragma unroll
@@ -2892,9 +2781,6 @@ void combine4(wsc_ctx *ctx, hipStream_t st, const LatticeDev &L, const float *pa
     if (L.sorted_dest)
         hipLaunchKernelGGL(combine4_kernel<true>, dim3(grid_rep((long long)L.rows * L.rep, 256 / LP, L.rep)), dim3(256), 0,
                            st, (const f32x4_t *)part, L.row_slot_start, LP, L.rows, L.n_slots, L.rep, (f32x4_t *)val);
-    else if (L.rep == 1 && L.part_row && CB_CHUNK > 0 && !(be && atoi(be) != 2))
-        hipLaunchKernelGGL(combine4_chunk_kernel, dim3((unsigned)((L.rows + CB_ROWS - 1) / CB_ROWS)), dim3(256), 0, st,
-                           (const f32x4_t *)part, L.row_slot_start, (const uint32_t *)L.part_row, LP, L.rows, (f32x4_t *)val);
     else if (L.rep == 1 && !(be && atoi(be) == 0))
         hipLaunchKernelGGL(combine4_balanced_kernel, dim3((unsigned)((L.rows + CB_ROWS - 1) / CB_ROWS)), dim3(256), 0, st,
                            (const f32x4_t *)part, L.row_slot_start, (const uint32_t *)L.part_row, LP, L.rows, (f32x4_t *)val);
