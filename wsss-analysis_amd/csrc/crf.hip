@@ -897,6 +897,8 @@ __global__ __launch_bounds__(256) void tile_slots_kernel(const int32_t *__restri
     const int ne = tb.cw * tb.ch * dp1;
     const long long ebase = ((long long)b * N + tb.ebase) * dp1;
     const unsigned cw_magic = tile_div_magic(tb.cw);
+    // (round 6, measured and rejected: a thread's <= 6 entries requested together, then their rows together -- 155 -> 175 us: the
+    // registers cost a block per CU; slice_norm_tile_kernel and slot_ones_kernel did gain from the same change: 160 -> 136, 36 -> 28 us)
     for (int i = threadIdx.x; i < ne; i += 256) {
         const int ss = sslot_in[ebase + i];
         const int row = slot2row[(long long)b * cap + (ss & 0x0fffffff)];
@@ -1100,7 +1102,20 @@ __global__ __launch_bounds__(256) void slot_ones_kernel(const int32_t *__restric
     // instead of <= 32 dependent trips to L2 (a tile has ~120 slots: half the block's threads each own a chain)
     __shared__ float w[TILE_PIX * 6];
     const int ne = tb.cw * tb.ch * dp1;
-    for (int i = threadIdx.x; i < ne; i += 256) w[i] = tent_w[ebase + i];
+    {
+        constexpr int EN = (TILE_PIX * 6 + 255) / 256;
+        float ew[EN];
+#pragma unroll
+        for (int k = 0; k < EN; ++k) {
+            const int i = (int)threadIdx.x + k * 256;
+            ew[k] = i < ne ? tent_w[ebase + i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < EN; ++k) {
+            const int i = (int)threadIdx.x + k * 256;
+            if (i < ne) w[i] = ew[k];
+        }
+    }
     __syncthreads();
     for (int s = tslot_start[tile] + threadIdx.x; s < tslot_start[tile + 1]; s += 256) {
         const int2 d = slot_desc[s];
@@ -1742,16 +1757,28 @@ __global__ __launch_bounds__(256) void slice_norm_tile_kernel(const int32_t *__r
     const int ty = (int)(((unsigned)t * cw_magic) >> 16), tx = t - ty * tb.cw;
     const long long p = (long long)b * N + (long long)(tb.y0 + ty) * tg.W + tb.x0 + tx;
     if (t < np) {
-        float acc = 0.f;
-        for (int r = 0; r < dp1; ++r) {
-            const int o = offset[p * dp1 + r];
-            const float w = bary[p * dp1 + r];
-            acc += w * val[o] * alpha;
-            if (rec) {
-                lrec[t * 13 + r] = (uint32_t)o;
-                lrec[t * 13 + 6 + r] = __float_as_uint(w);
-            }
+        // (round 6: the d+1 row ids and weights first, then the d+1 row values -- two memory round trips instead of a chain of
+        // 2 (d+1) dependent ones per pixel; same products, added in the same order)
+        constexpr int DMAX = 6;
+        int o[DMAX];
+        float w[DMAX], v[DMAX];
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) {
+            o[r] = r < dp1 ? offset[p * dp1 + r] : 0;
+            w[r] = r < dp1 ? bary[p * dp1 + r] : 0.f;
         }
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) v[r] = r < dp1 ? val[o[r]] : 0.f;
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r)
+            if (r < dp1) {
+                acc += w[r] * v[r] * alpha;
+                if (rec) {
+                    lrec[t * 13 + r] = (uint32_t)o[r];
+                    lrec[t * 13 + 6 + r] = __float_as_uint(w[r]);
+                }
+            }
         const float nv = (float)(1.0 / sqrt((double)acc + 1e-20));
         norm[p] = nv;
         lnorm[t] = nv;
@@ -1767,7 +1794,22 @@ __global__ __launch_bounds__(256) void slice_norm_tile_kernel(const int32_t *__r
     }
     const int ne = np * dp1;
     const long long ebase = ((long long)b * N + tb.ebase) * dp1;
-    for (int i = t; i < ne; i += 256) tent_w[ebase + i] = tent_w[ebase + i] * lnorm[(int)tent_p[ebase + i]];
+    {   // entry weights x norm[pixel]: all of a thread's entries requested before the first is used
+        constexpr int EN = (TILE_PIX * 6 + 255) / 256;
+        float ew[EN];
+        int ep[EN];
+#pragma unroll
+        for (int k = 0; k < EN; ++k) {
+            const int i = t + k * 256;
+            ew[k] = i < ne ? tent_w[ebase + i] : 0.f;
+            ep[k] = i < ne ? (int)tent_p[ebase + i] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < EN; ++k) {
+            const int i = t + k * 256;
+            if (i < ne) tent_w[ebase + i] = ew[k] * lnorm[ep[k]];
+        }
+    }
 }
 
 // everything the update kernel needs to know about a pixel in 80 contiguous bytes: one thread per 16-byte piece
