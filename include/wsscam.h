@@ -85,7 +85,8 @@ typedef enum {
     WSC_OPT_RW_TILED = 5,          /* default -1 (by batch size); 0: flat random-walk step; 1: tiled step */
     WSC_OPT_STEM_POOL_FUSED = 6,   /* default 1; 0: the f16x3 ResNet stem as conv_igemm + max-pool launches instead of stem_pool_kernel */
     WSC_OPT_CONV_WINDOW = 7,       /* default 1; 0: per-tap A tiles instead of the LDS input window of the f16x3 3x3 / stride 1 layers (same bits) */
-    WSC_OPT_CAM_HEAD_STREAM = 8,   /* default 1; 0: the 1x1 CAM / Grad-CAM head through the tiled conv kernel instead of cam_head_kernel */
+    WSC_OPT_CAM_HEAD_STREAM = 8,   /* default 1; 0: the 1x1 CAM / Grad-CAM head through the tiled conv kernel instead of cam_head_kernel
+                                      (the one selector whose two paths are equal to fp32 round-off, not bit-identical: K is summed in four quarters) */
     WSC_OPT_CRF_MSG_IN_UPDATE = 9, /* default 1; 0: gauss_msg_kernel + update_splat_kernel as two launches with E = -U + Gaussian message in HBM between
                                       them, instead of the message formed inside the update kernel (same bits) */
     WSC_OPT_COUNT = 10

@@ -105,11 +105,19 @@ __global__ __launch_bounds__(256, 2) void cam_head_kernel(HeadArgs p) {
 
 } // namespace
 
-// x / x_lo: IEEE-half planes [M][K] (x_lo null: one plane, f16 mode); w: conv_igemm packing with CoutPad >= 32 rows of Kw elements.
-// Returns WSC_ERR_INVALID for shapes the streaming form does not take (the caller keeps the tiled kernel for those).
-int launch_cam_head(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int M, int K, const bf16_t *w, int Kw, const float *s1,
-                    const float *b1, int C, int relu, float *y) {
+// x / x_lo: IEEE-half planes [M][K] (x_lo null: one plane, f16 mode); w: conv_igemm packing with CoutPad >= 32 rows of Kw elements
+// (x_lo given: the f16x3 interleaving, per 32-channel chunk [32 hi | 32 lo], Kw = 2 K; else Kw = K).
+// Returns WSC_ERR_INVALID for anything the streaming form does not take (the caller keeps the tiled kernel for those): the kernel
+// reads weight rows 0 .. 31 unconditionally, indexes the packed rows with (k >> 5) * 64, and moves 16-byte pieces of both planes
+// through one per-lane offset -- all of that is checked HERE, not left to the caller.
+int launch_cam_head(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int M, int K, const bf16_t *w, int Kw, int CoutPad,
+                    const float *s1, const float *b1, int C, int relu, float *y) {
     WSC_CHECK(M > 0 && K > 0 && K % 256 == 0 && C > 0 && C <= 32, WSC_ERR_INVALID, "cam head: M=%d K=%d C=%d (K in multiples of 256)", M, K, C);
+    WSC_CHECK(CoutPad >= 32 && Kw == K * (x_lo ? 2 : 1), WSC_ERR_INVALID, "cam head: CoutPad=%d Kw=%d for K=%d (%s packing)", CoutPad, Kw, K,
+              x_lo ? "f16x3" : "f16");
+    const auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    WSC_CHECK(x && w && y && s1 && b1 && al16(x) && al16(w) && (x_lo == nullptr || (al16(x_lo) && ((x_lo - x) & 7) == 0)), WSC_ERR_INVALID,
+              "cam head: operands must be 16-byte aligned (x %p, x_lo %p, w %p)", (const void *)x, (const void *)x_lo, (const void *)w);
     HeadArgs a;
     a.x = x; a.x_lo = x_lo; a.w = w; a.s1 = s1; a.b1 = b1; a.y = y;
     a.M = M; a.K = K; a.C = C; a.Kw = Kw; a.relu = relu;

@@ -146,7 +146,9 @@ struct wsc_ctx {
     PinSlot pin_ring[PIN_SLOTS];
     int pin_next = 0;
     // path selectors (wsc_ctx_set_option): every one picks between two paths that both exist for some inputs and give the
-    // same bits -- the tests hold them to that.  Defaults: wsc_option in include/wsscam.h.
+    // same bits -- the tests hold them to that -- with ONE exception: WSC_OPT_CAM_HEAD_STREAM.  cam_head_kernel sums K in four
+    // per-wave quarters, a different fp32 summation order from the tiled kernel: equal to fp32 round-off (test bound 2e-6
+    // relative), not bit-identical.  Defaults: wsc_option in include/wsscam.h.
     int opt[WSC_OPT_COUNT] = {1, 1, 1, 0, 0, -1, 1, 1, 1, 1};
     void *pinned = nullptr; // (legacy single buffer: unused)
     size_t pinned_bytes = 0;
@@ -236,8 +238,8 @@ struct ConvLaunch {
 };
 int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p);
 // cam_head.hip: the 1x1 head with <= 32 output channels as a streaming GEMM (IEEE-half planes, fp32 [M][C] output)
-int launch_cam_head(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int M, int K, const bf16_t *w, int Kw, const float *s1,
-                    const float *b1, int C, int relu, float *y);
+int launch_cam_head(wsc_ctx *ctx, const bf16_t *x, const bf16_t *x_lo, int M, int K, const bf16_t *w, int Kw, int CoutPad,
+                    const float *s1, const float *b1, int C, int relu, float *y);
 
 // ---- misc kernels ---------------------------------------------------------------------
 int launch_nchw_to_nhwc4(wsc_ctx *ctx, const float *x, int N, int H, int W, bf16_t *y, bf16_t *y_lo, int fmt);

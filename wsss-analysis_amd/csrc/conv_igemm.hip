@@ -1371,7 +1371,11 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
         // tiles, two blocks per CU instead of three): measured 129.2 -> 138.4 us, rejected; they take the window up to 320 positions too)
         // (window source offsets are 32-bit counts of 16-byte units, the lo plane's distance included)
         const long long lo_d = a.lo_delta < 0 ? -a.lo_delta : a.lo_delta;
-        if (need <= 320 && last_pos < (1ll << 31) && (long long)p.N * p.H * p.W * p.Cin + lo_d < (1ll << 33) && (a.lo_delta & 7) == 0) {
+        // (the window's per-piece source offsets are non-negative 32-bit counts of 16-byte units measured from x: a lo plane that
+        // lies BELOW x -- two separate allocations in the wrong order -- keeps the per-tap tiles instead of relying on the
+        // arithmetic shift of a negative offset: ADVICE r5)
+        if (need <= 320 && last_pos < (1ll << 31) && a.lo_delta >= 0 && (long long)p.N * p.H * p.W * p.Cin + lo_d < (1ll << 33) &&
+            (a.lo_delta & 7) == 0) {
             a.win_Wp = Wp; a.win_HpWp = HpWp; a.win_N = p.N;
             fastdiv((unsigned)HpWp, a.div_hpwp_mul, a.div_hpwp_s1, a.div_hpwp_s2);
             fastdiv((unsigned)Wp, a.div_wp_mul, a.div_wp_s1, a.div_wp_s2);

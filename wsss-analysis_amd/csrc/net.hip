@@ -871,9 +871,12 @@ int wsc_net_cam_size_hw(const wsc_net *net, int H, int W, int *h_out, int *w_out
 static int run_head(wsc_ctx *ctx, const wsc_net *net, const ConvLaunch &L) {
     // (K % 256: each wave's quarter of K is whole trips of four 16-channel slices)
     if (L.fmt == 1 && L.split != 1 && L.Cout <= 32 && L.CoutPad >= 32 && L.Cin % 256 == 0 && L.y_f32 != nullptr &&
-        ctx->opt[WSC_OPT_CAM_HEAD_STREAM] != 0)
-        return launch_cam_head(ctx, L.x, L.split == 2 ? L.x_lo : nullptr, L.N * L.Ho * L.Wo, L.Cin, L.w, L.Cin * (L.split == 2 ? 2 : 1),
-                               L.s1, L.b1, L.Cout, L.relu, L.y_f32);
+        ctx->opt[WSC_OPT_CAM_HEAD_STREAM] != 0) {
+        // (the streaming form checks packing and alignment itself; anything it does not take goes to the tiled kernel)
+        const int st = launch_cam_head(ctx, L.x, L.split == 2 ? L.x_lo : nullptr, L.N * L.Ho * L.Wo, L.Cin, L.w,
+                                       L.Cin * (L.split == 2 ? 2 : 1), L.CoutPad, L.s1, L.b1, L.Cout, L.relu, L.y_f32);
+        if (st != WSC_ERR_INVALID) return st;
+    }
     (void)net;
     return conv_igemm_launch(ctx, L);
 }

@@ -287,7 +287,8 @@ class Context:
         check(self._lib.wsc_memcpy_d2h_async(self.h, pinned.ptr + dst_offset, _ptr(src_dev) + src_offset, int(nbytes)))
 
     def set_option(self, option, value):
-        """A path selector of this context (OPT_*): forces a fallback path that gives the same bits (testing / debugging)."""
+        """A path selector of this context (OPT_*): forces a fallback path that gives the same bits (testing / debugging) --
+        except OPT_CAM_HEAD_STREAM, whose two paths sum K in different orders and agree to fp32 round-off (2e-6 relative) only."""
         check(self._lib.wsc_ctx_set_option(self.h, int(option), int(value)))
         self._options[int(option)] = int(value)
 

@@ -184,7 +184,7 @@ def run_batches_on_lanes(n_batches, ctxs, one_batch):
 
 
 def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size, is_verbose=False, all_classes=None, stats=None,
-                n_lanes=2):
+                n_lanes=3):
     """demo.py:271-380 for one ADP model: per batch scores >= thresholds -> HSN Grad-CAM at (size, size) -> per
     HTT type {morph, func}: scatter into the valid-class stack, modify_by_htt (background / other channels),
     get_cs_gradcam, dense CRF with that type's configuration.  `images` are uint8 RGB (any size; resized like
