@@ -47,7 +47,11 @@ def run():
     ctx = model.ctx
     rgb, U, _ = helpers.synth_crf_case(np.random.default_rng(5), 97, 97, 5, sharp=2.0)
     cfg = (1.5, 3, 40, 13, 10, 10)
+    # (a size's second use brings the tile vertex sets of the on-chip Gaussian message: the object the check runs on takes the
+    # production path -- the message formed inside the update kernel)
+    _lib.Crf(ctx, ctx.to_device(rgb), 1, 97, 97, cfg[0], cfg[2], cfg[3]).close()
     crf = _lib.Crf(ctx, ctx.to_device(rgb), 1, 97, 97, cfg[0], cfg[2], cfg[3])
+    assert crf.gaussian_on_chip(5)
     q_dev = ctx.alloc(5 * 97 * 97 * 4)
     a_dev = ctx.alloc(97 * 97 * 4)
     crf.inference(ctx.to_device(U), 5, cfg[1], cfg[4], cfg[5], q_dev, a_dev)
