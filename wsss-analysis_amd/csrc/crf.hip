@@ -1324,7 +1324,11 @@ constexpr int BL_THREADS = 1024;
 constexpr int BL_NVAR = 5;
 constexpr int BL_VAR[BL_NVAR][2] = {{4, 4}, {4, 10}, {3, 13}, {2, 20}, {1, 26}};
 inline int blur_lds_variant(int rows) {
-    for (int v = 0; v < BL_NVAR; ++v)
+    int v0 = 0;
+#ifdef WSC_AB_KNOBS
+    if (const char *e = getenv("WSC_BLUR_LDS_MINVAR")) v0 = atoi(e); // A/B: start at a later variant (fewer classes per workgroup)
+#endif
+    for (int v = v0; v < BL_NVAR; ++v)
         if (rows <= BL_VAR[v][1] * BL_THREADS && (size_t)(rows + 1) * BL_VAR[v][0] * 4 <= 160 * 1024 && rows < 65535) return v;
     return -1;
 }
