@@ -253,6 +253,42 @@ def test_make_sem_seg_labels_end_to_end(tmp_path):
         assert (png == ref).mean() >= 0.99, (png == ref).mean()
 
 
+def test_sem_seg_batches_in_flight_equal_serial():
+    """Round 6: make_sem_seg_labels keeps several batches in flight on their own streams (sem_seg_batches); the label maps of
+    a batch do not depend on its lane: seven images in batches of two on three lanes == sem_seg_batch one batch after the
+    other on the model's own context, bit for bit, in batch order."""
+    import types
+
+    from wsscam.net import vgg16_irn
+    from wsscam.step import make_sem_seg_labels as mssl
+
+    rng = np.random.default_rng(31)
+    sd = irn_ref.make_vgg16_irn_state_dict(seed=6)
+    model = vgg16_irn.EdgeDisplacement(None, "voc12", "", 20, None, crop_size=96, stride=4, precision=_lib.PREC_F16X3)
+    model.load_state_dict(sd, strict=False)
+    model.eval().cuda(0)
+    packs, cams = [], []
+    for i in range(7):
+        packs.append({"name": "i%d" % i, "img": rng.normal(0, 1, (2, 3, 72, 88)).astype(np.float32), "size": (72, 88)})
+        K = 1 + i % 3
+        cams.append({"keys": np.sort(rng.choice(20, K, replace=False)), "cam": rng.random((K, 18, 22)).astype(np.float32)})
+    args = types.SimpleNamespace(dataset="voc12", beta=10, exp_times=5, sem_seg_bg_thres=0.25)
+    batches = [(packs[i:i + 2], cams[i:i + 2]) for i in range(0, 7, 2)]
+    serial = [mssl.sem_seg_batch(model, p, c, args) for p, c in batches]
+    for _ in range(2):
+        lanes = mssl.sem_seg_batches(model, batches, args, n_lanes=3)
+        assert len(lanes) == len(serial)
+        for a, b in zip(lanes, serial):
+            assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+    # the sink form (what _work uses): every batch delivered once, on its lane's thread
+    got = {}
+    mssl.sem_seg_batches(model, [lambda bt=bt: bt for bt in batches], args, n_lanes=2,
+                         sink=lambda bi, pk, preds: got.__setitem__(bi, (len(pk), [np.asarray(x).copy() for x in preds])))
+    assert sorted(got) == list(range(len(batches)))
+    for bi, (n, preds) in got.items():
+        assert n == len(batches[bi][0]) and all(np.array_equal(x, y) for x, y in zip(preds, serial[bi]))
+
+
 @pytest.mark.parametrize("dataset", ["adp_func", "deepglobe"])
 def test_sem_seg_other_datasets(dataset):
     """The ADP and DeepGlobe branches of make_sem_seg_labels._work (:71-99): no background padding, keys used as

@@ -521,6 +521,34 @@ def test_hsn_segment_adp_driver(precision, min_agree):
             assert agree >= min_agree, (htt, b, agree)
 
 
+def test_hsn_segment_adp_batches_in_flight_equal_serial():
+    """Round 6: segment_adp keeps several batches in flight, each on its own stream / buffer pool / thread
+    (hsn.demo.run_batches_on_lanes).  A batch's label maps must not depend on the lane it ran on nor on what ran beside it:
+    five patches in batches of two on three lanes == the same call on one lane (the reference's serial loop), bit for bit,
+    and the per-image CRF class counts come back in image order."""
+    from tests.test_gpu_edge import _adp_like_image
+    from wsscam.hsn import demo as hsn_demo
+
+    C, S = 31, 129
+    sd = cnn_ref.make_plain_state_dict("vgg16", cnn_ref.VGG16_CFG, C, False, seed=23)
+    model = _model(vgg16_cam.CAM, sd, C, _lib.PREC_F16X3)
+    rng = np.random.default_rng(24)
+    images = [_adp_like_image(rng, S, S) for _ in range(5)]
+    alpha = cnn_ref.grad_cam_weights(sd, "vgg16", cnn_ref.VGG16_CFG, 33, C)
+    thr = np.full((1, C), 0.5)
+    cfgs = {"morph": np.array([3 / 2, 3, 80 / 2, 13, 10, 3]), "func": np.array([3, 3, 50, 5, 10, 3])}
+    st1, st3 = {}, {}
+    serial = hsn_demo.segment_adp(model, alpha, thr, images, cfgs, S, 2, stats=st1, n_lanes=1)
+    for _ in range(2):  # (twice: the second call finds the lanes' contexts, pools and cached Gaussian lattices warm)
+        st3 = {}
+        lanes = hsn_demo.segment_adp(model, alpha, thr, images, cfgs, S, 2, stats=st3, n_lanes=3)
+        for htt in ("morph", "func"):
+            assert len(lanes[htt]) == 5
+            for b in range(5):
+                assert np.array_equal(lanes[htt][b], serial[htt][b]), (htt, b)
+        assert st1 == st3
+
+
 def test_hsn_adp_driver_resized_patches_and_adipose_indexing():
     """segment_adp on 272 x 272 patches at a 224 network size: (1) ADPCues.read_batch's uint8 contract (adp_cues.py:122-128:
     cv2.resize into a uint8 batch -- the oracle quantises with its own loop statement of OpenCV's 8-bit rule); (2) the

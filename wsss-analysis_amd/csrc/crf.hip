@@ -3139,7 +3139,9 @@ int build_lattice(wsc_crf *crf, LatticeDev &L, const uint8_t *rgb_dev, float sxy
             redo_count = zblk + 1; // (zeroed above)
             hipLaunchKernelGGL(tile_embed_kernel<D>, dim3((unsigned)L.n_tiles), dim3(256), 0, ctx->stream, ea, tg, L.tent_w, L.tent_p,
                                sslot, tile_nslots, fb, redo_list, redo_count);
-            hipLaunchKernelGGL(tile_embed_full_kernel<D>, dim3((unsigned)std::min(L.n_tiles, 2048)), dim3(256), 0, ctx->stream, ea,
+            // (the redo list is usually empty or short: three blocks per CU -- what the 53 KB table admits -- walk it; 2048 blocks
+            // that mostly found nothing to do took 23 us to come and go)
+            hipLaunchKernelGGL(tile_embed_full_kernel<D>, dim3((unsigned)std::min(L.n_tiles, 3 * ctx->num_cus)), dim3(256), 0, ctx->stream, ea,
                                tg, L.tent_w, L.tent_p, sslot, tile_nslots, fb, (const int32_t *)redo_list,
                                (const unsigned *)redo_count, L.n_tiles);
         }
