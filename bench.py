@@ -155,10 +155,12 @@ class Workload:
             for c in (self.ctx, self.ctx_build, self.ctx_crf):
                 c.set_option(int(o), int(v))
         self.pending = None  # lattices of the step whose mean-field loop is still in flight
-        # step_pipelined(): the loops of the last TWO steps may be in flight.  done[p] is a stream that only ever waits for the
-        # loop that last used parity p's buffers, so the host can wait for exactly that loop (two steps old: normally finished)
-        # instead of the newest one -- the mean-field stream always has the next loop queued behind the running one
-        self.done = [_lib.Context(device), _lib.Context(device)]
+        # step_pipelined(): the loops of the last TWO steps may be in flight.  Marker p of the mean-field context is recorded
+        # behind the loop that last used parity p's buffers (wsc_ctx_mark), so the host can wait for exactly that loop (two
+        # steps old: normally finished) instead of the newest one -- the mean-field stream always has the next loop queued
+        # behind the running one.  (Rounds 4-5 used two extra streams that only waited: with more streams than hardware queues
+        # their wait packets could sit in front of the conv / build stream's kernels.  WSC_BENCH_DONE_STREAMS=1: that form.)
+        self.done = [_lib.Context(device), _lib.Context(device)] if os.environ.get("WSC_BENCH_DONE_STREAMS") == "1" else None
         self.inflight = [None, None]
         prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "f16x3": _lib.PREC_F16X3}[precision]
         # seeded random weights of the named architecture (no checkpoints offline), wsscam.synth
@@ -221,7 +223,7 @@ class Workload:
 
     def close(self):
         self.drain()
-        for c in (self.ctx, self.ctx_build, self.ctx_crf, self.done[0], self.done[1]):
+        for c in (self.ctx, self.ctx_build, self.ctx_crf) + (tuple(self.done) if self.done else ()):
             c.sync()
         self.net.close()
 
@@ -259,7 +261,10 @@ class Workload:
     def _retire(self, p):
         """Wait for the loop that last used parity p's unary / label buffers and release its lattices."""
         if self.inflight[p] is not None:
-            self.done[p].sync()
+            if self.done:
+                self.done[p].sync()
+            else:
+                self.ctx_crf.wait_mark(p)
             self.inflight[p].close()
             self.inflight[p] = None
 
@@ -286,7 +291,10 @@ class Workload:
         self.ctx_crf.wait_for(self.ctx)
         self.ctx_crf.wait_for(self.ctx_build)
         self.crf_infer(crf, ctx=self.ctx_crf)   # queued behind step i-1's loop on the same stream: no host round trip between them
-        self.done[p].wait_for(self.ctx_crf)
+        if self.done:
+            self.done[p].wait_for(self.ctx_crf)
+        else:
+            self.ctx_crf.mark(p)
         self.inflight[p] = crf
 
     def step(self, sequential=False):

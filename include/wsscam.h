@@ -128,6 +128,13 @@ int wsc_ctx_range_status(wsc_ctx *ctx, int *flag_out, int clear);
  * of the same device (e.g. the lattice build of a batch, which needs only the RGB images, with its
  * CNN forward pass) and join them before the stage that needs both. */
 int wsc_ctx_wait(wsc_ctx *ctx, wsc_ctx *other);
+/* Markers: wsc_ctx_mark records marker `slot` (0 .. 7) at the current end of the ctx's stream; wsc_ctx_wait_mark blocks the
+ * HOST until everything enqueued before that record has completed (and returns at once for a slot never recorded).  A caller
+ * that keeps several steps in flight on one stream waits for "the step two back" this way -- without a wsc_sync that would
+ * also wait for the newest one, and without an extra stream whose wait packets can end up in front of another stream's
+ * kernels on a shared hardware queue (replaces the `torch.cuda.synchronize()` granularity of 03b_irn/step/make_cam.py:81-85). */
+int wsc_ctx_mark(wsc_ctx *ctx, int slot);
+int wsc_ctx_wait_mark(wsc_ctx *ctx, int slot);
 /* name of the device's gcnArchName ("gfx950...") and CU count */
 int wsc_device_info(wsc_ctx *ctx, char *arch_name, size_t arch_name_len, int *num_cus);
 

@@ -249,6 +249,8 @@ void wsc_ctx_destroy(wsc_ctx *ctx) {
     }
     if (ctx->pinned_ev) (void)hipEventDestroy(ctx->pinned_ev);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
+    for (hipEvent_t e : ctx->marks)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->aux_done_ev) (void)hipEventDestroy(ctx->aux_done_ev);
     if (ctx->aux_stream) {
@@ -278,6 +280,23 @@ int wsc_ctx_range_status(wsc_ctx *ctx, int *flag_out, int clear) {
     if (flag_out) *flag_out = (int)*f;
     if (clear) *f = 0u;
     return WSC_OK;
+}
+
+int wsc_ctx_mark(wsc_ctx *ctx, int slot) {
+    WSC_CHECK(ctx && slot >= 0 && slot < 8, WSC_ERR_INVALID, "wsc_ctx_mark: slot %d outside [0, 8)", slot);
+    WSC_HIP(hipSetDevice(ctx->device));
+    if (!ctx->marks[slot]) WSC_HIP(hipEventCreateWithFlags(&ctx->marks[slot], hipEventDisableTiming));
+    WSC_HIP(hipEventRecord(ctx->marks[slot], ctx->stream));
+    ctx->mark_set[slot] = true;
+    return WSC_OK;
+}
+
+int wsc_ctx_wait_mark(wsc_ctx *ctx, int slot) {
+    WSC_CHECK(ctx && slot >= 0 && slot < 8, WSC_ERR_INVALID, "wsc_ctx_wait_mark: slot %d outside [0, 8)", slot);
+    if (!ctx->mark_set[slot]) return WSC_OK;
+    WSC_HIP(hipSetDevice(ctx->device));
+    WSC_HIP(hipEventSynchronize(ctx->marks[slot]));
+    return wsc_ctx_range_check(ctx);
 }
 
 int wsc_ctx_wait(wsc_ctx *ctx, wsc_ctx *other) {

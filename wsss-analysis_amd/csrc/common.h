@@ -161,6 +161,8 @@ struct wsc_ctx {
     bool pinned_busy = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t join_ev = nullptr; // wsc_ctx_wait
+    hipEvent_t marks[8] = {};     // wsc_ctx_mark / wsc_ctx_wait_mark (created on first use)
+    bool mark_set[8] = {};
     // side stream for work that is independent inside one call (crf.hip: the bilateral lattice's combine + blur passes run
     // beside the Gaussian lattice's fused blur); forked from / joined into `stream` with the two events
     hipStream_t aux_stream = nullptr;

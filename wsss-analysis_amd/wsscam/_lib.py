@@ -75,6 +75,8 @@ _SIGNATURES = {
     "wsc_sync": (_i, [_vp]),
     "wsc_ctx_range_status": (_i, [_vp, ctypes.POINTER(_i), _i]),
     "wsc_ctx_wait": (_i, [_vp, _vp]),
+    "wsc_ctx_mark": (_i, [_vp, _i]),
+    "wsc_ctx_wait_mark": (_i, [_vp, _i]),
     "wsc_device_info": (_i, [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(_i)]),
     "wsc_malloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     "wsc_free": (_i, [_vp, _vp]),
@@ -235,6 +237,14 @@ class Context:
         f = _i(0)
         check(self._lib.wsc_ctx_range_status(self.h, ctypes.byref(f), 1 if clear else 0))
         return int(f.value)
+
+    def mark(self, slot):
+        """Records marker `slot` (0 .. 7) at the current end of this context's stream (wsc_ctx_mark)."""
+        check(self._lib.wsc_ctx_mark(self.h, int(slot)))
+
+    def wait_mark(self, slot):
+        """Host wait for everything enqueued before the marker's last record (returns at once if never recorded)."""
+        check(self._lib.wsc_ctx_wait_mark(self.h, int(slot)))
 
     def wait_for(self, other):
         """Device-side join: later work on this ctx waits for everything enqueued so far on `other`."""
