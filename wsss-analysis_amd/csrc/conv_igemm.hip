@@ -77,10 +77,9 @@ struct ConvKArgs {
     long long lo_delta2; // SPLIT 2: x2_lo - x2
     int cc2, H2, W2, C2, stride2;
     int ldx;            // pixel pitch of x in elements (Cin; the first source's channel count when there are two)
-    // LDS input window of a 3 x 3 / stride 1 / pad 1 layer (WPT > 0 variants): positions of the zero-padded raster
-    // [N][H + 2][W + 2]; the block's window starts at the padded position of (its first output pixel's row - 1, column - 1)
-    int win_Wp, win_HpWp, win_N;
-    unsigned div_hpwp_mul, div_hpwp_s1, div_hpwp_s2, div_wp_mul, div_wp_s1, div_wp_s2;
+    // LDS input window of a 3 x 3 / stride 1 / pad 1 layer (WPT > 0 variants): positions of the input raster [N][H][W]
+    // starting at index (first output pixel of the block) - W - 1; win_npix = N H W (pieces outside the tensor load zeros)
+    int win_npix;
     int stem_rows;      // host side only: the padded-input stem form (a K-step = one kernel row of 8 pixels x 4 channels)
     int kw_real;        // host side only: kernel width of the layer (FLOP accounting; kw is 1 in the stem form)
     unsigned *range;    // the ctx's range flag (common.h): raised by an IEEE-half epilogue that stores a value at the half ceiling
@@ -112,10 +111,16 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 // MFMA products: 1.5x the matrix work per LDS byte of the one-plane kernel instead of 3x its staging.
 //
 // WPT > 0 (LDS input WINDOW, f16x3 single-staged 128-row tiles, 3 x 3 / stride 1 / pad 1): the A operand of all nine taps of a
-// 32-channel chunk is ONE window of the zero-padded input raster -- the block's 128 output pixels are consecutive in (n, ho, wo)
-// order, so their input pixels for tap (r, s) are the window positions q(m) - q(m0) + r (W + 2) + s -- staged once per chunk
-// (WPT x 32 positions x [32 hi | 32 lo], same 128-byte rows and XOR swizzle as an A tile, so the fragment reads only change
-// their base address per tap) instead of nine per-tap A tiles: 2.4-4.9x fewer A bytes through L2 -> LDS.  The next chunk's
+// 32-channel chunk is ONE window of the input raster [N][H][W] -- output pixel m of a same-size convolution sits at raster index m,
+// so the block's 128 consecutive output pixels read, for tap (r, s), the window positions (m - m0) + r W + s of the window that
+// starts at raster index m0 - W - 1 -- staged once per chunk (WPT x 32 positions x [32 hi | 32 lo], same 128-byte rows and XOR
+// swizzle as an A tile, so the fragment reads only change their base address per tap) instead of nine per-tap A tiles: 2.7-5.6x
+// fewer A bytes through L2 -> LDS.  Round 6: the raster is NOT padded.  Where a tap leaves the image (left / right column, top /
+// bottom row) the position holds the neighbouring row's or image's pixel, and the lane reads the window's ZERO ROW instead (a
+// 9-bit per-lane tap mask decided once; one v_cndmask per fragment address).  The positions of 32 consecutive output pixels are
+// then consecutive for every tap, which is what the swizzle needs to be conflict-free: round 5's zero-padded raster jumped by
+// two positions at a row's end and lost 21-30 % of its LDS cycles to bank conflicts there.  It is also smaller: 127 + 2 W + 4
+// positions (21 x 21: 173, 41 x 41: 213, 81 x 81: 293) against 236 / 312 / 468.  The next chunk's
 // window travels in registers (WPT 16-byte loads per thread, issued at the chunk's first tap) and is written to LDS between
 // the chunk's last tap and the next one's first; the weight tiles keep their per-K-step LDS-DMA double buffer.  Same MFMA
 // sequence on the same operands as the per-tap kernel: bit-identical results (tests/test_gpu_conv.py).
@@ -511,37 +516,32 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                 *reinterpret_cast<u32x4_t *>(smem + lds_off(g >> 3, g & 7)) = wreg[i];
             }
         };
+        unsigned tapmask[MI]; // bit (3 r + s): tap (r, s) of the lane's output pixel lies outside the image
+        constexpr int WIN_ZERO = WPT * 32 - 1; // the window's last position: a row of zeros (no piece of the tensor lands there)
         if constexpr (WIN) {
-            auto q_of = [&](int m) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int mr = m0 + wm * WMT + mi * 32 + l31;
+                const int m = mr < p.m_end ? mr : p.m_end - 1; // (rows past the end: a valid position, results never stored)
                 const unsigned t1 = __umulhi(p.div_howo_mul, (unsigned)m);
                 const int n = (int)((t1 + (((unsigned)m - t1) >> p.div_howo_s1)) >> p.div_howo_s2);
                 const int rem = m - n * p.HoWo;
                 const unsigned t2 = __umulhi(p.div_wo_mul, (unsigned)rem);
                 const int ho = (int)((t2 + (((unsigned)rem - t2) >> p.div_wo_s1)) >> p.div_wo_s2);
                 const int wo = rem - ho * p.Wo;
-                return n * p.win_HpWp + (ho + 1) * p.win_Wp + wo + 1;
-            };
-            const int qm0 = q_of(m0);
-            const int q0 = qm0 - p.win_Wp - 1; // window position 0: the padded pixel above-left of the first output pixel
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int m = m0 + wm * WMT + mi * 32 + l31;
-                qm[mi] = q_of(m < p.m_end ? m : p.m_end - 1) - qm0; // (rows past the end: a valid position, results never stored)
+                qm[mi] = m - m0; // window position of the pixel's tap (0, 0)
+                const unsigned left = wo == 0 ? 0x49u : 0u, right = wo == p.W - 1 ? 0x124u : 0u;   // s = 0: bits 0, 3, 6; s = 2: 2, 5, 8
+                const unsigned top = ho == 0 ? 0x7u : 0u, bottom = ho == p.H - 1 ? 0x1c0u : 0u;     // r = 0: bits 0-2; r = 2: bits 6-8
+                tapmask[mi] = left | right | top | bottom;
             }
+            const int u0 = m0 - p.W - 1; // raster index of window position 0
 #pragma unroll
             for (int i = 0; i < WP; ++i) {
                 const int g = i * NT + t;
-                const unsigned Q = (unsigned)(q0 + (g >> 3));
-                const int sl = g & 7;
-                const unsigned t1 = __umulhi(p.div_hpwp_mul, Q);
-                const int n = (int)((t1 + ((Q - t1) >> p.div_hpwp_s1)) >> p.div_hpwp_s2);
-                const unsigned rr = Q - (unsigned)n * (unsigned)p.win_HpWp;
-                const unsigned t2 = __umulhi(p.div_wp_mul, rr);
-                const int hp = (int)((t2 + ((rr - t2) >> p.div_wp_s1)) >> p.div_wp_s2);
-                const int wp = (int)rr - hp * p.win_Wp;
-                const bool ok = n < p.win_N && hp >= 1 && hp <= p.H && wp >= 1 && wp <= p.W;
-                const long long e = (((long long)n * p.H + (hp - 1)) * p.W + (wp - 1)) * (long long)p.ldx + (sl & 3) * 8 +
-                                    ((sl & 4) ? p.lo_delta : 0ll);
+                const int wpos = g >> 3, sl = g & 7;
+                const int u = u0 + wpos;
+                const bool ok = u >= 0 && u < p.win_npix && wpos != WIN_ZERO;
+                const long long e = (long long)u * (long long)p.ldx + (sl & 3) * 8 + ((sl & 4) ? p.lo_delta : 0ll);
                 woff[i] = ok ? (int)(e >> 3) : 0;
                 wvalid |= ok ? (1u << i) : 0u;
             }
@@ -613,10 +613,11 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 && FAST != 0) ? 4 : 2) void co
                 unsigned aw[MI][4];
                 if constexpr (WIN) {
                     if ((c_khi | c_kwi) == 0 && c_cc + 1 < p.cchunks) win_load(c_cc + 1);
-                    const int toff = c_khi * p.win_Wp + c_kwi;
+                    const int toff = c_khi * p.W + c_kwi;
+                    const unsigned tbit = 1u << (c_khi * 3 + c_kwi);
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
-                        const int pos = qm[mi] + toff;
+                        const int pos = (tapmask[mi] & tbit) ? WIN_ZERO : qm[mi] + toff;
                         const unsigned b0 = lds0 + (unsigned)pos * 128u, sw = (unsigned)(pos >> 1) & 7u;
 #pragma unroll
                         for (int pr = 0; pr < 4; ++pr) aw[mi][pr] = b0 + ((((unsigned)(pr * 2 + kgrp)) ^ sw) << 4);
@@ -1200,8 +1201,7 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     a.y = p.y; a.y_lo = p.y_lo; a.y_f32 = p.y_f32;
     a.H = p.H; a.W = p.W; a.Cin = p.Cin; a.Ho = p.Ho; a.Wo = p.Wo; a.Cout = p.Cout;
     a.ldy = p.ldy > 0 ? p.ldy : p.Cout;
-    a.win_Wp = a.win_HpWp = a.win_N = 0;
-    a.div_hpwp_mul = a.div_hpwp_s1 = a.div_hpwp_s2 = a.div_wp_mul = a.div_wp_s1 = a.div_wp_s2 = 0;
+    a.win_npix = 0;
     a.ldx = p.Cin; a.x2 = nullptr; a.lo_delta2 = 0; a.cc2 = 0; a.H2 = a.W2 = a.C2 = 0; a.stride2 = 1;
     a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.relu = p.relu;
     a.M = p.N * p.Ho * p.Wo;
@@ -1350,35 +1350,22 @@ int conv_igemm_launch(wsc_ctx *ctx, const ConvLaunch &p) {
     const int BMsel = big ? 256 : 128;
     a.nblocks = ((a.M + BMsel - 1) / BMsel) * a.ntiles_n;
     // LDS input window (north star: "3x3 convolutions as MFMA-tiled direct convs with LDS-staged input windows"): the f16x3
-    // 3 x 3 / stride 1 / pad 1 layers on 128 x 128 tiles whose window -- the padded-raster positions from (first output pixel's
-    // row - 1, column - 1) to (last output pixel's row + 1, column + 1) -- fits 256 or 320 positions (32 / 40 KB next to the
-    // weight tiles' 32 KB: two blocks per CU stay): ResNet50 @321 layer2 / layer3 conv2 (41 x 41: 312, 21 x 21: 236 positions).
-    // Larger maps keep the per-tap A tiles (81 x 81 would need 468 positions = 60 KB, one block per CU).
+    // 3 x 3 / stride 1 / pad 1 layers on 128-row tiles whose window -- the raster positions from (first output pixel - W - 1) to
+    // (last output pixel + W + 1), plus the zero row -- fits 256 or 320 positions (32 / 40 KB next to the weight tiles' 32 / 16 KB:
+    // two blocks per CU): ResNet50 @321 layer2 / layer3 conv2 (41 x 41: 213, 21 x 21: 173 positions) and, since round 6's
+    // unpadded raster, layer1 conv2 (81 x 81: 293).
     if (!big && single_staged && a.fast == 1 && p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad == 1 && p.x2 == nullptr &&
         p.Ho == p.H && p.Wo == p.W && ctx->opt[WSC_OPT_CONV_WINDOW] != 0) {
-        const int Wp = p.W + 2, HpWp = (p.H + 2) * Wp;
-        auto q_of = [&](long long m) {
-            const long long n = m / a.HoWo, rem = m - n * a.HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            return n * HpWp + (ho + 1) * Wp + wo + 1;
-        };
-        long long need = 0;
-        for (long long m0 = a.m_base; m0 < a.m_end; m0 += 128) {
-            const long long ml = std::min<long long>(m0 + 127, a.m_end - 1);
-            need = std::max(need, q_of(ml) - q_of(m0) + 2 * Wp + 3);
-        }
-        const long long last_pos = q_of(a.m_end - 1) + Wp + 1 + 320; // (padded positions are decoded with 32-bit arithmetic)
-        // (64-column tiles -- Cout = 64: ResNet50 layer1 conv2 at 81 x 81 -- would fit a 480-position window (60 KB + 16 KB of weight
-        // tiles, two blocks per CU instead of three): measured 129.2 -> 138.4 us, rejected; they take the window up to 320 positions too)
-        // (window source offsets are 32-bit counts of 16-byte units, the lo plane's distance included)
-        const long long lo_d = a.lo_delta < 0 ? -a.lo_delta : a.lo_delta;
-        // (the window's per-piece source offsets are non-negative 32-bit counts of 16-byte units measured from x: a lo plane that
-        // lies BELOW x -- two separate allocations in the wrong order -- keeps the per-tap tiles instead of relying on the
-        // arithmetic shift of a negative offset: ADVICE r5)
-        if (need <= 320 && last_pos < (1ll << 31) && a.lo_delta >= 0 && (long long)p.N * p.H * p.W * p.Cin + lo_d < (1ll << 33) &&
-            (a.lo_delta & 7) == 0) {
-            a.win_Wp = Wp; a.win_HpWp = HpWp; a.win_N = p.N;
-            fastdiv((unsigned)HpWp, a.div_hpwp_mul, a.div_hpwp_s1, a.div_hpwp_s2);
-            fastdiv((unsigned)Wp, a.div_wp_mul, a.div_wp_s1, a.div_wp_s2);
+        // positions of a block's window: its 128 output pixels' raster span, one row + one pixel before and after, and the
+        // zero row at the window's last position
+        const long long need = 127 + 2ll * p.W + 3 + 1;
+        const long long npix = (long long)p.N * p.H * p.W;
+        // (64-column tiles -- Cout = 64: ResNet50 layer1 conv2 at 81 x 81 -- take the 320-position window: 40 KB + 16 KB of weight
+        // tiles, two blocks per CU instead of three -- measured below; round 5's padded raster needed 480 positions there: rejected)
+        // (window source offsets are non-negative 32-bit counts of 16-byte units measured from x, the lo plane's distance included:
+        // a lo plane BELOW x keeps the per-tap tiles -- ADVICE r5)
+        if (need <= 320 && npix < (1ll << 30) && a.lo_delta >= 0 && npix * p.Cin + a.lo_delta < (1ll << 33) && (a.lo_delta & 7) == 0) {
+            a.win_npix = (int)npix;
             if (BN == 128) return need <= 256 ? launch_window<8>(ctx, a) : launch_window<10>(ctx, a);
             return need <= 256 ? launch_window<8, 64>(ctx, a) : launch_window<10, 64>(ctx, a);
         }
