@@ -387,8 +387,11 @@ class Workload:
                     "pin_out": [self.ctx.host_alloc((max(self.s_tot, 1) + max(self.h_tot, 1)) * 4) for _ in range(2)],
                     "pin_lab": [self.ctx_crf.host_alloc(self.B * S * S * 4) for _ in range(2)],
                     "stage": [None, None], "fin": [None, None], "crf": [None, None],
-                    "finisher": ThreadPoolExecutor(1), "out": [self._lib.Context(self.device) for _ in range(2)],
-                    "outc": [self._lib.Context(self.device) for _ in range(2)], "io": self._lib.Context(self.device), "fed": False,
+                    # ONE copy stream for every host <-> device transfer of the leg (round 6; rounds 4-5: an input stream and two
+                    # pairs of output streams -- eight streams on the runtime's four hardware queues, whose wait packets could sit in
+                    # front of the conv stream's kernels).  Markers on it: 0 / 1 input batch of parity q on the device, 2 / 3 cam +
+                    # high_res of parity p in page-locked memory, 4 / 5 label maps of parity p in page-locked memory
+                    "finisher": ThreadPoolExecutor(1), "io": self._lib.Context(self.device), "fed": False,
                     "x": [self.ctx.alloc(self.x_host.nbytes) for _ in range(2)],
                     "u8d": [self.ctx.alloc(int(self.u8_offs[-1])) for _ in range(2)]}
         os.makedirs(out_dir, exist_ok=True)
@@ -412,7 +415,7 @@ class Workload:
         waits for exactly that step's copies), then hands the files to the writer threads.  The main thread never waits for
         the newest mean-field loop."""
         e = self.e2e
-        e["out"][p].sync()
+        e["io"].wait_mark(4 + p)  # (the copy stream is in order: the step's cam / high_res copies are done too)
         return [e["pool"].submit(self._e2e_save, p, b, s_off, h_off, shapes) for b in range(self.B)]
 
     def _e2e_retire(self, p):
@@ -443,34 +446,37 @@ class Workload:
         if not e["fed"]:
             self._e2e_feed(p)            # (first step: nobody has fed this one)
             e["fed"] = True
-        self.ctx.wait_for(e["io"])       # batch i is on the device
-        self._e2e_feed(p ^ 1)            # batch i + 1 follows while step i computes
+        self.ctx.wait_for_mark(e["io"], p)   # batch i is on the device (and nothing the copy stream was given after it)
+        self._e2e_feed(p ^ 1)                # batch i + 1 follows while step i computes
         x_keep, self.x_dev = self.x_dev, e["x"][p]
         if e["u8"]:
             self._lib.msf_input_u8(self.ctx, e["u8d"][p], [im.shape[:2] for im in self.native], self.u8_offs[:-1], S,
                                    (104.0, 117.0, 123.0), (255.0, 255.0, 255.0), e["x"][p], pre_div255=False, pair=True)
         self.run_cnn()
+        self.ctx.mark(p)                 # conv stack i has read input buffer p: the copy stream may refill it (two steps on)
         self.x_dev = x_keep
         crf = self.crf_create()
-        self.ctx.wait_for(e["outc"][p ^ 1])  # step i-1's cam / high_res copy-out has left the buffers the tail rewrites
+        self.ctx.wait_for_mark(e["io"], 2 + (p ^ 1))  # step i-1's cam / high_res copy-out has left the buffers the tail rewrites
         self.run_tail()
+        self.ctx.mark(2 + p)
         _, _, s_off, h_off, shapes = self.tail_meta
-        oc = e["outc"][p]                # copy-out of cam / high_res on its own stream: the conv stream goes on with the unaries
-        oc.wait_for(self.ctx)
-        oc.d2h_async(e["pin_out"][p], self.strided_dev, max(self.s_tot, 1) * 4)
-        oc.d2h_async(e["pin_out"][p], self.highres_dev, max(self.h_tot, 1) * 4, dst_offset=max(self.s_tot, 1) * 4)
+        io = e["io"]                     # copy-out of cam / high_res: the conv stream goes on with the unaries
+        io.wait_for_mark(self.ctx, 2 + p)
+        io.d2h_async(e["pin_out"][p], self.strided_dev, max(self.s_tot, 1) * 4)
+        io.d2h_async(e["pin_out"][p], self.highres_dev, max(self.h_tot, 1) * 4, dst_offset=max(self.s_tot, 1) * 4)
+        io.mark(2 + p)
         self.run_unary()
         self.ctx_crf.wait_for(self.ctx)
         self.ctx_crf.wait_for(self.ctx_build)
         self.crf_infer(crf, ctx=self.ctx_crf)  # queued behind step i-1's loop, no host round trip
-        out = e["out"][p]
-        out.wait_for(oc)             # cam / high_res copies of this step
-        out.wait_for(self.ctx_crf)   # this step's labels
-        out.d2h_async(e["pin_lab"][p], self.label_bufs[p], self.B * S * S * 4)
+        self.ctx_crf.mark(p)
+        io.wait_for_mark(self.ctx_crf, p)      # this step's labels
+        io.d2h_async(e["pin_lab"][p], self.label_bufs[p], self.B * S * S * 4)
+        io.mark(4 + p)
         e["crf"][p] = crf
         e["fin"][p] = e["finisher"].submit(self._e2e_finish, p, s_off, h_off, shapes)
-        # batch i + 2 -> the page-locked staging buffers batch i came from (every copy-in issued so far has finished)
-        e["io"].sync()
+        # batch i + 2 -> the page-locked staging buffers batch i came from, once its copy-in (issued a step ago) has finished
+        io.wait_mark(p)
         e["stage"][p] = self._e2e_stage(p)
 
     def _e2e_feed(self, q):
@@ -480,7 +486,7 @@ class Workload:
             f.result()
         e["stage"][q] = None
         io = e["io"]
-        io.wait_for(self.ctx)  # the conv stack that read buffer q (two steps ago) has been enqueued before this point
+        io.wait_for_mark(self.ctx, q)  # the conv stack that last read device input buffer q (two steps ago) has finished
         if e["u8"]:
             # decoded images in: only the copy runs on the input stream; the dataset transform (resize, normalise, flip pair:
             # a 45 us kernel) is the first launch of the step's conv stream (step_e2e).  On the input stream it had to find
@@ -489,6 +495,7 @@ class Workload:
             io.h2d_async(e["u8d"][q], e["pin_u8"][q], int(self.u8_offs[-1]))
         else:
             io.h2d_async(e["x"][q], e["pin_in"][q], self.x_host.nbytes)
+        io.mark(q)
 
     def _e2e_stage(self, p):
         """Submits the host -> page-locked copy of one batch to the pool's threads; -> futures."""

@@ -135,6 +135,9 @@ int wsc_ctx_wait(wsc_ctx *ctx, wsc_ctx *other);
  * kernels on a shared hardware queue (replaces the `torch.cuda.synchronize()` granularity of 03b_irn/step/make_cam.py:81-85). */
 int wsc_ctx_mark(wsc_ctx *ctx, int slot);
 int wsc_ctx_wait_mark(wsc_ctx *ctx, int slot);
+/* Device-side: work enqueued on `ctx` after this call waits for marker `slot` of `other` (its last record) -- and for nothing
+ * `other` enqueued after that record, unlike wsc_ctx_wait.  No-op for a slot never recorded.  Same device. */
+int wsc_ctx_wait_for_mark(wsc_ctx *ctx, wsc_ctx *other, int slot);
 /* name of the device's gcnArchName ("gfx950...") and CU count */
 int wsc_device_info(wsc_ctx *ctx, char *arch_name, size_t arch_name_len, int *num_cus);
 

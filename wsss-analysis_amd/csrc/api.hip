@@ -299,6 +299,15 @@ int wsc_ctx_wait_mark(wsc_ctx *ctx, int slot) {
     return wsc_ctx_range_check(ctx);
 }
 
+int wsc_ctx_wait_for_mark(wsc_ctx *ctx, wsc_ctx *other, int slot) {
+    WSC_CHECK(ctx && other && slot >= 0 && slot < 8, WSC_ERR_INVALID, "wsc_ctx_wait_for_mark: bad argument (slot %d)", slot);
+    WSC_CHECK(ctx->device == other->device, WSC_ERR_INVALID, "wsc_ctx_wait_for_mark: contexts are on different devices");
+    if (!other->mark_set[slot] || ctx == other) return WSC_OK;
+    WSC_HIP(hipSetDevice(ctx->device));
+    WSC_HIP(hipStreamWaitEvent(ctx->stream, other->marks[slot], 0));
+    return WSC_OK;
+}
+
 int wsc_ctx_wait(wsc_ctx *ctx, wsc_ctx *other) {
     WSC_CHECK(ctx && other, WSC_ERR_INVALID, "wsc_ctx_wait: null ctx");
     WSC_CHECK(ctx->device == other->device, WSC_ERR_INVALID, "wsc_ctx_wait: contexts are on different devices");

@@ -77,6 +77,7 @@ _SIGNATURES = {
     "wsc_ctx_wait": (_i, [_vp, _vp]),
     "wsc_ctx_mark": (_i, [_vp, _i]),
     "wsc_ctx_wait_mark": (_i, [_vp, _i]),
+    "wsc_ctx_wait_for_mark": (_i, [_vp, _vp, _i]),
     "wsc_device_info": (_i, [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(_i)]),
     "wsc_malloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     "wsc_free": (_i, [_vp, _vp]),
@@ -245,6 +246,11 @@ class Context:
     def wait_mark(self, slot):
         """Host wait for everything enqueued before the marker's last record (returns at once if never recorded)."""
         check(self._lib.wsc_ctx_wait_mark(self.h, int(slot)))
+
+    def wait_for_mark(self, other, slot):
+        """Device-side join with marker `slot` of `other`: later work on this ctx waits for what `other` had enqueued when it
+        last recorded the marker -- not for anything it enqueued afterwards."""
+        check(self._lib.wsc_ctx_wait_for_mark(self.h, other.h, int(slot)))
 
     def wait_for(self, other):
         """Device-side join: later work on this ctx waits for everything enqueued so far on `other`."""
