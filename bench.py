@@ -374,26 +374,45 @@ class Workload:
 
     # -- end to end: host batch in, files out ---------------------------------------------------------------
     def setup_e2e(self, out_dir, n_writers=8, u8=False):
+        """End-to-end leg: a host batch in, .npy files out, around the pipelined step.
+
+        Who issues what (round 6; profiles/r06_step_timeline_e2e.txt is the trace that led here):
+          main thread      step i's kernels on the conv / build / mean-field streams; the copy-in of batch i+1, issued only
+                           after the host has SEEN conv stack i-1 finish (the device buffer it fills is free)
+          cam copier       sleeps until tail i is done, then copies cam / high_res out
+          finisher         sleeps until loop i is done, copies the label maps out, hands the 64 files to the writer pool
+        No copy is ever handed to the runtime before what it waits for has happened.  Rounds 4-5 queued every copy at once behind
+        stream waits: the runtime turns a copy's dependency into a poll command on the DMA engine's own queue, so the label copy of
+        step i (waiting ~20 ms for loop i) held back the copy-in of batch i+2 queued behind it on the same engine, the next conv stack
+        waited for THAT, and every other step ran its loop with nothing beside it (13.5 ms per step against 12.1 resident).
+        Outputs live in a ring of R = 3 steps (page-locked buffers, cam / unary / label device buffers, lattices): with 2, step i
+        could not be enqueued before step i-2's files were on disk, which is ~2 ms after loop i-2 -- itself sharing the GPU with
+        conv stack i-1 -- has finished."""
         from concurrent.futures import ThreadPoolExecutor
 
         np = self.np
         if self.e2e is not None:
-            self.e2e["pool"].shutdown(wait=True)
-            self.e2e["finisher"].shutdown(wait=True)
+            for k in ("pool", "finisher", "camcopier"):
+                self.e2e[k].shutdown(wait=True)
         self.u8_offs = np.concatenate(([0], np.cumsum([im.size for im in self.native]))).astype(np.int64)
-        self.e2e = {"dir": out_dir, "pool": ThreadPoolExecutor(n_writers), "u8": u8,
+        R = max(2, min(3, int(os.environ.get("WSC_BENCH_E2E_RING", "3"))))
+        while len(self.unary_bufs) < R:
+            self.unary_bufs.append(self.ctx.alloc(self.unary_bufs[0].nbytes))
+            self.label_bufs.append(self.ctx.alloc(self.label_bufs[0].nbytes))
+        mk = lambda: self._lib.Context(self.device)
+        self.e2e = {"dir": out_dir, "pool": ThreadPoolExecutor(n_writers), "u8": u8, "ring": R, "step": 0, "fed": False,
+                    "finisher": ThreadPoolExecutor(1), "camcopier": ThreadPoolExecutor(1),
                     "pin_u8": [self.ctx.host_alloc(int(self.u8_offs[-1])) for _ in range(2)],
                     "pin_in": [self.ctx.host_alloc(self.x_host.nbytes) for _ in range(2)],
-                    "pin_out": [self.ctx.host_alloc((max(self.s_tot, 1) + max(self.h_tot, 1)) * 4) for _ in range(2)],
-                    "pin_lab": [self.ctx_crf.host_alloc(self.B * S * S * 4) for _ in range(2)],
-                    "stage": [None, None], "fin": [None, None], "crf": [None, None],
-                    # ONE copy stream for every host <-> device transfer of the leg (round 6; rounds 4-5: an input stream and two
-                    # pairs of output streams -- eight streams on the runtime's four hardware queues, whose wait packets could sit in
-                    # front of the conv stream's kernels).  Markers on it: 0 / 1 input batch of parity q on the device, 2 / 3 cam +
-                    # high_res of parity p in page-locked memory, 4 / 5 label maps of parity p in page-locked memory
-                    "finisher": ThreadPoolExecutor(1), "io": self._lib.Context(self.device), "fed": False,
+                    "pin_out": [self.ctx.host_alloc((max(self.s_tot, 1) + max(self.h_tot, 1)) * 4) for _ in range(R)],
+                    "pin_lab": [self.ctx_crf.host_alloc(self.B * S * S * 4) for _ in range(R)],
+                    "strided": [self.strided_dev] + [self.ctx.alloc(max(self.s_tot, 1) * 4) for _ in range(R - 1)],
+                    "highres": [self.highres_dev] + [self.ctx.alloc(max(self.h_tot, 1) * 4) for _ in range(R - 1)],
+                    "stage": [None, None], "fin": [None] * R, "crf": [None] * R,
                     "x": [self.ctx.alloc(self.x_host.nbytes) for _ in range(2)],
-                    "u8d": [self.ctx.alloc(int(self.u8_offs[-1])) for _ in range(2)]}
+                    "u8d": [self.ctx.alloc(int(self.u8_offs[-1])) for _ in range(2)],
+                    # copy streams: batch in / cam + high_res out / label maps out (never given a device-side wait)
+                    "io": mk(), "oc": mk(), "ol": mk()}
         os.makedirs(out_dir, exist_ok=True)
 
     def _e2e_save(self, p, b, s_off, h_off, shapes):
@@ -410,16 +429,29 @@ class Workload:
         lab = e["pin_lab"][p].view((self.B, S, S), np.int32)[b]
         save_npy_array(os.path.join(e["dir"], "img%03d_crf.npy" % b), lab.astype(np.uint8))
 
-    def _e2e_finish(self, p, s_off, h_off, shapes):
-        """Finisher thread: sleeps until the outputs of the step that used parity p are in page-locked memory (its own stream
-        waits for exactly that step's copies), then hands the files to the writer threads.  The main thread never waits for
-        the newest mean-field loop."""
+    def _e2e_copy_cam(self, p):
+        """Cam-copier thread: sleeps until the tail of the step in ring slot p has run (marker 2 + p of the conv stream), then
+        copies cam / high_res of that slot into page-locked memory."""
         e = self.e2e
-        e["io"].wait_mark(4 + p)  # (the copy stream is in order: the step's cam / high_res copies are done too)
+        self.ctx.wait_mark(2 + p)
+        oc = e["oc"]
+        oc.d2h_async(e["pin_out"][p], e["strided"][p], max(self.s_tot, 1) * 4)
+        oc.d2h_async(e["pin_out"][p], e["highres"][p], max(self.h_tot, 1) * 4, dst_offset=max(self.s_tot, 1) * 4)
+        oc.sync()
+
+    def _e2e_finish(self, p, cam_copy, s_off, h_off, shapes):
+        """Finisher thread: sleeps until the mean-field loop of the step in ring slot p is done (marker p of its stream), copies
+        the label maps out, and hands the 64 files of the step to the writer pool; returns their futures."""
+        e = self.e2e
+        self.ctx_crf.wait_mark(p)
+        ol = e["ol"]
+        ol.d2h_async(e["pin_lab"][p], self.label_bufs[p], self.B * S * S * 4)
+        ol.sync()
+        cam_copy.result()
         return [e["pool"].submit(self._e2e_save, p, b, s_off, h_off, shapes) for b in range(self.B)]
 
     def _e2e_retire(self, p):
-        """The step that last used parity p (two steps ago): its files are on disk, its lattices can go."""
+        """The step that last used ring slot p (R steps ago): its files are on disk, its lattices can go."""
         e = self.e2e
         if e["fin"][p] is not None:
             for f in e["fin"][p].result():
@@ -432,73 +464,81 @@ class Workload:
     def step_e2e(self):
         """step_pipelined() with the host boundary of the reference around it: a pageable float32 batch (what the
         DataLoader hands over) is staged through page-locked memory and copied in; cam / high_res and the label maps
-        are copied out and written as .npy files by writer threads while the next step computes."""
+        are copied out and written as .npy files by writer threads while the next steps compute."""
         np = self.np
         e = self.e2e
         if self.pending is not None or self.inflight[0] is not None or self.inflight[1] is not None:
             self.drain()  # (loops left by another step function)
-        self.parity ^= 1
-        p = self.parity
-        self._e2e_retire(p)  # the files of step i-2 are on disk: its staging buffers are free again
+        R = e["ring"]
+        p = e["step"] % R                # ring slot of the step's outputs
+        q = e["step"] % 2                # parity of its input buffers
+        e["step"] += 1
+        self.parity = q
+        tr = e.setdefault("trace", {}) if os.environ.get("WSC_BENCH_E2E_TRACE") else None
+        t = [time.perf_counter()]
+        self._e2e_retire(p)              # the files of step i-R are on disk: its staging buffers are free again
+        t.append(time.perf_counter())
         self.unary_dev, self.label_dev = self.unary_bufs[p], self.label_bufs[p]
-        # Input: the copy-in of batch i runs on its own stream ONE STEP AHEAD of the conv stack (two device input buffers), so the
-        # conv stream never waits behind a 79 MB PCIe transfer; the staging copy of batch i + 1 was submitted a step ago.
+        strided_keep, highres_keep = self.strided_dev, self.highres_dev
+        self.strided_dev, self.highres_dev = e["strided"][p], e["highres"][p]
         if not e["fed"]:
-            self._e2e_feed(p)            # (first step: nobody has fed this one)
+            self._e2e_feed(q)            # (first step: nobody has fed this one)
             e["fed"] = True
-        self.ctx.wait_for_mark(e["io"], p)   # batch i is on the device (and nothing the copy stream was given after it)
-        self._e2e_feed(p ^ 1)                # batch i + 1 follows while step i computes
-        x_keep, self.x_dev = self.x_dev, e["x"][p]
+        self.ctx.wait_for_mark(e["io"], q)   # batch i is on the device (its copy-in was issued a step ago)
+        x_keep, self.x_dev = self.x_dev, e["x"][q]
         if e["u8"]:
-            self._lib.msf_input_u8(self.ctx, e["u8d"][p], [im.shape[:2] for im in self.native], self.u8_offs[:-1], S,
-                                   (104.0, 117.0, 123.0), (255.0, 255.0, 255.0), e["x"][p], pre_div255=False, pair=True)
+            # decoded images in: the dataset transform (resize, normalise, flip pair: a 45 us kernel) is the first launch of the
+            # step's conv stream (on the copy stream it had to find free compute units between the conv stack's workgroups, and
+            # the u8 leg, which moves 6x fewer bytes, was the slower one: VERDICT r5 weak #9)
+            self._lib.msf_input_u8(self.ctx, e["u8d"][q], [im.shape[:2] for im in self.native], self.u8_offs[:-1], S,
+                                   (104.0, 117.0, 123.0), (255.0, 255.0, 255.0), e["x"][q], pre_div255=False, pair=True)
         self.run_cnn()
-        self.ctx.mark(p)                 # conv stack i has read input buffer p: the copy stream may refill it (two steps on)
+        self.ctx.mark(q)                 # conv stack i has read device input buffer q
         self.x_dev = x_keep
         crf = self.crf_create()
-        self.ctx.wait_for_mark(e["io"], 2 + (p ^ 1))  # step i-1's cam / high_res copy-out has left the buffers the tail rewrites
         self.run_tail()
         self.ctx.mark(2 + p)
+        cam_copy = e["camcopier"].submit(self._e2e_copy_cam, p)
         _, _, s_off, h_off, shapes = self.tail_meta
-        io = e["io"]                     # copy-out of cam / high_res: the conv stream goes on with the unaries
-        io.wait_for_mark(self.ctx, 2 + p)
-        io.d2h_async(e["pin_out"][p], self.strided_dev, max(self.s_tot, 1) * 4)
-        io.d2h_async(e["pin_out"][p], self.highres_dev, max(self.h_tot, 1) * 4, dst_offset=max(self.s_tot, 1) * 4)
-        io.mark(2 + p)
+        self.strided_dev, self.highres_dev = strided_keep, highres_keep
         self.run_unary()
         self.ctx_crf.wait_for(self.ctx)
         self.ctx_crf.wait_for(self.ctx_build)
         self.crf_infer(crf, ctx=self.ctx_crf)  # queued behind step i-1's loop, no host round trip
         self.ctx_crf.mark(p)
-        io.wait_for_mark(self.ctx_crf, p)      # this step's labels
-        io.d2h_async(e["pin_lab"][p], self.label_bufs[p], self.B * S * S * 4)
-        io.mark(4 + p)
         e["crf"][p] = crf
-        e["fin"][p] = e["finisher"].submit(self._e2e_finish, p, s_off, h_off, shapes)
-        # batch i + 2 -> the page-locked staging buffers batch i came from, once its copy-in (issued a step ago) has finished
-        io.wait_mark(p)
-        e["stage"][p] = self._e2e_stage(p)
+        e["fin"][p] = e["finisher"].submit(self._e2e_finish, p, cam_copy, s_off, h_off, shapes)
+        t.append(time.perf_counter())
+        # batch i + 2 -> the page-locked staging buffers batch i came from (its copy-in, issued a step ago, has long finished);
+        # batch i + 1 -> device input buffer q^1 once conv stack i-1, which read it, is done
+        e["io"].wait_mark(q)
+        e["stage"][q] = self._e2e_stage(q)
+        t.append(time.perf_counter())
+        self.ctx.wait_mark(q ^ 1)
+        t.append(time.perf_counter())
+        self._e2e_feed(q ^ 1)
+        t.append(time.perf_counter())
+        if tr is not None:  # host time of the step by phase (profiles/e2e_probe.py prints the averages)
+            for k, v in zip(("retire", "enqueue", "stage_submit", "wait_conv", "feed"), np.diff(t)):
+                tr[k] = tr.get(k, 0.0) + float(v)
+            tr["steps"] = tr.get("steps", 0) + 1
 
     def _e2e_feed(self, q):
-        """Copy-in of the batch staged in parity q's page-locked buffers, on the input stream, into device input buffer q."""
+        """Copy-in of the batch staged in parity q's page-locked buffers into device input buffer q (the caller has seen the
+        conv stack that last read it finish)."""
         e = self.e2e
         for f in (e["stage"][q] or self._e2e_stage(q)):
             f.result()
         e["stage"][q] = None
         io = e["io"]
-        io.wait_for_mark(self.ctx, q)  # the conv stack that last read device input buffer q (two steps ago) has finished
         if e["u8"]:
-            # decoded images in: only the copy runs on the input stream; the dataset transform (resize, normalise, flip pair:
-            # a 45 us kernel) is the first launch of the step's conv stream (step_e2e).  On the input stream it had to find
-            # free compute units between the conv stack's workgroups, and the host's wait for "the staging buffer is free
-            # again" waited for it: the u8 leg, which moves 6x fewer bytes, was the slower one (VERDICT r5 weak #9)
             io.h2d_async(e["u8d"][q], e["pin_u8"][q], int(self.u8_offs[-1]))
         else:
             io.h2d_async(e["x"][q], e["pin_in"][q], self.x_host.nbytes)
         io.mark(q)
 
     def _e2e_stage(self, p):
-        """Submits the host -> page-locked copy of one batch to the pool's threads; -> futures."""
+        """The DataLoader's batch (pageable memory) -> parity p's page-locked staging buffers, on the pool."""
         np = self.np
         e = self.e2e
         if e["u8"]:
@@ -511,8 +551,8 @@ class Workload:
             nn = len(self.native)
             nchunk = min(8, nn)
             return [e["pool"].submit(_cp, nn * c // nchunk, nn * (c + 1) // nchunk) for c in range(nchunk)]
-        # pageable -> page-locked staging copy of the 79 MB batch, split over the pool's threads (numpy releases the GIL
-        # for the copy; one thread moves ~9 GB/s)
+        # float32: the 79 MB copy is split over the pool (numpy releases the interpreter lock for the copy; one thread
+        # moves ~9 GB/s)
         dst = e["pin_in"][p].view(self.x_host.shape, np.float32)
         nchunk = min(8, self.x_host.shape[0])
         bounds = [self.x_host.shape[0] * c // nchunk for c in range(nchunk + 1)]
@@ -521,10 +561,11 @@ class Workload:
 
     def drain_e2e(self):
         e = self.e2e
-        for p in (self.parity ^ 1, self.parity):
-            self._e2e_retire(p)
+        for k in range(e["ring"]):
+            self._e2e_retire((e["step"] + k) % e["ring"])
         self.ctx.sync()
-        e["io"].sync()
+        for c in (e["io"], e["oc"], e["ol"]):
+            c.sync()
         for st in e["stage"]:
             for f in st or []:
                 f.result()
@@ -1048,8 +1089,8 @@ def main():
             stages["end_to_end_u8_input"] = ("as value_end_to_end, but the host hands over the DECODED native-size images (%.1f MB "
                                              "per step); float64 resize + normalise + flip pair on the device, bit-identical"
                                              % (wl.u8_offs[-1] / 1e6))
-            wl.e2e["pool"].shutdown(wait=True)
-            wl.e2e["finisher"].shutdown(wait=True)
+            for k in ("pool", "finisher", "camcopier"):
+                wl.e2e[k].shutdown(wait=True)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
         if world == 1:

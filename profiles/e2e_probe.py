@@ -31,18 +31,23 @@ try:
             wl.ctx.sync()
             dt = time.perf_counter() - t0
             print("u8=%d  %.1f images/s  %.3f ms/step" % (u8, 32 * K / dt, dt / K * 1e3), flush=True)
+            tr = wl.e2e.pop("trace", None)
+            if tr:  # WSC_BENCH_E2E_TRACE=1: host time of a step by blocking call (includes the warm-up steps)
+                n = tr.pop("steps")
+                print("   host ms/step: " + "  ".join("%s %.3f" % (k, v / n * 1e3) for k, v in tr.items()), flush=True)
     # reference point: the resident-input pipelined step
-    for _ in range(4):
+    for _ in range(0 if os.environ.get("E2E_NO_RESIDENT") else 4):
         wl.step_pipelined()
     wl.drain()
     t0 = time.perf_counter()
-    for _ in range(K):
+    for _ in range(0 if os.environ.get("E2E_NO_RESIDENT") else K):
         wl.step_pipelined()
     wl.drain()
     wl.ctx.sync()
     dt = time.perf_counter() - t0
-    print("resident input: %.1f images/s  %.3f ms/step" % (32 * K / dt, dt / K * 1e3))
+    if not os.environ.get("E2E_NO_RESIDENT"):
+        print("resident input: %.1f images/s  %.3f ms/step" % (32 * K / dt, dt / K * 1e3))
 finally:
-    wl.e2e["pool"].shutdown(wait=True)
-    wl.e2e["finisher"].shutdown(wait=True)
+    for k in ("pool", "finisher", "camcopier"):
+        wl.e2e[k].shutdown(wait=True)
     shutil.rmtree(tmp, ignore_errors=True)
