@@ -484,7 +484,13 @@ class Workload:
         if not e["fed"]:
             self._e2e_feed(q)            # (first step: nobody has fed this one)
             e["fed"] = True
-        self.ctx.wait_for_mark(e["io"], q)   # batch i is on the device (its copy-in was issued a step ago)
+        # batch i is on the device: its copy-in was issued a step ago, the host just checks.  (No marker / device-side wait on a
+        # copy stream: a marker is a barrier packet in the stream's hardware queue, the runtime maps all streams onto four of
+        # those, and behind another stream's mean-field kernels the marker -- and the conv stack waiting for it -- sat ~1 ms)
+        if os.environ.get("WSC_BENCH_E2E_IO_MARK") == "1":
+            self.ctx.wait_for_mark(e["io"], q)
+        else:
+            e["io"].sync()
         x_keep, self.x_dev = self.x_dev, e["x"][q]
         if e["u8"]:
             # decoded images in: the dataset transform (resize, normalise, flip pair: a 45 us kernel) is the first launch of the
@@ -511,7 +517,6 @@ class Workload:
         t.append(time.perf_counter())
         # batch i + 2 -> the page-locked staging buffers batch i came from (its copy-in, issued a step ago, has long finished);
         # batch i + 1 -> device input buffer q^1 once conv stack i-1, which read it, is done
-        e["io"].wait_mark(q)
         e["stage"][q] = self._e2e_stage(q)
         t.append(time.perf_counter())
         self.ctx.wait_mark(q ^ 1)
@@ -535,7 +540,8 @@ class Workload:
             io.h2d_async(e["u8d"][q], e["pin_u8"][q], int(self.u8_offs[-1]))
         else:
             io.h2d_async(e["x"][q], e["pin_in"][q], self.x_host.nbytes)
-        io.mark(q)
+        if os.environ.get("WSC_BENCH_E2E_IO_MARK") == "1":
+            io.mark(q)
 
     def _e2e_stage(self, p):
         """The DataLoader's batch (pageable memory) -> parity p's page-locked staging buffers, on the pool."""
@@ -784,11 +790,12 @@ def hsn_measure(args, device):
         out = step(eff_m)
     # The timed region is ONE driver call over steps x batch patches (the reference's dataset loop, 03c_hsn/demo.py:318-380):
     # the driver keeps two batches in flight on two streams, so a batch's host decisions hide behind the other's kernels
-    hsn_demo.segment_adp(model, alpha, thr, images * 3, cfgs, S_, args.batch)  # (untimed: the other lanes' contexts and workspaces)
+    hsn_lanes = int(os.environ.get("WSC_BENCH_HSN_LANES", "3"))  # (segment_adp's default)
+    hsn_demo.segment_adp(model, alpha, thr, images * 3, cfgs, S_, args.batch, n_lanes=hsn_lanes)  # (untimed: the other lanes' contexts and workspaces)
     model.ctx.sync()
     ctx = model.ctx
     t0 = time.perf_counter()
-    hsn_demo.segment_adp(model, alpha, thr, images * args.steps, cfgs, S_, args.batch)
+    hsn_demo.segment_adp(model, alpha, thr, images * args.steps, cfgs, S_, args.batch, n_lanes=hsn_lanes)
     ctx.sync()
     elapsed = time.perf_counter() - t0
     ctx.profile_begin()

@@ -158,6 +158,11 @@ int wsc_host_free(wsc_ctx *ctx, void *host);
  * the bytes of an .npy container as [header | metadata | array | metadata | array ...] writes the arrays straight from where
  * they are (e.g. the page-locked staging buffer of a D2H copy) without the interpreter lock: wsscam.step.make_cam.save_npy_object. */
 int wsc_host_write_segments(const char *path, int n, const void *const *ptrs, const size_t *sizes);
+/* Asynchronous copies on the context's stream (page-locked host memory).  Scheduling note for callers with several contexts in
+ * flight: the runtime hands a queued copy to a DMA engine at once and turns "after the kernels before it on the stream" into a
+ * poll command on that engine's in-order queue -- every copy submitted later to the same engine, from ANY context, waits behind
+ * it.  Issue a copy when its producers have (nearly) finished: wsc_ctx_mark after the producer, wsc_ctx_wait_mark on a helper
+ * thread, then the copy (bench.py's end-to-end leg, wsscam.step.pipeline._copy_out); wsc_memcpy_d2h does that wait itself. */
 int wsc_memcpy_h2d_async(wsc_ctx *ctx, void *dst_dev, const void *src_pinned_host, size_t bytes);
 int wsc_memcpy_d2h_async(wsc_ctx *ctx, void *dst_pinned_host, const void *src_dev, size_t bytes);
 

@@ -21,7 +21,7 @@ try:
             if only and (only == "u8") != u8:
                 continue
             wl.setup_e2e(tmp, n_writers=int(os.environ.get("E2E_WRITERS", 8)), u8=u8)
-            for _ in range(3):
+            for _ in range(int(os.environ.get("E2E_WARM", 3))):
                 wl.step_e2e()
             wl.drain_e2e()
             t0 = time.perf_counter()

@@ -180,6 +180,9 @@ def _stub_pipeline(world, out_dir, S):
         def _make_lane(self, device, batch_images, S_):
             return _StubLane(batch_images, S_, self.n_sc)
 
+        def _copy_out(self, lane, s_tot, h_tot):
+            pass
+
         def _device_step(self, lane, n, metas):  # the device's part of a batch: sizes only, outputs stay zero
             keys = [self.keys_fn(m, None) for m in metas]
             sizes = [tuple(int(v) for v in m["size"]) for m in metas]

@@ -357,6 +357,10 @@ int wsc_memcpy_h2d(wsc_ctx *ctx, void *dst_dev, const void *src_host, size_t byt
 int wsc_memcpy_d2h(wsc_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     WSC_CHECK(ctx && (bytes == 0 || (dst_host && src_dev)), WSC_ERR_INVALID, "wsc_memcpy_d2h: null argument");
     if (bytes == 0) return WSC_OK;
+    // Wait for the producers on the host FIRST, then copy: a copy queued behind unfinished kernels becomes a poll command on the
+    // DMA engine's in-order queue and holds back every copy submitted after it, other contexts' uploads included, for as long as
+    // those kernels run (round 6, profiles/r06_step_timeline_e2e_before.txt)
+    WSC_HIP(hipStreamSynchronize(ctx->stream));
     WSC_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     WSC_HIP(hipStreamSynchronize(ctx->stream));
     return wsc_ctx_range_check(ctx);

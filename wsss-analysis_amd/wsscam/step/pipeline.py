@@ -130,9 +130,20 @@ class CamPipeline:
         lane.x_view[k] = img  # page-locked: the H2D below is a straight DMA
         return {key: v for key, v in pack.items() if key != "img"}
 
-    def _finish(self, lane, metas, keys, shapes, s_off, h_off, s_tot):
+    def _copy_out(self, lane, s_tot, h_tot):
+        """cam / high_res of a finished batch -> the lane's page-locked buffer.  Issued by the finisher AFTER it has seen the
+        lane's kernels finish, not queued behind them: the runtime turns a queued copy's dependency into a poll command on the
+        DMA engine's own in-order queue, where it holds back every copy submitted after it -- the next lane's batch upload
+        included -- until this lane's conv stack is done (measured on the bench's end-to-end leg, round 6: 1.4 ms per step)."""
+        ctx = lane.ctx
+        ctx.d2h_async(lane.pin_out, lane.s_dev, max(s_tot, 1) * 4)
+        ctx.d2h_async(lane.pin_out, lane.h_dev, max(h_tot, 1) * 4, dst_offset=max(s_tot, 1) * 4)
+        ctx.sync()
+
+    def _finish(self, lane, metas, keys, shapes, s_off, h_off, s_tot, h_tot):
         try:
             lane.ctx.sync()  # this lane's stream only; the other lanes keep running
+            self._copy_out(lane, s_tot, h_tot)
             strided = lane.pin_out.view((max(s_tot, 1),), np.float32)
             highres = lane.pin_out.view((lane.out_cap // 4 - max(s_tot, 1),), np.float32, offset_bytes=max(s_tot, 1) * 4)
             futs = []
@@ -153,11 +164,12 @@ class CamPipeline:
         n = len(indices)
         metas = [f.result() for f in [self.loaders.submit(self._load_into, lane, k, dataset, i) for k, i in enumerate(indices)]]
         keys, shapes, s_off, h_off, s_tot = self._device_step(lane, n, metas)
+        h_tot = sum(K * H0 * W0 for K, _, _, H0, W0 in shapes)
         lane.free.clear()
-        self.finishers.submit(self._finish, lane, metas, keys, shapes, s_off, h_off, s_tot)
+        self.finishers.submit(self._finish, lane, metas, keys, shapes, s_off, h_off, s_tot, h_tot)
 
     def _device_step(self, lane, n, metas):
-        """Everything a batch does on its lane's stream (H2D, conv stack, CAM head, tail, D2H -- all asynchronous): returns what
+        """Everything a batch does on its lane's stream (H2D, conv stack, CAM head, tail -- all asynchronous; the finisher copies out): returns what
         the finisher needs to cut the outputs out of the lane's staging buffer.  (The CPU tests of the N-worker host side
         replace this method and _make_lane; nothing else of the pipeline touches the device.)"""
         ctx = lane.ctx
@@ -208,9 +220,7 @@ class CamPipeline:
         lane.ensure_out(s_tot, h_tot)
         _, _, s_off, h_off, shapes = _lib.cam_postprocess(ctx, cam_dev, n, C, self.h, self.h, sizes, keys,
                                                           lane.s_dev, lane.h_dev)
-        ctx.d2h_async(lane.pin_out, lane.s_dev, max(s_tot, 1) * 4)
-        ctx.d2h_async(lane.pin_out, lane.h_dev, max(h_tot, 1) * 4, dst_offset=max(s_tot, 1) * 4)
-        return keys, shapes, s_off, h_off, s_tot
+        return keys, shapes, s_off, h_off, s_tot  # (the copy-out is the finisher's: _copy_out)
 
     # -- driver --------------------------------------------------------------------------------------------
     def run(self, dataset, indices=None):
