@@ -50,4 +50,7 @@ python profiles/make_traffic_json.py $out/pmc_f/*/*_results.db $out/pmc_w/*/*_re
 # round 6: configs 4 and 5 through their drivers under the kernel trace (busy timelines + per-kernel stats), VGG16 counter table
 bash profiles/r06_cfg54_prof.sh > $out/${tag}_cfg54_prof.log 2>&1
 bash profiles/r06_conv_probe.sh > $out/${tag}_conv_probe.log 2>&1
+# round 6: the end-to-end leg alone under the kernel + memory-copy trace (busy fraction, per-stream timeline), and its rates
+bash profiles/r06_e2e_prof.sh > $out/${tag}_e2e_prof.log 2>&1
+E2E_REPS=3 timeout 200 python profiles/e2e_probe.py > $out/${tag}_e2e_probe.txt 2>&1
 ls -la $out | grep ${tag}_

@@ -210,6 +210,7 @@ class CamPipeline:
             cam_dev = lane.sum_dev
         score = None
         if self.needs_score:  # predicted labels decide which maps are produced: one small read-back
+            ctx.sync()  # (first the kernels, then the copy: see _copy_out)
             ctx.d2h_async(lane.pin_score, lane.score_dev, n * self.n_sc * self.C * 4)
             ctx.sync()
             score = lane.pin_score.view((n, self.n_sc, self.C), np.float32)[:, 0].copy()  # labels[0]: the first scale's
