@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="images per step per GPU")
     ap.add_argument("--precision", default="f16x3", choices=["bf16", "f16", "bf16x3", "f16x3"],
                     help="conv operand mode: f16x3 = fp32-class (headline), f16 / bf16 = fast 16-bit modes, bf16x3 = the round-1 split")
-    ap.add_argument("--workload", default="cam_crf", choices=["cam_crf", "cam", "hsn"],
+    ap.add_argument("--workload", default="cam_crf", choices=["cam_crf", "cam", "hsn", "make_cam"],
                     help="cam_crf: the BASELINE.json metric; cam: make_cam only; hsn: BASELINE config 5 (HistoSegNet on ADP-like "
                          "321x321 patches: VGG16 Grad-CAM -> modify_by_htt -> cs-gradcam -> dense CRF for the 29 morphological "
                          "and the 5 functional classes, 03c_hsn/demo.py:271-380), an extra measurement")
@@ -891,6 +891,60 @@ def irn_measure(device, precision, arch="resnet50", n_images=32, reps=3):
                         % (arch, K, h, w, n_images)}
 
 
+def make_cam_measure(device, precision, n_small=288, n_large=1056, batch=32):
+    """BASELINE config 1 (ResNet50 CAM over VOC2012 images at 321 x 321, batch 32) through the PRODUCT driver
+    `step.make_cam.run(args)` (03b_irn/step/make_cam.py:95-124): a dataset of decoded 375 x 500 images (two positive classes each)
+    -> loader threads -> page-locked lane -> resize / normalise / flip pair + conv stack + CAM head + native-size tail on the
+    device -> `cam` / `high_res` copied out -> one .npy per image on a tmpfs.  Reported: the MARGINAL rate between a run over
+    n_small and a run over n_large images (the constructor, weight packing and the first batches drop out).  Seeded random
+    weights and synthetic images."""
+    import shutil
+    import tempfile
+
+    import numpy as np
+
+    from wsscam import _lib, synth
+    from wsscam.step import make_cam
+
+    prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "f16x3": _lib.PREC_F16X3}[precision]
+    sd = synth.resnet50_cam_state_dict(20, seed=0)
+    rng = np.random.default_rng(0)
+    imgs = [synth.synth_image(rng, 375, 500) for _ in range(batch)]
+    labels = []
+    for i in range(batch):
+        lab = np.zeros(20, np.float32)
+        lab[[i % 20, (7 * i + 3) % 20]] = 1
+        labels.append(lab)
+    tmp_root = "/dev/shm" if os.path.isdir("/dev/shm") else None
+
+    def once(n):
+        packs = [{"name": "im%05d" % i, "img_u8": imgs[i % batch], "size": (375, 500), "label": labels[i % batch]} for i in range(n)]
+        d = tempfile.mkdtemp(prefix="wsc_mc_", dir=tmp_root)
+        a = argparse.Namespace(cam_network="net.resnet50_cam", model_dir=None, dataset="voc12", tag="", num_classes=20,
+                               use_cls=list(range(20)), model_id="resnet50", state_dict=sd, split="train_aug", dataset_obj=packs,
+                               cam_out_dir=d, outsize=(S, S), n_gpus=1, cam_device_ids=[device], cam_batch_images=batch,
+                               cam_precision=prec, cam_weights_name="unused", norm_mode="int", val_list=None, dev_root=None,
+                               cam_scales=(1.0,), class_names={"bg": ["background"], "fg": ["c%d" % i for i in range(20)]})
+        try:
+            t0 = time.perf_counter()
+            make_cam.run(a)
+            dt = time.perf_counter() - t0
+            n_files = len(os.listdir(d))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        if n_files != n:
+            raise RuntimeError("make_cam wrote %d files for %d images" % (n_files, n))
+        return dt
+
+    once(2 * batch)  # (library, lanes, thread pools, page cache)
+    t1, t2 = once(n_small), once(n_large)
+    rate = (n_large - n_small) / max(t2 - t1, 1e-9)
+    return {"value": round(rate, 2), "unit": "images/s", "dtype": precision, "seconds": [round(t1, 3), round(t2, 3)], "images": [n_small, n_large],
+            "workload": "make_cam driver (BASELINE config 1): ResNet50 CAM, decoded 375x500 uint8 images in, device transform to 321x321 + "
+                        "flip pair, batch %d, three lanes; keys / cam (2,94,125) / high_res (2,375,500) per image written as .npy on %s; "
+                        "marginal rate between the two runs" % (batch, "tmpfs" if tmp_root else "the system temp dir")}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -917,6 +971,13 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
+    if args.workload == "make_cam":  # BASELINE config 1 through step.make_cam.run alone (also a leg of the default line)
+        if rank == 0:
+            print(json.dumps(make_cam_measure(device, args.precision)))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload == "hsn":
         if rank == 0:
             run_hsn(args, device)
@@ -1117,6 +1178,10 @@ def main():
                 stages["value_irn"] = irn_measure(device, args.precision)
             except Exception as e:
                 stages["value_irn"] = {"error": repr(e)}
+            try:  # BASELINE config 1 through the product driver step.make_cam.run (files on a tmpfs)
+                stages["value_make_cam"] = make_cam_measure(device, args.precision)
+            except Exception as e:
+                stages["value_make_cam"] = {"error": repr(e)}
 
     if rank == 0:
         images = args.batch * (steps if args.scaling == "strong" else steps * world)
