@@ -791,11 +791,12 @@ def hsn_measure(args, device):
     # The timed region is ONE driver call over steps x batch patches (the reference's dataset loop, 03c_hsn/demo.py:318-380):
     # the driver keeps two batches in flight on two streams, so a batch's host decisions hide behind the other's kernels
     hsn_lanes = int(os.environ.get("WSC_BENCH_HSN_LANES", "3"))  # (segment_adp's default)
-    hsn_demo.segment_adp(model, alpha, thr, images * 3, cfgs, S_, args.batch, n_lanes=hsn_lanes)  # (untimed: the other lanes' contexts and workspaces)
+    chain = os.environ.get("WSC_BENCH_CHAIN", "0") == "1"  # (A/B: 1 = the lanes' conv stacks take turns; the driver's default is 0)
+    hsn_demo.segment_adp(model, alpha, thr, images * 3, cfgs, S_, args.batch, n_lanes=hsn_lanes, chain_stacks=chain)  # (untimed: the other lanes' contexts and workspaces)
     model.ctx.sync()
     ctx = model.ctx
     t0 = time.perf_counter()
-    hsn_demo.segment_adp(model, alpha, thr, images * args.steps, cfgs, S_, args.batch, n_lanes=hsn_lanes)
+    hsn_demo.segment_adp(model, alpha, thr, images * args.steps, cfgs, S_, args.batch, n_lanes=hsn_lanes, chain_stacks=chain)
     ctx.sync()
     elapsed = time.perf_counter() - t0
     ctx.profile_begin()
@@ -879,10 +880,11 @@ def irn_measure(device, precision, arch="resnet50", n_images=32, reps=3):
     dargs = types.SimpleNamespace(dataset="voc12", beta=10, exp_times=8, sem_seg_bg_thres=0.25)
     # the driver's dataset loop (make_sem_seg_labels._work) over `reps` batches: two batches in flight on two streams
     n_lanes = int(os.environ.get("WSC_BENCH_IRN_LANES", "3"))  # (the driver's default, make_sem_seg_labels._work)
-    mssl.sem_seg_batches(model, [(packs, cam_dicts)] * n_lanes, dargs, n_lanes=n_lanes)
+    chain = os.environ.get("WSC_BENCH_CHAIN", "0") == "1"  # (A/B: 1 = the lanes' network passes take turns; the driver's default is 0)
+    mssl.sem_seg_batches(model, [(packs, cam_dicts)] * n_lanes, dargs, n_lanes=n_lanes, chain_stacks=chain)
     model.ctx.sync()
     t0 = time.perf_counter()
-    mssl.sem_seg_batches(model, [(packs, cam_dicts)] * reps, dargs, n_lanes=n_lanes)
+    mssl.sem_seg_batches(model, [(packs, cam_dicts)] * reps, dargs, n_lanes=n_lanes, chain_stacks=chain)
     model.ctx.sync()
     dt = (time.perf_counter() - t0) / reps
     return {"value": round(n_images / dt, 2), "unit": "images/s", "ms_per_image": round(dt / n_images * 1e3, 3), "dtype": precision,
@@ -924,7 +926,8 @@ def make_cam_measure(device, precision, n_small=288, n_large=1824, batch=32):
                                use_cls=list(range(20)), model_id="resnet50", state_dict=sd, split="train_aug", dataset_obj=packs,
                                cam_out_dir=d, outsize=(S, S), n_gpus=1, cam_device_ids=[device], cam_batch_images=batch,
                                cam_precision=prec, cam_weights_name="unused", norm_mode="int", val_list=None, dev_root=None,
-                               cam_scales=(1.0,), class_names={"bg": ["background"], "fg": ["c%d" % i for i in range(20)]})
+                               cam_scales=(1.0,), class_names={"bg": ["background"], "fg": ["c%d" % i for i in range(20)]},
+                               cam_pipeline_chain=os.environ.get("WSC_BENCH_CHAIN", "1") != "0")  # (A/B: 0 = interleaved stacks)
         try:
             t0 = time.perf_counter()
             make_cam.run(a)

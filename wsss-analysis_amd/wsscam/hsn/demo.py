@@ -184,7 +184,7 @@ def run_batches_on_lanes(n_batches, ctxs, one_batch):
 
 
 def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size, is_verbose=False, all_classes=None, stats=None,
-                n_lanes=3):
+                n_lanes=3, chain_stacks=False):
     """demo.py:271-380 for one ADP model: per batch scores >= thresholds -> HSN Grad-CAM at (size, size) -> per
     HTT type {morph, func}: scatter into the valid-class stack, modify_by_htt (background / other channels),
     get_cs_gradcam, dense CRF with that type's configuration.  `images` are uint8 RGB (any size; resized like
@@ -196,7 +196,8 @@ def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size
     (B, Cv) class-mass flags and the final labels.  `stats` (optional dict): per HTT type the list of every image's number of
     classes with mass -- the M its dense CRF ran with (dcrf_process keeps the classes whose maps are not all zero, :425).
     `n_lanes` batches are in flight at once, each on its own stream (run_batches_on_lanes); a batch's results do not depend
-    on the lane it ran on."""
+    on the lane it ran on.  `chain_stacks`: the lanes' VGG16 passes take turns on the device (_lib.StackChain) -- measured neutral
+    here (1067-1140 against 1053-1181 images/s, profiles/r06_chain_ab.txt: a batch is mostly CRF), so off by default."""
     from .. import _lib
 
     ac = ADPClasses(all_classes)
@@ -209,6 +210,8 @@ def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size
     adipose_all = adipose_source_channels(ac)
     bounds = [(lo, min(lo + batch_size, len(images))) for lo in range(0, len(images), batch_size)]
     model.gradcam_net(np.asarray(alpha))  # (built once, before the lanes' threads ask for it)
+    # several batches in flight: their VGG16 stacks take turns on the device, everything else of a batch overlaps (_lib.StackChain)
+    chain = model.__dict__.setdefault("_stack_chain", _lib.StackChain()) if int(n_lanes) > 1 and chain_stacks else None
 
     def one_batch(bi, ctx):
         lo, hi = bounds[bi]
@@ -218,7 +221,7 @@ def segment_adp(model, alpha, thresholds, images, dcrf_configs, size, batch_size
         raw = read_batch_u8(chunk, (size, size), ctx=ctx)  # ADPCues.read_batch: cv2.resize's uint8 batch (adp_cues.py:122-128)
         # (raw - 193.09203) / 56.450138 (adp_cues.py:130) and the NHWC -> NCHW layout on the device
         H_dev, scores, is_pass, _, raw_dev = hu.grad_cam_device(model, alpha, None, thresholds, [size, size], raw_u8=raw,
-                                                                mean_std=(193.09203, 56.450138), ctx=ctx)
+                                                                mean_std=(193.09203, 56.450138), ctx=ctx, chain=chain)
         bg_dev = ctx.alloc(B * N * 8, pooled=True)
         _lib.hsn_background(ctx, raw_dev, B, size, size, bg_dev)
         for htt in ("morph", "func"):

@@ -9,7 +9,8 @@ from ..cues import utilities as cues_utilities
 from ..misc.imutils import default_context, unary_from_softmax
 
 
-def grad_cam_device(input_model, weights, images, thresholds, orig_sz, raw_u8=None, mean_std=None, out=None, ctx=None):
+def grad_cam_device(input_model, weights, images, thresholds, orig_sz, raw_u8=None, mean_std=None, out=None, ctx=None,
+                    chain=None):
     """HSN grad_cam with everything after the batch upload on the device: one CNN pass (einsum maps + scores,
     SURVEY Q9), score gate, per-map upsample + max(., 0), per-image normalisation (03c_hsn/utilities.py:258-277 with
     the class gating of demo.py:127-131 / :335-341).  `images`: normalised (B,S,S,3) floats, or None with `raw_u8`
@@ -38,7 +39,10 @@ def grad_cam_device(input_model, weights, images, thresholds, orig_sz, raw_u8=No
     assert int(orig_sz[1]) == S, "square output size"
     cams_dev = ctx.alloc(B * h * h * C * 4, pooled=True)
     score_dev = ctx.alloc(B * C * 4, pooled=True)
-    net.forward_gradcam(x_dev, B, S_in, False, cams_dev, score_dev, ctx=ctx)
+    if chain is not None:  # (a driver with several batches in flight: one conv stack at a time, _lib.StackChain)
+        chain.run(ctx, lambda: net.forward_gradcam(x_dev, B, S_in, False, cams_dev, score_dev, ctx=ctx))
+    else:
+        net.forward_gradcam(x_dev, B, S_in, False, cams_dev, score_dev, ctx=ctx)
     scores = ctx.to_host(score_dev, (B, C), np.float32)  # 4 B C bytes: the gate is a host decision in the reference too
     is_pass = np.greater_equal(scores, np.asarray(thresholds).reshape(1, -1))
     gate_dev = ctx.to_device((scores * is_pass).astype(np.float32), pooled=True)

@@ -22,11 +22,12 @@ class EdgeDisplacementBase(DeviceCAMBase):
         ctx = self._ctx
         return ctx.to_host(edge_dev, (B, 1, fh, fw), np.float32), ctx.to_host(dp_dev, (B, 2, fh, fw), np.float32)
 
-    def forward_batch_device(self, x, ctx=None):
+    def forward_batch_device(self, x, ctx=None, chain=None):
         """forward_batch with the outputs left in HBM: (edge_dev float32 [B][fh][fw], dp_dev [B][2][fh][fw], (B, fh, fw)).
         x: (B,2,3,h,w) array / tensor, or a list of B (2,3,h,w) arrays of one size (copied straight into the page-locked,
         zero-padded staging batch: no stacked temporary, no pageable upload).  `ctx`: run on this context (a lane of the
-        make_sem_seg_labels driver: its own stream, staging batch and workspace) instead of the model's own."""
+        make_sem_seg_labels driver: its own stream, staging batch and workspace) instead of the model's own; `chain`: that
+        driver's _lib.StackChain (the lanes' network passes take turns on the device)."""
         net = self._ensure_net()
         if isinstance(x, (list, tuple)):
             items = [np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32) for v in x]
@@ -59,7 +60,10 @@ class EdgeDisplacementBase(DeviceCAMBase):
         ctx.h2d_async(st["dev"], st["pin"], B * 2 * 3 * S * S * 4)
         edge_dev = ctx.alloc(B * fh * fw * 4, pooled=True)
         dp_dev = ctx.alloc(B * 2 * fh * fw * 4, pooled=True)
-        net.forward_edge(st["dev"], B, S, fh, fw, edge_dev, dp_dev, ctx=ctx)
+        if chain is not None:  # (a driver with several batches in flight: one conv stack at a time, _lib.StackChain)
+            chain.run(ctx, lambda: net.forward_edge(st["dev"], B, S, fh, fw, edge_dev, dp_dev, ctx=ctx))
+        else:
+            net.forward_edge(st["dev"], B, S, fh, fw, edge_dev, dp_dev, ctx=ctx)
         return edge_dev, dp_dev, (B, fh, fw)
 
     def forward(self, x):

@@ -290,7 +290,8 @@ def _work(process_id, model, dataset, args):
                        save_fn=lambda name, keys, sc, hc: _save(args, name, keys, sc, hc), needs_score=needs_score,
                        n_lanes=int(getattr(args, "cam_pipeline_lanes", 3)), n_loaders=None if lt is None else int(lt),
                        n_writers=None if wt is None else int(wt), norm=norm, n_scales=n_sc,
-                       world=int(getattr(args, "n_gpus", 0)) or len(dataset))
+                       world=int(getattr(args, "n_gpus", 0)) or len(dataset),
+                       chain_stacks=bool(getattr(args, "cam_pipeline_chain", True)))
     try:
         pipe.run(databin)
     finally:

@@ -34,14 +34,14 @@ def _build_model(args):
         return cls(args.model_dir, args.num_classes, **kw)
 
 
-def sem_seg_batch(model, packs, cam_dicts, args, ctx=None):
+def sem_seg_batch(model, packs, cam_dicts, args, ctx=None, chain=None):
     """A list of images -> list of label maps, device resident between the batch upload and the label maps: one
     EdgeDisplacement pass, the boundary maps resized to each image's CAM size on the device, ONE random-walk pass for all
     images (every stencil step is a single launch over the whole list) and one tail pass (upsample, / max, background
     channel, arg-max, keys: wsc_sem_seg_finish); the host sees the uint8 label maps.  (Round 1 / mid round 2: edges, walk
     results and upsampled maps each went to the host and back, the arg-max ran in numpy.)"""
     ctx = ctx or model.ctx  # (a lane of sem_seg_batches: its own stream, staging batch and buffer pool)
-    edge_dev, _dp_dev, (B, fh, fw) = model.forward_batch_device([p["img"] for p in packs], ctx=ctx)
+    edge_dev, _dp_dev, (B, fh, fw) = model.forward_batch_device([p["img"] for p in packs], ctx=ctx, chain=chain)
     voc = args.dataset == "voc12"
     dg = args.dataset in ("deepglobe", "deepglobe_balanced")
     if not (voc or dg or args.dataset in ("adp_morph", "adp_func")):
@@ -97,18 +97,24 @@ def sem_seg_batch(model, packs, cam_dicts, args, ctx=None):
     return out
 
 
-def sem_seg_batches(model, batches, args, n_lanes=3, sink=None):
+def sem_seg_batches(model, batches, args, n_lanes=3, sink=None, chain_stacks=False):
     """The dataset loop of _work over a list of (packs, cam_dicts) batches with `n_lanes` batches in flight, each on its own
     stream (hsn.demo.run_batches_on_lanes): the host side of a batch -- 72 MB of float32 inputs copied into the page-locked,
     zero-padded staging batch, the upload, the read-back -- runs beside the other lane's EdgeDisplacement pass and random
     walk (the serial loop left the device idle ~45 % of a batch: VERDICT r5 weak #8).  `batches[i]` may be a callable
     returning the pair (so that only the batches in flight are in memory); `sink(i, packs, label maps)` consumes a batch's
     results on its lane's thread (PNG writers), else the lists are returned in batch order."""
+    from .. import _lib
     from ..hsn.demo import lane_contexts, run_batches_on_lanes
+
+    # chain_stacks: the lanes' EdgeDisplacement passes take turns on the device (_lib.StackChain).  Measured neutral to slightly
+    # negative here (708-739 against 706-765 images/s, profiles/r06_chain_ab.txt: with three lanes one is usually in its random
+    # walk and one on the host anyway), so off by default; step.pipeline, where every lane is a conv stack, gains 11-20 % from it
+    chain = model.__dict__.setdefault("_stack_chain", _lib.StackChain()) if int(n_lanes) > 1 and chain_stacks else None
 
     def one(bi, ctx):
         packs, cams = batches[bi]() if callable(batches[bi]) else batches[bi]
-        preds = sem_seg_batch(model, packs, cams, args, ctx=ctx)
+        preds = sem_seg_batch(model, packs, cams, args, ctx=ctx, chain=chain)
         if sink is not None:
             sink(bi, packs, preds)
             return None

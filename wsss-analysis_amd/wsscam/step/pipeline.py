@@ -92,9 +92,9 @@ class CamPipeline:
     `save_fn(name, keys, strided, highres)` are the driver's own (make_cam._valid_cat / _save)."""
 
     def __init__(self, model, device, batch_images, S, keys_fn, save_fn, needs_score, n_lanes=3, n_loaders=None, n_writers=None,
-                 norm=None, n_scales=1, world=1):
+                 norm=None, n_scales=1, world=1, chain_stacks=True):
         """n_loaders / n_writers None: sized from the host cores this worker may use when `world` workers share the host
-        (host_thread_budget)."""
+        (host_thread_budget).  chain_stacks: the lanes' conv stacks run one after the other on the device (_device_step)."""
         budget = host_thread_budget(world)
         n_loaders = budget["n_loaders"] if n_loaders is None else int(n_loaders)
         n_writers = budget["n_writers"] if n_writers is None else int(n_writers)
@@ -113,6 +113,7 @@ class CamPipeline:
         self.finishers = ThreadPoolExecutor(n_lanes, thread_name_prefix="wsc-finish")
         self.errors = []
         self.images_done = 0
+        self.chain = _lib.StackChain() if chain_stacks else None  # (see _device_step)
 
     def _make_lane(self, device, batch_images, S):
         return _Lane(device, batch_images, S, self.C, self.h, self.n_sc, self.model.adp_out_channels() if self.adp else 0)
@@ -192,8 +193,17 @@ class CamPipeline:
                               pre_div255=norm.norm_mode == "float", pair=True)
         else:
             ctx.h2d_async(lane.x_dev, lane.pin_in, n * self.n_sc * 2 * 3 * self.S * self.S * 4)
-        self.model._ensure_net().forward_cam(lane.x_dev, n * self.n_sc, self.S, lane.cam_dev,
-                                             lane.score_dev if self.needs_score else None, ctx=ctx)
+        # One conv stack at a time (_lib.StackChain): the stack of batch i waits on the device for the stack of batch i-1, which
+        # ran on another lane; the uploads, the input transform, the tails and the copy-outs of the other lanes still overlap it
+        net = self.model._ensure_net()
+
+        def stack():
+            net.forward_cam(lane.x_dev, n * self.n_sc, self.S, lane.cam_dev, lane.score_dev if self.needs_score else None, ctx=ctx)
+
+        if self.chain is not None:
+            self.chain.run(ctx, stack)
+        else:
+            stack()
         cam_dev, C = lane.cam_dev, self.C
         if self.adp:
             # common_cam.py:31-92 on the device: the original (un-flipped) image of every scale travels as uint8 through the
