@@ -53,4 +53,6 @@ bash profiles/r06_conv_probe.sh > $out/${tag}_conv_probe.log 2>&1
 # round 6: the end-to-end leg alone under the kernel + memory-copy trace (busy fraction, per-stream timeline), and its rates
 bash profiles/r06_e2e_prof.sh > $out/${tag}_e2e_prof.log 2>&1
 E2E_REPS=3 timeout 200 python profiles/e2e_probe.py > $out/${tag}_e2e_probe.txt 2>&1
+# round 6: the make_cam driver leg (config 1 through step.make_cam.run) under the kernel + memory-copy trace
+bash profiles/r06_make_cam_prof.sh > $out/${tag}_make_cam_prof.log 2>&1
 ls -la $out | grep ${tag}_

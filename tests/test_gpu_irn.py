@@ -275,8 +275,8 @@ def test_sem_seg_batches_in_flight_equal_serial():
     args = types.SimpleNamespace(dataset="voc12", beta=10, exp_times=5, sem_seg_bg_thres=0.25)
     batches = [(packs[i:i + 2], cams[i:i + 2]) for i in range(0, 7, 2)]
     serial = [mssl.sem_seg_batch(model, p, c, args) for p, c in batches]
-    for _ in range(2):
-        lanes = mssl.sem_seg_batches(model, batches, args, n_lanes=3)
+    for chain in (False, True):  # (chain_stacks: the lanes' network passes take turns on the device, _lib.StackChain)
+        lanes = mssl.sem_seg_batches(model, batches, args, n_lanes=3, chain_stacks=chain)
         assert len(lanes) == len(serial)
         for a, b in zip(lanes, serial):
             assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))

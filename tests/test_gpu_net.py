@@ -539,9 +539,11 @@ def test_hsn_segment_adp_batches_in_flight_equal_serial():
     cfgs = {"morph": np.array([3 / 2, 3, 80 / 2, 13, 10, 3]), "func": np.array([3, 3, 50, 5, 10, 3])}
     st1, st3 = {}, {}
     serial = hsn_demo.segment_adp(model, alpha, thr, images, cfgs, S, 2, stats=st1, n_lanes=1)
-    for _ in range(2):  # (twice: the second call finds the lanes' contexts, pools and cached Gaussian lattices warm)
+    # (twice: the second call finds the lanes' contexts, pools and cached Gaussian lattices warm; with chain_stacks the lanes'
+    # VGG16 passes take turns on the device -- _lib.StackChain -- and the maps are the same)
+    for chain in (False, True):
         st3 = {}
-        lanes = hsn_demo.segment_adp(model, alpha, thr, images, cfgs, S, 2, stats=st3, n_lanes=3)
+        lanes = hsn_demo.segment_adp(model, alpha, thr, images, cfgs, S, 2, stats=st3, n_lanes=3, chain_stacks=chain)
         for htt in ("morph", "func"):
             assert len(lanes[htt]) == 5
             for b in range(5):
