@@ -487,10 +487,7 @@ class Workload:
         # batch i is on the device: its copy-in was issued a step ago, the host just checks.  (No marker / device-side wait on a
         # copy stream: a marker is a barrier packet in the stream's hardware queue, the runtime maps all streams onto four of
         # those, and behind another stream's mean-field kernels the marker -- and the conv stack waiting for it -- sat ~1 ms)
-        if os.environ.get("WSC_BENCH_E2E_IO_MARK") == "1":
-            self.ctx.wait_for_mark(e["io"], q)
-        else:
-            e["io"].sync()
+        e["io"].sync()
         x_keep, self.x_dev = self.x_dev, e["x"][q]
         if e["u8"]:
             # decoded images in: the dataset transform (resize, normalise, flip pair: a 45 us kernel) is the first launch of the
@@ -540,8 +537,6 @@ class Workload:
             io.h2d_async(e["u8d"][q], e["pin_u8"][q], int(self.u8_offs[-1]))
         else:
             io.h2d_async(e["x"][q], e["pin_in"][q], self.x_host.nbytes)
-        if os.environ.get("WSC_BENCH_E2E_IO_MARK") == "1":
-            io.mark(q)
 
     def _e2e_stage(self, p):
         """The DataLoader's batch (pageable memory) -> parity p's page-locked staging buffers, on the pool."""
