@@ -29,6 +29,8 @@ def main():
     from wsscam.misc.indexing import PathIndex
 
     ctx = _lib.Context(0)
+    if os.environ.get("BENCH_IRN_TILED"):  # A/B: 1 = the tiled random-walk step whatever the batch, 0 = the flat one
+        ctx.set_option(_lib.OPT_RW_TILED, int(os.environ["BENCH_IRN_TILED"]))
     prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "f16x3": _lib.PREC_F16X3}[args.precision]
     sd = synth.irn_state_dict(args.arch, 0)  # seeded random weights (no trained IRNet weights offline)
     arch = _lib.ARCH_VGG16_IRN if args.arch == "vgg16" else _lib.ARCH_RESNET50_IRN
@@ -57,7 +59,7 @@ def main():
 
     t_net = timed(lambda: net.forward_edge(x_dev, B, S, fh, fw, edge_dev, dp_dev), args.steps)
     t_rw1 = timed(lambda: _lib.rw_propagate(ctx, cams_dev, e2_dev, K, h, w, dirs, start, yx, 10.0, 256, rw_dev), args.steps)
-    RB = 32  # images per random-walk pass (make_sem_seg_labels mirror: args.irn_batch_images)
+    RB = int(os.environ.get("BENCH_IRN_RB", 32))  # images per random-walk pass (make_sem_seg_labels mirror: args.irn_batch_images)
     cams_b = ctx.to_device(rng.random((RB, K, h, w)).astype(np.float32))
     e2_b = ctx.to_device((rng.random((RB, h, w)) ** 2).astype(np.float32))
     rw_b = ctx.alloc(RB * K * h * w * 4)

@@ -128,13 +128,24 @@ __global__ __launch_bounds__(RW_T * RW_T) void rw_step_tile_kernel(const RwImg *
                                                                     const float *__restrict__ S_all,
                                                                     const double *__restrict__ inv_col_all,
                                                                     const int32_t *__restrict__ dirs, int D,
-                                                                    double *__restrict__ out_all, float *__restrict__ out_f32_all) {
+                                                                    double *__restrict__ out_all, float *__restrict__ out_f32_all,
+                                                                    int max_tiles, int xcd_map) {
     __shared__ double vt[RW_KC][RW_W * RW_W];
-    const RwImg im = imgs[blockIdx.y];
+    // 1-D grid of n_img * max_tiles blocks.  Blocks go round-robin over the 8 XCDs (block b -> XCD b % 8): with the plain order
+    // every XCD's 4 MB L2 sees tiles of every image, i.e. all 34 weight maps of the whole batch (51 MB at 32 VOC images) plus
+    // the halo overlap.  The bijective remap gives an XCD a contiguous range of logical ids = whole images (4 of 32), whose
+    // weights and state it then re-reads from its own L2 for all 2^8 steps.
+    int lb = (int)blockIdx.x;
+    if (xcd_map) {
+        const int nb = (int)gridDim.x, xcd = lb & 7, q = nb >> 3, r = nb & 7;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lb >> 3);
+    }
+    const int img = lb / max_tiles, tile = lb - img * max_tiles;
+    const RwImg im = imgs[img];
     const int h = im.h, w = im.w, hw = im.hw;
     const int ntx = (w + RW_T - 1) / RW_T, nty = (h + RW_T - 1) / RW_T;
-    if ((int)blockIdx.x >= ntx * nty) return;
-    const int ty0 = ((int)blockIdx.x / ntx) * RW_T, tx0 = ((int)blockIdx.x % ntx) * RW_T;
+    if (tile >= ntx * nty) return;
+    const int ty0 = (tile / ntx) * RW_T, tx0 = (tile % ntx) * RW_T;
     const int ty = (int)threadIdx.x / RW_T, tx = (int)threadIdx.x % RW_T;
     const int y = ty0 + ty, x = tx0 + tx;
     const bool ok = y < h && x < w;
@@ -157,6 +168,9 @@ __global__ __launch_bounds__(RW_T * RW_T) void rw_step_tile_kernel(const RwImg *
             double acc[RW_KC];
 #pragma unroll
             for (int k = 0; k < RW_KC; ++k) acc[k] = vt[k][lc];
+            // (requesting the weights of four directions together before using them -- 8 loads in flight per thread instead
+            // of 2 -- measured 7 % slower: 36 VGPRs instead of 12 and the predicates kept twice, 0.269 -> 0.287 ms per image;
+            // unrolling this loop by 2 / 4: 0.267 / 0.265 -- the step is not waiting for its weight loads)
             for (int d = 0; d < D; ++d) {
                 const int dy = dirs[2 * d], dx = dirs[2 * d + 1]; // (uniform)
                 const int qy = y + dy, qx = x + dx;
@@ -282,20 +296,26 @@ extern "C" int wsc_rw_propagate_batch(wsc_ctx *ctx, int n_img, const int32_t *K_
         max_tiles = std::max(max_tiles, t);
         all_tiles += t;
     }
-    // a thread of the tiled kernel owns ALL maps of a pixel: it needs a batch that fills the chip with tiles several times
-    // over (32 images of 94 x 125 = 1536 tiles: 0.48 -> 0.31 ms per image; 16 images, 768 tiles: 2 % slower than the flat
-    // kernel; a single image, 48 tiles: 4.0 -> 5.3 ms): smaller calls keep the flat kernel
-    if (ctx->opt[WSC_OPT_RW_TILED] < 0) tiled = tiled && all_tiles >= 5ll * ctx->num_cus;
+    // a thread of the tiled kernel owns ALL maps of a pixel, so a small call has too few threads for it.  With the
+    // XCD-contiguous block order (round 6) it wins from 4 VOC-sized images on -- ms per image, flat / tiled, 94 x 125, K = 2,
+    // 2^8 steps: 1 image (48 tiles) 3.95 / 4.95, 2: 2.03 / 2.46, 4: 1.53 / 1.22, 8: 0.91 / 0.62, 16: 0.50 / 0.35, 24: 0.61 / 0.34,
+    // 32: - / 0.27 (0.31 before the block order) -- smaller calls keep the flat kernel
+    if (ctx->opt[WSC_OPT_RW_TILED] < 0) tiled = tiled && all_tiles * 8 >= 5ll * ctx->num_cus;
+#ifdef WSC_AB_KNOBS
+    static const int xcd_map = [] { const char *e = getenv("WSC_RW_XCD"); return e ? atoi(e) : 1; }();
+#else
+    constexpr int xcd_map = 1;
+#endif
     for (int s = 0; s < n_steps; ++s) {
         if (tiled) {
-            const dim3 tg((unsigned)max_tiles, (unsigned)n_img);
+            const dim3 tg((unsigned)max_tiles * (unsigned)n_img);
             float *of = s == n_steps - 1 ? rw_dev : (float *)nullptr;
             if (max_K <= 2)
-                hipLaunchKernelGGL(rw_step_tile_kernel<2>, tg, dim3(RW_T * RW_T), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt, of);
+                hipLaunchKernelGGL(rw_step_tile_kernel<2>, tg, dim3(RW_T * RW_T), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt, of, max_tiles, xcd_map);
             else if (max_K <= 4)
-                hipLaunchKernelGGL(rw_step_tile_kernel<4>, tg, dim3(RW_T * RW_T), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt, of);
+                hipLaunchKernelGGL(rw_step_tile_kernel<4>, tg, dim3(RW_T * RW_T), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt, of, max_tiles, xcd_map);
             else
-                hipLaunchKernelGGL(rw_step_tile_kernel<8>, tg, dim3(RW_T * RW_T), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt, of);
+                hipLaunchKernelGGL(rw_step_tile_kernel<8>, tg, dim3(RW_T * RW_T), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt, of, max_tiles, xcd_map);
         }
         else
         hipLaunchKernelGGL(rw_step_kernel, g_khw, dim3(256), 0, ctx->stream, imgs_dev, cur, S, inv_col, dirs, D, nxt,
