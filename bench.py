@@ -935,7 +935,8 @@ def make_cam_measure(device, precision, n_small=288, n_large=1824, batch=32):
         return dt
 
     once(2 * batch)  # (library, lanes, thread pools, page cache)
-    t1, t2 = once(n_small), once(n_large)
+    t1, t2 = min(once(n_small), once(n_small)), min(once(n_large), once(n_large))  # (best of two: the difference of two
+    # sub-second runs moves by several per cent with a single late batch)
     rate = (n_large - n_small) / max(t2 - t1, 1e-9)
     return {"value": round(rate, 2), "unit": "images/s", "dtype": precision, "seconds": [round(t1, 3), round(t2, 3)], "images": [n_small, n_large],
             "workload": "make_cam driver (BASELINE config 1): ResNet50 CAM, decoded 375x500 uint8 images in, device transform to 321x321 + "
